@@ -1,0 +1,20 @@
+"""CPU oracle for the AdVoc hot path.  TEST INFRASTRUCTURE ONLY.
+
+Everything under ``oracle/`` is a CPU restatement of the reference algorithm
+(paarthneekhara/advoc, TF1 / lws / librosa) used as the *checker* for the HIP
+kernels.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product package
+(``advoc_amd``) never does: it fails loudly if the HIP library is missing.
+
+Pinning status ("Oracle"):
+  * spectral_np  -- pinned against the reference's own known-answer constants
+                    (tests/test_spectral.py:33-46,74-76) and the r9y9 fixture.
+  * audioio      -- pinned against outputs of the reference's advoc/audioio.py
+                    imported in the build container (tests/golden/make_golden.py).
+  * advoc_torch  -- PARITY UNPINNED: the reference holds no test or golden
+                    output for the conv stack, losses or optimiser; the oracle
+                    is a torch-CPU restatement of TF1 semantics cross-checked
+                    against closed-form micro cases (tests/test_oracle_conv.py).
+  * loader_np    -- PARITY UNPINNED (no reference test); restates
+                    advoc/loader.py:133-186 and tf.contrib.signal.frame.
+"""
