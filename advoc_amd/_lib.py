@@ -1,0 +1,119 @@
+"""ctypes binding of libadvoc_hip.so (the C ABI declared in include/advoc_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call
+returns an error code, this module raises.  The product never computes the hot
+path on the CPU.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libadvoc_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'advoc_hip.h')
+
+_p = ctypes.c_void_p
+_i32 = ctypes.c_int32
+_i64 = ctypes.c_int64
+_f32 = ctypes.c_float
+
+
+class AdvocHipError(RuntimeError):
+  pass
+
+
+class Tensor4(ctypes.Structure):
+  """struct advoc_tensor4 (include/advoc_hip.h)."""
+  _fields_ = [('p', _p), ('n', _i32), ('h', _i32), ('w', _i32), ('c', _i32), ('w_pitch', _i32)]
+
+
+class ConvLayer(ctypes.Structure):
+  """struct advoc_conv_layer (include/advoc_hip.h)."""
+  _fields_ = [
+      ('kind', _i32), ('kh', _i32), ('kw', _i32), ('sh', _i32), ('sw', _i32),
+      ('pad_t', _i32), ('pad_l', _i32), ('in_act', _i32),
+      ('x0', Tensor4), ('x1', Tensor4),
+      ('in_scale', _p), ('in_shift', _p),
+      ('y', Tensor4),
+      ('w', _p), ('b', _p),
+      ('drop_mask', _p), ('drop_scale', _f32),
+  ]
+
+
+# name -> (restype, argtypes).  Must list every symbol include/advoc_hip.h declares
+# (tests/test_abi.py checks the two against each other and against `nm -D`).
+PROTOTYPES = {
+    'advoc_abi_version': (ctypes.c_int, []),
+    'advoc_error_string': (ctypes.c_char_p, [ctypes.c_int]),
+    'advoc_target_arch': (ctypes.c_char_p, []),
+    'advoc_stft_mag_f32': (ctypes.c_int, [_p, _i64, _i64, _p, _i32, _i32, _i64, _p, _p]),
+    'advoc_stft_c64': (ctypes.c_int, [_p, _i64, _i64, _p, _i32, _i32, _i64, _p, _p]),
+    'advoc_matmul_nt_f32': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
+    'advoc_mel_dbnorm_f32': (ctypes.c_int, [_p, _i64, _f32, _f32, _f32, _p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+  """Loads libadvoc_hip.so once; raises AdvocHipError if it has not been built."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  with _lock:
+    if _lib is not None:
+      return _lib
+    if not os.path.isfile(LIB_PATH):
+      raise AdvocHipError(
+          'libadvoc_hip.so not found at {} -- build it first '
+          '(python -c "import __graft_entry__ as g; g.build()" or make -C advoc_amd/csrc). '
+          'advoc_amd has no CPU fallback for the hot path.'.format(LIB_PATH))
+    try:
+      lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+      raise AdvocHipError('cannot load {}: {}'.format(LIB_PATH, e))
+    for name, (res, args) in PROTOTYPES.items():
+      try:
+        fn = getattr(lib, name)
+      except AttributeError:
+        raise AdvocHipError('{} does not export {} (stale build?)'.format(LIB_PATH, name))
+      fn.restype = res
+      fn.argtypes = args
+    if lib.advoc_abi_version() != 1:
+      raise AdvocHipError('ABI version mismatch: library reports {}'.format(lib.advoc_abi_version()))
+    _lib = lib
+  return _lib
+
+
+def check(rc, what=''):
+  if rc != 0:
+    msg = load().advoc_error_string(rc).decode()
+    raise AdvocHipError('{} failed: {} ({})'.format(what or 'libadvoc_hip call', msg, rc))
+
+
+def require_device(t, name='tensor'):
+  """Every tensor handed to the C ABI must be a contiguous float32 tensor in HBM."""
+  import torch
+  if not isinstance(t, torch.Tensor) or not t.is_cuda:
+    raise AdvocHipError('{} must be a torch tensor on a HIP device (no CPU path exists)'.format(name))
+  if not t.is_contiguous():
+    raise AdvocHipError('{} must be contiguous'.format(name))
+  return t
+
+
+def ptr(t):
+  return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def stream():
+  import torch
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device():
+  """The HIP device everything runs on; raises if there is none (no CPU fallback)."""
+  import torch
+  if not torch.cuda.is_available():
+    raise AdvocHipError('no HIP device visible: advoc_amd runs its hot path only on MI355X (gfx950)')
+  return torch.device('cuda', torch.cuda.current_device())

@@ -1,0 +1,246 @@
+// STFT-magnitude feature extractor for gfx950 (MI355X).
+//
+// Replaces tf.contrib.signal.stft (+ tf.abs) reached from the reference at
+// advoc/spectral.py:60-83 and advoc/loader.py:116-128: frame 1024 / hop 256, multiply by the
+// lws sqrt-Hann window, real FFT, |.|.
+//
+// Mapping to the hardware
+//   * one workgroup (4 wavefronts) = 16 consecutive frames of one clip.  The
+//     (16-1)*hop+1024 sample span is read from HBM once, coalesced, into LDS: the 75 %
+//     overlap between neighbouring frames is served from LDS, not re-fetched.
+//   * one wavefront = one frame at a time.  The 1024-point real FFT is a 512-point complex
+//     FFT (z[n] = x[2n] + i x[2n+1]) held 8 complex values per lane, computed as three
+//     radix-8 passes (512 = 8*8*8); the two inter-pass transposes go through a private,
+//     bank-conflict-free LDS plane per wave (no workgroup barrier inside the frame loop).
+//   * twiddles and the window live in registers for the life of the kernel (they depend only
+//     on the lane), evaluated once with sincospif.
+//   * the real-FFT split pairs Z[k] with Z[512-k] by one cross-lane permute per value, then
+//     each lane stores 8 magnitudes: 256 B contiguous per store instruction.
+// HBM-bound: algorithmic traffic is 256 new samples in + 513 floats out per frame.
+#include "common.h"
+
+namespace {
+
+using advoc::wave_lds_sync;
+
+constexpr int kNfft = 1024;
+constexpr int kBins = kNfft / 2 + 1;
+constexpr int kWaves = 4;
+constexpr int kFramesPerWave = 4;
+constexpr int kFramesPerBlock = kWaves * kFramesPerWave;
+constexpr int kPlane = 576;  // 64 rows x 9 floats (8 + 1 pad): conflict-free transposes
+
+// forward 8-point DFT in place: v[p] = sum_a v[a] * exp(-2*pi*i*a*p/8)
+__device__ __forceinline__ void dft8(float (&re)[8], float (&im)[8]) {
+  const float h = 0.70710678118654752440f;
+  // radix-2 DIF stage: sums feed even outputs, twiddled differences feed odd outputs
+  float sr[4], si[4], dr[4], di[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    sr[n] = re[n] + re[n + 4];
+    si[n] = im[n] + im[n + 4];
+    dr[n] = re[n] - re[n + 4];
+    di[n] = im[n] - im[n + 4];
+  }
+  // d[n] *= W8^n
+  {
+    float r1 = (dr[1] + di[1]) * h, i1 = (di[1] - dr[1]) * h;  // * (1 - i)/sqrt2
+    dr[1] = r1; di[1] = i1;
+    float r2 = di[2], i2 = -dr[2];                             // * (-i)
+    dr[2] = r2; di[2] = i2;
+    float r3 = (di[3] - dr[3]) * h, i3 = -(dr[3] + di[3]) * h; // * (-1 - i)/sqrt2
+    dr[3] = r3; di[3] = i3;
+  }
+  // 4-point DFT of s -> even bins, of d -> odd bins
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float* xr = half ? dr : sr;
+    float* xi = half ? di : si;
+    float b0r = xr[0] + xr[2], b0i = xi[0] + xi[2];
+    float b2r = xr[0] - xr[2], b2i = xi[0] - xi[2];
+    float b1r = xr[1] + xr[3], b1i = xi[1] + xi[3];
+    float b3r = xi[1] - xi[3], b3i = -(xr[1] - xr[3]);  // (x1 - x3) * (-i)
+    re[0 + half] = b0r + b1r; im[0 + half] = b0i + b1i;
+    re[4 + half] = b0r - b1r; im[4 + half] = b0i - b1i;
+    re[2 + half] = b2r + b3r; im[2 + half] = b2i + b3i;
+    re[6 + half] = b2r - b3r; im[6 + half] = b2i - b3i;
+  }
+}
+
+template <bool kComplexOut>
+__global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
+    const float* __restrict__ wav, int64_t nsamps, const float* __restrict__ window, int nhop,
+    int64_t nframes, float* __restrict__ out, int tiles_per_clip) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int span = (kFramesPerBlock - 1) * nhop + kNfft;
+  float* stage = smem;
+  const int span_pad = (span + 3) & ~3;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t clip = blockIdx.x / tiles_per_clip;
+  const int tile = blockIdx.x % tiles_per_clip;
+  const int64_t f0 = (int64_t)tile * kFramesPerBlock;
+
+  float* xr_plane = smem + span_pad + wave * (2 * kPlane);
+  float* xi_plane = xr_plane + kPlane;
+
+  // ---- stage the sample span (zero beyond the end of the clip: pad_end) ----
+  {
+    const float* src = wav + clip * nsamps;
+    const int64_t s0 = f0 * nhop;
+    for (int i = threadIdx.x; i < span; i += kWaves * 64) {
+      const int64_t s = s0 + i;
+      stage[i] = (s < nsamps) ? src[s] : 0.f;
+    }
+  }
+
+  // ---- per-lane constants ----
+  const int hi = lane >> 3, lo = lane & 7;
+  float w0[8], w1[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const float2 w = *reinterpret_cast<const float2*>(window + 128 * a + 2 * lane);
+    w0[a] = w.x;
+    w1[a] = w.y;
+  }
+  float t1r[8], t1i[8], t2r[8], t2i[8], tsn[8], tcs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    // pass-1 twiddle W64^(b*p): lane = (b=hi, c=lo), p = j
+    sincospif(-(float)(hi * j) * (1.f / 32.f), &t1i[j], &t1r[j]);
+    // pass-2 twiddle W512^(c*(p+8q)): lane = (p=hi, c=lo), q = j
+    sincospif(-(float)(lo * (hi + 8 * j)) * (1.f / 256.f), &t2i[j], &t2r[j]);
+    // split twiddle: theta = 2*pi*k/1024, k = lane + 64 j
+    sincospif((float)(lane + 64 * j) * (1.f / 512.f), &tsn[j], &tcs[j]);
+  }
+  const int partner = (64 - lane) & 63;
+
+  __syncthreads();
+
+  for (int fi = 0; fi < kFramesPerWave; ++fi) {
+    const int fl = wave * kFramesPerWave + fi;
+    const int64_t f = f0 + fl;
+    if (f >= nframes) break;  // wave-uniform
+
+    float re[8], im[8];
+    // z[n] = x[2n] w[2n] + i x[2n+1] w[2n+1], n = 64 a + lane
+    const float* fs = stage + fl * nhop;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const float2 v = *reinterpret_cast<const float2*>(fs + 128 * a + 2 * lane);
+      re[a] = v.x * w0[a];
+      im[a] = v.y * w1[a];
+    }
+
+    // pass 1: DFT over a -> p, twiddle, transpose (b,c | p) -> (p,c | b)
+    dft8(re, im);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const float r = re[p] * t1r[p] - im[p] * t1i[p];
+      const float i = re[p] * t1i[p] + im[p] * t1r[p];
+      const int addr = (8 * p + hi) * 9 + lo;
+      xr_plane[addr] = r;
+      xi_plane[addr] = i;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int addr = (8 * hi + b) * 9 + lo;
+      re[b] = xr_plane[addr];
+      im[b] = xi_plane[addr];
+    }
+    wave_lds_sync();
+
+    // pass 2: DFT over b -> q, twiddle, transpose (p,c | q) -> (q,p | c)
+    dft8(re, im);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float r = re[q] * t2r[q] - im[q] * t2i[q];
+      const float i = re[q] * t2i[q] + im[q] * t2r[q];
+      const int addr = (8 * q + hi) * 9 + lo;
+      xr_plane[addr] = r;
+      xi_plane[addr] = i;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int addr = lane * 9 + c;
+      re[c] = xr_plane[addr];
+      im[c] = xi_plane[addr];
+    }
+    wave_lds_sync();
+
+    // pass 3: DFT over c -> r.  Lane now holds Z[lane + 64 r].
+    dft8(re, im);
+
+    // real-FFT split: X[k] = ((Zk + conj(Zm)) - i W1024^k (Zk - conj(Zm))) / 2, m = 512 - k
+    float* orow = out + ((clip * nframes + f) * kBins) * (kComplexOut ? 2 : 1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float c = __shfl(re[7 - r], partner, 64);
+      float d = __shfl(im[7 - r], partner, 64);
+      if (lane == 0) {  // k = 64 r pairs with 512 - 64 r = 64 (8 - r) on the same lane
+        c = re[(8 - r) & 7];
+        d = im[(8 - r) & 7];
+      }
+      const float a = re[r], b = im[r];
+      const float sr = a + c, si = b - d, dr = a - c, di = b + d;
+      const float xr = 0.5f * (sr - (tsn[r] * dr - tcs[r] * di));
+      const float xi = 0.5f * (si - (tsn[r] * di + tcs[r] * dr));
+      const int k = lane + 64 * r;
+      if (kComplexOut) {
+        *reinterpret_cast<float2*>(orow + 2 * k) = make_float2(xr, xi);
+      } else {
+        orow[k] = sqrtf(xr * xr + xi * xi);
+      }
+    }
+    if (lane == 0) {  // Nyquist bin: X[512] = Re Z0 - Im Z0
+      const float xn = re[0] - im[0];
+      if (kComplexOut) {
+        *reinterpret_cast<float2*>(orow + 2 * (kBins - 1)) = make_float2(xn, 0.f);
+      } else {
+        orow[kBins - 1] = fabsf(xn);
+      }
+    }
+  }
+}
+
+int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* window, int32_t nfft,
+                int32_t nhop, int64_t nframes, float* out, bool complex_out, hipStream_t stream) {
+  if (!wav || !window || !out) return ADVOC_ERR_NULL;
+  if (batch < 0 || nsamps < 0 || nframes < 0 || nhop <= 0) return ADVOC_ERR_BAD_SHAPE;
+  if (nfft != kNfft || (nhop & 1) || nhop > 4096) return ADVOC_ERR_UNSUPPORTED;
+  if (batch == 0 || nframes == 0) return ADVOC_OK;
+  const int tiles = (int)advoc::ceil_div(nframes, kFramesPerBlock);
+  const int64_t blocks = batch * tiles;
+  if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  const int span = (kFramesPerBlock - 1) * nhop + kNfft;
+  const size_t lds = sizeof(float) * (((span + 3) & ~3) + kWaves * 2 * kPlane);
+  if (lds > 160 * 1024) return ADVOC_ERR_UNSUPPORTED;
+  if (complex_out) {
+    hipLaunchKernelGGL(stft1024_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream,
+                       wav, nsamps, window, nhop, nframes, out, tiles);
+  } else {
+    hipLaunchKernelGGL(stft1024_kernel<false>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream,
+                       wav, nsamps, window, nhop, nframes, out, tiles);
+  }
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+}  // namespace
+
+extern "C" int advoc_stft_mag_f32(const float* wav, int64_t batch, int64_t nsamps,
+                                  const float* window, int32_t nfft, int32_t nhop, int64_t nframes,
+                                  float* mag, advoc_stream_t stream) {
+  return launch_stft(wav, batch, nsamps, window, nfft, nhop, nframes, mag, false,
+                     advoc::as_stream(stream));
+}
+
+extern "C" int advoc_stft_c64(const float* wav, int64_t batch, int64_t nsamps, const float* window,
+                              int32_t nfft, int32_t nhop, int64_t nframes, float* out,
+                              advoc_stream_t stream) {
+  return launch_stft(wav, batch, nsamps, window, nfft, nhop, nframes, out, true,
+                     advoc::as_stream(stream));
+}

@@ -1,0 +1,384 @@
+"""STFT / mel feature extractor on MI355X -- drop-in for the reference's ``advoc.spectral``.
+
+Same function names, argument names, defaults, shape conventions and error
+behaviour as /root/reference/advoc/spectral.py; the arithmetic runs in the HIP
+kernels of libadvoc_hip.so (csrc/stft.hip, csrc/features.hip).
+
+Two calling conventions, as in the reference:
+  * "numpy" API (``stft``, ``waveform_to_melspec`` ...): ``[n, 1, 1] float32``
+    numpy in, ``[T, F, 1]`` complex128 / float64 numpy out.  The reference runs
+    these through lws in float64 on the host (spectral.py:11-41); here they are
+    computed by the same float32 HIP kernels and widened on return
+    (|rel err| ~1e-7 versus the float64 path, far inside the 1e-4 parity bar).
+  * tensor API (``stft_tf``, ``waveform_to_melspec_tf`` ...): ``[b, n, 1, ch]``
+    float32 in, ``[b, T, F, ch]`` out.  The reference returns lazy TF tensors;
+    these return eager ``torch.Tensor``s resident in HBM (numpy input is
+    uploaded first).
+
+The mel filterbank and its pseudo-inverse are float64 host constants computed
+once (reference: librosa.filters.mel + np.linalg.pinv, spectral.py:86-94).
+
+Phase reconstruction (Griffin-Lim / LWS, spectral.py:294-326) is the step AFTER
+this path and is not implemented yet.
+"""
+from functools import lru_cache
+
+import numpy as np
+import torch
+
+from advoc_amd import _lib
+
+# ---------------------------------------------------------------------------------------------
+# constants built on the host once
+# ---------------------------------------------------------------------------------------------
+
+
+@lru_cache(maxsize=8)
+def _lws_window_f64(nfft, nhop):
+  # lws.hann(nfft, symmetric=True, use_offset=False): half-sample-offset Hann;
+  # analysis window sqrt(hann * 2 * hop / nfft)   (reference spectral.py:55-56)
+  phase = (np.arange(nfft, dtype=np.float64) + 0.5) * (2.0 * np.pi / nfft)
+  return np.sqrt((0.5 - 0.5 * np.cos(phase)) * 2 * nhop / nfft)
+
+
+def lws_hann_default(nfft, nhop, dtype=torch.float32):
+  """Default LWS sqrt-Hann analysis window, shape [nfft] (reference spectral.py:44-57)."""
+  return torch.from_numpy(_lws_window_f64(int(nfft), int(nhop)).copy()).to(dtype)
+
+
+_dev_cache = {}
+
+
+def _device_const(key, make):
+  dev = _lib.device()
+  k = (key, dev.index)
+  t = _dev_cache.get(k)
+  if t is None:
+    t = make().to(dev).contiguous()
+    _dev_cache[k] = t
+  return t
+
+
+def _device_window(nfft, nhop):
+  return _device_const(('win', nfft, nhop), lambda: lws_hann_default(nfft, nhop, torch.float32))
+
+
+def _slaney_hz_to_mel(hz):
+  hz = np.atleast_1d(np.asarray(hz, dtype=np.float64))
+  lin = hz * (3.0 / 200.0)
+  log = 15.0 + np.log(np.maximum(hz, 1e-300) / 1000.0) * (27.0 / np.log(6.4))
+  return np.where(hz >= 1000.0, log, lin)
+
+
+def _slaney_mel_to_hz(mel):
+  mel = np.atleast_1d(np.asarray(mel, dtype=np.float64))
+  lin = mel * (200.0 / 3.0)
+  log = 1000.0 * np.exp((np.log(6.4) / 27.0) * (mel - 15.0))
+  return np.where(mel >= 15.0, log, lin)
+
+
+@lru_cache(maxsize=4)
+def create_mel_filterbank(*args, **kwargs):
+  """Slaney-scale, area-normalised triangular mel filterbank, float64 [n_mels, 1+n_fft/2].
+
+  Call as the reference does: ``create_mel_filterbank(fs, nfft, fmin=, fmax=, n_mels=)``
+  (spectral.py:86-88 -> librosa 0.6.3 ``filters.mel(sr, n_fft, n_mels=128, fmin=0.0,
+  fmax=None, htk=False, norm=1)``).
+  """
+  def _sig(sr, n_fft, n_mels=128, fmin=0.0, fmax=None):
+    return sr, n_fft, n_mels, fmin, fmax
+  sr, n_fft, n_mels, fmin, fmax = _sig(*args, **kwargs)
+  if fmax is None:
+    fmax = float(sr) / 2
+  n_mels = int(n_mels)
+  nbins = 1 + int(n_fft) // 2
+  bin_hz = np.linspace(0, float(sr) / 2, nbins, endpoint=True)
+  lo, hi = _slaney_hz_to_mel(fmin)[0], _slaney_hz_to_mel(fmax)[0]
+  edges = _slaney_mel_to_hz(np.linspace(lo, hi, n_mels + 2))           # band edges in Hz
+  width = np.diff(edges)
+  dist = edges[:, None] - bin_hz[None, :]                              # [n_mels+2, nbins]
+  rising = -dist[:n_mels] / width[:n_mels, None]
+  falling = dist[2:] / width[1:, None]
+  tri = np.maximum(0, np.minimum(rising, falling))
+  tri *= (2.0 / (edges[2:] - edges[:n_mels]))[:, None]
+  return tri
+
+
+@lru_cache(maxsize=4)
+def create_inverse_mel_filterbank(*args, **kwargs):
+  """np.linalg.pinv of the mel filterbank, float64 [1+n_fft/2, n_mels] (spectral.py:91-94)."""
+  return np.linalg.pinv(create_mel_filterbank(*args, **kwargs))
+
+
+def mel_bin_map(W):
+  """(first, last) non-zero FFT bin of every mel band, int32 [n_mels, 2]."""
+  nz = np.asarray(W) > 0
+  first = nz.argmax(axis=1)
+  last = nz.shape[1] - 1 - nz[:, ::-1].argmax(axis=1)
+  return np.stack([first, last], axis=1).astype(np.int32)
+
+
+# ---------------------------------------------------------------------------------------------
+# device kernels
+# ---------------------------------------------------------------------------------------------
+def _frames_pad_end(nsamps, nhop):
+  return -(-nsamps // nhop)
+
+
+def _frames_tf_nopad(nsamps, nfft, nhop):
+  return max(0, 1 + (nsamps - nfft) // nhop)
+
+
+def _frames_lws(nsamps, nfft, nhop):
+  if nsamps <= 0:
+    return 0
+  return max(1, -(-(nsamps - nfft) // nhop) + 1)
+
+
+def _to_device_f32(x):
+  if isinstance(x, np.ndarray):
+    x = torch.from_numpy(np.ascontiguousarray(x))
+  if not isinstance(x, torch.Tensor):
+    raise ValueError('expected a numpy array or torch tensor')
+  return x.to(_lib.device())
+
+
+def _run_stft(wav2d, nfft, nhop, nframes, complex_out):
+  """wav2d: [clips, n] float32 contiguous on device -> [clips, T, F] (mag) or [clips,T,F,2]."""
+  clips, n = wav2d.shape
+  nbins = nfft // 2 + 1
+  shape = (clips, nframes, nbins, 2) if complex_out else (clips, nframes, nbins)
+  out = torch.empty(shape, dtype=torch.float32, device=wav2d.device)
+  fn = _lib.load().advoc_stft_c64 if complex_out else _lib.load().advoc_stft_mag_f32
+  win = _device_window(nfft, nhop)
+  _lib.check(fn(_lib.ptr(wav2d), clips, n, _lib.ptr(win), nfft, nhop, nframes, _lib.ptr(out),
+                _lib.stream()), 'advoc_stft')
+  return out
+
+
+def _clips_first(x):
+  """[b, n, 1, ch] -> contiguous [b*ch, n]."""
+  b, n, _, ch = x.shape
+  if ch == 1:
+    return x.reshape(b, n).contiguous()
+  return x[:, :, 0, :].permute(0, 2, 1).reshape(b * ch, n).contiguous()
+
+
+def _channels_last(y, b, ch):
+  """[b*ch, T, F(, 2)] -> [b, T, F, ch(, 2)]."""
+  if ch == 1:
+    return y.unsqueeze(3)
+  y = y.reshape((b, ch) + tuple(y.shape[1:]))
+  return y.movedim(1, 3).contiguous()
+
+
+def stft_magnitude(x, nfft, nhop, pad_end=True):
+  """|STFT| straight from the fused HIP kernel: [b,n,1,ch] f32 -> [b,T,F,ch] f32.
+
+  This is what the loader's magspec branch (reference loader.py:116-128:
+  ``tf.abs(stft_tf(...))``) runs; the complex spectrum is never materialised.
+  """
+  x = _to_device_f32(x)
+  b, n, nfeats, ch = x.shape
+  if nfeats != 1:
+    raise ValueError()
+  if x.dtype != torch.float32:
+    raise ValueError()
+  T = _frames_pad_end(n, nhop) if pad_end else _frames_tf_nopad(n, nfft, nhop)
+  mag = _run_stft(_clips_first(x), nfft, nhop, T, complex_out=False)
+  return _channels_last(mag, b, ch)
+
+
+def stft_tf(x, nfft, nhop, pad_end=True):
+  """Short-time Fourier transform of a waveform batch (reference spectral.py:60-83).
+
+  Args:
+    x: float32 [b, nsamps, 1, nch] (torch tensor, or numpy which is uploaded).
+  Returns:
+    complex64 torch tensor [b, ntsteps, nfft // 2 + 1, nch] in HBM.
+  """
+  x = _to_device_f32(x)
+  b, n, nfeats, ch = x.shape
+  if nfeats != 1:
+    raise ValueError()
+  if x.dtype != torch.float32:
+    raise ValueError()
+  T = _frames_pad_end(n, nhop) if pad_end else _frames_tf_nopad(n, nfft, nhop)
+  X = _run_stft(_clips_first(x), nfft, nhop, T, complex_out=True)
+  X = torch.view_as_complex(X)
+  return _channels_last(X, b, ch)
+
+
+def stft(x, nfft, nhop, pad_end=True):
+  """STFT of one mono waveform, numpy API (reference spectral.py:11-41).
+
+  Args:
+    x: nd-array float32 [nsamps, 1, 1].
+  Returns:
+    nd-array complex128 [ntsteps, nfft // 2 + 1, 1].
+  """
+  nsamps, nfeats, nch = x.shape
+  if nfeats != 1:
+    raise ValueError()
+  if nch != 1:
+    raise NotImplementedError('Can only take STFT of monaural signals')
+  if pad_end:
+    T = int(np.ceil(float(nsamps) / nhop) + 1e-6)
+  else:
+    T = _frames_lws(nsamps, nfft, nhop)   # lws zero-pads the last partial frame
+  wav = _to_device_f32(np.asarray(x[:, 0, 0], dtype=np.float32)).reshape(1, nsamps)
+  X = torch.view_as_complex(_run_stft(wav, nfft, nhop, T, complex_out=True))[0]
+  return X.cpu().numpy().astype(np.complex128)[:, :, np.newaxis]
+
+
+def matmul_last(x, w_dev):
+  """x [..., K] (device f32) times w_dev[N, K]^T -> [..., N] through advoc_matmul_nt_f32."""
+  K = x.shape[-1]
+  N = w_dev.shape[0]
+  x2 = x.reshape(-1, K).contiguous()
+  out = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
+  _lib.check(_lib.load().advoc_matmul_nt_f32(_lib.ptr(x2), _lib.ptr(w_dev), _lib.ptr(out),
+                                             x2.shape[0], K, N, _lib.stream()),
+             'advoc_matmul_nt_f32')
+  return out.reshape(tuple(x.shape[:-1]) + (N,))
+
+
+def _device_melbank(fs, nfft, mel_min, mel_max, mel_num_bins):
+  key = ('mel', fs, nfft, mel_min, mel_max, mel_num_bins)
+  return _device_const(key, lambda: torch.from_numpy(create_mel_filterbank(
+      fs, nfft, fmin=mel_min, fmax=mel_max, n_mels=mel_num_bins).astype(np.float32)))
+
+
+def waveform_to_melspec_tf(
+    x,
+    fs,
+    nfft,
+    nhop,
+    mel_min=125,
+    mel_max=7600,
+    mel_num_bins=80,
+    norm_allow_clipping=True,
+    norm_min_level_db=-100,
+    norm_ref_level_db=20):
+  """Waveform batch -> dB-normalised mel spectrogram (reference spectral.py:158-227).
+
+  Args:
+    x: float32 [b, nsamps, 1, nch].
+  Returns:
+    float32 torch tensor [b, ntsteps, mel_num_bins, nch] in HBM, values in [0, 1].
+  """
+  x = _to_device_f32(x)
+  b, n, one, ch = x.shape
+  if one != 1:
+    raise ValueError()
+  if x.dtype != torch.float32:
+    raise ValueError()
+  if not norm_allow_clipping:
+    raise NotImplementedError()
+  T = _frames_pad_end(n, nhop)
+  mag = _run_stft(_clips_first(x), nfft, nhop, T, complex_out=False)       # [b*ch, T, F]
+  mel = matmul_last(mag, _device_melbank(fs, nfft, mel_min, mel_max, mel_num_bins))
+  min_level = float(np.float32(np.exp(norm_min_level_db / 20 * np.log(10))))
+  _lib.check(_lib.load().advoc_mel_dbnorm_f32(_lib.ptr(mel), mel.numel(), min_level,
+                                              float(norm_ref_level_db), float(norm_min_level_db),
+                                              _lib.stream()), 'advoc_mel_dbnorm_f32')
+  return _channels_last(mel, b, ch)
+
+
+def waveform_to_melspec(
+    x,
+    fs,
+    nfft,
+    nhop,
+    mel_min=125,
+    mel_max=7600,
+    mel_num_bins=80,
+    norm_allow_clipping=True,
+    norm_min_level_db=-100,
+    norm_ref_level_db=20):
+  """One mono waveform -> mel spectrogram, numpy API (reference spectral.py:98-154).
+
+  Args:
+    x: nd-array float32 [nsamps, 1, 1].
+  Returns:
+    nd-array float64 [ntsteps, mel_num_bins, 1].
+  """
+  if x.dtype != np.float32:
+    raise ValueError()
+  nsamps, nfeats, nch = x.shape
+  if nfeats != 1:
+    raise ValueError()
+  if nch != 1:
+    raise NotImplementedError('Can only extract features from monaural signals')
+  y = waveform_to_melspec_tf(x[np.newaxis], fs, nfft, nhop, mel_min=mel_min, mel_max=mel_max,
+                             mel_num_bins=mel_num_bins, norm_allow_clipping=True,
+                             norm_min_level_db=norm_min_level_db,
+                             norm_ref_level_db=norm_ref_level_db)
+  y = y[0].cpu().numpy().astype(np.float64)
+  if not norm_allow_clipping:
+    assert y.max() < 1 and y.min() > 0
+  return y
+
+
+def waveform_to_tacotron2_melspec(x):
+  """Tacotron-2 style features: 24 kHz, nfft 1200, hop 300, -40 dB floor (spectral.py:230-247)."""
+  return waveform_to_melspec(x, fs=24000, nfft=1200, nhop=300, norm_min_level_db=-40)
+
+
+def waveform_to_r9y9_melspec(x, fs=22050):
+  """r9y9/wavenet_vocoder features: nfft 1024, hop 256 (spectral.py:250-269)."""
+  return waveform_to_melspec(x, fs=fs, nfft=1024, nhop=256)
+
+
+def waveform_to_r9y9_melspec_tf(x, fs=22050):
+  """Batched r9y9 features (spectral.py:272-291)."""
+  return waveform_to_melspec_tf(x, fs=fs, nfft=1024, nhop=256)
+
+
+# ---------------------------------------------------------------------------------------------
+# inversion -- the step after this path, not built yet
+# ---------------------------------------------------------------------------------------------
+def _not_yet(name):
+  raise NotImplementedError(
+      name + ': phase reconstruction (lws / Griffin-Lim + iSTFT) follows the MI355X hot path '
+      'and is not implemented yet (SURVEY.md §8f-1)')
+
+
+def magspec_to_waveform_griffin_lim(X_mag, nfft, nhop, ngl=60):
+  nsamps, nbins, nch = X_mag.shape
+  if nch != 1:
+    raise NotImplementedError('Can only invert monaural signals')
+  _not_yet('magspec_to_waveform_griffin_lim')
+
+
+def magspec_to_waveform_lws(X_mag, nfft, nhop):
+  nsamps, nbins, nch = X_mag.shape
+  if nch != 1:
+    raise NotImplementedError('Can only invert monaural signals')
+  _not_yet('magspec_to_waveform_lws')
+
+
+def melspec_to_waveform(
+    X_mel_dbnorm,
+    fs,
+    nfft,
+    nhop,
+    mel_min=125,
+    mel_max=7600,
+    norm_min_level_db=-100,
+    norm_ref_level_db=20,
+    phase_estimation='lws',
+    waveform_len=None):
+  if X_mel_dbnorm.dtype != np.float64:
+    raise ValueError()
+  nsamps, mel_num_bins, nch = X_mel_dbnorm.shape
+  if nch != 1:
+    raise NotImplementedError('Can only invert monaural signals')
+  if phase_estimation != 'lws' and phase_estimation[:2] != 'gl':
+    raise ValueError()
+  _not_yet('melspec_to_waveform')
+
+
+def r9y9_melspec_to_waveform(X_mel_dbnorm, fs=22050, phase_estimation='lws', waveform_len=None):
+  return melspec_to_waveform(X_mel_dbnorm, fs=fs, nfft=1024, nhop=256,
+                             phase_estimation=phase_estimation, waveform_len=waveform_len)

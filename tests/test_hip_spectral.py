@@ -1,0 +1,213 @@
+"""HIP feature extractor (through the C ABI) vs the CPU oracle and the reference's
+known-answer constants.  Tolerance: north_star's 1e-4 relative L2 on magnitude
+spectrograms (achieved: ~1e-7); mel bin map bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spectral_np as O
+
+pytestmark = pytest.mark.gpu
+
+REL_L2 = 1e-4   # north_star bar
+TIGHT = 2e-6    # what fp32 butterflies actually deliver
+
+
+def rel_l2(a, b):
+  a = np.asarray(a, np.float64)
+  b = np.asarray(b, np.float64)
+  return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope='module')
+def S(hip):
+  from advoc_amd import spectral
+  return spectral
+
+
+@pytest.fixture(scope='module')
+def sc09(golden_dir):
+  from advoc_amd.audioio import decode_audio
+  return decode_audio(os.path.join(golden_dir, 'sc09.wav'), fastwav=True)[1]
+
+
+def test_reference_known_answers_numpy_api(S, sc09, golden_dir):
+  """reference tests/test_spectral.py:27-46 executed against the HIP path."""
+  X = S.stft(sc09, 1024, 256, pad_end=True)
+  assert X.dtype == np.complex128 and X.shape == (63, 513, 1)
+  assert S.stft(sc09, 1024, 256, pad_end=False).shape == (60, 513, 1)
+  x = np.pad(sc09, [[0, 384], [0, 0], [0, 0]], 'constant')
+  X = S.stft(x, 1024, 256, pad_end=True)
+  assert X.shape == (64, 513, 1)
+  mag = np.abs(X)
+  assert mag.dtype == np.float64
+  assert round(abs(mag.sum() - 2148.69), 2) == 0
+  assert round(abs(mag[33].sum() - 55.45), 2) == 0
+  assert round(abs(mag[40].sum() - 20.35), 2) == 0
+  ref = O.stft(x, 1024, 256, pad_end=True)
+  assert rel_l2(X.real, ref.real) < TIGHT and rel_l2(X.imag, ref.imag) < TIGHT
+  assert rel_l2(S.stft(sc09, 1024, 256, pad_end=False), O.stft(sc09, 1024, 256, pad_end=False)) < TIGHT
+
+
+def test_reference_known_answers_tensor_api(S, sc09):
+  """reference tests/test_spectral.py:49-76 (row 1 of the batch; row 0 needs librosa resampling)."""
+  x = np.pad(sc09[np.newaxis], [[0, 0], [0, 384], [0, 0], [0, 0]], 'constant')
+  rng = np.random.default_rng(3)
+  other = rng.uniform(-0.3, 0.3, size=x.shape).astype(np.float32)
+  xb = np.concatenate([other, x], axis=0)
+  X = S.stft_tf(xb, 1024, 256, pad_end=True)
+  assert X.dtype == torch.complex64 and tuple(X.shape) == (2, 64, 513, 1) and X.is_cuda
+  mag = X.abs().cpu().numpy()
+  assert mag.dtype == np.float32
+  assert round(abs(float(mag[1].sum(dtype=np.float64)) - 2148.69), 2) == 0
+  assert round(abs(float(mag[1, 33].sum(dtype=np.float64)) - 55.45), 2) == 0
+  assert round(abs(float(mag[1, 40].sum(dtype=np.float64)) - 20.35), 2) == 0
+  assert tuple(S.stft_tf(sc09[np.newaxis], 1024, 256).shape) == (1, 63, 513, 1)
+  assert tuple(S.stft_tf(sc09[np.newaxis], 1024, 256, pad_end=False).shape) == (1, 59, 513, 1)
+  Xo = O.stft_tf(xb, 1024, 256)
+  Xh = X.cpu().numpy()
+  assert rel_l2(Xh.real, Xo.real) < TIGHT and rel_l2(Xh.imag, Xo.imag) < TIGHT
+
+
+@pytest.mark.parametrize('n,hop', [(66304, 256), (16000, 256), (1024, 256), (1025, 256), (700, 256),
+                                   (1, 256), (5000, 128), (4096, 512), (3000, 300)])
+def test_magnitude_vs_oracle_ragged(S, n, hop):
+  rng = np.random.default_rng(n)
+  t = np.arange(n) / 22050.
+  x = rng.uniform(-0.5, 0.5, size=(3, n)).astype(np.float32)
+  x += (0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3000 * t))[None, :].astype(np.float32)
+  x = x[:, :, None, None]
+  for pad_end in (True, False):
+    got = S.stft_magnitude(x, 1024, hop, pad_end=pad_end)
+    want = np.abs(O.stft_tf(x, 1024, hop, pad_end=pad_end))
+    assert tuple(got.shape) == want.shape
+    if want.size:
+      exact = O.stft_mag_f64(x, 1024, hop, pad_end=pad_end)
+      g = got.cpu().numpy()
+      assert rel_l2(g, exact) < TIGHT, (n, hop, pad_end)
+      assert rel_l2(g, want) < REL_L2
+      assert np.abs(g - exact).max() < 1e-4 * max(1.0, exact.max())
+
+
+def test_multichannel_layout(S):
+  rng = np.random.default_rng(7)
+  x = rng.uniform(-1, 1, size=(2, 5000, 1, 3)).astype(np.float32)
+  got = S.stft_magnitude(x, 1024, 256).cpu().numpy()
+  want = O.stft_mag_f64(x, 1024, 256)
+  assert got.shape == (2, 20, 513, 3)
+  assert rel_l2(got, want) < TIGHT
+  Xc = S.stft_tf(x, 1024, 256)
+  assert tuple(Xc.shape) == (2, 20, 513, 3)
+  assert rel_l2(Xc.abs().cpu().numpy(), want) < TIGHT
+
+
+def test_linearity_and_shift_properties_full_size(S):
+  """Size-independent properties at the BASELINE clip size (32 x 66304 samples)."""
+  g = torch.Generator().manual_seed(1234)
+  a = (torch.rand(32, 66304, 1, 1, generator=g) - 0.5)
+  b = (torch.rand(32, 66304, 1, 1, generator=g) - 0.5)
+  Xa = S.stft_tf(a, 1024, 256)
+  Xb = S.stft_tf(b, 1024, 256)
+  Xs = S.stft_tf(2 * a - 3 * b, 1024, 256)
+  lin = (2 * Xa - 3 * Xb)
+  assert tuple(Xa.shape) == (32, 259, 513, 1)
+  assert float((Xs - lin).abs().max()) < 2e-4 * float(lin.abs().max())
+  # Parseval with the tight sqrt-Hann frame: interior frames hold the signal energy
+  mag = S.stft_magnitude(a, 1024, 256)
+  assert torch.allclose(mag, Xa.abs(), rtol=1e-5, atol=1e-6)
+  # shifting the waveform by one hop shifts the frames by one
+  sh = torch.cat([a[:, 256:], torch.zeros(32, 256, 1, 1)], dim=1)
+  ms = S.stft_magnitude(sh, 1024, 256)
+  assert torch.allclose(ms[:, :-1], mag[:, 1:], rtol=0, atol=0)        # bit-identical
+  # DC and Nyquist bins of a real signal are real: imag == 0
+  assert float(Xa[..., 0, :].imag.abs().max()) == 0.0 and float(Xa[..., 512, :].imag.abs().max()) == 0.0
+
+
+def test_impulse_and_tone_closed_form(S):
+  w = O.lws_hann_default(1024, 256, np.float64)
+  x = np.zeros((1, 4096, 1, 1), np.float32)
+  x[0, 1500] = 1.0
+  got = S.stft_magnitude(x, 1024, 256).cpu().numpy()[0, :, :, 0]
+  for t in range(got.shape[0]):
+    k = 1500 - 256 * t
+    want = w[k] if 0 <= k < 1024 else 0.0
+    np.testing.assert_allclose(got[t], np.full(513, want), atol=2e-6)
+  # bin-centred tone: energy at bin 64
+  n = np.arange(8192)
+  x = np.cos(2 * np.pi * 64 * n / 1024).astype(np.float32)[None, :, None, None]
+  got = S.stft_magnitude(x, 1024, 256, pad_end=False).cpu().numpy()[0, :, :, 0]
+  assert (got.argmax(axis=1) == 64).all()
+  np.testing.assert_allclose(got[:, 64], w.sum() / 2, rtol=1e-5)
+
+
+def test_mel_bin_map_bit_exact_and_filterbank(S):
+  for fs in (22050, 16000):
+    Wp = S.create_mel_filterbank(fs, 1024, fmin=125, fmax=7600, n_mels=80)
+    Wo = O.create_mel_filterbank(fs, 1024, fmin=125, fmax=7600, n_mels=80)
+    assert np.array_equal(S.mel_bin_map(Wp), O.mel_bin_map(Wo))
+    assert np.array_equal(Wp > 0, Wo > 0)
+    np.testing.assert_allclose(Wp, Wo, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(S.create_inverse_mel_filterbank(fs, 1024, fmin=125, fmax=7600, n_mels=80),
+                               O.create_inverse_mel_filterbank(fs, 1024, fmin=125, fmax=7600, n_mels=80),
+                               rtol=1e-9, atol=1e-12)
+
+
+def test_melspec_vs_oracle_and_fixture(S, golden_dir):
+  from scipy.signal import resample_poly
+  from advoc_amd.audioio import decode_audio
+  _, m = decode_audio(os.path.join(golden_dir, 'mono.wav'), fastwav=True)
+  m22 = resample_poly(m[:, 0, 0].astype(np.float64), 1, 2).astype(np.float32)[:, None, None]
+  mel = S.waveform_to_r9y9_melspec(m22)
+  assert mel.dtype == np.float64 and mel.shape == (322, 80, 1)
+  want = O.waveform_to_r9y9_melspec(m22)
+  assert np.abs(mel - want).max() < 2e-5
+  ref = np.swapaxes(np.load(os.path.join(golden_dir, 'mono_22k_r9y9.npy')), 0, 1)[3:, :, np.newaxis]
+  assert np.abs(mel - ref).mean() < 1e-4
+  np.random.seed(0)
+  noise = np.random.uniform(-1, 1, size=(1, 82432, 1, 1)).astype(np.float32)
+  xb = np.concatenate([noise, m22[np.newaxis]], axis=3)
+  xb = np.concatenate([np.random.uniform(-1, 1, size=xb.shape).astype(np.float32), xb], axis=0)
+  got = S.waveform_to_r9y9_melspec_tf(xb)
+  assert got.dtype == torch.float32 and tuple(got.shape) == (2, 322, 80, 2)
+  wo = O.waveform_to_r9y9_melspec_tf(xb)
+  assert np.abs(got.cpu().numpy() - wo).max() < 2e-5
+  assert got.min() >= 0 and got.max() <= 1
+
+
+def test_matmul_nt_projection(S):
+  from advoc_amd import _lib
+  rng = np.random.default_rng(5)
+  W = O.create_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80).astype(np.float32)
+  Wi = O.create_inverse_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80).astype(np.float32)
+  mag = np.abs(rng.standard_normal((3, 256, 513, 1))).astype(np.float32)
+  dev = _lib.device()
+  mel = S.matmul_last(torch.from_numpy(mag[..., 0]).to(dev), torch.from_numpy(W).to(dev))
+  want = O.mag_to_mel_linear_spec(mag, W)[..., 0]
+  assert rel_l2(mel.cpu().numpy(), want) < 1e-6
+  inv = S.matmul_last(mel, torch.from_numpy(Wi).to(dev))
+  want2 = O.mel_linear_to_mag_spec(want[..., None], Wi)[..., 0]
+  assert tuple(inv.shape) == (3, 256, 513) and rel_l2(inv.cpu().numpy(), want2) < 1e-5
+  # ragged shapes
+  for rows, K, N in [(1, 1, 1), (65, 17, 3), (130, 80, 513), (7, 513, 80)]:
+    a = rng.standard_normal((rows, K)).astype(np.float32)
+    b = rng.standard_normal((N, K)).astype(np.float32)
+    got = S.matmul_last(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
+    assert rel_l2(got, a.astype(np.float64) @ b.T.astype(np.float64)) < 1e-6
+
+
+def test_error_behaviour(S):
+  with pytest.raises(ValueError):
+    S.stft(np.zeros((10, 2, 1), np.float32), 1024, 256)
+  with pytest.raises(NotImplementedError):
+    S.stft(np.zeros((10, 1, 2), np.float32), 1024, 256)
+  with pytest.raises(ValueError):
+    S.stft_tf(np.zeros((1, 10, 2, 1), np.float32), 1024, 256)
+  with pytest.raises(ValueError):
+    S.waveform_to_melspec(np.zeros((10, 1, 1), np.float64), 22050, 1024, 256)
+  with pytest.raises(NotImplementedError):
+    S.waveform_to_melspec_tf(np.zeros((1, 2048, 1, 1), np.float32), 22050, 1024, 256,
+                             norm_allow_clipping=False)
+  assert tuple(S.stft_tf(np.zeros((2, 0, 1, 1), np.float32), 1024, 256).shape) == (2, 0, 513, 1)
