@@ -46,6 +46,7 @@ PROTOTYPES = {
     'advoc_abi_version': (ctypes.c_int, []),
     'advoc_error_string': (ctypes.c_char_p, [ctypes.c_int]),
     'advoc_target_arch': (ctypes.c_char_p, []),
+    'advoc_last_hip_error': (ctypes.c_char_p, []),
     'advoc_stft_mag_f32': (ctypes.c_int, [_p, _i64, _i64, _p, _i32, _i32, _i64, _p, _p]),
     'advoc_stft_c64': (ctypes.c_int, [_p, _i64, _i64, _p, _i32, _i32, _i64, _p, _p]),
     'advoc_matmul_nt_f32': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
@@ -69,6 +70,11 @@ def load():
           'libadvoc_hip.so not found at {} -- build it first '
           '(python -c "import __graft_entry__ as g; g.build()" or make -C advoc_amd/csrc). '
           'advoc_amd has no CPU fallback for the hot path.'.format(LIB_PATH))
+    # torch ships its own libamdhip64.so.7; import it FIRST so the process holds exactly one
+    # HIP runtime (the one that owns torch's device memory and streams) and our library's
+    # NEEDED libamdhip64.so.7 binds to it.  Loading /opt/rocm's copy first leaves two
+    # runtimes in the process and ours reports hipErrorNoDevice.
+    import torch  # noqa: F401
     try:
       lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
@@ -89,6 +95,8 @@ def load():
 def check(rc, what=''):
   if rc != 0:
     msg = load().advoc_error_string(rc).decode()
+    if rc == -3:
+      msg += ': ' + load().advoc_last_hip_error().decode()
     raise AdvocHipError('{} failed: {} ({})'.format(what or 'libadvoc_hip call', msg, rc))
 
 

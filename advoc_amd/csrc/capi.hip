@@ -1,6 +1,15 @@
 // Library-level entry points of libadvoc_hip.so (version / error strings).
 #include "common.h"
 
+namespace advoc {
+static thread_local hipError_t g_last_hip_error = hipSuccess;
+void note_hip_error(hipError_t e) { g_last_hip_error = e; }
+}  // namespace advoc
+
+extern "C" const char* advoc_last_hip_error(void) {
+  return hipGetErrorString(advoc::g_last_hip_error);
+}
+
 extern "C" int advoc_abi_version(void) { return ADVOC_ABI_VERSION; }
 
 extern "C" const char* advoc_target_arch(void) { return "gfx950"; }

@@ -5,12 +5,23 @@
 
 #include "advoc_hip.h"
 
-#define ADVOC_RETURN_IF_LAUNCH_FAILED()                \
-  do {                                                 \
-    if (hipGetLastError() != hipSuccess) return ADVOC_ERR_HIP; \
+// hipGetLastError() is sticky per host thread and the host framework leaves benign codes
+// there (e.g. hipErrorNotReady from event queries), so clear it right before each launch and
+// read it right after: only OUR launch's status is reported.
+#define ADVOC_CLEAR_LAUNCH_ERROR() (void)hipGetLastError()
+#define ADVOC_RETURN_IF_LAUNCH_FAILED()                 \
+  do {                                                  \
+    const hipError_t advoc_e_ = hipGetLastError();      \
+    if (advoc_e_ != hipSuccess) {                       \
+      advoc::note_hip_error(advoc_e_);                  \
+      return ADVOC_ERR_HIP;                             \
+    }                                                   \
   } while (0)
 
 namespace advoc {
+
+// last HIP error seen by this host thread inside the library (diagnostics only)
+void note_hip_error(hipError_t e);
 
 constexpr int kWave = 64;  // CDNA wavefront
 

@@ -87,6 +87,7 @@ extern "C" int advoc_matmul_nt_f32(const float* x, const float* w, float* out, i
   const int64_t gx = advoc::ceil_div(rows, kTM);
   if (gx > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
   dim3 grid((unsigned)gx, (unsigned)advoc::ceil_div(n, kTN));
+  ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(matmul_nt_kernel, grid, dim3(256), 0, advoc::as_stream(stream), x, w, out,
                      rows, k, n);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
@@ -99,6 +100,7 @@ extern "C" int advoc_mel_dbnorm_f32(float* v, int64_t count, float min_level, fl
   if (count < 0 || min_db >= 0.f) return ADVOC_ERR_BAD_SHAPE;
   if (count == 0) return ADVOC_OK;
   const int64_t blocks = advoc::ceil_div(count, 256);
+  ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(mel_dbnorm_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256),
                      0, advoc::as_stream(stream), v, count, min_level, ref_db, min_db);
   ADVOC_RETURN_IF_LAUNCH_FAILED();

@@ -208,10 +208,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
 
 int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* window, int32_t nfft,
                 int32_t nhop, int64_t nframes, float* out, bool complex_out, hipStream_t stream) {
-  if (!wav || !window || !out) return ADVOC_ERR_NULL;
   if (batch < 0 || nsamps < 0 || nframes < 0 || nhop <= 0) return ADVOC_ERR_BAD_SHAPE;
   if (nfft != kNfft || (nhop & 1) || nhop > 4096) return ADVOC_ERR_UNSUPPORTED;
-  if (batch == 0 || nframes == 0) return ADVOC_OK;
+  if (batch == 0 || nframes == 0) return ADVOC_OK;  // empty output: nothing to touch
+  if (!wav || !window || !out) return ADVOC_ERR_NULL;
   const int tiles = (int)advoc::ceil_div(nframes, kFramesPerBlock);
   const int64_t blocks = batch * tiles;
   if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
@@ -219,9 +219,11 @@ int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* wi
   const size_t lds = sizeof(float) * (((span + 3) & ~3) + kWaves * 2 * kPlane);
   if (lds > 160 * 1024) return ADVOC_ERR_UNSUPPORTED;
   if (complex_out) {
+    ADVOC_CLEAR_LAUNCH_ERROR();
     hipLaunchKernelGGL(stft1024_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream,
                        wav, nsamps, window, nhop, nframes, out, tiles);
   } else {
+    ADVOC_CLEAR_LAUNCH_ERROR();
     hipLaunchKernelGGL(stft1024_kernel<false>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream,
                        wav, nsamps, window, nhop, nframes, out, tiles);
   }

@@ -41,6 +41,9 @@ typedef void* advoc_stream_t; /* hipStream_t */
 
 int advoc_abi_version(void);
 const char* advoc_error_string(int code);
+/* text of the last HIP runtime error this host thread hit inside the library (diagnostics for
+ * ADVOC_ERR_HIP; thread-local, never reset) */
+const char* advoc_last_hip_error(void);
 /* name of the GPU arch the kernels in this library were compiled for ("gfx950") */
 const char* advoc_target_arch(void);
 

@@ -54,6 +54,7 @@ def test_code_object_is_gfx950_only():
 def test_null_and_shape_errors_need_no_gpu(lib):
   # argument validation happens before any HIP call
   assert lib.advoc_stft_mag_f32(None, 1, 1024, None, 1024, 256, 4, None, None) == -4
+  assert lib.advoc_stft_mag_f32(None, 1, 700, None, 1024, 256, 0, None, None) == 0
   assert lib.advoc_matmul_nt_f32(None, None, None, 1, 1, 1, None) == -4
   one = 1  # a non-null dummy address; never dereferenced on these paths
   assert lib.advoc_stft_mag_f32(one, 1, 1024, one, 1000, 250, 4, one, None) == -2
