@@ -51,6 +51,9 @@ PROTOTYPES = {
     'advoc_stft_c64': (ctypes.c_int, [_p, _i64, _i64, _p, _i32, _i32, _i64, _p, _p]),
     'advoc_matmul_nt_f32': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
     'advoc_mel_dbnorm_f32': (ctypes.c_int, [_p, _i64, _f32, _f32, _f32, _p]),
+    'advoc_conv_forward': (ctypes.c_int, [_p, _p]),
+    'advoc_conv_backward_data': (ctypes.c_int, [_p, _p, _p, _p, _i32, _i32, _p]),
+    'advoc_conv_backward_weight': (ctypes.c_int, [_p, _p, _p, _p, _p]),
 }
 
 _lock = threading.Lock()

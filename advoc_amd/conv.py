@@ -1,0 +1,108 @@
+"""Thin Python binding of the convolution-stack C ABI (advoc_conv_* in include/advoc_hip.h).
+
+One ``Layer`` object = one conv / transposed-conv of the reference graph
+(/root/reference/models/advoc/advoc_model.py:25-69) with its fused input
+activation, skip concat, width trim, bias and dropout.  All tensors are
+float32 NHWC torch tensors resident in HBM; this module only fills
+``advoc_conv_layer`` structs and calls into libadvoc_hip.so -- no arithmetic
+happens in Python/torch.
+"""
+import ctypes
+
+import torch
+
+from advoc_amd import _lib
+
+CONV = 0
+DECONV = 1
+ACT_NONE = 0
+ACT_LRELU = 1
+ACT_RELU = 2
+
+
+def same_pad(n, k, s):
+  """TF 'SAME' padding: (before, after) for input size n (tf.layers.conv2d, advoc_model.py:46-51)."""
+  out = -(-n // s)
+  total = max((out - 1) * s + k - n, 0)
+  return total // 2, total - total // 2
+
+
+def _t4(t, w=None):
+  """advoc_tensor4 view of a contiguous NHWC tensor; w = logical width (<= physical)."""
+  if t is None:
+    return _lib.Tensor4(None, 0, 0, 0, 0, 0)
+  _lib.require_device(t)
+  if t.dtype != torch.float32 or t.dim() != 4:
+    raise _lib.AdvocHipError('expected float32 NHWC tensor, got {} {}'.format(t.dtype, tuple(t.shape)))
+  n, h, wp, c = t.shape
+  w = wp if w is None else w
+  if not 0 < w <= wp:
+    raise _lib.AdvocHipError('logical width {} outside physical width {}'.format(w, wp))
+  return _lib.Tensor4(t.data_ptr(), n, h, w, c, wp)
+
+
+class Layer(object):
+  """A bound conv layer: holds the ctypes struct and keeps every tensor it points at alive."""
+
+  def __init__(self, kind, x0, y, weight, bias=None, x1=None, in_w=None, out_w=None, stride=(2, 2),
+               pad=(1, 1), in_act=ACT_NONE, drop_mask=None, drop_scale=0., in_scale=None,
+               in_shift=None):
+    kh, kw = int(weight.shape[0]), int(weight.shape[1])
+    cin = x0.shape[3] + (x1.shape[3] if x1 is not None else 0)
+    cout = y.shape[3]
+    want = (kh, kw, cin, cout) if kind == CONV else (kh, kw, cout, cin)
+    if tuple(weight.shape) != want:
+      raise _lib.AdvocHipError('kernel shape {} != {}'.format(tuple(weight.shape), want))
+    if bias is not None and tuple(bias.shape) != (cout,):
+      raise _lib.AdvocHipError('bias shape {} != ({},)'.format(tuple(bias.shape), cout))
+    for t in (weight, bias, drop_mask, in_scale, in_shift):
+      if t is not None:
+        _lib.require_device(t)
+    if drop_mask is not None and (drop_mask.dtype != torch.uint8 or tuple(drop_mask.shape) != tuple(y.shape)):
+      raise _lib.AdvocHipError('dropout mask must be uint8 with the shape of y')
+    self.kind = kind
+    self.tensors = (x0, x1, y, weight, bias, drop_mask, in_scale, in_shift)
+    self.x0, self.x1, self.y, self.weight, self.bias = x0, x1, y, weight, bias
+    s = _lib.ConvLayer()
+    s.kind = kind
+    s.kh, s.kw = kh, kw
+    s.sh, s.sw = stride
+    s.pad_t, s.pad_l = pad
+    s.in_act = in_act
+    s.x0 = _t4(x0, in_w)
+    s.x1 = _t4(x1, in_w)
+    s.in_scale = _lib.ptr(in_scale)
+    s.in_shift = _lib.ptr(in_shift)
+    s.y = _t4(y, out_w)
+    s.w = _lib.ptr(weight)
+    s.b = _lib.ptr(bias)
+    s.drop_mask = _lib.ptr(drop_mask)
+    s.drop_scale = float(drop_scale)
+    self.struct = s
+
+  def forward(self):
+    _lib.check(_lib.load().advoc_conv_forward(ctypes.byref(self.struct), _lib.stream()),
+               'advoc_conv_forward')
+    return self.y
+
+  def backward_data(self, dy, dx0=None, dx1=None, accum0=False, accum1=False):
+    _lib.require_device(dy)
+    if tuple(dy.shape) != tuple(self.y.shape):
+      raise _lib.AdvocHipError('dy shape {} != y shape {}'.format(tuple(dy.shape), tuple(self.y.shape)))
+    for d, x in ((dx0, self.x0), (dx1, self.x1)):
+      if d is not None:
+        _lib.require_device(d)
+        if x is None or tuple(d.shape) != tuple(x.shape):
+          raise _lib.AdvocHipError('dx must have the shape of the matching input')
+    _lib.check(_lib.load().advoc_conv_backward_data(
+        ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dx0), _lib.ptr(dx1), int(accum0),
+        int(accum1), _lib.stream()), 'advoc_conv_backward_data')
+
+  def backward_weight(self, dy, dw, db=None):
+    _lib.require_device(dy)
+    _lib.require_device(dw)
+    if tuple(dw.shape) != tuple(self.weight.shape):
+      raise _lib.AdvocHipError('dw shape mismatch')
+    _lib.check(_lib.load().advoc_conv_backward_weight(
+        ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), _lib.stream()),
+        'advoc_conv_backward_weight')

@@ -1,0 +1,277 @@
+// C-ABI entry points of the convolution stack: validate an advoc_conv_layer, translate each
+// direction into a gather-GEMM / weight-gradient problem and pick the kernel: the fp32-MFMA
+// implicit GEMM (igemm.hip, wgrad.hip) for the wide layers, the direct HBM-bound kernels
+// (edge.hip, wgrad.hip thin path) for the layers with 1-2 input channels or 1 output channel.
+//
+// Reference graph being replaced: models/advoc/advoc_model.py:25-69 (layer builders),
+// :89-158 (generator), :184-202 (discriminator) and their TF gradients.
+#include "conv_internal.h"
+
+namespace advoc {
+
+static inline int pack_tap(int dy, int dx, int wtap) {
+  return (dy & 0xff) | ((dx & 0xff) << 8) | (wtap << 16);
+}
+
+int validate_layer(const advoc_conv_layer* L) {
+  if (!L) return ADVOC_ERR_NULL;
+  if (!L->x0.p || !L->y.p || !L->w) return ADVOC_ERR_NULL;
+  if (L->kind != ADVOC_CONV && L->kind != ADVOC_DECONV) return ADVOC_ERR_UNSUPPORTED;
+  const advoc_tensor4 &x0 = L->x0, &x1 = L->x1, &y = L->y;
+  if (x0.n <= 0 || x0.h <= 0 || x0.w <= 0 || x0.c <= 0 || x0.w_pitch < x0.w) return ADVOC_ERR_BAD_SHAPE;
+  if (y.n != x0.n || y.h <= 0 || y.w <= 0 || y.c <= 0 || y.w_pitch < y.w) return ADVOC_ERR_BAD_SHAPE;
+  if (x1.p) {
+    if (x1.n != x0.n || x1.h != x0.h || x1.w != x0.w || x1.c <= 0 || x1.w_pitch < x1.w)
+      return ADVOC_ERR_BAD_SHAPE;
+  }
+  if (L->kh < 1 || L->kw < 1 || L->kh * L->kw > kMaxTaps || L->sh < 1 || L->sw < 1) return ADVOC_ERR_UNSUPPORTED;
+  if (L->pad_t < 0 || L->pad_l < 0 || L->pad_t >= L->kh || L->pad_l >= L->kw) return ADVOC_ERR_UNSUPPORTED;
+  if (L->in_act < ADVOC_ACT_NONE || L->in_act > ADVOC_ACT_RELU) return ADVOC_ERR_UNSUPPORTED;
+  if ((L->in_scale == nullptr) != (L->in_shift == nullptr)) return ADVOC_ERR_NULL;
+  if (L->kind == ADVOC_CONV) {
+    // every output pixel's window must start inside the padded input
+    if ((int64_t)(y.h - 1) * L->sh - L->pad_t >= x0.h || (int64_t)(y.w - 1) * L->sw - L->pad_l >= x0.w)
+      return ADVOC_ERR_BAD_SHAPE;
+  } else {
+    if (L->kh != 4 || L->kw != 4 || L->sh != 2 || L->sw != 2 || L->pad_t != 1 || L->pad_l != 1)
+      return ADVOC_ERR_UNSUPPORTED;
+    if (y.h != 2 * x0.h || y.w > 2 * x0.w || y.w < 2 * x0.w - 1) return ADVOC_ERR_BAD_SHAPE;
+  }
+  return ADVOC_OK;
+}
+
+namespace {
+
+int cin_of(const advoc_conv_layer* L) { return L->x0.c + (L->x1.p ? L->x1.c : 0); }
+
+// taps of one sub-pixel phase of a stride-2 transposed gather:
+//   out index o = 2 g + par reads in index g + d for every k with (par + pad - k) even,
+//   d = (par + pad - k) / 2
+int phase_taps(int par, int pad, int ksize, int* ks, int* ds) {
+  int n = 0;
+  for (int k = 0; k < ksize; ++k) {
+    const int t = par + pad - k;
+    if ((t & 1) == 0) {
+      ks[n] = k;
+      ds[n] = t / 2;   // t even: exact for negatives too
+      ++n;
+    }
+  }
+  return n;
+}
+
+void dense_taps(GatherGemmParams& p, const advoc_conv_layer* L, bool flipped) {
+  p.nphase = 1;
+  p.ntaps = L->kh * L->kw;
+  for (int ky = 0; ky < L->kh; ++ky)
+    for (int kx = 0; kx < L->kw; ++kx)
+      p.tap[0][ky * L->kw + kx] = flipped ? pack_tap(L->pad_t - ky, L->pad_l - kx, ky * L->kw + kx)
+                                          : pack_tap(ky - L->pad_t, kx - L->pad_l, ky * L->kw + kx);
+  p.osy = p.osx = 1;
+}
+
+int subpixel_taps(GatherGemmParams& p, const advoc_conv_layer* L) {
+  p.sy = p.sx = 1;
+  p.osy = p.osx = 2;
+  p.nphase = 4;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      int kys[kMaxTaps], dys[kMaxTaps], kxs[kMaxTaps], dxs[kMaxTaps];
+      const int ny = phase_taps(py, L->pad_t, L->kh, kys, dys);
+      const int nx = phase_taps(px, L->pad_l, L->kw, kxs, dxs);
+      if (ny * 2 != L->kh || nx * 2 != L->kw) return ADVOC_ERR_UNSUPPORTED;  // even kernels only
+      const int ph = py * 2 + px;
+      p.ntaps = ny * nx;
+      for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b)
+          p.tap[ph][a * nx + b] = pack_tap(dys[a], dxs[b], kys[a] * L->kw + kxs[b]);
+      p.ooy[ph] = py;
+      p.oox[ph] = px;
+    }
+  return ADVOC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward:   K = cin, N = cout
+// ---------------------------------------------------------------------------------------------
+int build_forward(const advoc_conv_layer* L, GatherGemmParams& p, bool& b_kn) {
+  p = GatherGemmParams{};
+  p.a0 = L->x0.p; p.c0 = L->x0.c; p.a0_pitch = L->x0.w_pitch;
+  p.a1 = L->x1.p; p.c1 = L->x1.p ? L->x1.c : 0; p.a1_pitch = L->x1.p ? L->x1.w_pitch : 0;
+  p.a_h = L->x0.h; p.in_h = L->x0.h; p.in_w = L->x0.w;
+  p.in_scale = L->in_scale; p.in_shift = L->in_shift; p.in_act = L->in_act;
+  p.batch = L->x0.n;
+  p.w = L->w;
+  p.n_total = p.n_split = L->y.c;
+  p.d[0].p = L->y.p; p.d[0].pitch = L->y.w_pitch; p.d[0].c = L->y.c;
+  p.out_h = L->y.h; p.out_w = L->y.w;
+  p.bias = L->b;
+  p.y_mask = L->drop_mask; p.y_mask_scale = L->drop_scale;
+  if (L->kind == ADVOC_CONV) {
+    p.gh = L->y.h; p.gw = L->y.w;
+    p.sy = L->sh; p.sx = L->sw;
+    dense_taps(p, L, false);
+    b_kn = true;    // kernel [kh,kw,ci,co]: K rows, N contiguous
+    return ADVOC_OK;
+  }
+  // transposed conv, stride 2: four dense sub-pixel phases over the INPUT grid
+  p.gh = L->x0.h; p.gw = L->x0.w;
+  b_kn = false;     // kernel [kh,kw,co,ci]: N rows, K contiguous
+  return subpixel_taps(p, L);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward data:   K = cout, N = cin
+// ---------------------------------------------------------------------------------------------
+int build_backward_data(const advoc_conv_layer* L, const float* dy, float* dx0, float* dx1, int accum0,
+                        int accum1, GatherGemmParams& p, bool& b_kn) {
+  if (L->in_scale) return ADVOC_ERR_UNSUPPORTED;   // BN-folded prologue: backward not built yet
+  p = GatherGemmParams{};
+  p.a0 = dy; p.c0 = L->y.c; p.a0_pitch = L->y.w_pitch;
+  p.a_h = L->y.h; p.in_h = L->y.h; p.in_w = L->y.w;
+  p.in_act = ADVOC_ACT_NONE;
+  p.a_mask = L->drop_mask; p.a_mask_scale = L->drop_scale;
+  p.batch = L->x0.n;
+  p.w = L->w;
+  const int c0 = L->x0.c, c1 = L->x1.p ? L->x1.c : 0;
+  p.n_total = c0 + c1;
+  p.n_split = c0;
+  p.d[0].p = dx0; p.d[0].xpre = L->x0.p; p.d[0].pitch = L->x0.w_pitch; p.d[0].c = c0; p.d[0].accum = accum0;
+  p.d[1].p = c1 ? dx1 : nullptr; p.d[1].xpre = L->x1.p; p.d[1].pitch = c1 ? L->x1.w_pitch : 0;
+  p.d[1].c = c1; p.d[1].accum = accum1;
+  p.out_h = L->x0.h; p.out_w = L->x0.w;
+  p.grad_act = L->in_act;
+  if (L->kind == ADVOC_DECONV) {
+    // dIn[iy,ix,ci] = sum dOut[2 iy - pad + ky, 2 ix - pad + kx, co] * w[ky,kx,co,ci]
+    p.gh = L->x0.h; p.gw = L->x0.w;
+    p.sy = L->sh; p.sx = L->sw;
+    dense_taps(p, L, false);
+    b_kn = true;    // [tap][co = K][ci = N]
+    return ADVOC_OK;
+  }
+  b_kn = false;     // [tap][ci = N][co = K]
+  if (L->sh == 1 && L->sw == 1) {
+    // dX[iy,ix] = sum dY[iy + pad - ky, ix + pad - kx] * w[ky,kx]
+    p.gh = L->x0.h; p.gw = L->x0.w;
+    p.sy = p.sx = 1;
+    dense_taps(p, L, true);
+    return ADVOC_OK;
+  }
+  if (L->sh != 2 || L->sw != 2) return ADVOC_ERR_UNSUPPORTED;
+  p.gh = (L->x0.h + 1) / 2; p.gw = (L->x0.w + 1) / 2;
+  return subpixel_taps(p, L);
+}
+
+int run_gather(const GatherGemmParams& p, bool b_kn, hipStream_t stream) {
+  const int K = p.c0 + p.c1, N = p.n_total;
+  if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0)
+    return launch_gather_gemm(p, b_kn, stream);
+  if (N <= 2 && K % 4 == 0 && p.c0 % 4 == 0) return launch_gather_dot(p, b_kn, stream);
+  if (K <= 2) return launch_gather_outer(p, b_kn, stream);
+  return ADVOC_ERR_UNSUPPORTED;
+}
+
+void operand_from_inputs(const advoc_conv_layer* L, Operand& o) {
+  o = Operand{};
+  o.p0 = L->x0.p; o.c0 = L->x0.c; o.pitch0 = L->x0.w_pitch;
+  o.p1 = L->x1.p; o.c1 = L->x1.p ? L->x1.c : 0; o.pitch1 = L->x1.p ? L->x1.w_pitch : 0;
+  o.h = L->x0.h; o.w = L->x0.w;
+  o.act = L->in_act; o.scale = L->in_scale; o.shift = L->in_shift;
+}
+
+void operand_from_dy(const advoc_conv_layer* L, const float* dy, Operand& o) {
+  o = Operand{};
+  o.p0 = dy; o.c0 = L->y.c; o.pitch0 = L->y.w_pitch;
+  o.h = L->y.h; o.w = L->y.w;
+  o.act = ADVOC_ACT_NONE;
+  o.mask = L->drop_mask; o.mask_scale = L->drop_scale;
+}
+
+// dw has the layout of L->w.  conv: [tap][ci][co] -> rows a = ci (gathered input), cols b = co (dY
+// at the output grid).  deconv: [tap][co][ci] -> rows a = co (dOut gathered at 2*iy - pad + k),
+// cols b = ci (input at the input grid).  When the row operand would be wide but the column
+// operand thin (conv with cout = 1, stride 1) the roles are swapped by walking the INPUT grid:
+// dw[tap][ci][0] = sum_in x[in][ci] * dY[in + pad - k].
+int build_backward_weight(const advoc_conv_layer* L, const float* dy, float* dw, WgradParams& p) {
+  p = WgradParams{};
+  p.batch = L->x0.n;
+  p.dw = dw;
+  p.ntaps = L->kh * L->kw;
+  const int cout = L->y.c;
+  if (L->kind == ADVOC_DECONV) {
+    operand_from_dy(L, dy, p.P);
+    operand_from_inputs(L, p.Q);
+    p.gh = L->x0.h; p.gw = L->x0.w;
+    p.sy = L->sh; p.sx = L->sw;
+    for (int ky = 0; ky < L->kh; ++ky)
+      for (int kx = 0; kx < L->kw; ++kx)
+        p.tap[ky * L->kw + kx] = pack_tap(ky - L->pad_t, kx - L->pad_l, ky * L->kw + kx);
+    return ADVOC_OK;
+  }
+  if (cout <= 2 && cin_of(L) > 2) {
+    if (L->sh != 1 || L->sw != 1 || cout != 1) return ADVOC_ERR_UNSUPPORTED;
+    operand_from_dy(L, dy, p.P);
+    operand_from_inputs(L, p.Q);
+    p.gh = L->x0.h; p.gw = L->x0.w;
+    p.sy = p.sx = 1;
+    for (int ky = 0; ky < L->kh; ++ky)
+      for (int kx = 0; kx < L->kw; ++kx)
+        p.tap[ky * L->kw + kx] = pack_tap(L->pad_t - ky, L->pad_l - kx, ky * L->kw + kx);
+    return ADVOC_OK;
+  }
+  operand_from_inputs(L, p.P);
+  operand_from_dy(L, dy, p.Q);
+  p.gh = L->y.h; p.gw = L->y.w;
+  p.sy = L->sh; p.sx = L->sw;
+  for (int ky = 0; ky < L->kh; ++ky)
+    for (int kx = 0; kx < L->kw; ++kx)
+      p.tap[ky * L->kw + kx] = pack_tap(ky - L->pad_t, kx - L->pad_l, ky * L->kw + kx);
+  return ADVOC_OK;
+}
+
+}  // namespace
+}  // namespace advoc
+
+using namespace advoc;
+
+extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stream) {
+  int rc = validate_layer(L);
+  if (rc != ADVOC_OK) return rc;
+  GatherGemmParams p;
+  bool b_kn;
+  rc = build_forward(L, p, b_kn);
+  if (rc != ADVOC_OK) return rc;
+  return run_gather(p, b_kn, as_stream(stream));
+}
+
+extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* dy, float* dx0,
+                                        float* dx1, int32_t accum0, int32_t accum1,
+                                        advoc_stream_t stream) {
+  int rc = validate_layer(L);
+  if (rc != ADVOC_OK) return rc;
+  if (!dy) return ADVOC_ERR_NULL;
+  if (!dx0 && !(dx1 && L->x1.p)) return ADVOC_OK;
+  GatherGemmParams p;
+  bool b_kn;
+  rc = build_backward_data(L, dy, dx0, dx1, accum0, accum1, p, b_kn);
+  if (rc != ADVOC_OK) return rc;
+  return run_gather(p, b_kn, as_stream(stream));
+}
+
+extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float* dy, float* dw,
+                                          float* db, advoc_stream_t stream) {
+  int rc = validate_layer(L);
+  if (rc != ADVOC_OK) return rc;
+  if (!dy || !dw) return ADVOC_ERR_NULL;
+  if (L->in_scale) return ADVOC_ERR_UNSUPPORTED;
+  WgradParams p;
+  rc = build_backward_weight(L, dy, dw, p);
+  if (rc != ADVOC_OK) return rc;
+  const int ca = p.P.c0 + p.P.c1;
+  rc = ca <= 2 ? launch_wgrad_thin(p, as_stream(stream)) : launch_wgrad_mfma(p, as_stream(stream));
+  if (rc != ADVOC_OK) return rc;
+  if (db)
+    rc = launch_bias_grad(dy, L->drop_mask, L->drop_scale, (int64_t)L->y.n * L->y.h, L->y.w,
+                          L->y.w_pitch, L->y.c, db, as_stream(stream));
+  return rc;
+}

@@ -1,0 +1,51 @@
+// Internal declarations shared by conv.hip, igemm.hip, wgrad.hip and edge.hip.
+#pragma once
+#include "common.h"
+#include "igemm.h"
+
+namespace advoc {
+
+int validate_layer(const advoc_conv_layer* L);
+
+// ---- thin layers (<= 2 input channels or 1 output channel): direct HBM-bound kernels ----
+// Both take the SAME GatherGemmParams a gather-GEMM launch would get.
+//   gather_dot  : n_total <= 2 outputs per grid point, K channels wide (wave per grid point)
+//   gather_outer: K = c0 + c1 <= 2 input channels, n_total wide (thread per output element)
+int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream);
+int launch_gather_outer(const GatherGemmParams& p, bool b_kn, hipStream_t stream);
+
+// ---- weight gradient ----
+// An NHWC activation view (optionally the channel concat of two tensors) with the layer's fused
+// input transform.
+struct Operand {
+  const float* p0;
+  const float* p1;
+  int c0, c1;
+  int pitch0, pitch1;
+  int h, w;            // rows per image, logical width
+  int act;
+  const float* scale;  // optional per-channel affine before act
+  const float* shift;
+  const uint8_t* mask; // optional {0,1} mask (single source only), indexed like p0
+  float mask_scale;
+};
+
+// dw[tap][a][b] = sum over grid points g of P[g*s + d(tap)][a] * Q[g][b]
+struct WgradParams {
+  Operand P;   // gathered operand -> rows a
+  Operand Q;   // grid operand     -> cols b
+  int batch, gh, gw;
+  int sy, sx;
+  int ntaps;
+  int tap[kMaxTaps];   // (dy & 0xff) | (dx & 0xff) << 8 | wtap << 16
+  float* dw;           // zero-filled by the launcher, accumulated with atomics
+};
+
+int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream);   // both operands wide (% 32)
+int launch_wgrad_thin(const WgradParams& p, hipStream_t stream);   // P has <= 2 channels
+
+// db[c] = sum over pixels of dy[., c] (* mask * scale)
+int launch_bias_grad(const float* dy, const uint8_t* mask, float mask_scale, int64_t rows, int w,
+                     int pitch, int c, float* db, hipStream_t stream);
+
+}  // namespace advoc

@@ -1,0 +1,65 @@
+// Parameter block of the gather-GEMM ("implicit GEMM") kernels shared by conv.hip (host-side
+// translation of advoc_conv_layer) and igemm.hip (the gfx950 MFMA kernel).
+//
+// GEMM view of every conv / transposed-conv direction in the model:
+//   rows  m  = (image, gy, gx) over a grid of batch x gh x gw points
+//   cols  n  = output channel
+//   depth k  = (tap, input channel);  A[m, k] = act(in[image, gy*sy + dy[tap], gx*sx + dx[tap], ci])
+//                                      (zero outside the logical input), B[k, n] = w_tap[ci][n]
+//   result row m is stored at pixel (gy*osy + ooy[phase], gx*osx + oox[phase]) of the destination.
+// Stride-2 transposed convolutions (decoder forward, encoder backward-data) run as 4 sub-pixel
+// phases (blockIdx.z), each a dense 2x2-tap GEMM -- no zero-insertion, no wasted MACs.
+#pragma once
+#include <stdint.h>
+
+namespace advoc {
+
+constexpr int kMaxPhases = 4;
+constexpr int kMaxTaps = 16;
+
+struct GemmDest {
+  float* p;           // destination tensor (NHWC, `c` channels, rows `pitch` pixels apart)
+  const float* xpre;  // same geometry: pre-activation forward value, for act'(x) gating (or null)
+  int pitch;
+  int c;
+  int accum;          // 1: add into destination
+};
+
+struct GatherGemmParams {
+  // ---- A operand ----
+  const float* a0;
+  const float* a1;
+  int c0, c1;              // channels per source; c1 == 0 -> single source
+  int a0_pitch, a1_pitch;  // row pitch in pixels
+  int a_h;                 // rows per image (physical == logical)
+  int in_h, in_w;          // logical gather bounds
+  const float* in_scale;   // optional per-channel affine applied before the activation
+  const float* in_shift;
+  int in_act;
+  const uint8_t* a_mask;   // optional {0,1} mask multiplied into A (indexed like a0), c1 must be 0
+  float a_mask_scale;
+  // ---- grid / taps ----
+  int batch, gh, gw;
+  int sy, sx;
+  int nphase, ntaps;
+  int tap[kMaxPhases][kMaxTaps];  // (dy & 0xff) | (dx & 0xff) << 8 | wtap << 16
+  // ---- B operand ----
+  const float* w;
+  int n_total;
+  // ---- output ----
+  int osy, osx;
+  int ooy[kMaxPhases], oox[kMaxPhases];
+  int out_h, out_w;
+  GemmDest d[2];
+  int n_split;             // channels [0, n_split) -> d[0], the rest -> d[1]
+  const float* bias;
+  const uint8_t* y_mask;   // forward dropout mask, indexed like d[0]
+  float y_mask_scale;
+  int grad_act;            // != ADVOC_ACT_NONE: multiply result by act'(d[i].xpre)
+};
+
+// B_KN = true : weights stored [tap][K][N] (N contiguous)   conv fwd, deconv bwd-data
+// B_KN = false: weights stored [tap][N][K] (K contiguous)   deconv fwd, conv bwd-data
+int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream);
+
+}  // namespace advoc

@@ -1,0 +1,389 @@
+// Weight / bias gradient kernels (gfx950).
+//
+// Replaces TF Conv2DBackpropFilter and BiasAddGrad for every layer built at
+// models/advoc/advoc_model.py:25-69.   dw[tap][a][b] = sum_g P[g*s + d(tap)][a] * Q[g][b]
+// (conv_internal.h): a GEMM per tap whose reduction axis is the pixel grid.
+//
+//   * wgrad_mfma_kernel: both operands >= 32 channels.  Block tile (32 MT WGM) x (32 NT WGN)
+//     channels, K step = 16 grid points, exact-fp32 v_mfma_f32_32x32x2_f32.  Both operand tiles
+//     land in LDS as [pixel][channel] straight from coalesced float4 channel loads (the layout
+//     the MFMA operands want: lane = channel, register = pixel).  The pixel axis is split over
+//     blockIdx.z; partial tiles are combined with hardware fp32 atomics into the zeroed dw.
+//   * wgrad_thin_kernel: the gathered operand has <= 2 channels (encoder_1, layer_1, decoder_1,
+//     layer_5): HBM-bound outer products, threads own channels of the wide operand.
+//   * bias_grad_kernel: per-channel column sums.
+#include "conv_internal.h"
+
+namespace advoc {
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == ADVOC_ACT_LRELU02) return fmaxf(0.2f * v, v);
+  if (act == ADVOC_ACT_RELU) return fmaxf(v, 0.f);
+  return v;
+}
+
+// float4 of `op` at (img, y, x), channels ch..ch+3 of the concatenated view, transformed.
+__device__ __forceinline__ float4 load_op4(const Operand& op, int img, int y, int x, int ch) {
+  const bool second = ch >= op.c0;
+  const float* src = second ? op.p1 : op.p0;
+  const int cs = second ? op.c1 : op.c0;
+  const int pitch = second ? op.pitch1 : op.pitch0;
+  const int64_t off = (((int64_t)img * op.h + y) * pitch + x) * cs + (second ? ch - op.c0 : ch);
+  float4 v = *reinterpret_cast<const float4*>(src + off);
+  if (op.scale) {
+    const float4 sc = *reinterpret_cast<const float4*>(op.scale + ch);
+    const float4 sh = *reinterpret_cast<const float4*>(op.shift + ch);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+  }
+  v.x = act_fwd(v.x, op.act); v.y = act_fwd(v.y, op.act);
+  v.z = act_fwd(v.z, op.act); v.w = act_fwd(v.w, op.act);
+  if (op.mask) {
+    const uchar4 mk = *reinterpret_cast<const uchar4*>(op.mask + off);
+    v.x *= mk.x * op.mask_scale; v.y *= mk.y * op.mask_scale;
+    v.z *= mk.z * op.mask_scale; v.w *= mk.w * op.mask_scale;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float load_op1(const Operand& op, int img, int y, int x, int ch) {
+  const bool second = ch >= op.c0;
+  const float* src = second ? op.p1 : op.p0;
+  const int cs = second ? op.c1 : op.c0;
+  const int pitch = second ? op.pitch1 : op.pitch0;
+  const int64_t off = (((int64_t)img * op.h + y) * pitch + x) * cs + (second ? ch - op.c0 : ch);
+  float v = src[off];
+  if (op.scale) v = v * op.scale[ch] + op.shift[ch];
+  v = act_fwd(v, op.act);
+  if (op.mask) v *= op.mask[off] * op.mask_scale;
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA weight gradient
+// ---------------------------------------------------------------------------------------------
+constexpr int WK = 16;  // grid points per K step
+
+template <int MT, int NT, int WGM, int WGN>
+struct WCfg {
+  static constexpr int BM = 32 * MT * WGM;   // channels of P per block
+  static constexpr int BN = 32 * NT * WGN;   // channels of Q per block
+  static constexpr int LDP = BM + 4;
+  static constexpr int LDQ = BN + 4;
+  static constexpr int P_LOADS = (WK * BM / 4 + 255) / 256;
+  static constexpr int Q_LOADS = (WK * BN / 4 + 255) / 256;
+  static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (WK * LDP + WK * LDQ);
+};
+
+template <int MT, int NT, int WGM, int WGN>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p, int tiles_n,
+                                                         int chunk) {
+  using C = WCfg<MT, NT, WGM, WGN>;
+  constexpr int BM = C::BM, BN = C::BN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ps = smem;                      // [2][WK][LDP]
+  float* Qs = smem + 2 * WK * C::LDP;    // [2][WK][LDQ]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int a0 = (blockIdx.x / tiles_n) * BM;
+  const int b0 = (blockIdx.x % tiles_n) * BN;
+  const int tp = p.tap[blockIdx.y];
+  const int dy = (int)(int8_t)(tp & 0xff), dx = (int)(int8_t)((tp >> 8) & 0xff), wtap = tp >> 16;
+  const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
+  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  const int64_t g_begin = (int64_t)blockIdx.z * chunk;
+  const int64_t g_end = g_begin + chunk < M ? g_begin + chunk : M;
+  const int nkt = (int)((g_end - g_begin + WK - 1) / WK);
+
+  // loader slots: slot i covers pixel (idx / (B/4)) of the K step, channel quad (idx % (B/4))
+  float4 rp[C::P_LOADS], rq[C::Q_LOADS];
+
+  auto load_tiles = [&](int kt) {
+    const int64_t gbase = g_begin + (int64_t)kt * WK;
+#pragma unroll
+    for (int i = 0; i < C::P_LOADS; ++i) {
+      const int idx = tid + 256 * i;
+      const int k = idx / (BM / 4), cq = idx % (BM / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int64_t g = gbase + k;
+      if (k < WK && g < g_end) {
+        const int gx = (int)(g % p.gw);
+        const int64_t t = g / p.gw;
+        const int y = (int)(t % p.gh) * p.sy + dy, x = gx * p.sx + dx;
+        if ((unsigned)y < (unsigned)p.P.h && (unsigned)x < (unsigned)p.P.w && a0 + 4 * cq < ca)
+          v = load_op4(p.P, (int)(t / p.gh), y, x, a0 + 4 * cq);
+      }
+      rp[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < C::Q_LOADS; ++i) {
+      const int idx = tid + 256 * i;
+      const int k = idx / (BN / 4), cq = idx % (BN / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int64_t g = gbase + k;
+      if (k < WK && g < g_end && b0 + 4 * cq < cb) {
+        const int gx = (int)(g % p.gw);
+        const int64_t t = g / p.gw;
+        v = load_op4(p.Q, (int)(t / p.gh), (int)(t % p.gh), gx, b0 + 4 * cq);
+      }
+      rq[i] = v;
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    float* Pb = Ps + buf * WK * C::LDP;
+    float* Qb = Qs + buf * WK * C::LDQ;
+#pragma unroll
+    for (int i = 0; i < C::P_LOADS; ++i) {
+      const int idx = tid + 256 * i;
+      const int k = idx / (BM / 4), cq = idx % (BM / 4);
+      if (k < WK) *reinterpret_cast<float4*>(Pb + k * C::LDP + 4 * cq) = rp[i];
+    }
+#pragma unroll
+    for (int i = 0; i < C::Q_LOADS; ++i) {
+      const int idx = tid + 256 * i;
+      const int k = idx / (BN / 4), cq = idx % (BN / 4);
+      if (k < WK) *reinterpret_cast<float4*>(Qb + k * C::LDQ + 4 * cq) = rq[i];
+    }
+  };
+
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nkt > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tiles(kt + 1);
+    const float* Pb = Ps + buf * WK * C::LDP;
+    const float* Qb = Qs + buf * WK * C::LDQ;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float a[MT], b[NT];
+      const int k = 2 * s + half;   // MFMA K slot: lanes 0-31 -> k, lanes 32-63 -> k+1
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = Pb[k * C::LDP + (wm * MT + i) * 32 + l32];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = Qb[k * C::LDQ + (wn * NT + j) * 32 + l32];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (nkt == 0) return;
+  float* out = p.dw + (int64_t)wtap * ca * cb;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int b = b0 + (wn * NT + j) * 32 + l32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int a = a0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (a < ca && b < cb) unsafeAtomicAdd(out + (int64_t)a * cb + b, acc[i][j][r]);
+      }
+    }
+}
+
+template <int MT, int NT, int WGM, int WGN>
+int launch_wcfg(const WgradParams& p, hipStream_t stream) {
+  using C = WCfg<MT, NT, WGM, WGN>;
+  const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
+  const int tiles_m = (ca + C::BM - 1) / C::BM, tiles_n = (cb + C::BN - 1) / C::BN;
+  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  // split the pixel axis so the launch has ~1024 workgroups (4 per CU)
+  const int64_t tiles = (int64_t)tiles_m * tiles_n * p.ntaps;
+  int64_t ksplit = ceil_div(1024, tiles);
+  const int64_t max_split = ceil_div(M, 8 * WK);
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit < 1) ksplit = 1;
+  int64_t chunk = ceil_div(ceil_div(M, ksplit), WK) * WK;
+  ksplit = ceil_div(M, chunk);
+  if (chunk > 0x7fffffffLL || ksplit > 65535) return ADVOC_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)p.ntaps, (unsigned)ksplit);
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL((wgrad_mfma_kernel<MT, NT, WGM, WGN>), grid, dim3(256), C::LDS_BYTES, stream, p,
+                     tiles_n, (int)chunk);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// thin weight gradient: P has <= 2 channels.  Thread = one channel b of Q; a block walks a
+// chunk of grid points; per point the (<= 2 x ntaps) P scalars are wave-uniform broadcasts.
+// ---------------------------------------------------------------------------------------------
+template <int CA>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(const WgradParams p, int chunk) {
+  __shared__ float red[256];
+  const int cb = p.Q.c0 + p.Q.c1;
+  // threads: tb = channel lane within a 64-wide channel group, tg = pixel sub-group
+  const int lanes_b = cb < 64 ? cb : 64;            // cb is a multiple of 32
+  const int groups = 256 / lanes_b;
+  const int tb = threadIdx.x % lanes_b, tg = threadIdx.x / lanes_b;
+  const int b = blockIdx.y * lanes_b + tb;
+  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  const int64_t g_begin = (int64_t)blockIdx.x * chunk;
+  const int64_t g_end = g_begin + chunk < M ? g_begin + chunk : M;
+
+  float acc[kMaxTaps][CA];
+#pragma unroll
+  for (int t = 0; t < kMaxTaps; ++t)
+#pragma unroll
+    for (int a = 0; a < CA; ++a) acc[t][a] = 0.f;
+
+  for (int64_t g = g_begin + tg; g < g_end; g += groups) {
+    const int gx = (int)(g % p.gw);
+    const int64_t tt = g / p.gw;
+    const int gy = (int)(tt % p.gh), img = (int)(tt / p.gh);
+    const float q = load_op1(p.Q, img, gy, gx, b);
+#pragma unroll
+    for (int t = 0; t < kMaxTaps; ++t) {
+      if (t < p.ntaps) {
+        const int tp = p.tap[t];
+        const int y = gy * p.sy + (int)(int8_t)(tp & 0xff), x = gx * p.sx + (int)(int8_t)((tp >> 8) & 0xff);
+        if ((unsigned)y < (unsigned)p.P.h && (unsigned)x < (unsigned)p.P.w) {
+#pragma unroll
+          for (int a = 0; a < CA; ++a) acc[t][a] = fmaf(load_op1(p.P, img, y, x, a), q, acc[t][a]);
+        }
+      }
+    }
+  }
+  // reduce the pixel sub-groups through LDS, one (tap, a) at a time, then one atomic per channel
+#pragma unroll
+  for (int t = 0; t < kMaxTaps; ++t) {
+    if (t >= p.ntaps) break;
+#pragma unroll
+    for (int a = 0; a < CA; ++a) {
+      red[threadIdx.x] = acc[t][a];
+      __syncthreads();
+      if (tg == 0) {
+        float s = 0.f;
+        for (int k = 0; k < groups; ++k) s += red[k * lanes_b + tb];
+        const int wtap = p.tap[t] >> 16;
+        unsafeAtomicAdd(p.dw + ((int64_t)wtap * CA + a) * cb + b, s);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bias gradient
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy,
+                                                        const uint8_t* __restrict__ mask,
+                                                        float mask_scale, int64_t rows, int w,
+                                                        int pitch, int c, float* __restrict__ db) {
+  __shared__ float red[256];
+  // thread -> channel (fast) x pixel sub-group; for c < 256 several pixels per pass
+  const int lanes_c = c < 256 ? c : 256;
+  const int groups = 256 / lanes_c;
+  const int tc = threadIdx.x % lanes_c, tg = threadIdx.x / lanes_c;
+  const bool idle = tg >= groups;   // 256 % c != 0
+  const int64_t npix = rows * w;
+  for (int cbase = 0; cbase < c; cbase += lanes_c) {
+    const int ch = cbase + tc;
+    float s = 0.f;
+    if (!idle && ch < c) {
+      for (int64_t q = (int64_t)blockIdx.x * groups + tg; q < npix; q += (int64_t)gridDim.x * groups) {
+        const int64_t row = q / w;
+        const int x = (int)(q - row * w);
+        const int64_t off = (row * pitch + x) * c + ch;
+        float v = dy[off];
+        if (mask) v *= mask[off] * mask_scale;
+        s += v;
+      }
+    }
+    red[threadIdx.x] = idle ? 0.f : s;
+    __syncthreads();
+    if (tg == 0 && ch < c) {
+      float tot = 0.f;
+      for (int k = 0; k < groups; ++k) tot += red[k * lanes_c + tc];
+      unsafeAtomicAdd(db + ch, tot);
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream) {
+  const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
+  if (ca % 32 || cb % 32 || p.P.c0 % 4 || p.Q.c0 % 4) return ADVOC_ERR_UNSUPPORTED;
+  if (p.P.c1 && p.P.c0 % 32) return ADVOC_ERR_UNSUPPORTED;  // a block's channel tile stays in one source
+  if (p.Q.c1 && p.Q.c0 % 32) return ADVOC_ERR_UNSUPPORTED;
+  hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
+  if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  // pick the tile with the least padded work (ties: the larger tile); edges are masked
+  const int bm[4] = {128, 64, 32, 128}, bn[4] = {128, 64, 128, 32};
+  int best = 0;
+  int64_t best_cost = -1;
+  for (int i = 0; i < 4; ++i) {
+    const int64_t cost = ceil_div(ca, bm[i]) * bm[i] * ceil_div(cb, bn[i]) * bn[i];
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = i; }
+  }
+  switch (best) {
+    case 0: return launch_wcfg<2, 2, 2, 2>(p, stream);
+    case 1: return launch_wcfg<1, 1, 2, 2>(p, stream);
+    case 2: return launch_wcfg<1, 1, 1, 4>(p, stream);
+    default: return launch_wcfg<1, 1, 4, 1>(p, stream);
+  }
+}
+
+int launch_wgrad_thin(const WgradParams& p, hipStream_t stream) {
+  const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
+  if (ca < 1 || ca > 2 || cb % 32) return ADVOC_ERR_UNSUPPORTED;
+  hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
+  if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  const int lanes_b = cb < 64 ? cb : 64;
+  const int by = cb / lanes_b;
+  int64_t nblk = 2048 / by;
+  if (nblk < 1) nblk = 1;
+  int64_t chunk = ceil_div(M, nblk);
+  if (chunk < 64) chunk = 64;
+  nblk = ceil_div(M, chunk);
+  if (chunk > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)nblk, (unsigned)by);
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  if (ca == 1) hipLaunchKernelGGL(wgrad_thin_kernel<1>, grid, dim3(256), 0, stream, p, (int)chunk);
+  else hipLaunchKernelGGL(wgrad_thin_kernel<2>, grid, dim3(256), 0, stream, p, (int)chunk);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+int launch_bias_grad(const float* dy, const uint8_t* mask, float mask_scale, int64_t rows, int w,
+                     int pitch, int c, float* db, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)c, stream);
+  if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  const int lanes_c = c < 256 ? c : 256;
+  const int groups = 256 / lanes_c;
+  int64_t blocks = ceil_div(rows * w, (int64_t)groups * 64);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, mask,
+                     mask_scale, rows, w, pitch, c, db);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+}  // namespace advoc

@@ -83,6 +83,67 @@ int advoc_matmul_nt_f32(const float* x, const float* w, float* out, int64_t rows
 int advoc_mel_dbnorm_f32(float* v, int64_t count, float min_level, float ref_db, float min_db,
                          advoc_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution stack (pix2pix generator + PatchGAN discriminator)
+ * ---------------------------------------------------------------------------------------- */
+
+/* NHWC float32 tensor view.  `w` is the LOGICAL width; rows are `w_pitch` pixels apart
+ * (w_pitch >= w), images h * w_pitch pixels apart.  The reference's `[:, :, :-1, :]` trims
+ * (advoc_model.py:137,154,156) are views with w = w_pitch - 1: never materialised. */
+typedef struct advoc_tensor4 {
+  float* p;
+  int32_t n, h, w, c;
+  int32_t w_pitch;
+} advoc_tensor4;
+
+#define ADVOC_CONV 0   /* y[oy,ox] = sum in[oy*sh - pad_t + ky, ox*sw - pad_l + kx] * w[ky,kx,ci,co] */
+#define ADVOC_DECONV 1 /* y[iy*sh - pad_t + ky, ix*sw - pad_l + kx] += in[iy,ix] * w[ky,kx,co,ci]   */
+
+/* One conv / transposed-conv layer of the reference graph, with everything the reference
+ * applies around it folded in:
+ *   input  = act( scale * concat_c(x0, x1) + shift )      (x1.p may be NULL; scale/shift NULL = none)
+ *   y      = (conv(input, w) + b) * drop_mask * drop_scale   (drop_mask NULL = no dropout)
+ * ADVOC_CONV   : tf.layers.conv2d, kernel [kh,kw,cin,cout]  (advoc_model.py:25-32, 34-51);
+ *                SAME padding is passed explicitly as pad_t/pad_l (bottom/right implied by y.h/y.w).
+ * ADVOC_DECONV : tf.layers.conv2d_transpose, kernel [kh,kw,cout,cin], 4x4 stride 2 "same"
+ *                == pad_t = pad_l = 1, y.h = 2*x.h; y.w <= 2*x.w clips the output (advoc_model.py:53-69,156).
+ * x0 and x1 share n, h and the logical w; cin = x0.c + x1.c (skip concat, advoc_model.py:137,154;
+ * discriminator input concat, :184).  drop_mask is uint8 {0,1} indexed exactly like y (tf.nn.dropout,
+ * advoc_model.py:144-149; drop_scale = 1/keep_prob). */
+typedef struct advoc_conv_layer {
+  int32_t kind;
+  int32_t kh, kw, sh, sw, pad_t, pad_l;
+  int32_t in_act;
+  advoc_tensor4 x0, x1;
+  const float* in_scale;
+  const float* in_shift;
+  advoc_tensor4 y;
+  const float* w;
+  const float* b;
+  const uint8_t* drop_mask;
+  float drop_scale;
+} advoc_conv_layer;
+
+/* Forward.  Replaces TF Conv2D / Conv2DBackpropInput(+BiasAdd, activations, concat, dropout)
+ * built at advoc_model.py:89-158 (generator) and :184-202 (discriminator). */
+int advoc_conv_forward(const advoc_conv_layer* layer, advoc_stream_t stream);
+
+/* Gradient w.r.t. the layer's (pre-activation) inputs: dx0 / dx1 have the geometry of x0 / x1.
+ *   dx = act'(x) * conv_backward_data(dy * drop_mask * drop_scale, w)
+ * accum != 0 adds into the destination (an encoder output receives gradient from its next
+ * encoder AND its skip decoder).  dx1 may be NULL when x1 is absent or its gradient is unwanted;
+ * dx0 may be NULL likewise.  Pixels of dx0/dx1 at columns >= logical w are NOT written.
+ * Replaces the TF gradient ops of the same graph (tf.gradients via AdamOptimizer.minimize,
+ * advoc_model.py:254-257). */
+int advoc_conv_backward_data(const advoc_conv_layer* layer, const float* dy, float* dx0, float* dx1,
+                             int32_t accum0, int32_t accum1, advoc_stream_t stream);
+
+/* Gradient w.r.t. kernel and bias: dw has the layout of layer->w, db is [cout] (NULL = skip).
+ * Overwrites dw / db.  Replaces Conv2DBackpropFilter / BiasAddGrad. */
+int advoc_conv_backward_weight(const advoc_conv_layer* layer, const float* dy, float* dw, float* db,
+                               advoc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

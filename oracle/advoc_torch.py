@@ -147,7 +147,9 @@ def _nhwc(x):
 
 
 def lrelu(x, alpha=0.2):
-  return torch.maximum(alpha * x, x)
+  # tf.maximum(alpha * x, x) (advoc_model.py:86-87); written with where() so that the gradient at
+  # x == 0 is alpha, as TF's MaximumGrad gives (tie -> first argument), not torch.maximum's 0.6
+  return torch.where(x > 0, x, alpha * x)
 
 
 def gen_conv(x, kernel, bias, strides=(2, 2)):

@@ -1,0 +1,194 @@
+"""Every conv / transposed-conv direction of the C ABI against the torch-CPU oracle
+(oracle/advoc_torch.py), layer shapes mirroring each layer type of AdVoc / AdVoc-small at
+reduced size, including the odd widths (SAME pad (1,2)), the skip concat, the [:, :, :-1, :]
+trims, dropout masks and the thin edge layers.  Tolerance: fp32 summation-order noise."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import advoc_torch as A
+
+gpu = pytest.mark.gpu
+TOL = 2e-5
+
+
+def rel(a, b):
+  a = a.detach().double().cpu()
+  b = b.detach().double().cpu()
+  return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _act(x, act):
+  if act == 1:
+    return A.lrelu(x)
+  if act == 2:
+    return torch.relu(x)
+  return x
+
+
+def oracle_layer(kind, x0, x1, in_w, w, b, stride, pad, act, mask, keep, out_w, dy):
+  """Forward + all gradients in float64 on the CPU.  Returns y, dx0, dx1, dw, db."""
+  x0 = x0.double().requires_grad_(True)
+  x1 = x1.double().requires_grad_(True) if x1 is not None else None
+  w = w.double().requires_grad_(True)
+  b = b.double().requires_grad_(True)
+  parts = [x0[:, :, :in_w, :]] + ([x1[:, :, :in_w, :]] if x1 is not None else [])
+  inp = _act(torch.cat(parts, dim=3), act)
+  if kind == 0:
+    H, W = inp.shape[1], inp.shape[2]
+    # explicit pads: top/left as given, bottom/right whatever the output size needs
+    oh, ow = dy.shape[1], out_w
+    pb = max((oh - 1) * stride[0] + w.shape[0] - H - pad[0], 0)
+    pr = max((ow - 1) * stride[1] + w.shape[1] - W - pad[1], 0)
+    xp = torch.nn.functional.pad(inp.permute(0, 3, 1, 2), (pad[1], pr, pad[0], pb))
+    y = torch.nn.functional.conv2d(xp, w.permute(3, 2, 0, 1).contiguous(), b, stride=stride).permute(0, 2, 3, 1)
+    y = y[:, :oh, :ow]
+  else:
+    y = A.gen_deconv(inp, w, b)[:, :, :out_w, :]
+  if mask is not None:
+    y = (y / keep) * mask.double()[:, :, :out_w]
+  g = torch.autograd.grad(y, [x0, w, b] + ([x1] if x1 is not None else []), dy.double()[:, :, :out_w])
+  return y.detach(), g[0], (g[3] if x1 is not None else None), g[1], g[2]
+
+
+CASES = [
+    # name, kind, (B,H,W), c0, c1, cout, trim, stride, pad(None=SAME), act, dropout, clip_out
+    ('enc_same_odd',   0, (2, 16, 33), 32, 0, 64, 0, (2, 2), None, 1, False, 0),
+    ('enc_same_wide',  0, (2, 8, 17), 128, 0, 128, 0, (2, 2), None, 1, False, 0),
+    ('enc_n256',       0, (1, 8, 9), 64, 0, 256, 0, (2, 2), None, 1, False, 0),
+    ('enc_n32',        0, (3, 10, 13), 32, 0, 32, 0, (2, 2), None, 1, False, 0),
+    ('enc1_cin1',      0, (2, 32, 65), 1, 0, 32, 0, (2, 2), None, 0, False, 0),
+    ('dec_first_drop', 1, (2, 4, 9), 64, 0, 64, 0, (2, 2), (1, 1), 2, True, 0),
+    ('dec_skip_trim',  1, (2, 8, 17), 64, 64, 32, 1, (2, 2), (1, 1), 2, False, 0),
+    ('dec_skip_drop',  1, (2, 8, 17), 128, 64, 128, 1, (2, 2), (1, 1), 2, True, 0),
+    ('dec1_cout1',     1, (2, 16, 33), 32, 32, 1, 1, (2, 2), (1, 1), 2, False, 1),
+    ('dec1_cout1_big', 1, (1, 8, 9), 128, 128, 1, 1, (2, 2), (1, 1), 2, False, 1),
+    ('d1_cin2',        0, (2, 32, 65), 1, 1, 32, 0, (2, 2), (1, 1), 0, False, 0),
+    ('d2_even',        0, (2, 16, 32), 32, 0, 64, 0, (2, 2), (1, 1), 1, False, 0),
+    ('d4_s1',          0, (2, 9, 12), 64, 0, 128, 0, (1, 1), (1, 1), 1, False, 0),
+    ('d5_cout1',       0, (2, 9, 11), 128, 0, 1, 0, (1, 1), (1, 1), 1, False, 0),
+]
+
+
+def build_case(case, seed=0):
+  name, kind, (B, H, W), c0, c1, cout, trim, stride, pad, act, drop, clip = case
+  g = torch.Generator().manual_seed(seed)
+  x0 = torch.randn(B, H, W + trim, c0, generator=g)
+  x1 = torch.randn(B, H, W, c1, generator=g) if c1 else None
+  cin = c0 + c1
+  if kind == 0:
+    if pad is None:
+      pt, _ = A.same_pad(H, 4, stride[0])
+      pl, _ = A.same_pad(W, 4, stride[1])
+      oh, ow = -(-H // stride[0]), -(-W // stride[1])
+    else:
+      pt, pl = pad
+      oh = (H + 2 * pt - 4) // stride[0] + 1
+      ow = (W + 2 * pl - 4) // stride[1] + 1
+    w = torch.randn(4, 4, cin, cout, generator=g) * 0.05
+  else:
+    pt, pl = 1, 1
+    oh, ow = 2 * H, 2 * W - clip
+    w = torch.randn(4, 4, cout, cin, generator=g) * 0.05
+  b = torch.randn(cout, generator=g) * 0.1
+  mask = (torch.rand(B, oh, ow, cout, generator=g) >= 0.5).to(torch.uint8) if drop else None
+  dy = torch.randn(B, oh, ow, cout, generator=g)
+  return dict(kind=kind, x0=x0, x1=x1, in_w=W, w=w, b=b, stride=stride, pad=(pt, pl), act=act,
+              mask=mask, keep=0.5, out_w=ow, dy=dy, oh=oh)
+
+
+@gpu
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_layer_all_directions(hip, case):
+  from advoc_amd import conv
+  c = build_case(case)
+  dev = torch.device('cuda')
+  y_o, dx0_o, dx1_o, dw_o, db_o = oracle_layer(c['kind'], c['x0'], c['x1'], c['in_w'], c['w'], c['b'],
+                                               c['stride'], c['pad'], c['act'], c['mask'], c['keep'],
+                                               c['out_w'], c['dy'])
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w, b, dy = c['w'].to(dev), c['b'].to(dev), c['dy'].to(dev)
+  mask = c['mask'].to(dev) if c['mask'] is not None else None
+  y = torch.full((x0.shape[0], c['oh'], c['out_w'], w.shape[3] if c['kind'] == 0 else w.shape[2]),
+                 float('nan'), device=dev)
+  L = conv.Layer(c['kind'], x0, y, w, b, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'],
+                 in_act=c['act'], drop_mask=mask, drop_scale=1 / c['keep'] if mask is not None else 0.)
+  L.forward()
+  assert torch.isfinite(y).all()
+  assert rel(y, y_o) < TOL, ('fwd', rel(y, y_o))
+
+  # backward data: poison, then check every logical column; the trimmed column stays untouched
+  dx0 = torch.full_like(x0, 7.0)
+  dx1 = torch.full_like(x1, 7.0) if x1 is not None else None
+  L.backward_data(dy, dx0, dx1)
+  assert rel(dx0[:, :, :c['in_w']], dx0_o[:, :, :c['in_w']]) < TOL, ('dx0', rel(dx0[:, :, :c['in_w']], dx0_o[:, :, :c['in_w']]))
+  if x0.shape[2] > c['in_w']:
+    assert (dx0[:, :, c['in_w']:] == 7.0).all()
+    assert float(dx0_o[:, :, c['in_w']:].abs().max()) == 0.0
+  if x1 is not None:
+    assert rel(dx1, dx1_o) < TOL, ('dx1', rel(dx1, dx1_o))
+    # accumulate flag: second call adds on top
+    keep = dx1.clone()
+    L.backward_data(dy, None if c['x0'].shape[3] * 0 else dx0, dx1, accum0=False, accum1=True)
+    assert rel(dx1, 2 * keep) < TOL
+
+  dw = torch.full_like(w, float('nan'))
+  db = torch.full_like(b, float('nan'))
+  L.backward_weight(dy, dw, db)
+  assert rel(dw, dw_o) < TOL, ('dw', rel(dw, dw_o))
+  assert rel(db, db_o) < TOL, ('db', rel(db, db_o))
+
+
+@gpu
+def test_discriminator_input_gradient_only_target(hip):
+  """layer_1 backward in the G step: only d/d(target) is wanted (dx0 = NULL)."""
+  from advoc_amd import conv
+  c = build_case(CASES[10])
+  dev = torch.device('cuda')
+  _, _, dx1_o, _, _ = oracle_layer(c['kind'], c['x0'], c['x1'], c['in_w'], c['w'], c['b'], c['stride'],
+                                   c['pad'], c['act'], None, 1.0, c['out_w'], c['dy'])
+  x0, x1 = c['x0'].to(dev), c['x1'].to(dev)
+  y = torch.empty((x0.shape[0], c['oh'], c['out_w'], 32), device=dev)
+  L = conv.Layer(0, x0, y, c['w'].to(dev), c['b'].to(dev), x1=x1, stride=c['stride'], pad=c['pad'])
+  dx1 = torch.zeros_like(x1)
+  L.backward_data(c['dy'].to(dev), None, dx1)
+  assert rel(dx1, dx1_o) < TOL
+
+
+@gpu
+def test_closed_form_impulse(hip):
+  """1-channel impulse through an all-ones 4x4 stride-2 SAME conv: counts window membership,
+  pinning the asymmetric (1,2) width padding independently of torch."""
+  from advoc_amd import conv
+  dev = torch.device('cuda')
+  H, W = 8, 9      # odd width -> pad (1, 2)
+  x = torch.zeros(1, H, W, 16, device=dev)
+  x[0, 3, 8, :] = 1.0     # last column
+  w = torch.ones(4, 4, 16, 32, device=dev)
+  y = torch.empty(1, 4, 5, 32, device=dev)
+  conv.Layer(0, x, y, w, None, stride=(2, 2), pad=(1, 1)).forward()
+  want = np.zeros((4, 5))
+  for oy in range(4):
+    for ox in range(5):
+      for ky in range(4):
+        for kx in range(4):
+          if oy * 2 - 1 + ky == 3 and ox * 2 - 1 + kx == 8:
+            want[oy, ox] += 16
+  assert np.array_equal(y[0, :, :, 0].cpu().numpy(), want)
+  assert want[:, 4].sum() > 0     # the column that only exists because of the right pad of 2
+
+
+@gpu
+def test_abi_rejects_bad_layers(hip):
+  from advoc_amd import _lib, conv
+  dev = torch.device('cuda')
+  x = torch.zeros(1, 8, 8, 24, device=dev)      # 24 channels: not a multiple of 16, not thin
+  y = torch.zeros(1, 4, 4, 32, device=dev)
+  w = torch.zeros(4, 4, 24, 32, device=dev)
+  with pytest.raises(_lib.AdvocHipError):
+    conv.Layer(0, x, y, w, None, stride=(2, 2), pad=(1, 1)).forward()
+  with pytest.raises(_lib.AdvocHipError):
+    conv.Layer(0, x, y, torch.zeros(4, 4, 32, 24, device=dev), None)
+  with pytest.raises(_lib.AdvocHipError):
+    conv.Layer(0, torch.zeros(1, 8, 8, 32), y, torch.zeros(4, 4, 32, 32, device=dev), None)
