@@ -54,6 +54,10 @@ PROTOTYPES = {
     'advoc_conv_forward': (ctypes.c_int, [_p, _p]),
     'advoc_conv_backward_data': (ctypes.c_int, [_p, _p, _p, _p, _i32, _i32, _p]),
     'advoc_conv_backward_weight': (ctypes.c_int, [_p, _p, _p, _p, _p]),
+    'advoc_gan_d_loss': (ctypes.c_int, [_p, _p, _i64, _p, _p, _p, _p]),
+    'advoc_gan_g_loss': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _f32, _f32, _p, _p, _i32, _p, _p]),
+    'advoc_adam_tf_f32': (ctypes.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p]),
+    'advoc_dropout_mask_u8': (ctypes.c_int, [_p, _i64, ctypes.c_uint64, ctypes.c_uint64, _f32, _p]),
 }
 
 _lock = threading.Lock()

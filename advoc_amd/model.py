@@ -1,0 +1,579 @@
+"""AdVoc generator / discriminator / train step on MI355X.
+
+Drop-in for the model objects of /root/reference/models/advoc:
+  model.py:1-18            Model, Modes
+  util.py:1-20             override_model_attrs
+  advoc_model.py:9-289     class Advoc        (full: ngf = ndf = 64, 8 encoders)
+  advoc_model_small.py     class Advoc(small) (ngf = ndf = 32, 1 + 4 encoders)  -> AdvocSmall here
+
+What is different by construction (MI355X-first, not a TF1 graph):
+  * no graph / session: layers are bound once to pre-allocated HBM buffers (a static plan of
+    C-ABI calls, advoc_amd/conv.py) and replayed every step;
+  * parameters, gradients and Adam slots of each network live in ONE flat fp32 arena
+    (laid out in backward-completion order) so the optimiser is a single kernel launch and
+    data-parallel gradient exchange is a few large RCCL all-reduces;
+  * real and fake discriminator passes of the D step run as one 2B batch;
+  * every elementwise op of the reference graph (lrelu / relu, concat, [:, :, :-1, :] trims, bias,
+    dropout, sigmoid + log losses) is fused into the conv / loss kernels.
+Semantics kept: TF SAME padding, kernel layouts and variable names, N(0, 0.02) init,
+dropout 0.5 in every mode, D update on one batch then G update on the NEXT batch, TF Adam.
+"""
+import collections
+import math
+
+import torch
+
+from advoc_amd import _lib
+from advoc_amd import conv as C
+
+EPS = 1e-12
+
+
+class Modes(object):
+  TRAIN = 'train'
+  EVAL = 'eval'
+  INFER = 'infer'
+
+
+class Model(object):
+  def __init__(self, mode, *args, **kwargs):
+    self.mode = mode
+
+  def __call__(self):
+    raise Exception('Abstract method')
+
+  def train_loop(self):
+    raise Exception('Abstract method')
+
+  def eval_ckpt(self, ckpt_fp):
+    raise Exception('Abstract method')
+
+
+def override_model_attrs(model, overrides):
+  """'a=b,c=d' -> setattr with the type of the current attribute (reference util.py:1-20).
+  Returns (model, 'attr,value' summary of public non-callable attributes, sorted)."""
+  if overrides is not None and len(overrides.strip()):
+    for pair in overrides.split(','):
+      key, val = pair.split('=')
+      kind = type(getattr(model, key))
+      if kind == bool:
+        val = val in ['True', 'true', 't', '1']
+      elif kind == list:
+        val = val.split(';')
+      else:
+        val = kind(val)
+      setattr(model, key, val)
+  names = sorted(k for k in dir(model) if not k.startswith('_') and not callable(getattr(model, k)))
+  return model, '\n'.join('{},{}'.format(k, getattr(model, k)) for k in names)
+
+
+class _Arena(object):
+  """Flat fp32 storage for a set of named tensors; every entry starts 16-byte aligned."""
+
+  def __init__(self, specs, device):
+    self.offsets = collections.OrderedDict()
+    off = 0
+    for name, shape in specs:
+      self.offsets[name] = (off, tuple(shape))
+      n = 1
+      for s in shape:
+        n *= s
+      off += (n + 3) // 4 * 4
+    self.size = off
+    self.device = device
+
+  def new(self):
+    return torch.zeros(self.size, dtype=torch.float32, device=self.device)
+
+  def views(self, flat):
+    out = collections.OrderedDict()
+    for name, (off, shape) in self.offsets.items():
+      n = 1
+      for s in shape:
+        n *= s
+      out[name] = flat[off:off + n].view(shape)
+    return out
+
+
+class Advoc(Model):
+  audio_fs = 22050
+  subseq_len = 256
+  n_mels = 80
+  ngf = 64
+  ndf = 64
+  gan_weight = 1.
+  l1_weight = 10.
+  train_batch_size = 8
+  eval_batch_size = 1
+  separable_conv = False
+  use_batchnorm = False
+  generator_type = "pix2pix"  # only "pix2pix" is on the MI355X hot path
+
+  # --- structure (advoc_model.py:96-128) ---
+  _enc_mult = [2, 4, 8, 8, 8, 8, 8]
+  _dec_spec = [(8, 0.5), (8, 0.5), (8, 0.5), (8, 0.0), (4, 0.0), (2, 0.0), (1, 0.0)]
+  _nbins = 513
+
+  # Adam (advoc_model.py:250-251)
+  _lr, _beta1, _beta2, _adam_eps = 0.0002, 0.5, 0.999, 1e-8
+
+  def __init__(self, mode, *args, **kwargs):
+    super(Advoc, self).__init__(mode)
+    self._built = None
+    self._seed = 0
+    self._feed = None
+    self._injected_masks = None
+    self._dropout_calls = 0
+    self.step = 0
+    self.world_size = 1
+    self.rank = 0
+    self._allreduce = None
+
+  # ------------------------------------------------------------------------------------------
+  # structure helpers
+  # ------------------------------------------------------------------------------------------
+  def _encoder_channels(self):
+    return [self.ngf] + [self.ngf * m for m in self._enc_mult]
+
+  def _decoder_specs(self):
+    """[(decoder index, out channels, dropout)] for decoder_N .. decoder_2."""
+    n_enc = len(self._encoder_channels())
+    return [(n_enc - i, self.ngf * m, d) for i, (m, d) in enumerate(self._dec_spec)]
+
+  def _check_supported(self):
+    if self.generator_type != 'pix2pix':
+      raise NotImplementedError('generator_type {!r}: only "pix2pix" runs on the MI355X path'
+                                .format(self.generator_type))
+    if self.separable_conv:
+      raise NotImplementedError('separable_conv=True is a non-default ablation outside the hot path')
+    if self.use_batchnorm:
+      raise NotImplementedError('use_batchnorm=True is not built yet (default is False)')
+    if self.subseq_len % (2 ** len(self._encoder_channels())):
+      raise NotImplementedError('subseq_len must be a multiple of 2^#encoders; the (1,2)-stride '
+                                'layers of advoc_model.py:115-120 are outside the BASELINE configs')
+
+  def variable_specs(self):
+    """TF variable names and shapes.  Generator entries are ordered decoder_1 .. decoder_N,
+    encoder_N .. encoder_1 (the order their gradients complete in the backward pass)."""
+    enc = self._encoder_channels()
+    dec = self._decoder_specs()
+    g = []
+    prev = dec[-1][1] if dec else enc[-1]
+    g.append(('generator/decoder_1/conv2d_transpose', (4, 4, 1, prev + enc[0])))
+    for j in range(len(dec) - 1, -1, -1):
+      idx, c, _ = dec[j]
+      cin = enc[-1] if j == 0 else dec[j - 1][1] + enc[idx - 1]
+      g.append(('generator/decoder_%d/conv2d_transpose' % idx, (4, 4, c, cin)))
+    for i in range(len(enc) - 1, -1, -1):
+      cin = 1 if i == 0 else enc[i - 1]
+      g.append(('generator/encoder_%d/conv2d' % (i + 1), (4, 4, cin, enc[i])))
+    d = []
+    chans = [self.ndf, self.ndf * 2, self.ndf * 4, self.ndf * 8, 1]
+    for i in range(4, -1, -1):
+      cin = 2 if i == 0 else chans[i - 1]
+      d.append(('discriminator/layer_%d/conv2d' % (i + 1), (4, 4, cin, chans[i])))
+
+    def expand(lst):
+      out = []
+      for scope, kshape in lst:
+        cout = kshape[2] if 'transpose' in scope else kshape[3]
+        out.append((scope + '/kernel', kshape))
+        out.append((scope + '/bias', (cout,)))
+      return out
+    return expand(g), expand(d)
+
+  # ------------------------------------------------------------------------------------------
+  # build: allocate arenas + activation buffers, bind layers
+  # ------------------------------------------------------------------------------------------
+  def build(self, batch_size=None, seed=None, device=None):
+    """Allocates parameters (N(0,0.02) kernels, zero biases: advoc_model.py:30,36) and the
+    per-batch activation plan.  Called lazily by the first forward / train_loop."""
+    self._check_supported()
+    _lib.load()
+    dev = device or _lib.device()
+    if seed is not None:
+      self._seed = seed
+    B = int(batch_size or (self.train_batch_size if self.mode == Modes.TRAIN else self.eval_batch_size))
+    if self._built is not None and self._built['B'] == B:
+      return self
+    st = self._built or {}
+    gspec, dspec = self.variable_specs()
+    if 'g_arena' not in st:
+      st['g_arena'], st['d_arena'] = _Arena(gspec, dev), _Arena(dspec, dev)
+      for net in ('g', 'd'):
+        ar = st[net + '_arena']
+        st[net + '_param'] = ar.new()
+        st[net + '_grad'] = ar.new()
+        st[net + '_m'] = ar.new()
+        st[net + '_v'] = ar.new()
+        st[net + '_P'] = ar.views(st[net + '_param'])
+        st[net + '_G'] = ar.views(st[net + '_grad'])
+      gen = torch.Generator().manual_seed(self._seed)
+      for net in ('g', 'd'):
+        for name, t in st[net + '_P'].items():
+          if name.endswith('/kernel'):
+            t.copy_(torch.randn(t.shape, generator=gen) * 0.02)
+      st['g_t'] = st['d_t'] = 0
+      st['sums'] = torch.zeros(4, dtype=torch.float32, device=dev)
+    st['B'] = B
+    self._bind(st, B, dev)
+    self._built = st
+    return self
+
+  def _bind(self, st, B, dev):
+    f32 = dict(dtype=torch.float32, device=dev)
+    T, F = self.subseq_len, self._nbins
+    enc_c = self._encoder_channels()
+    dec = self._decoder_specs()
+    P, G = st['g_P'], st['g_G']
+
+    # ---- generator buffers ----
+    st['x_in'] = torch.zeros(B, T, F, 1, **f32)
+    # discriminator inputs for a 2B batch: [real ; fake]; G writes its output into the fake half
+    st['d_cond'] = torch.zeros(2 * B, T, F, 1, **f32)
+    st['d_target'] = torch.zeros(2 * B, T, F, 1, **f32)
+    gen_out = st['d_target'][B:]
+    st['gen_out'] = gen_out
+    st['g_gen_out'] = torch.zeros(B, T, F, 1, **f32)
+    e, ge = [], []
+    h, w = T, F
+    for c in enc_c:
+      h, w = -(-h // 2), -(-w // 2)
+      e.append(torch.zeros(B, h, w, c, **f32))
+      ge.append(torch.zeros(B, h, w, c, **f32))
+    st['enc'], st['g_enc'] = e, ge
+    d, gd, masks = {}, {}, {}
+    for j, (idx, c, drop) in enumerate(dec):
+      src = e[-1] if j == 0 else d[dec[j - 1][0]]
+      hh = src.shape[1] * 2
+      ww = (src.shape[2] if j == 0 else e[idx - 1].shape[2]) * 2
+      d[idx] = torch.zeros(B, hh, ww, c, **f32)
+      gd[idx] = torch.zeros(B, hh, ww, c, **f32)     # trimmed column stays zero forever
+      if drop > 0:
+        masks[idx] = (torch.zeros(B, hh, ww, c, dtype=torch.uint8, device=dev), 1.0 - drop)
+    st['dec'], st['g_dec'], st['masks'] = d, gd, masks
+
+    # ---- generator layers ----
+    L = collections.OrderedDict()
+    x = st['x_in']
+    for i, c in enumerate(enc_c):
+      s = 'generator/encoder_%d/conv2d' % (i + 1)
+      src = x if i == 0 else e[i - 1]
+      pt, _ = C.same_pad(src.shape[1], 4, 2)
+      pl, _ = C.same_pad(src.shape[2], 4, 2)
+      L['encoder_%d' % (i + 1)] = C.Layer(C.CONV, src, e[i], P[s + '/kernel'], P[s + '/bias'],
+                                          stride=(2, 2), pad=(pt, pl),
+                                          in_act=C.ACT_NONE if i == 0 else C.ACT_LRELU)
+    for j, (idx, c, drop) in enumerate(dec):
+      s = 'generator/decoder_%d/conv2d_transpose' % idx
+      if j == 0:
+        x0, x1, in_w = e[-1], None, None
+      else:
+        x0, x1 = d[dec[j - 1][0]], e[idx - 1]
+        in_w = x1.shape[2]                      # layers[-1][:, :, :-1, :]  (advoc_model.py:137)
+      mk = masks.get(idx)
+      L['decoder_%d' % idx] = C.Layer(C.DECONV, x0, d[idx], P[s + '/kernel'], P[s + '/bias'], x1=x1,
+                                      in_w=in_w, stride=(2, 2), pad=(1, 1), in_act=C.ACT_RELU,
+                                      drop_mask=mk[0] if mk else None,
+                                      drop_scale=1.0 / mk[1] if mk else 0.)
+    s = 'generator/decoder_1/conv2d_transpose'
+    last = d[dec[-1][0]] if dec else e[-1]
+    L['decoder_1'] = C.Layer(C.DECONV, last, gen_out, P[s + '/kernel'], P[s + '/bias'], x1=e[0],
+                             in_w=e[0].shape[2], out_w=F, stride=(2, 2), pad=(1, 1), in_act=C.ACT_RELU)
+    st['g_layers'] = L
+
+    # ---- discriminator buffers + layers: full 2B batch (D step) and fake half only (G step) ----
+    chans = [self.ndf, self.ndf * 2, self.ndf * 4, self.ndf * 8, 1]
+    strides = [2, 2, 2, 1, 1]
+    a, ga = [], []
+    h, w = T, F
+    for c, s_ in zip(chans, strides):
+      h, w = (h + 2 - 4) // s_ + 1, (w + 2 - 4) // s_ + 1
+      a.append(torch.zeros(2 * B, h, w, c, **f32))
+      ga.append(torch.zeros(2 * B, h, w, c, **f32))
+    st['d_act'], st['g_d_act'] = a, ga
+    DP = st['d_P']
+
+    def d_layers(lo):
+      out = []
+      for i in range(5):
+        s = 'discriminator/layer_%d/conv2d' % (i + 1)
+        if i == 0:
+          lay = C.Layer(C.CONV, st['d_cond'][lo:], a[0][lo:], DP[s + '/kernel'], DP[s + '/bias'],
+                        x1=st['d_target'][lo:], stride=(2, 2), pad=(1, 1), in_act=C.ACT_NONE)
+        else:
+          lay = C.Layer(C.CONV, a[i - 1][lo:], a[i][lo:], DP[s + '/kernel'], DP[s + '/bias'],
+                        stride=(strides[i],) * 2, pad=(1, 1), in_act=C.ACT_LRELU)
+        out.append(lay)
+      return out
+    st['d_layers_2b'] = d_layers(0)
+    st['d_layers_fake'] = d_layers(B)
+    st['g_d_target'] = torch.zeros(2 * B, T, F, 1, **f32)
+
+  # ------------------------------------------------------------------------------------------
+  # parameters in / out (TF variable names)
+  # ------------------------------------------------------------------------------------------
+  def state_dict(self):
+    self.build()
+    out = collections.OrderedDict()
+    for net in ('g', 'd'):
+      for k, v in self._built[net + '_P'].items():
+        out[k] = v.detach().clone()
+    out['global_step'] = torch.tensor(self.step)
+    return out
+
+  def load_state_dict(self, state):
+    self.build()
+    for net in ('g', 'd'):
+      for k, v in self._built[net + '_P'].items():
+        if k in state:
+          v.copy_(state[k].to(v.device, torch.float32))
+    if 'global_step' in state:
+      self.step = int(state['global_step'])
+
+  def optimizer_state(self):
+    st = self._built
+    return {k: st[k].detach().clone() for k in ('g_m', 'g_v', 'd_m', 'd_v')}, (st['g_t'], st['d_t'])
+
+  def load_optimizer_state(self, tensors, steps):
+    st = self._built
+    for k in ('g_m', 'g_v', 'd_m', 'd_v'):
+      st[k].copy_(tensors[k])
+    st['g_t'], st['d_t'] = steps
+
+  @property
+  def G_vars(self):
+    self.build()
+    return list(self._built['g_P'].keys())
+
+  @property
+  def D_vars(self):
+    self.build()
+    return list(self._built['d_P'].keys())
+
+  # ------------------------------------------------------------------------------------------
+  # dropout
+  # ------------------------------------------------------------------------------------------
+  def set_dropout_masks(self, masks):
+    """Inject {0,1} masks {'decoder_N': tensor like the layer output} (parity tests); None
+    returns to the on-device Philox stream."""
+    self._injected_masks = masks
+
+  def _refresh_masks(self, clip_offset=0):
+    st = self._built
+    if self._injected_masks is not None:
+      for idx, (buf, keep) in st['masks'].items():
+        buf.copy_(self._injected_masks['decoder_%d' % idx].to(buf.device).to(torch.uint8))
+      return
+    lib = _lib.load()
+    self._dropout_calls += 1
+    for idx, (buf, keep) in st['masks'].items():
+      per_clip = buf[0].numel()
+      seed = (self._seed * 1000003 + idx) * 2654435761 + self._dropout_calls
+      _lib.check(lib.advoc_dropout_mask_u8(_lib.ptr(buf), buf.numel(), seed & (2 ** 64 - 1),
+                                           (clip_offset * per_clip + 3) // 4 * 4, keep, _lib.stream()),
+                 'advoc_dropout_mask_u8')
+
+  # ------------------------------------------------------------------------------------------
+  # forward passes
+  # ------------------------------------------------------------------------------------------
+  def _gen_forward(self, x):
+    st = self._built
+    if x.data_ptr() != st['x_in'].data_ptr():
+      st['x_in'].copy_(x)
+    self._refresh_masks(self.rank * st['B'])
+    for lay in st['g_layers'].values():
+      lay.forward()
+    return st['gen_out']
+
+  def build_generator(self, x):
+    """x: [B, subseq_len, 513, 1] float32 -> generated magnitude spectrogram, same shape
+    (advoc_model.py:75-166).  Dropout is active in every mode, as in the reference."""
+    x = x if isinstance(x, torch.Tensor) else torch.as_tensor(x)
+    x = x.to(_lib.device(), torch.float32)
+    self.build(batch_size=x.shape[0])
+    return self._gen_forward(x).clone()
+
+  def build_discriminator(self, discrim_inputs, discrim_targets):
+    """[B,T,513,1] x2 -> patch probabilities [B, 30, 62, 1] (advoc_model.py:168-204)."""
+    dev = _lib.device()
+    cond = torch.as_tensor(discrim_inputs).to(dev, torch.float32)
+    tgt = torch.as_tensor(discrim_targets).to(dev, torch.float32)
+    self.build(batch_size=cond.shape[0])
+    st = self._built
+    B = st['B']
+    st['d_cond'][B:].copy_(cond)
+    st['d_target'][B:].copy_(tgt)
+    for lay in st['d_layers_fake']:
+      lay.forward()
+    return torch.sigmoid(st['d_act'][4][B:])
+
+  # ------------------------------------------------------------------------------------------
+  # train step
+  # ------------------------------------------------------------------------------------------
+  def __call__(self, x, target=None, x_wav=None, x_mel_spec=None):
+    """Wires the model to its inputs (the reference builds the loss / optimiser graph here,
+    advoc_model.py:206-281).  `x` is either a callable returning a fresh
+    (x_inverted, x_magspec, x_wav, x_melspec) tuple per call -- the analogue of the reference's
+    iterator-backed tensors, each train op pulling a NEW batch -- or a fixed batch
+    (x, target[, x_wav, x_mel_spec]) of device tensors that every step reuses."""
+    if callable(x):
+      self._feed = x
+    else:
+      fixed = (x, target, x_wav, x_mel_spec)
+      self._feed = lambda: fixed
+    return self
+
+  def _adam(self, net):
+    st = self._built
+    st[net + '_t'] += 1
+    t = st[net + '_t']
+    lr_t = self._lr * math.sqrt(1 - self._beta2 ** t) / (1 - self._beta1 ** t)
+    flat = st[net + '_grad']
+    if self._allreduce is not None:
+      self._allreduce(flat)
+    _lib.check(_lib.load().advoc_adam_tf_f32(
+        _lib.ptr(st[net + '_param']), _lib.ptr(flat), _lib.ptr(st[net + '_m']), _lib.ptr(st[net + '_v']),
+        flat.numel(), lr_t, self._beta1, self._beta2, self._adam_eps, 1.0 / self.world_size,
+        _lib.stream()), 'advoc_adam_tf_f32')
+
+  def _load_batch(self, batch):
+    st = self._built
+    B = st['B']
+    x, target = batch[0], batch[1]
+    st['x_in'].copy_(x)
+    st['d_cond'][:B].copy_(x)
+    st['d_cond'][B:].copy_(x)
+    st['d_target'][:B].copy_(target)
+
+  def d_step(self, batch):
+    """One discriminator update on `batch` (advoc_model.py:238,257): G forward, D over
+    [real ; fake] as one 2B batch, discrim_loss, D weight gradients, Adam."""
+    st = self._built
+    lib = _lib.load()
+    B = st['B']
+    self._load_batch(batch)
+    self._gen_forward(st['x_in'])
+    Ld = st['d_layers_2b']
+    for lay in Ld:
+      lay.forward()
+    logits = st['d_act'][4]
+    glog = st['g_d_act'][4]
+    n = logits[:B].numel()
+    _lib.check(lib.advoc_gan_d_loss(_lib.ptr(logits[:B]), _lib.ptr(logits[B:]), n, _lib.ptr(glog[:B]),
+                                    _lib.ptr(glog[B:]), _lib.ptr(st['sums'][0:1]), _lib.stream()),
+               'advoc_gan_d_loss')
+    DG = st['d_G']
+    for i in range(4, -1, -1):
+      s = 'discriminator/layer_%d/conv2d' % (i + 1)
+      Ld[i].backward_weight(st['g_d_act'][i], DG[s + '/kernel'], DG[s + '/bias'])
+      if i > 0:
+        Ld[i].backward_data(st['g_d_act'][i], st['g_d_act'][i - 1])
+    self._adam('d')
+    st['last_counts_d'] = n
+
+  def g_step(self, batch):
+    """One generator update on `batch` (advoc_model.py:239-245,254-255): G forward, D(fake)
+    forward, gen_loss, backward through D to the generator output, G backward, Adam."""
+    st = self._built
+    lib = _lib.load()
+    B = st['B']
+    self._load_batch(batch)
+    gen = self._gen_forward(st['x_in'])
+    use_gan = self.gan_weight > 0
+    g_out = st['g_d_target'][B:]            # gradient w.r.t. the generator output
+    logits = st['d_act'][4][B:]
+    glog = st['g_d_act'][4][B:]
+    Lf = st['d_layers_fake']
+    if use_gan:
+      for lay in Lf:
+        lay.forward()
+    _lib.check(lib.advoc_gan_g_loss(
+        _lib.ptr(logits) if use_gan else None, logits.numel(), _lib.ptr(gen), _lib.ptr(st['d_target'][:B]),
+        gen.numel(), float(self.gan_weight), float(self.l1_weight), _lib.ptr(glog) if use_gan else None,
+        _lib.ptr(g_out), 0, _lib.ptr(st['sums'][1:3]), _lib.stream()), 'advoc_gan_g_loss')
+    if use_gan:
+      for i in range(4, 0, -1):
+        Lf[i].backward_data(st['g_d_act'][i][B:], st['g_d_act'][i - 1][B:])
+      Lf[0].backward_data(st['g_d_act'][0][B:], None, g_out, accum1=True)
+    # generator backward: decoder_1 .. decoder_N, then encoder_N .. encoder_1
+    GL, GG = st['g_layers'], st['g_G']
+    dec = self._decoder_specs()
+    e, ge, gd = st['enc'], st['g_enc'], st['g_dec']
+    s = 'generator/decoder_1/conv2d_transpose'
+    GL['decoder_1'].backward_weight(g_out, GG[s + '/kernel'], GG[s + '/bias'])
+    last_idx = dec[-1][0] if dec else None
+    GL['decoder_1'].backward_data(g_out, gd[last_idx] if dec else ge[-1], ge[0])
+    for j in range(len(dec) - 1, -1, -1):
+      idx = dec[j][0]
+      s = 'generator/decoder_%d/conv2d_transpose' % idx
+      lay = GL['decoder_%d' % idx]
+      lay.backward_weight(gd[idx], GG[s + '/kernel'], GG[s + '/bias'])
+      if j == 0:
+        lay.backward_data(gd[idx], ge[-1])
+      else:
+        lay.backward_data(gd[idx], gd[dec[j - 1][0]], ge[idx - 1])
+    for i in range(len(e) - 1, -1, -1):
+      s = 'generator/encoder_%d/conv2d' % (i + 1)
+      lay = GL['encoder_%d' % (i + 1)]
+      lay.backward_weight(ge[i], GG[s + '/kernel'], GG[s + '/bias'])
+      if i > 0:
+        lay.backward_data(ge[i], ge[i - 1], accum0=True)
+    self._adam('g')
+    self.step += 1
+    st['last_counts_g'] = (logits.numel(), gen.numel())
+
+  def train_loop(self, sess=None):
+    """D update on one batch, G update on the NEXT batch; returns the global step
+    (reference advoc_model.py:285-289; `sess` is accepted and ignored)."""
+    if self._feed is None:
+      raise RuntimeError('call model(feed) first')
+    batch = self._feed()
+    self.build(batch_size=batch[0].shape[0])
+    if self.gan_weight > 0:
+      self.d_step(batch)
+      batch = self._feed()
+    self.g_step(batch)
+    return self.step
+
+  def losses(self):
+    """Last step's loss scalars (one device->host sync): the tf.summary.scalar values of
+    advoc_model.py:272-275."""
+    st = self._built
+    s = st['sums'].cpu()
+    out = {}
+    if 'last_counts_d' in st:
+      out['disc_loss'] = float(s[0]) / st['last_counts_d']
+    if 'last_counts_g' in st:
+      nl, ns = st['last_counts_g']
+      out['gen_loss_GAN'] = float(s[1]) / nl
+      out['gen_loss_L1'] = float(s[2]) / ns
+      out['gen_loss_total'] = (out['gen_loss_GAN'] * self.gan_weight if self.gan_weight > 0 else 0.) \
+          + out['gen_loss_L1'] * self.l1_weight
+    return out
+
+  def l1_eval(self, x, target):
+    """mean |target - G(x)| (train_evaluate.py:137, eval mode)."""
+    gen = self.build_generator(x)
+    st = self._built
+    tgt = torch.as_tensor(target).to(gen.device, torch.float32).contiguous()
+    _lib.check(_lib.load().advoc_gan_g_loss(None, 0, _lib.ptr(gen), _lib.ptr(tgt), gen.numel(), 0.0, 1.0,
+                                            None, None, 0, _lib.ptr(st['sums'][1:3]), _lib.stream()),
+               'advoc_gan_g_loss')
+    return float(st['sums'][2].cpu()) / gen.numel(), gen
+
+
+class AdvocSmall(Advoc):
+  """advoc_model_small.py: ngf = ndf = 32, encoder_1 + 4 encoders, dropout on decoder_5/4."""
+  ngf = 32
+  ndf = 32
+  num_enc_layers = 4
+  _dec_spec_small = [(8, 0.5), (8, 0.5), (8, 0.5), (8, 0.5), (4, 0.5), (2, 0.0), (1, 0.0)]
+
+  def _encoder_channels(self):
+    return [self.ngf] + [self.ngf * m for m in self._enc_mult[:self.num_enc_layers]]
+
+  def _decoder_specs(self):
+    spec = self._dec_spec_small[len(self._dec_spec_small) - self.num_enc_layers:]
+    n_enc = 1 + self.num_enc_layers
+    return [(n_enc - i, self.ngf * m, d) for i, (m, d) in enumerate(spec)]

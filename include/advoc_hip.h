@@ -144,6 +144,38 @@ int advoc_conv_backward_data(const advoc_conv_layer* layer, const float* dy, flo
 int advoc_conv_backward_weight(const advoc_conv_layer* layer, const float* dy, float* dw, float* db,
                                advoc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Losses, optimiser, dropout masks
+ * ---------------------------------------------------------------------------------------- */
+
+/* Discriminator loss (advoc_model.py:238) on raw layer_5 logits (the sigmoid of :201 is fused):
+ *   loss_sum[0] = sum_i -(log(sigmoid(zr_i) + 1e-12) + log(1 - sigmoid(zf_i) + 1e-12))
+ *   dlogit_* = d(mean loss)/dz  (NULL = not wanted).  discrim_loss = loss_sum[0] / n. */
+int advoc_gan_d_loss(const float* logit_real, const float* logit_fake, int64_t n, float* dlogit_real,
+                     float* dlogit_fake, float* loss_sum, advoc_stream_t stream);
+
+/* Generator loss (advoc_model.py:239-245):  gan_weight * mean(-log(sigmoid(zf) + 1e-12))
+ *                                          + l1_weight * mean(|target - gen|)
+ *   loss_sums[0] = sum -log(sigmoid(zf)+1e-12), loss_sums[1] = sum |target - gen|
+ *   dlogit_fake  = d gen_loss / d zf;  dgen (+)= l1 part of d gen_loss / d gen (accum_dgen != 0 adds).
+ * logit_fake may be NULL (gan_weight <= 0, or the eval L1 metric of train_evaluate.py:143). */
+int advoc_gan_g_loss(const float* logit_fake, int64_t n_logits, const float* gen, const float* target,
+                     int64_t n_spec, float gan_weight, float l1_weight, float* dlogit_fake, float* dgen,
+                     int32_t accum_dgen, float* loss_sums, advoc_stream_t stream);
+
+/* One TF-style Adam step over a flat parameter arena (tf.train.AdamOptimizer, advoc_model.py:250-257):
+ *   g' = grad_scale * g;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
+ *   param -= lr_t * m / (sqrt(v) + epsilon),   lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) from the caller.
+ * All four arrays must be 16-byte aligned. */
+int advoc_adam_tf_f32(float* param, const float* grad, float* m, float* v, int64_t count, float lr_t,
+                      float beta1, float beta2, float epsilon, float grad_scale, advoc_stream_t stream);
+
+/* tf.nn.dropout keep mask (advoc_model.py:144-149): mask[i] = floor(keep_prob + u_i) in {0,1},
+ * u_i = Philox-4x32-10(seed, offset + i) -- a pure function of (seed, offset + i), so a global
+ * batch sharded over GPUs draws the same mask as the unsharded batch.  offset % 4 == 0. */
+int advoc_dropout_mask_u8(uint8_t* mask, int64_t count, uint64_t seed, uint64_t offset, float keep_prob,
+                          advoc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

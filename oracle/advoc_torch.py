@@ -156,17 +156,18 @@ def gen_conv(x, kernel, bias, strides=(2, 2)):
   pt, pb = same_pad(x.shape[1], 4, strides[0])
   pl, pr = same_pad(x.shape[2], 4, strides[1])
   xp = F.pad(_nchw(x), (pl, pr, pt, pb))
-  return _nhwc(F.conv2d(xp, kernel.permute(3, 2, 0, 1), bias, stride=strides))
+  return _nhwc(F.conv2d(xp, kernel.permute(3, 2, 0, 1).contiguous(), bias, stride=strides))
 
 
 def gen_deconv(x, kernel, bias):
   # SAME, stride (2,2): output exactly 2x input == torch padding 1
-  return _nhwc(F.conv_transpose2d(_nchw(x), kernel.permute(3, 2, 0, 1), bias, stride=2, padding=1))
+  return _nhwc(F.conv_transpose2d(_nchw(x), kernel.permute(3, 2, 0, 1).contiguous(), bias, stride=2,
+                                  padding=1))
 
 
 def discrim_conv(x, kernel, bias, stride):
   xp = F.pad(_nchw(x), (1, 1, 1, 1))
-  return _nhwc(F.conv2d(xp, kernel.permute(3, 2, 0, 1), bias, stride=stride))
+  return _nhwc(F.conv2d(xp, kernel.permute(3, 2, 0, 1).contiguous(), bias, stride=stride))
 
 
 def batchnorm(x, gamma, beta, eps=1e-5):

@@ -1,0 +1,214 @@
+"""AdVoc / AdVoc-small networks, losses, gradients and one full train_loop on MI355X against
+the torch-CPU oracle (same weights, same inputs, injected dropout masks).
+Bar: 1e-4 relative L2 (north_star); fp32-exact MFMA typically lands at ~1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import advoc_torch as A
+
+gpu = pytest.mark.gpu
+BAR = 1e-4        # north_star bar, applied to every forward tensor (achieved: ~1e-6)
+GRAD_BAR = 5e-4   # gradients through up to 37 stacked fp32 layers (G step: G fwd, D fwd, D bwd, G bwd);
+                  # the oracle side is float64, and a float32 torch-CPU run of the same graph is
+                  # measured alongside to show this is fp32 round-off, not a defect
+
+
+def rel(a, b):
+  a = a.detach().double().cpu()
+  b = b.detach().double().cpu()
+  return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def make(small, subseq_len, B, seed=0):
+  from advoc_amd.model import Advoc, AdvocSmall, Modes
+  cfg = A.Config(small=small, subseq_len=subseq_len)
+  P = A.init_params(cfg, seed=seed)
+  # non-zero biases so the bias path is exercised
+  g = torch.Generator().manual_seed(seed + 1)
+  for k in P:
+    if k.endswith('/bias'):
+      P[k] = torch.randn(P[k].shape, generator=g) * 0.05
+  m = (AdvocSmall if small else Advoc)(Modes.TRAIN)
+  m.subseq_len = subseq_len
+  m.train_batch_size = B
+  m.build(batch_size=B)
+  m.load_state_dict(P)
+  return cfg, P, m
+
+
+def batch(B, T, seed):
+  g = torch.Generator().manual_seed(seed)
+  target = torch.rand(B, T, 513, 1, generator=g) * 2
+  x = target * (0.5 + torch.rand(B, T, 513, 1, generator=g)) - 0.1
+  return x, target
+
+
+def dev_masks(masks):
+  return {k: v.to(torch.uint8) for k, v in masks.items()}
+
+
+@gpu
+@pytest.mark.parametrize('small,T,B', [(True, 32, 2), (True, 64, 1), (False, 256, 1)])
+def test_forward_losses_and_gradients(hip, small, T, B):
+  cfg, P, m = make(small, T, B)
+  x, target = batch(B, T, 5)
+  masks = A.make_dropout_masks(cfg, B, seed=3)
+  m.set_dropout_masks(dev_masks(masks))
+  dev = torch.device('cuda')
+  xb, tb = x.to(dev), target.to(dev)
+
+  # generator forward, every layer
+  coll = []
+  gen_o = A.build_generator(P, x, cfg, masks, coll)
+  gen = m.build_generator(xb)
+  st = m._built
+  for i, e in enumerate(st['enc']):
+    assert rel(e, coll[i]) < BAR, ('encoder', i + 1, rel(e, coll[i]))
+  assert rel(gen, gen_o) < BAR
+  assert tuple(gen.shape) == (B, T, 513, 1)
+
+  # discriminator probabilities
+  p_o = A.build_discriminator(P, x, target, cfg)
+  p = m.build_discriminator(xb, tb)
+  assert tuple(p.shape) == tuple(p_o.shape) and rel(p, p_o) < BAR
+
+  # D step gradients + loss (float64 oracle)
+  P64 = {k: v.double() for k, v in P.items()}
+  m64 = {k: v.double() for k, v in masks.items()}
+  gD, LD = A.grads(P64, x.double(), target.double(), cfg, m64, 'D')
+  m._allreduce = None
+  lr = m._lr
+  m._lr = 0.0           # freeze parameters: inspect raw gradients
+  m.d_step((xb, tb))
+  assert abs(m.losses()['disc_loss'] - float(LD['d_loss'])) < 1e-4 * max(1, abs(float(LD['d_loss'])))
+  for k, v in gD.items():
+    assert rel(st['d_G'][k], v) < GRAD_BAR, (k, rel(st['d_G'][k], v))
+
+  # G step gradients + losses
+  gG, LG = A.grads(P64, x.double(), target.double(), cfg, m64, 'G')
+  gG32, _ = A.grads(P, x, target, cfg, masks, 'G')
+  m.g_step((xb, tb))
+  ls = m.losses()
+  assert abs(ls['gen_loss_GAN'] - float(LG['g_gan'])) < 1e-4 * max(1, abs(float(LG['g_gan'])))
+  assert abs(ls['gen_loss_L1'] - float(LG['g_l1'])) < 1e-4 * max(1, abs(float(LG['g_l1'])))
+  assert abs(ls['gen_loss_total'] - float(LG['g_loss'])) < 1e-4 * max(1, abs(float(LG['g_loss'])))
+  worst = max(rel(st['g_G'][k], v) for k, v in gG.items())
+  worst32 = max(rel(gG32[k], v) for k, v in gG.items())
+  print('worst G-grad rel-L2 vs float64 oracle: HIP %.3g, torch-CPU float32 %.3g' % (worst, worst32))
+  for k, v in gG.items():
+    # the 16-layer full model is ill-conditioned in fp32 at its 1x3 bottleneck (ReLU gates flip on
+    # round-off): judge each tensor against what plain fp32 evaluation of the same graph achieves
+    assert rel(st['g_G'][k], v) < max(GRAD_BAR, 3 * rel(gG32[k], v)), (k, rel(st['g_G'][k], v), rel(gG32[k], v))
+  assert worst < 4 * max(worst32, 2e-5)     # no worse than ordinary fp32 evaluation of the same graph
+  m._lr = lr
+
+
+@gpu
+def test_train_loop_matches_oracle_trainer(hip):
+  """Two full train_loop iterations (D on batch k, G on batch k+1, TF Adam) vs the oracle."""
+  small, T, B = True, 32, 2
+  cfg, P, m = make(small, T, B, seed=7)
+  tr = A.Trainer(cfg, seed=7)
+  tr.P = {k: v.clone() for k, v in P.items()}
+  Gk, Dk = A.split_vars(tr.P)
+  tr.g_opt, tr.d_opt = A.AdamTF(Gk, tr.P), A.AdamTF(Dk, tr.P)
+  dev = torch.device('cuda')
+  batches = [batch(B, T, 100 + i) for i in range(4)]
+  masks = [A.make_dropout_masks(cfg, B, seed=50 + i) for i in range(4)]
+  it = iter(range(4))
+
+  def feed():
+    i = next(it)
+    m.set_dropout_masks(dev_masks(masks[i]))
+    return batches[i][0].to(dev), batches[i][1].to(dev)
+  m(feed)
+  for step in range(2):
+    s_o, info = tr.train_loop(batches[2 * step], batches[2 * step + 1], masks[2 * step], masks[2 * step + 1])
+    s = m.train_loop()
+    assert s == s_o == step + 1
+    ls = m.losses()
+    assert abs(ls['disc_loss'] - info['d_loss']) < 1e-4 * max(1, abs(info['d_loss']))
+    assert abs(ls['gen_loss_total'] - info['g_loss']) < 1e-4 * max(1, abs(info['g_loss']))
+  sd = m.state_dict()
+  for k, v in tr.P.items():
+    # Adam's first steps move every weight by ~lr regardless of gradient size: compare the UPDATE
+    upd_o = v - P[k]
+    upd = sd[k].cpu() - P[k]
+    assert rel(upd, upd_o) < 2e-3, (k, rel(upd, upd_o))
+    assert rel(sd[k], v) < 1e-5, k
+
+
+@gpu
+def test_reference_train_schedule_consumes_two_batches(hip):
+  """train_loop pulls TWO batches per iteration when gan_weight > 0, one otherwise
+  (advoc_model.py:285-289)."""
+  cfg, P, m = make(True, 32, 1)
+  dev = torch.device('cuda')
+  calls = []
+
+  def feed():
+    calls.append(1)
+    x, t = batch(1, 32, len(calls))
+    return x.to(dev), t.to(dev)
+  m(feed)
+  m.train_loop()
+  assert len(calls) == 2
+  m.gan_weight = 0.
+  m.train_loop()
+  assert len(calls) == 3 and m.step == 2
+  d_before = m.state_dict()
+  m.train_loop()
+  d_after = m.state_dict()
+  # with gan_weight <= 0 the discriminator is not updated
+  for k in d_before:
+    if k.startswith('discriminator'):
+      assert torch.equal(d_before[k], d_after[k])
+
+
+@gpu
+def test_dropout_stream_statistics_and_determinism(hip):
+  from advoc_amd import _lib
+  dev = torch.device('cuda')
+  n = 1 << 20
+  a = torch.zeros(n, dtype=torch.uint8, device=dev)
+  b = torch.zeros(n, dtype=torch.uint8, device=dev)
+  lib = _lib.load()
+  for keep in (0.5, 0.8):
+    _lib.check(lib.advoc_dropout_mask_u8(_lib.ptr(a), n, 1234, 0, keep, _lib.stream()))
+    _lib.check(lib.advoc_dropout_mask_u8(_lib.ptr(b), n, 1234, 0, keep, _lib.stream()))
+    assert torch.equal(a, b)
+    assert abs(float(a.float().mean()) - keep) < 3e-3
+    assert set(a.unique().tolist()) <= {0, 1}
+  # sharding invariance: the second half drawn with an offset equals the tail of the full draw
+  _lib.check(lib.advoc_dropout_mask_u8(_lib.ptr(a), n, 99, 0, 0.5, _lib.stream()))
+  half = torch.zeros(n // 2, dtype=torch.uint8, device=dev)
+  _lib.check(lib.advoc_dropout_mask_u8(_lib.ptr(half), n // 2, 99, n // 2, 0.5, _lib.stream()))
+  assert torch.equal(half, a[n // 2:])
+  _lib.check(lib.advoc_dropout_mask_u8(_lib.ptr(b), n, 100, 0, 0.5, _lib.stream()))
+  assert not torch.equal(a, b)
+
+
+@gpu
+def test_adam_matches_tf_formula(hip):
+  from advoc_amd import _lib
+  import math
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(0)
+  n = 1000 + 3
+  p0 = torch.zeros(n)   # start at 0 so the update itself is what is compared (no cancellation)
+  grads = [torch.randn(n, generator=g) * 10 ** (-i) for i in range(3)]
+  p = p0.clone().to(dev)
+  pad = lambda t: t  # noqa: E731
+  m_ = torch.zeros(n, device=dev)
+  v_ = torch.zeros(n, device=dev)
+  pr, mr, vr = p0.double().clone(), torch.zeros(n).double(), torch.zeros(n).double()
+  for t, gr in enumerate(grads, 1):
+    lr_t = 0.0002 * math.sqrt(1 - 0.999 ** t) / (1 - 0.5 ** t)
+    _lib.check(_lib.load().advoc_adam_tf_f32(_lib.ptr(p), _lib.ptr(gr.to(dev)), _lib.ptr(m_), _lib.ptr(v_),
+                                             n, lr_t, 0.5, 0.999, 1e-8, 0.5, _lib.stream()))
+    gd = gr.double() * 0.5
+    mr = 0.5 * mr + 0.5 * gd
+    vr = 0.999 * vr + 0.001 * gd * gd
+    pr = pr - lr_t * mr / (vr.sqrt() + 1e-8)
+  assert rel(p.cpu() - p0, (pr - p0.double())) < 1e-5
