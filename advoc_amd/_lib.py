@@ -54,6 +54,8 @@ PROTOTYPES = {
     'advoc_conv_forward': (ctypes.c_int, [_p, _p]),
     'advoc_conv_backward_data': (ctypes.c_int, [_p, _p, _p, _p, _i32, _i32, _p]),
     'advoc_conv_backward_weight': (ctypes.c_int, [_p, _p, _p, _p, _p]),
+    'advoc_conv_backward_bias': (ctypes.c_int, [_p, _p, _p, _p]),
+    'advoc_conv_kernel_name': (ctypes.c_int, [_p, _i32, ctypes.c_char_p, _i32]),
     'advoc_gan_d_loss': (ctypes.c_int, [_p, _p, _i64, _p, _p, _p, _p]),
     'advoc_gan_g_loss': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _f32, _f32, _p, _p, _i32, _p, _p]),
     'advoc_adam_tf_f32': (ctypes.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p]),

@@ -41,8 +41,38 @@ def _t4(t, w=None):
   return _lib.Tensor4(t.data_ptr(), n, h, w, c, wp)
 
 
+class LaunchProfiler(object):
+  """Optional per-launch timing with HIP events recorded on the launch stream (bench.py).
+  Nothing is synchronised until `rows()` is called."""
+
+  def __init__(self):
+    self.records = []
+
+  def timed(self, name, flops, nbytes, fn):
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    self.records.append((name, flops, nbytes, e0, e1))
+
+  def rows(self):
+    """{kernel name: dict(launches, ms, flops, bytes)}; synchronises."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, flops, nbytes, e0, e1 in self.records:
+      r = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+      r['launches'] += 1
+      r['ms'] += e0.elapsed_time(e1)
+      r['flops'] += flops
+      r['bytes'] += nbytes
+    return out
+
+
 class Layer(object):
   """A bound conv layer: holds the ctypes struct and keeps every tensor it points at alive."""
+
+  profiler = None   # set to a LaunchProfiler to time every launch
 
   def __init__(self, kind, x0, y, weight, bias=None, x1=None, in_w=None, out_w=None, stride=(2, 2),
                pad=(1, 1), in_act=ACT_NONE, drop_mask=None, drop_scale=0., in_scale=None,
@@ -79,10 +109,33 @@ class Layer(object):
     s.drop_mask = _lib.ptr(drop_mask)
     s.drop_scale = float(drop_scale)
     self.struct = s
+    self._names = {}
+    lw = s.x0.w
+    grid = (y.shape[1] * s.y.w) if kind == CONV else (x0.shape[1] * lw)
+    self.flops = 2.0 * x0.shape[0] * grid * kh * kw * cin * cout
+    # algorithmic HBM bytes of one pass: every input element once, every output element once, weights
+    self.bytes_fwd = 4.0 * (x0.shape[0] * x0.shape[1] * lw * cin + y.shape[0] * y.shape[1] * s.y.w * cout
+                            + kh * kw * cin * cout)
+
+  def kernel_name(self, direction):
+    """Kernel template instance this layer launches for direction 0 fwd / 1 bwd-data / 2 bwd-weight."""
+    if direction not in self._names:
+      buf = ctypes.create_string_buffer(128)
+      _lib.check(_lib.load().advoc_conv_kernel_name(ctypes.byref(self.struct), direction, buf, 128),
+                 'advoc_conv_kernel_name')
+      self._names[direction] = buf.value.decode()
+    return self._names[direction]
+
+  def _run(self, direction, fn):
+    prof = Layer.profiler
+    if prof is None:
+      fn()
+    else:
+      prof.timed(self.kernel_name(direction), self.flops, self.bytes_fwd, fn)
 
   def forward(self):
-    _lib.check(_lib.load().advoc_conv_forward(ctypes.byref(self.struct), _lib.stream()),
-               'advoc_conv_forward')
+    self._run(0, lambda: _lib.check(
+        _lib.load().advoc_conv_forward(ctypes.byref(self.struct), _lib.stream()), 'advoc_conv_forward'))
     return self.y
 
   def backward_data(self, dy, dx0=None, dx1=None, accum0=False, accum1=False):
@@ -94,15 +147,24 @@ class Layer(object):
         _lib.require_device(d)
         if x is None or tuple(d.shape) != tuple(x.shape):
           raise _lib.AdvocHipError('dx must have the shape of the matching input')
-    _lib.check(_lib.load().advoc_conv_backward_data(
+    self._run(1, lambda: _lib.check(_lib.load().advoc_conv_backward_data(
         ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dx0), _lib.ptr(dx1), int(accum0),
-        int(accum1), _lib.stream()), 'advoc_conv_backward_data')
+        int(accum1), _lib.stream()), 'advoc_conv_backward_data'))
 
   def backward_weight(self, dy, dw, db=None):
     _lib.require_device(dy)
     _lib.require_device(dw)
     if tuple(dw.shape) != tuple(self.weight.shape):
       raise _lib.AdvocHipError('dw shape mismatch')
-    _lib.check(_lib.load().advoc_conv_backward_weight(
-        ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), _lib.stream()),
-        'advoc_conv_backward_weight')
+    self._run(2, lambda: _lib.check(_lib.load().advoc_conv_backward_weight(
+        ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dw), None, _lib.stream()),
+        'advoc_conv_backward_weight'))
+    if db is not None:
+      _lib.require_device(db)
+      call = lambda: _lib.check(_lib.load().advoc_conv_backward_bias(      # noqa: E731
+          ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(db), _lib.stream()), 'advoc_conv_backward_bias')
+      prof = Layer.profiler
+      if prof is None:
+        call()
+      else:
+        prof.timed('bias_grad_kernel', 0.0, 4.0 * dy.numel(), call)

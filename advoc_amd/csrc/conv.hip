@@ -162,12 +162,12 @@ int build_backward_data(const advoc_conv_layer* L, const float* dy, float* dx0, 
   return subpixel_taps(p, L);
 }
 
-int run_gather(const GatherGemmParams& p, bool b_kn, hipStream_t stream) {
+int run_gather(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only = nullptr) {
   const int K = p.c0 + p.c1, N = p.n_total;
   if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0)
-    return launch_gather_gemm(p, b_kn, stream);
-  if (N <= 2 && K % 4 == 0 && p.c0 % 4 == 0) return launch_gather_dot(p, b_kn, stream);
-  if (K <= 2) return launch_gather_outer(p, b_kn, stream);
+    return launch_gather_gemm(p, b_kn, stream, name_only);
+  if (N <= 2 && K % 4 == 0 && p.c0 % 4 == 0) return launch_gather_dot(p, b_kn, stream, name_only);
+  if (K <= 2) return launch_gather_outer(p, b_kn, stream, name_only);
   return ADVOC_ERR_UNSUPPORTED;
 }
 
@@ -274,4 +274,43 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
     rc = launch_bias_grad(dy, L->drop_mask, L->drop_scale, (int64_t)L->y.n * L->y.h, L->y.w,
                           L->y.w_pitch, L->y.c, db, as_stream(stream));
   return rc;
+}
+
+extern "C" int advoc_conv_backward_bias(const advoc_conv_layer* L, const float* dy, float* db,
+                                        advoc_stream_t stream) {
+  const int rc = validate_layer(L);
+  if (rc != ADVOC_OK) return rc;
+  if (!dy || !db) return ADVOC_ERR_NULL;
+  return launch_bias_grad(dy, L->drop_mask, L->drop_scale, (int64_t)L->y.n * L->y.h, L->y.w,
+                          L->y.w_pitch, L->y.c, db, as_stream(stream));
+}
+
+extern "C" int advoc_conv_kernel_name(const advoc_conv_layer* L, int32_t direction, char* buf_host,
+                                      int32_t buf_len) {
+  int rc = validate_layer(L);
+  if (rc != ADVOC_OK) return rc;
+  if (!buf_host || buf_len < 2) return ADVOC_ERR_NULL;
+  const char* name = nullptr;
+  if (direction == 0 || direction == 1) {
+    GatherGemmParams p;
+    bool b_kn;
+    float dummy = 0.f;
+    rc = direction == 0 ? build_forward(L, p, b_kn)
+                        : build_backward_data(L, &dummy, &dummy, L->x1.p ? &dummy : nullptr, 0, 0, p, b_kn);
+    if (rc != ADVOC_OK) return rc;
+    rc = run_gather(p, b_kn, nullptr, &name);
+  } else if (direction == 2) {
+    WgradParams p;
+    float dummy = 0.f;
+    rc = build_backward_weight(L, &dummy, &dummy, p);
+    if (rc != ADVOC_OK) return rc;
+    rc = (p.P.c0 + p.P.c1) <= 2 ? launch_wgrad_thin(p, nullptr, &name) : launch_wgrad_mfma(p, nullptr, &name);
+  } else {
+    return ADVOC_ERR_UNSUPPORTED;
+  }
+  if (rc != ADVOC_OK) return rc;
+  int i = 0;
+  for (; name[i] && i < buf_len - 1; ++i) buf_host[i] = name[i];
+  buf_host[i] = 0;
+  return ADVOC_OK;
 }

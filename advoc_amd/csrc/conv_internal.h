@@ -11,8 +11,10 @@ int validate_layer(const advoc_conv_layer* L);
 // Both take the SAME GatherGemmParams a gather-GEMM launch would get.
 //   gather_dot  : n_total <= 2 outputs per grid point, K channels wide (wave per grid point)
 //   gather_outer: K = c0 + c1 <= 2 input channels, n_total wide (thread per output element)
-int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream);
-int launch_gather_outer(const GatherGemmParams& p, bool b_kn, hipStream_t stream);
+int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
+                      const char** name_only = nullptr);
+int launch_gather_outer(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
+                        const char** name_only = nullptr);
 
 // ---- weight gradient ----
 // An NHWC activation view (optionally the channel concat of two tensors) with the layer's fused
@@ -41,8 +43,10 @@ struct WgradParams {
   float* dw;           // zero-filled by the launcher, accumulated with atomics
 };
 
-int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream);   // both operands wide (% 32)
-int launch_wgrad_thin(const WgradParams& p, hipStream_t stream);   // P has <= 2 channels
+int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream,
+                      const char** name_only = nullptr);   // both operands wide (% 32)
+int launch_wgrad_thin(const WgradParams& p, hipStream_t stream,
+                      const char** name_only = nullptr);   // P has <= 2 channels
 
 // db[c] = sum over pixels of dy[., c] (* mask * scale)
 int launch_bias_grad(const float* dy, const uint8_t* mask, float mask_scale, int64_t rows, int w,

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void gather_outer_kernel(const GatherGemmParam
 
 }  // namespace
 
-int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream) {
+int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only) {
   const int ktot = p.c0 + p.c1;
   if (p.n_total < 1 || p.n_total > 2 || ktot % 4 || p.c0 % 4) return ADVOC_ERR_UNSUPPORTED;
   if (p.n_total == 2 && b_kn) return ADVOC_ERR_UNSUPPORTED;
@@ -173,6 +173,11 @@ int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream) 
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   int G = 8;
   while (G < 64 && G * 4 < ktot) G *= 2;
+  if (name_only) {
+    *name_only = G == 8 ? "gather_dot_kernel<8>" : G == 16 ? "gather_dot_kernel<16>"
+                 : G == 32 ? "gather_dot_kernel<32>" : "gather_dot_kernel<64>";
+    return ADVOC_OK;
+  }
   const int64_t blocks = ceil_div(M, 256 / G);
   if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
   dim3 grid((unsigned)blocks, 1, (unsigned)p.nphase);
@@ -187,10 +192,14 @@ int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream) 
   return ADVOC_OK;
 }
 
-int launch_gather_outer(const GatherGemmParams& p, bool b_kn, hipStream_t stream) {
+int launch_gather_outer(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only) {
   const int ktot = p.c0 + p.c1;
   if (ktot < 1 || ktot > 2) return ADVOC_ERR_UNSUPPORTED;
   if (p.a_mask && p.c1) return ADVOC_ERR_UNSUPPORTED;
+  if (name_only) {
+    *name_only = b_kn ? "gather_outer_kernel<true>" : "gather_outer_kernel<false>";
+    return ADVOC_OK;
+  }
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   const int64_t blocks = ceil_div(M * p.n_total, 256);
   if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;

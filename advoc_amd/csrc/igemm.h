@@ -60,6 +60,8 @@ struct GatherGemmParams {
 
 // B_KN = true : weights stored [tap][K][N] (N contiguous)   conv fwd, deconv bwd-data
 // B_KN = false: weights stored [tap][N][K] (K contiguous)   deconv fwd, conv bwd-data
-int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream);
+// name_only != nullptr: do not launch, just report the kernel instance that would run
+int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
+                       const char** name_only = nullptr);
 
 }  // namespace advoc

@@ -19,6 +19,8 @@
 //     other LDS buffer after them: one s_barrier per K tile, HBM/L2 latency hidden under MFMA.
 //   * epilogue: bias, dropout mask, act'(x) gating, optional accumulate, split over two
 //     destinations (skip-connection gradients); 128 B contiguous per 32-lane store.
+#include <string>
+
 #include "common.h"
 #include "igemm.h"
 
@@ -300,8 +302,15 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
 }
 
 template <int MT, int NT, int WGM, int WGN, bool B_KN>
-int launch_cfg(const GatherGemmParams& p, hipStream_t stream) {
+int launch_cfg(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
   using C = Cfg<MT, NT, WGM, WGN, B_KN>;
+  if (name_only) {
+    static const std::string name = std::string("gather_gemm_kernel<") + std::to_string(MT) + ", " +
+                                    std::to_string(NT) + ", " + std::to_string(WGM) + ", " +
+                                    std::to_string(WGN) + ", " + (B_KN ? "true" : "false") + ">";
+    *name_only = name.c_str();
+    return ADVOC_OK;
+  }
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   const int64_t gx = ceil_div(M, C::BM);
   if (gx > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
@@ -314,16 +323,16 @@ int launch_cfg(const GatherGemmParams& p, hipStream_t stream) {
 }
 
 template <bool B_KN>
-int dispatch(const GatherGemmParams& p, hipStream_t stream) {
+int dispatch(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
   const int N = p.n_total;
-  if (N % 128 == 0) return launch_cfg<2, 2, 2, 2, B_KN>(p, stream);   // 128 x 128
-  if (N % 64 == 0) return launch_cfg<2, 1, 2, 2, B_KN>(p, stream);    // 128 x 64
-  return launch_cfg<2, 1, 4, 1, B_KN>(p, stream);                     // 256 x 32
+  if (N % 128 == 0) return launch_cfg<2, 2, 2, 2, B_KN>(p, stream, name_only);   // 128 x 128
+  if (N % 64 == 0) return launch_cfg<2, 1, 2, 2, B_KN>(p, stream, name_only);    // 128 x 64
+  return launch_cfg<2, 1, 4, 1, B_KN>(p, stream, name_only);                     // 256 x 32
 }
 
 }  // namespace
 
-int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream) {
+int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only) {
   const int ktot = p.c0 + p.c1;
   if (p.batch <= 0 || p.gh <= 0 || p.gw <= 0 || ktot <= 0 || p.n_total <= 0) return ADVOC_ERR_BAD_SHAPE;
   if (ktot % BK || p.c0 % BK || p.n_total % 32 || p.n_split % 32) return ADVOC_ERR_UNSUPPORTED;
@@ -332,7 +341,7 @@ int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream)
   // 32-bit pixel indices in the epilogue
   if ((int64_t)p.batch * p.out_h * (int64_t)(p.d[0].pitch > p.d[1].pitch ? p.d[0].pitch : p.d[1].pitch) > 0x7fffffffLL)
     return ADVOC_ERR_UNSUPPORTED;
-  return b_kn ? dispatch<true>(p, stream) : dispatch<false>(p, stream);
+  return b_kn ? dispatch<true>(p, stream, name_only) : dispatch<false>(p, stream, name_only);
 }
 
 }  // namespace advoc

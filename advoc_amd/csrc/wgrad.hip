@@ -12,6 +12,8 @@
 //   * wgrad_thin_kernel: the gathered operand has <= 2 channels (encoder_1, layer_1, decoder_1,
 //     layer_5): HBM-bound outer products, threads own channels of the wide operand.
 //   * bias_grad_kernel: per-channel column sums.
+#include <string>
+
 #include "conv_internal.h"
 
 namespace advoc {
@@ -204,8 +206,20 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p, in
 }
 
 template <int MT, int NT, int WGM, int WGN>
-int launch_wcfg(const WgradParams& p, hipStream_t stream) {
+int launch_wcfg(const WgradParams& p, hipStream_t stream, const char** name_only) {
   using C = WCfg<MT, NT, WGM, WGN>;
+  if (name_only) {
+    static const std::string name = std::string("wgrad_mfma_kernel<") + std::to_string(MT) + ", " +
+                                    std::to_string(NT) + ", " + std::to_string(WGM) + ", " +
+                                    std::to_string(WGN) + ">";
+    *name_only = name.c_str();
+    return ADVOC_OK;
+  }
+  {
+    const int ca_ = p.P.c0 + p.P.c1, cb_ = p.Q.c0 + p.Q.c1;
+    hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca_ * cb_, stream);
+    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  }
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   const int tiles_m = (ca + C::BM - 1) / C::BM, tiles_n = (cb + C::BN - 1) / C::BN;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
@@ -325,13 +339,11 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
 
 }  // namespace
 
-int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream) {
+int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream, const char** name_only) {
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   if (ca % 32 || cb % 32 || p.P.c0 % 4 || p.Q.c0 % 4) return ADVOC_ERR_UNSUPPORTED;
   if (p.P.c1 && p.P.c0 % 32) return ADVOC_ERR_UNSUPPORTED;  // a block's channel tile stays in one source
   if (p.Q.c1 && p.Q.c0 % 32) return ADVOC_ERR_UNSUPPORTED;
-  hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
-  if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
   // pick the tile with the least padded work (ties: the larger tile); edges are masked
   const int bm[4] = {128, 64, 32, 128}, bn[4] = {128, 64, 128, 32};
   int best = 0;
@@ -341,16 +353,20 @@ int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream) {
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = i; }
   }
   switch (best) {
-    case 0: return launch_wcfg<2, 2, 2, 2>(p, stream);
-    case 1: return launch_wcfg<1, 1, 2, 2>(p, stream);
-    case 2: return launch_wcfg<1, 1, 1, 4>(p, stream);
-    default: return launch_wcfg<1, 1, 4, 1>(p, stream);
+    case 0: return launch_wcfg<2, 2, 2, 2>(p, stream, name_only);
+    case 1: return launch_wcfg<1, 1, 2, 2>(p, stream, name_only);
+    case 2: return launch_wcfg<1, 1, 1, 4>(p, stream, name_only);
+    default: return launch_wcfg<1, 1, 4, 1>(p, stream, name_only);
   }
 }
 
-int launch_wgrad_thin(const WgradParams& p, hipStream_t stream) {
+int launch_wgrad_thin(const WgradParams& p, hipStream_t stream, const char** name_only) {
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   if (ca < 1 || ca > 2 || cb % 32) return ADVOC_ERR_UNSUPPORTED;
+  if (name_only) {
+    *name_only = ca == 1 ? "wgrad_thin_kernel<1>" : "wgrad_thin_kernel<2>";
+    return ADVOC_OK;
+  }
   hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
   if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;

@@ -1,0 +1,81 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL over xGMI.
+
+The reference has no multi-GPU code; this is new functionality with one
+contract: an N-GPU step on a global batch equals the 1-GPU step on the same global batch.
+Each rank owns batch/N clips; after each backward pass the network's flat gradient arena
+(advoc_amd.model) is summed across ranks with a few large all-reduces -- xGMI is
+point-to-point, ring all-reduce is per-link bound, so buckets are big (default 64 MiB) -- and the
+fused Adam kernel applies 1/N.  Dropout masks are Philox streams keyed by the GLOBAL clip index,
+so sharding does not change them.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel(object):
+  def __init__(self, bucket_bytes=64 << 20):
+    self.bucket_elems = max(1, bucket_bytes // 4)
+    self.world_size = 1
+    self.rank = 0
+    self.local_rank = 0
+    self.enabled = False
+
+  def init_from_env(self, backend=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run)."""
+    self.world_size = int(os.environ.get('WORLD_SIZE', '1'))
+    self.rank = int(os.environ.get('RANK', '0'))
+    self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if self.world_size > 1:
+      os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+      if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+      if backend == 'nccl':
+        torch.cuda.set_device(self.local_rank)
+      if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+      self.enabled = True
+    elif torch.cuda.is_available():
+      torch.cuda.set_device(self.local_rank)
+    return self
+
+  def allreduce_(self, flat):
+    """Sum a flat fp32 tensor across ranks, in place, in large buckets."""
+    if not self.enabled:
+      return flat
+    n = flat.numel()
+    for lo in range(0, n, self.bucket_elems):
+      dist.all_reduce(flat[lo:min(n, lo + self.bucket_elems)], op=dist.ReduceOp.SUM)
+    return flat
+
+  def attach(self, model):
+    """Makes `model` (advoc_amd.model.Advoc) average gradients across ranks before Adam."""
+    model.world_size = self.world_size
+    model.rank = self.rank
+    model._allreduce = self.allreduce_ if self.enabled else None
+    return model
+
+  def broadcast_parameters(self, model):
+    """Rank 0's parameters and optimiser slots to everyone (identical start)."""
+    if not self.enabled:
+      return
+    st = model._built
+    for k in ('g_param', 'd_param', 'g_m', 'g_v', 'd_m', 'd_v'):
+      dist.broadcast(st[k], src=0)
+
+  def barrier(self):
+    if self.enabled:
+      dist.barrier()
+
+  def max_over_ranks(self, value):
+    if not self.enabled:
+      return value
+    dev = torch.device('cuda', self.local_rank) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+  def shard(self, items):
+    """This rank's strided share of a list (files, chunks)."""
+    return items[self.rank::self.world_size]

@@ -1,0 +1,75 @@
+"""Mel <-> linear-magnitude projections used around the model (drop-in for
+/root/reference/models/advoc/spectral_util.py:6-60).
+
+The filterbank [n_mels, 513] and its pseudo-inverse [513, n_mels] are float64 host constants
+(advoc_amd.spectral) cast to float32 and kept in HBM; the projections run in
+advoc_matmul_nt_f32.  As in the reference: linear-amplitude mel (no log), and NO >= 0 clamp
+after the pseudo-inverse (spectral_util.py:34-43)."""
+import numpy as np
+import torch
+
+from advoc_amd import _lib
+from advoc_amd import spectral
+
+
+class SpectralUtil(object):
+  NFFT = 1024
+  NHOP = 256
+  FMIN = 125.
+  FMAX = 7600.
+  NMELS = 80
+  fs = 22050
+
+  def __init__(self, n_mels=80, fs=22050):
+    self.NMELS = n_mels
+    self.fs = fs
+    self.meltrans_np = spectral.create_mel_filterbank(
+        self.fs, self.NFFT, fmin=self.FMIN, fmax=self.FMAX, n_mels=self.NMELS)
+    self.invmeltrans_np = spectral.create_inverse_mel_filterbank(
+        self.fs, self.NFFT, fmin=self.FMIN, fmax=self.FMAX, n_mels=self.NMELS)
+    self._dev = {}
+
+  def _const(self, name):
+    dev = _lib.device()
+    key = (name, dev.index)
+    if key not in self._dev:
+      src = self.meltrans_np if name == 'mel' else self.invmeltrans_np
+      self._dev[key] = torch.from_numpy(src.astype(np.float32)).to(dev).contiguous()
+    return self._dev[key]
+
+  @property
+  def meltrans(self):
+    return self._const('mel')
+
+  @property
+  def invmeltrans(self):
+    return self._const('inv')
+
+  def mag_to_mel_linear_spec(self, mag_spec):
+    """[B, T, 513, 1] -> [B, T, n_mels, 1]   (spectral_util.py:29-32)."""
+    mag_spec = mag_spec.to(_lib.device(), torch.float32)
+    return spectral.matmul_last(mag_spec[:, :, :, 0], self.meltrans).unsqueeze(-1)
+
+  def mel_linear_to_mag_spec(self, mel_spec, transform='inverse'):
+    """[B, T, n_mels, 1] -> [B, T, 513, 1]   (spectral_util.py:34-43)."""
+    if transform != 'inverse':
+      # the reference's 'transposed' branch reads an undefined name (spectral_util.py:38)
+      raise NotImplementedError()
+    mel_spec = mel_spec.to(_lib.device(), torch.float32)
+    return spectral.matmul_last(mel_spec[:, :, :, 0], self.invmeltrans).unsqueeze(-1)
+
+  def tacotron_mel_to_mag(self, X_mel_dbnorm):
+    """dB-normalised mel [T, n_mels] (numpy float64) -> linear magnitude [T, 513], float32 tensor
+    in HBM (spectral_util.py:52-60, scripts/spectrogram_advoc.py:15-22).  The de-normalisation is
+    80 values per frame on the host in float64 as in the reference; the [T,80]x[80,513]
+    projection runs on the GPU."""
+    norm_min_level_db = -100
+    norm_ref_level_db = 20
+    X_mel_db = (np.asarray(X_mel_dbnorm, dtype=np.float64) * -norm_min_level_db) + norm_min_level_db
+    X_mel = np.power(10, (X_mel_db + norm_ref_level_db) / 20)
+    mel = torch.from_numpy(X_mel.astype(np.float32)).to(_lib.device())
+    return spectral.matmul_last(mel, self.invmeltrans)
+
+  def audio_from_mag_spec(self, mag_spec):
+    raise NotImplementedError('LWS phase reconstruction is the step after the MI355X hot path '
+                              '(SURVEY.md §8f-1); not implemented yet')

@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Headline benchmark: AdVoc G+D train step throughput in mel-frames/s (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[1] -- AdVoc-small, LJSpeech geometry
+(22.05 kHz, nfft 1024 / hop 256, 256-frame clips), batch 32 per GPU.  One "step" = one reference
+train_loop (models/advoc/advoc_model.py:285-289): a discriminator update on one batch and a
+generator update on the NEXT batch, each batch going waveform -> |STFT| -> mel -> pseudo-inverse
+on the GPU first (advoc/loader.py:116-128 + models/advoc/train_evaluate.py:55-56).  Inputs are
+synthetic waveforms (uniform noise + 3 sinusoids, seeded) already resident in HBM; weights are
+N(0, 0.02) random init; dropout masks come from the on-device Philox stream.
+
+value = (global batch x 256 frames x steps) / wall time: the conservative accounting (the step
+consumes TWO batches; only one is counted).  N > 1: batch sharded 32 per GPU (weak scaling), RCCL
+all-reduce of the D and G gradient arenas.
+
+Extra objects on the JSON line:
+  roofline      the kernel instance with the largest total time in the timed region, timed per
+                launch with HIP events on the launch stream: algorithmic flops / measured time
+                against the dense fp32 MFMA peak (157.3 TFLOP/s).
+  cpu_baseline  the torch-CPU restatement of the reference graph (oracle/, "port") timed on this
+                box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0           # ibid., HBM3E peak BW
+CLIP_FRAMES = 256
+CLIP_SAMPLES = (CLIP_FRAMES - 1) * 256 + 1024   # 66304
+
+
+def synth_waveforms(batch, seed, device):
+  """uniform(-0.5, 0.5) noise + 3 seeded sinusoids per clip."""
+  import torch
+  g = torch.Generator().manual_seed(seed)
+  x = torch.rand(batch, CLIP_SAMPLES, generator=g) - 0.5
+  t = torch.arange(CLIP_SAMPLES, dtype=torch.float32) / 22050.0
+  for _ in range(3):
+    f = 100.0 + 4000.0 * torch.rand(batch, 1, generator=g)
+    a = 0.1 + 0.2 * torch.rand(batch, 1, generator=g)
+    x = x + a * torch.sin(2 * 3.141592653589793 * f * t[None, :])
+  return x.reshape(batch, CLIP_SAMPLES, 1, 1).to(device)
+
+
+def cpu_baseline(model_small=True, budget_s=20.0):
+  """Reference-equivalent CPU restatement (oracle/advoc_torch.py + oracle/spectral_np.py),
+  one train_loop = D update + G update, batch 8 (reference default, advoc_model.py:18)."""
+  import numpy as np
+  import torch
+  from oracle import advoc_torch as A
+  from oracle import spectral_np as S
+  B = 8
+  cfg = A.Config(small=model_small)
+  tr = A.Trainer(cfg, seed=0)
+  W = S.create_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80).astype(np.float32)
+  Wi = S.create_inverse_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80).astype(np.float32)
+  rng = np.random.default_rng(0)
+
+  def make_batch():
+    wav = rng.uniform(-0.5, 0.5, size=(B, CLIP_SAMPLES, 1, 1)).astype(np.float32)
+    mag = np.abs(S.stft_tf(wav, 1024, 256, pad_end=False)).astype(np.float32)
+    mel = S.mag_to_mel_linear_spec(mag, W)
+    inv = S.mel_linear_to_mag_spec(mel, Wi)
+    return torch.from_numpy(inv), torch.from_numpy(mag)
+  masks = A.make_dropout_masks(cfg, B, seed=1)
+  tr.train_loop(make_batch(), make_batch(), masks, masks)      # warm-up (thread pools, allocator)
+  n, t_total = 0, 0.0
+  while n == 0 or t_total < budget_s:
+    t0 = time.perf_counter()
+    tr.train_loop(make_batch(), make_batch(), masks, masks)
+    t_total += time.perf_counter() - t0
+    n += 1
+  return dict(value=B * CLIP_FRAMES * n / t_total, unit='mel-frames/s', cores=torch.get_num_threads(),
+              kind='port',
+              sample='%d train_loop iterations (1 D + 1 G update each) of AdVoc-small at batch %d, '
+                     'STFT/mel in numpy, convs in torch-CPU fp32' % (n, B))
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--model', choices=['small', 'regular'], default='small')
+  ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-launch-timing', action='store_true',
+                  help='skip per-launch HIP events (roofline object becomes null)')
+  args = ap.parse_args()
+
+  import torch
+  from advoc_amd import conv, spectral
+  from advoc_amd.model import Advoc, AdvocSmall, Modes
+  from advoc_amd.parallel import DataParallel
+  from advoc_amd.spectral_util import SpectralUtil
+
+  dp = DataParallel().init_from_env()
+  if dp.world_size != args.gpus:
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, dp.world_size))
+  dev = torch.device('cuda', dp.local_rank)
+  torch.cuda.set_device(dev)
+
+  B = args.batch
+  model = (AdvocSmall if args.model == 'small' else Advoc)(Modes.TRAIN)
+  model.train_batch_size = B
+  model.build(batch_size=B, seed=0)
+  dp.attach(model)
+  dp.broadcast_parameters(model)
+  su = SpectralUtil(n_mels=model.n_mels, fs=model.audio_fs)
+
+  pool = [synth_waveforms(B, 1234 + 17 * dp.rank + i, dev) for i in range(4)]
+  state = {'i': 0}
+
+  def feed():
+    wav = pool[state['i'] % len(pool)]
+    state['i'] += 1
+    mag = spectral.stft_magnitude(wav, 1024, 256, pad_end=False)          # [B,256,513,1]
+    mel = su.mag_to_mel_linear_spec(mag)
+    inv = su.mel_linear_to_mag_spec(mel)
+    return inv, mag, wav, mel
+  model(feed)
+
+  for _ in range(args.warmup):
+    model.train_loop()
+  torch.cuda.synchronize()
+  dp.barrier()
+  torch.cuda.synchronize()
+
+  prof = None
+  if not args.no_launch_timing:
+    prof = conv.LaunchProfiler()
+    conv.Layer.profiler = prof
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    model.train_loop()
+  torch.cuda.synchronize()
+  dp.barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  conv.Layer.profiler = None
+  elapsed = dp.max_over_ranks(elapsed)
+
+  frames = B * dp.world_size * CLIP_FRAMES * args.steps
+  value = frames / elapsed
+
+  roofline = None
+  if prof is not None:
+    rows = prof.rows()
+    name, r = max(rows.items(), key=lambda kv: kv[1]['ms'])
+    mfma = 'mfma' in name or 'gather_gemm' in name
+    if mfma:
+      achieved = r['flops'] / (r['ms'] * 1e-3) / 1e12
+      roofline = dict(bound='mfma', kernel=name, achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS,
+                      unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=None,
+                      launches=r['launches'], avg_launch_ms=r['ms'] / r['launches'],
+                      flops_per_launch=r['flops'] / r['launches'],
+                      share_of_step=r['ms'] / (elapsed * 1e3))
+    else:
+      achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
+      roofline = dict(bound='hbm', kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                      frac=achieved / HBM_PEAK_GBS, traffic=None, launches=r['launches'],
+                      avg_launch_ms=r['ms'] / r['launches'], share_of_step=r['ms'] / (elapsed * 1e3))
+    if dp.rank == 0 and os.environ.get('ADVOC_BENCH_VERBOSE'):
+      tot = sum(v['ms'] for v in rows.values())
+      for k, v in sorted(rows.items(), key=lambda kv: -kv[1]['ms']):
+        tf = v['flops'] / max(v['ms'], 1e-9) / 1e9
+        print('  %-44s launches %5d  %9.2f ms (%5.1f%%)  %7.2f TFLOP/s  %7.1f GB/s alg' % (
+            k, v['launches'], v['ms'], 100 * v['ms'] / tot, tf, v['bytes'] / max(v['ms'], 1e-9) / 1e6),
+            file=sys.stderr)
+      print('  conv-stack launches total %.2f ms of %.2f ms wall' % (tot, elapsed * 1e3), file=sys.stderr)
+
+  cpu = None
+  if dp.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+    cpu = cpu_baseline(model_small=(args.model == 'small'))
+
+  if dp.rank == 0:
+    losses = model.losses()
+    out = {
+        'metric': 'mel-frames/sec (AdVoc G+D train step)',
+        'value': value,
+        'unit': 'mel-frames/s',
+        'n_gpus': args.gpus,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': elapsed * 1e3 / args.steps,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {
+            'workload': 'AdVoc-%s train_loop (1 D update + 1 G update on fresh batches), LJSpeech '
+                        'geometry 22.05 kHz nfft 1024 hop 256, %d clips x 256 frames per GPU, HIP '
+                        'STFT/mel/pinv extractor in the loop' % (args.model, B),
+            'global_batch': B * dp.world_size,
+            'frames_per_clip': CLIP_FRAMES,
+            'parallelism': 'dp%d' % dp.world_size,
+            'frames_counted_per_step': 'global_batch*256 (the step consumes 2 batches; 1 is counted)',
+        },
+        'per_gpu_value': value / dp.world_size,
+        'losses': losses,
+        'roofline': roofline,
+        'cpu_baseline': cpu,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+  main()

@@ -139,6 +139,16 @@ int advoc_conv_forward(const advoc_conv_layer* layer, advoc_stream_t stream);
 int advoc_conv_backward_data(const advoc_conv_layer* layer, const float* dy, float* dx0, float* dx1,
                              int32_t accum0, int32_t accum1, advoc_stream_t stream);
 
+/* Bias gradient alone: db[co] = sum over pixels of dy * drop_mask * drop_scale (BiasAddGrad). */
+int advoc_conv_backward_bias(const advoc_conv_layer* layer, const float* dy, float* db,
+                             advoc_stream_t stream);
+
+/* Diagnostics: name of the kernel template instance a call on `layer` launches, e.g.
+ * "gather_gemm_kernel<2, 2, 2, 2, true>" -- the string rocprofv3 shows for it.
+ * direction: 0 forward, 1 backward-data, 2 backward-weight.  buf_host is HOST memory. */
+int advoc_conv_kernel_name(const advoc_conv_layer* layer, int32_t direction, char* buf_host,
+                           int32_t buf_len);
+
 /* Gradient w.r.t. kernel and bias: dw has the layout of layer->w, db is [cout] (NULL = skip).
  * Overwrites dw / db.  Replaces Conv2DBackpropFilter / BiasAddGrad. */
 int advoc_conv_backward_weight(const advoc_conv_layer* layer, const float* dy, float* dw, float* db,
