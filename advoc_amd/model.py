@@ -124,9 +124,10 @@ class Advoc(Model):
     self._feed = None
     self._injected_masks = None
     self._dropout_calls = 0
-    self.step = 0
-    self.world_size = 1
-    self.rank = 0
+    # public attributes appear in the printed attr summary (util.py:13-18); like the reference,
+    # `step`, `G_vars` and `D_vars` only exist once the model has been built
+    self._world_size = 1
+    self._rank = 0
     self._allreduce = None
 
   # ------------------------------------------------------------------------------------------
@@ -218,6 +219,10 @@ class Advoc(Model):
     st['B'] = B
     self._bind(st, B, dev)
     self._built = st
+    if not hasattr(self, 'step'):
+      self.step = 0
+    self.G_vars = list(st['g_P'].keys())
+    self.D_vars = list(st['d_P'].keys())
     return self
 
   def _bind(self, st, B, dev):
@@ -341,16 +346,6 @@ class Advoc(Model):
       st[k].copy_(tensors[k])
     st['g_t'], st['d_t'] = steps
 
-  @property
-  def G_vars(self):
-    self.build()
-    return list(self._built['g_P'].keys())
-
-  @property
-  def D_vars(self):
-    self.build()
-    return list(self._built['d_P'].keys())
-
   # ------------------------------------------------------------------------------------------
   # dropout
   # ------------------------------------------------------------------------------------------
@@ -381,7 +376,7 @@ class Advoc(Model):
     st = self._built
     if x.data_ptr() != st['x_in'].data_ptr():
       st['x_in'].copy_(x)
-    self._refresh_masks(self.rank * st['B'])
+    self._refresh_masks(self._rank * st['B'])
     for lay in st['g_layers'].values():
       lay.forward()
     return st['gen_out']
@@ -434,7 +429,7 @@ class Advoc(Model):
       self._allreduce(flat)
     _lib.check(_lib.load().advoc_adam_tf_f32(
         _lib.ptr(st[net + '_param']), _lib.ptr(flat), _lib.ptr(st[net + '_m']), _lib.ptr(st[net + '_v']),
-        flat.numel(), lr_t, self._beta1, self._beta2, self._adam_eps, 1.0 / self.world_size,
+        flat.numel(), lr_t, self._beta1, self._beta2, self._adam_eps, 1.0 / self._world_size,
         _lib.stream()), 'advoc_adam_tf_f32')
 
   def _load_batch(self, batch):

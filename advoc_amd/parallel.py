@@ -51,8 +51,8 @@ class DataParallel(object):
 
   def attach(self, model):
     """Makes `model` (advoc_amd.model.Advoc) average gradients across ranks before Adam."""
-    model.world_size = self.world_size
-    model.rank = self.rank
+    model._world_size = self.world_size
+    model._rank = self.rank
     model._allreduce = self.allreduce_ if self.enabled else None
     return model
 

@@ -1,0 +1,284 @@
+"""train / eval / infer driver for AdVoc on MI355X -- same command line as the reference's
+models/advoc/train_evaluate.py (argparse :338-371, datacfg parsing :375-382, dispatch :387-397).
+
+    python models/advoc/train_evaluate.py train WORK_DIR --data_cfg datacfg/ljspeech.txt \
+        --data_dir /path/to/wavs [--model_type small] [--model_overrides "train_batch_size=32"]
+
+Multi-GPU: launch one process per GPU with torch.distributed.run; every rank takes a strided
+shard of the file list and gradients are all-reduced over RCCL (advoc_amd/parallel.py).
+
+Differences from the reference, by necessity: checkpoints are torch files
+(WORK_DIR/model.ckpt-<step>.pt + a `checkpoint` index; variables keep their TF names), scalar
+summaries go to WORK_DIR/summaries.jsonl instead of TensorBoard event files, and audio summaries
+(host LWS phase reconstruction) are not produced yet.
+"""
+import glob
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+
+def _make_model(args, mode):
+  from advoc_amd.model import Advoc, AdvocSmall, override_model_attrs
+  if args.model_type == 'regular':
+    model = Advoc(mode)
+  elif args.model_type == 'small':
+    model = AdvocSmall(mode)
+  else:
+    raise NotImplementedError()
+  model, summary = override_model_attrs(model, args.model_overrides)
+  model.audio_fs = args.data_sample_rate
+  print('-' * 80)
+  print(summary)
+  print('-' * 80)
+  return model
+
+
+def latest_checkpoint(train_dir):
+  """Path of the newest checkpoint recorded in WORK_DIR/checkpoint (like tf.train.latest_checkpoint)."""
+  idx = os.path.join(train_dir, 'checkpoint')
+  if not os.path.isfile(idx):
+    return None
+  name = open(idx).read().strip()
+  fp = os.path.join(train_dir, name)
+  return fp if os.path.isfile(fp) else None
+
+
+def save_checkpoint(train_dir, model, generator_only=False, name=None):
+  state = {'model': {k: v.cpu() for k, v in model.state_dict().items()}, 'step': model.step}
+  if generator_only:
+    state['model'] = {k: v for k, v in state['model'].items()
+                      if k.startswith('generator') or k == 'global_step'}
+  else:
+    tensors, steps = model.optimizer_state()
+    state['optimizer'] = {k: v.cpu() for k, v in tensors.items()}
+    state['optimizer_steps'] = steps
+  name = name or 'model.ckpt-%d.pt' % model.step
+  tmp = os.path.join(train_dir, name + '.tmp')
+  torch.save(state, tmp)
+  os.replace(tmp, os.path.join(train_dir, name))
+  with open(os.path.join(train_dir, 'checkpoint.tmp'), 'w') as f:
+    f.write(name)
+  os.replace(os.path.join(train_dir, 'checkpoint.tmp'), os.path.join(train_dir, 'checkpoint'))
+  return os.path.join(train_dir, name)
+
+
+def restore_checkpoint(fp, model, with_optimizer=True):
+  state = torch.load(fp, map_location='cpu')
+  model.load_state_dict(state['model'])
+  model.step = int(state.get('step', 0))
+  if with_optimizer and 'optimizer' in state:
+    dev = model._built['g_m'].device
+    model.load_optimizer_state({k: v.to(dev) for k, v in state['optimizer'].items()},
+                               tuple(state['optimizer_steps']))
+  return model.step
+
+
+def _loader(fps, args, model, batch_size, training):
+  from advoc_amd.loader import decode_extract_and_batch
+  return decode_extract_and_batch(
+      fps,
+      batch_size=batch_size,
+      slice_len=model.subseq_len,
+      audio_fs=model.audio_fs,
+      audio_mono=True,
+      audio_normalize=args.data_normalize,
+      decode_fastwav=args.data_fastwav,
+      decode_parallel_calls=4,
+      extract_type='magspec',
+      extract_parallel_calls=8,
+      repeat=training,
+      shuffle=training,
+      shuffle_buffer_size=512 if training else None,
+      slice_first_only=args.data_slice_first_only,
+      slice_randomize_offset=args.data_slice_randomize_offset if training else False,
+      slice_overlap_ratio=args.data_slice_overlap_ratio if training else 0.,
+      slice_pad_end=args.data_slice_pad_end if training else True,
+      prefetch_size=batch_size * 8 if training else None,
+      prefetch_gpu_num=0 if training else None)
+
+
+def train(fps, args):
+  from advoc_amd.model import Modes
+  from advoc_amd.parallel import DataParallel
+  from advoc_amd.spectral_util import SpectralUtil
+  dp = DataParallel().init_from_env()
+  model = _make_model(args, Modes.TRAIN)
+  model.build(seed=0)
+  dp.attach(model)
+
+  pipe = _loader(dp.shard(sorted(fps)) if dp.enabled else fps, args, model, model.train_batch_size, True)
+  spectral = SpectralUtil(n_mels=model.n_mels, fs=model.audio_fs)
+
+  def feed():
+    x_magspec, x_wav = pipe.next()
+    x_melspec = spectral.mag_to_mel_linear_spec(x_magspec)
+    x_inverted_magspec = spectral.mel_linear_to_mag_spec(x_melspec, transform='inverse')
+    return x_inverted_magspec, x_magspec, x_wav, x_melspec
+  model(feed)
+
+  ckpt = latest_checkpoint(args.train_dir)
+  if ckpt is not None:
+    print('Restoring from {}'.format(ckpt))
+    restore_checkpoint(ckpt, model)
+  dp.broadcast_parameters(model)
+
+  last_ckpt = last_summary = time.time()
+  log = open(os.path.join(args.train_dir, 'summaries.jsonl'), 'a') if dp.rank == 0 else None
+  _step = model.step
+  while _step < args.max_steps:
+    _step = model.train_loop()
+    now = time.time()
+    if dp.rank == 0 and now - last_summary >= args.train_summary_every_nsecs:
+      rec = dict(step=_step, time=now, **model.losses())
+      log.write(json.dumps(rec) + '\n')
+      log.flush()
+      last_summary = now
+    if dp.rank == 0 and now - last_ckpt >= args.train_ckpt_every_nsecs:
+      save_checkpoint(args.train_dir, model)
+      last_ckpt = now
+  if dp.rank == 0:
+    save_checkpoint(args.train_dir, model)
+    log.write(json.dumps(dict(step=_step, time=time.time(), **model.losses())) + '\n')
+    log.close()
+  pipe.close()
+  print('Done!')
+
+
+def evaluate_checkpoint(fps, args, model, ckpt_fp):
+  """Mean of the per-batch L1 between target and generated magnitude spectrograms over the
+  whole dataset (reference train_evaluate.py:137,165-182)."""
+  from advoc_amd.spectral_util import SpectralUtil
+  restore_checkpoint(ckpt_fp, model, with_optimizer=False)
+  spectral = SpectralUtil(n_mels=model.n_mels, fs=model.audio_fs)
+  pipe = _loader(fps, args, model, model.eval_batch_size, False)
+  all_l1 = []
+  for x_magspec, _ in pipe.batches():
+    x_melspec = spectral.mag_to_mel_linear_spec(x_magspec)
+    x_inv = spectral.mel_linear_to_mag_spec(x_melspec, transform='inverse')
+    l1, _ = model.l1_eval(x_inv, x_magspec)
+    all_l1.append(l1)
+  pipe.close()
+  return float(np.mean(all_l1)) if all_l1 else float('nan'), len(all_l1)
+
+
+def eval(fps, args, poll=True):   # noqa: A001  (name kept from the reference)
+  from advoc_amd.model import Modes
+  eval_dir = os.path.join(args.train_dir, 'eval_{}'.format(args.eval_dataset_name)
+                          if args.eval_dataset_name is not None else 'eval_valid')
+  os.makedirs(eval_dir, exist_ok=True)
+  model = _make_model(args, Modes.EVAL)
+  model.build(batch_size=model.eval_batch_size)
+  ckpt_fp = None
+  best = np.inf
+  while True:
+    latest = latest_checkpoint(args.train_dir)
+    if latest is not None and latest != ckpt_fp:
+      ckpt_fp = latest
+      print('Evaluating {}'.format(ckpt_fp))
+      l1, n = evaluate_checkpoint(fps, args, model, ckpt_fp)
+      with open(os.path.join(eval_dir, 'summaries.jsonl'), 'a') as f:
+        f.write(json.dumps(dict(step=model.step, gen_loss_L1=l1, batches=n)) + '\n')
+      if l1 < best:
+        # the reference never updates its best value (train_evaluate.py:153,184-186), so it saves
+        # every evaluated checkpoint; here "best" means best.
+        best = l1
+        save_checkpoint(eval_dir, model, generator_only=True, name='best_gen_loss_l1-%d.pt' % model.step)
+        print('Saved best gen loss l1!')
+      print('Done!')
+    if not poll:
+      return best
+    time.sleep(1)
+
+
+def infer(fps, args):
+  """Runs the generator over the dataset from --infer_ckpt_path (or the latest checkpoint) and
+  writes input / target / generated magnitude spectrograms as .npy under WORK_DIR/infer_*.
+  (The reference writes LWS-vocoded audio summaries and then raises NotImplementedError,
+  train_evaluate.py:190-329; waveform synthesis is the next row of the build)"""
+  from advoc_amd.model import Modes
+  from advoc_amd.spectral_util import SpectralUtil
+  infer_dir = os.path.join(args.train_dir, 'infer_{}'.format(args.infer_dataset_name)
+                           if args.infer_dataset_name is not None else 'infer_valid')
+  os.makedirs(infer_dir, exist_ok=True)
+  model = _make_model(args, Modes.INFER)
+  model.build(batch_size=args.infer_batch_size)
+  ckpt_fp = args.infer_ckpt_path or latest_checkpoint(args.train_dir)
+  if ckpt_fp is None:
+    raise ValueError('no checkpoint to infer from')
+  print('Infereing From {}'.format(ckpt_fp))
+  restore_checkpoint(ckpt_fp, model, with_optimizer=False)
+  spectral = SpectralUtil(n_mels=model.n_mels, fs=model.audio_fs)
+  pipe = _loader(fps, args, model, args.infer_batch_size, False)
+  for i, (x_magspec, _) in enumerate(pipe.batches()):
+    x_melspec = spectral.mag_to_mel_linear_spec(x_magspec)
+    x_inv = spectral.mel_linear_to_mag_spec(x_melspec, transform='inverse')
+    gen = model.build_generator(x_inv)
+    np.save(os.path.join(infer_dir, 'batch%06d_gen_magspec.npy' % i), gen.cpu().numpy())
+    np.save(os.path.join(infer_dir, 'batch%06d_target_magspec.npy' % i), x_magspec.cpu().numpy())
+    np.save(os.path.join(infer_dir, 'batch%06d_input_magspec.npy' % i), x_inv.cpu().numpy())
+  pipe.close()
+  print('Done!')
+
+
+def build_parser():
+  from argparse import ArgumentParser
+  parser = ArgumentParser()
+  parser.add_argument('mode', type=str, choices=['train', 'eval', 'infer'])
+  parser.add_argument('train_dir', type=str)
+  parser.add_argument('--data_cfg', type=str, help='Path to dataset configuration')
+  parser.add_argument('--model_type', type=str, choices=['regular', 'small'])
+  parser.add_argument('--data_dir', type=str, required=True)
+  parser.add_argument('--model_overrides', type=str)
+  parser.add_argument('--train_ckpt_every_nsecs', type=int)
+  parser.add_argument('--max_steps', type=int)
+  parser.add_argument('--infer_batch_size', type=int)
+  parser.add_argument('--train_summary_every_nsecs', type=int)
+  parser.add_argument('--eval_dataset_name', type=str)
+  parser.add_argument('--eval_wavenet_meta_fp', type=str)
+  parser.add_argument('--eval_wavenet_ckpt_fp', type=str)
+  parser.add_argument('--infer_dataset_name', type=str)
+  parser.add_argument('--infer_ckpt_path', type=str)
+  parser.set_defaults(
+      mode=None, train_dir=None, model_type='regular', data_dir=None, model_overrides=None,
+      train_ckpt_every_nsecs=360, train_summary_every_nsecs=60, max_steps=100000, infer_batch_size=1,
+      eval_dataset_name=None, eval_wavenet_meta_fp=None, eval_wavenet_ckpt_fp=None,
+      infer_dataset_name=None, infer_ckpt_path=None)
+  return parser
+
+
+def parse_data_cfg(path, args):
+  """`key,value` lines -> args.data_<key>, int if it parses as int else float (:375-382)."""
+  with open(path, 'r') as f:
+    for line in f.read().strip().splitlines():
+      k, v = line.split(',')
+      try:
+        v = int(v)
+      except ValueError:
+        v = float(v)
+      setattr(args, 'data_' + k, v)
+  return args
+
+
+def main(argv=None):
+  args = build_parser().parse_args(argv)
+  parse_data_cfg(args.data_cfg, args)
+  if not os.path.isdir(args.train_dir):
+    os.makedirs(args.train_dir)
+  fps = glob.glob(os.path.join(args.data_dir, '*'))
+  print('Found {} audio files'.format(len(fps)))
+  if args.mode == 'train':
+    train(fps, args)
+  elif args.mode == 'eval':
+    eval(fps, args)
+  elif args.mode == 'infer':
+    infer(fps, args)
+  else:
+    raise NotImplementedError()
+
+
+if __name__ == '__main__':
+  main()
