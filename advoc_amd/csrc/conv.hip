@@ -167,6 +167,7 @@ int run_gather(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const c
   if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0)
     return launch_gather_gemm(p, b_kn, stream, name_only);
   if (N <= 2 && K % 4 == 0 && p.c0 % 4 == 0) return launch_gather_dot(p, b_kn, stream, name_only);
+  if (K <= 2 && N % 32 == 0 && p.ntaps * K <= 32) return launch_thin_k_gemm(p, b_kn, stream, name_only);
   if (K <= 2) return launch_gather_outer(p, b_kn, stream, name_only);
   return ADVOC_ERR_UNSUPPORTED;
 }
@@ -268,7 +269,13 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
   rc = build_backward_weight(L, dy, dw, p);
   if (rc != ADVOC_OK) return rc;
   const int ca = p.P.c0 + p.P.c1;
-  rc = ca <= 2 ? launch_wgrad_thin(p, as_stream(stream)) : launch_wgrad_mfma(p, as_stream(stream));
+  if (ca <= 2) {
+    const int cb = p.Q.c0 + p.Q.c1;
+    rc = (cb % 32 == 0 && p.ntaps * ca <= 32) ? launch_wgrad_thin_mfma(p, as_stream(stream))
+                                              : launch_wgrad_thin(p, as_stream(stream));
+  } else {
+    rc = launch_wgrad_mfma(p, as_stream(stream));
+  }
   if (rc != ADVOC_OK) return rc;
   if (db)
     rc = launch_bias_grad(dy, L->drop_mask, L->drop_scale, (int64_t)L->y.n * L->y.h, L->y.w,
@@ -304,7 +311,12 @@ extern "C" int advoc_conv_kernel_name(const advoc_conv_layer* L, int32_t directi
     float dummy = 0.f;
     rc = build_backward_weight(L, &dummy, &dummy, p);
     if (rc != ADVOC_OK) return rc;
-    rc = (p.P.c0 + p.P.c1) <= 2 ? launch_wgrad_thin(p, nullptr, &name) : launch_wgrad_mfma(p, nullptr, &name);
+    const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
+    if (ca <= 2)
+      rc = (cb % 32 == 0 && p.ntaps * ca <= 32) ? launch_wgrad_thin_mfma(p, nullptr, &name)
+                                                : launch_wgrad_thin(p, nullptr, &name);
+    else
+      rc = launch_wgrad_mfma(p, nullptr, &name);
   } else {
     return ADVOC_ERR_UNSUPPORTED;
   }

@@ -16,6 +16,10 @@ int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
 int launch_gather_outer(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
                         const char** name_only = nullptr);
 
+// MFMA versions of the thin kernels (thin.hip): K = c0 + c1 <= 2 and taps * K <= 32, N % 32 == 0
+int launch_thin_k_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
+                       const char** name_only = nullptr);
+
 // ---- weight gradient ----
 // An NHWC activation view (optionally the channel concat of two tensors) with the layer's fused
 // input transform.
@@ -47,6 +51,9 @@ int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream,
                       const char** name_only = nullptr);   // both operands wide (% 32)
 int launch_wgrad_thin(const WgradParams& p, hipStream_t stream,
                       const char** name_only = nullptr);   // P has <= 2 channels
+
+int launch_wgrad_thin_mfma(const WgradParams& p, hipStream_t stream,
+                           const char** name_only = nullptr);   // P <= 2 channels, Q % 32, on MFMA
 
 // db[c] = sum over pixels of dy[., c] (* mask * scale)
 int launch_bias_grad(const float* dy, const uint8_t* mask, float mask_scale, int64_t rows, int w,

@@ -59,10 +59,19 @@ struct Cfg {
       sizeof(float) * (2 * A_TILE + 2 * B_TILE) + sizeof(int) * (kMaxTaps + 2 * BM);
 };
 
+// act(v) = max(v, slope * v): slope 1 -> identity, 0.2 -> leaky ReLU, 0 -> ReLU (branch-free)
+__device__ __forceinline__ float act_slope(int act) {
+  return act == ADVOC_ACT_LRELU02 ? 0.2f : (act == ADVOC_ACT_RELU ? 0.f : 1.f);
+}
+
+// launch_bounds(256, 2): budget registers for 2 waves per SIMD (<= 256 VGPR+AGPR).  With the
+// default bound hipcc chases a higher occupancy and spills the prefetch registers to scratch,
+// which serialises the global loads behind s_waitcnt vmcnt(0).
 template <int MT, int NT, int WGM, int WGN, bool B_KN>
-__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams p) {
+__global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmParams p) {
   using C = Cfg<MT, NT, WGM, WGN, B_KN>;
   constexpr int BM = C::BM, BN = C::BN;
+  constexpr int AL = C::A_LOADS, BL = C::B_LOADS;
   static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -82,123 +91,112 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
   const int ktot = p.c0 + p.c1;
   const int kpt = ktot / BK;         // K tiles per tap
   const int nkt = kpt * p.ntaps;
+  const float slope = act_slope(p.in_act);
 
   if (tid < kMaxTaps) s_tap[tid] = p.tap[phase][tid];
 
-  // ---- per-thread A rows (fixed for the whole K loop) ----
+  // ---- per-thread A rows (fixed for the whole K loop); 32-bit element offsets ----
   const int kq = tid & 3;  // which float4 of the 16-wide K slice
-  int row_img[C::A_LOADS], row_y[C::A_LOADS], row_x[C::A_LOADS];
+  int row_y[AL], row_x[AL], base0[AL], base1[AL];
+  bool row_ok[AL];
 #pragma unroll
-  for (int i = 0; i < C::A_LOADS; ++i) {
+  for (int i = 0; i < AL; ++i) {
     const int64_t m = m0 + (tid >> 2) + 64 * i;
-    if (m < M) {
-      const int gx = (int)(m % p.gw);
-      const int64_t t = m / p.gw;
-      row_x[i] = gx * p.sx;
-      row_y[i] = (int)(t % p.gh) * p.sy;
-      row_img[i] = (int)(t / p.gh);
+    row_ok[i] = m < M;
+    const int64_t mm = row_ok[i] ? m : 0;
+    const int gx = (int)(mm % p.gw);
+    const int64_t t = mm / p.gw;
+    const int gy = (int)(t % p.gh), img = (int)(t / p.gh);
+    row_x[i] = gx * p.sx;
+    row_y[i] = gy * p.sy;
+    base0[i] = ((img * p.a_h + row_y[i]) * p.a0_pitch + row_x[i]) * p.c0 + 4 * kq;
+    base1[i] = ((img * p.a_h + row_y[i]) * p.a1_pitch + row_x[i]) * p.c1 + 4 * kq - base0[i];
+  }   // base1 holds the DIFFERENCE to base0: offset = base0 + sel * base1 (no array select -> no scratch)
+  // ---- per-thread B slots ----
+  // B_KN: slot = (k row, 4 consecutive n); else slot = (n row, 4 consecutive k).  Threads beyond
+  // the tile (BN = 32) re-read slot 0..: harmless, they skip the LDS store.
+  int b_goff[BL], b_loff[BL];
+  bool b_store[BL];
+#pragma unroll
+  for (int i = 0; i < BL; ++i) {
+    const int idx = tid + 256 * i;
+    b_store[i] = idx < BN * 4;
+    const int id = b_store[i] ? idx : idx % (BN * 4);
+    if (B_KN) {
+      const int k = id / (BN / 4), nq = id % (BN / 4);
+      b_goff[i] = k * p.n_total + n0 + 4 * nq;           // + (wtap*ktot + k0) * N per tile
+      b_loff[i] = k * C::LDB_KN + 4 * nq;
     } else {
-      row_img[i] = -1;
-      row_x[i] = row_y[i] = 0;
+      const int n = id >> 2, q = id & 3;
+      b_goff[i] = (n0 + n) * ktot + 4 * q;                // + wtap*N*ktot + k0 per tile
+      b_loff[i] = n * LDA + 4 * q;
     }
   }
   __syncthreads();
 
-  float4 ra[C::A_LOADS];
-  float4 rb[C::B_LOADS];
-  unsigned a_ok = 0;       // bit i: ra[i] holds real data (else zero padding)
-  int a_chan = 0;          // channel of ra[*].x in the concatenated input
-  int64_t a_off[C::A_LOADS];
+  float4 ra[AL], rb[BL];
+  unsigned a_ok = 0;
+  int a_chan = 0;
+  int a_moff[AL];
 
-  auto load_tile = [&](int kt) {
-    const int ti = kt / kpt;
-    const int k0 = (kt - ti * kpt) * BK;
-    const int tp = s_tap[ti];
-    const int dy = (int)(int8_t)(tp & 0xff), dx = (int)(int8_t)((tp >> 8) & 0xff);
-    const int wtap = tp >> 16;
-    // A: pick the source of this channel slice (uniform)
-    const bool second = k0 >= p.c0;
-    const float* src = second ? p.a1 : p.a0;
-    const int cs = second ? p.c1 : p.c0;
-    const int pitch = second ? p.a1_pitch : p.a0_pitch;
-    const int cofs = (second ? k0 - p.c0 : k0) + 4 * kq;
-    a_chan = k0 + 4 * kq;
-    a_ok = 0;
-#pragma unroll
-    for (int i = 0; i < C::A_LOADS; ++i) {
-      const int iy = row_y[i] + dy, ix = row_x[i] + dx;
-      const bool ok = row_img[i] >= 0 && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
-      if (ok) {
-        const int64_t off = (((int64_t)row_img[i] * p.a_h + iy) * pitch + ix) * cs + cofs;
-        a_off[i] = off;
-        ra[i] = *reinterpret_cast<const float4*>(src + off);
-        a_ok |= 1u << i;
-      } else {
-        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    // B
-    if (B_KN) {
-#pragma unroll
-      for (int i = 0; i < C::B_LOADS; ++i) {
-        const int idx = tid + 256 * i;
-        const int k = idx / (BN / 4), nq = idx % (BN / 4);
-        if (idx < BN * 4)
-          rb[i] = *reinterpret_cast<const float4*>(
-              p.w + ((int64_t)wtap * ktot + k0 + k) * p.n_total + n0 + 4 * nq);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < C::B_LOADS; ++i) {
-        const int n = (tid >> 2) + 64 * i;
-        if (n < BN)
-          rb[i] = *reinterpret_cast<const float4*>(
-              p.w + ((int64_t)wtap * p.n_total + n0 + n) * ktot + k0 + 4 * kq);
-      }
-    }
-  };
+#define ADVOC_LOAD_TILE(KT)                                                                          \
+  {                                                                                                  \
+    const int ti_ = (KT) / kpt;                                                                      \
+    const int k0_ = ((KT) - ti_ * kpt) * BK;                                                         \
+    const int tp_ = s_tap[ti_];                                                                      \
+    const int dy_ = (int)(int8_t)(tp_ & 0xff), dx_ = (int)(int8_t)((tp_ >> 8) & 0xff);              \
+    const int wtap_ = tp_ >> 16;                                                                     \
+    const bool second_ = k0_ >= p.c0;                                                                \
+    const int sel_ = second_ ? 1 : 0;                                                                \
+    const float* src_ = second_ ? p.a1 : p.a0;                                                       \
+    const int delta_ = second_ ? (dy_ * p.a1_pitch + dx_) * p.c1 + (k0_ - p.c0)                      \
+                               : (dy_ * p.a0_pitch + dx_) * p.c0 + k0_;                              \
+    a_chan = k0_ + 4 * kq;                                                                           \
+    a_ok = 0;                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                                 \
+      const int iy_ = row_y[i] + dy_, ix_ = row_x[i] + dx_;                                          \
+      const bool ok_ = row_ok[i] && (unsigned)iy_ < (unsigned)p.in_h && (unsigned)ix_ < (unsigned)p.in_w; \
+      const int off_ = base0[i] + sel_ * base1[i] + delta_;                                          \
+      a_moff[i] = off_;                                                                              \
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+      if (ok_) {                                                                                     \
+        ra[i] = *reinterpret_cast<const float4*>(src_ + off_);                                       \
+        a_ok |= 1u << i;                                                                             \
+      }                                                                                              \
+    }                                                                                                \
+    const float* wb_ = B_KN ? p.w + ((int64_t)wtap_ * ktot + k0_) * p.n_total                        \
+                            : p.w + (int64_t)wtap_ * p.n_total * ktot + k0_;                         \
+    _Pragma("unroll") for (int i = 0; i < BL; ++i)                                                   \
+        rb[i] = *reinterpret_cast<const float4*>(wb_ + b_goff[i]);                                   \
+  }
 
-  auto store_tile = [&](int buf) {
-    float* Ab = As + buf * C::A_TILE;
-    float* Bb = Bs + buf * C::B_TILE;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.in_scale) {
-      sc = *reinterpret_cast<const float4*>(p.in_scale + a_chan);
-      sh = *reinterpret_cast<const float4*>(p.in_shift + a_chan);
-    }
-#pragma unroll
-    for (int i = 0; i < C::A_LOADS; ++i) {
-      float4 v = ra[i];
-      if ((a_ok >> i) & 1u) {
-        if (p.in_scale) {
-          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
-          v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-        }
-        v.x = apply_act(v.x, p.in_act); v.y = apply_act(v.y, p.in_act);
-        v.z = apply_act(v.z, p.in_act); v.w = apply_act(v.w, p.in_act);
-        if (p.a_mask) {
-          const uchar4 mk = *reinterpret_cast<const uchar4*>(p.a_mask + a_off[i]);
-          v.x *= mk.x * p.a_mask_scale; v.y *= mk.y * p.a_mask_scale;
-          v.z *= mk.z * p.a_mask_scale; v.w *= mk.w * p.a_mask_scale;
-        }
-      }
-      *reinterpret_cast<float4*>(Ab + ((tid >> 2) + 64 * i) * LDA + 4 * kq) = v;
-    }
-    if (B_KN) {
-#pragma unroll
-      for (int i = 0; i < C::B_LOADS; ++i) {
-        const int idx = tid + 256 * i;
-        const int k = idx / (BN / 4), nq = idx % (BN / 4);
-        if (idx < BN * 4) *reinterpret_cast<float4*>(Bb + k * C::LDB_KN + 4 * nq) = rb[i];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < C::B_LOADS; ++i) {
-        const int n = (tid >> 2) + 64 * i;
-        if (n < BN) *reinterpret_cast<float4*>(Bb + n * LDA + 4 * kq) = rb[i];
-      }
-    }
-  };
+#define ADVOC_STORE_TILE(BUF)                                                                        \
+  {                                                                                                  \
+    float* Ab_ = As + (BUF) * C::A_TILE;                                                             \
+    float* Bb_ = Bs + (BUF) * C::B_TILE;                                                             \
+    float4 sc_ = make_float4(1.f, 1.f, 1.f, 1.f), sh_ = make_float4(0.f, 0.f, 0.f, 0.f);            \
+    if (p.in_scale) {                                                                                \
+      sc_ = *reinterpret_cast<const float4*>(p.in_scale + a_chan);                                   \
+      sh_ = *reinterpret_cast<const float4*>(p.in_shift + a_chan);                                   \
+    }                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                                 \
+      float4 v = ra[i];                                                                              \
+      const float live_ = ((a_ok >> i) & 1u) ? 1.f : 0.f;   /* zero padding stays zero */            \
+      v.x = fmaf(v.x, sc_.x, sh_.x * live_); v.y = fmaf(v.y, sc_.y, sh_.y * live_);                  \
+      v.z = fmaf(v.z, sc_.z, sh_.z * live_); v.w = fmaf(v.w, sc_.w, sh_.w * live_);                  \
+      v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);                                  \
+      v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);                                  \
+      if (p.a_mask) {                                                                                \
+        uchar4 mk_ = make_uchar4(0, 0, 0, 0);                                                        \
+        if ((a_ok >> i) & 1u) mk_ = *reinterpret_cast<const uchar4*>(p.a_mask + a_moff[i]);          \
+        v.x *= mk_.x * p.a_mask_scale; v.y *= mk_.y * p.a_mask_scale;                                \
+        v.z *= mk_.z * p.a_mask_scale; v.w *= mk_.w * p.a_mask_scale;                                \
+      }                                                                                              \
+      *reinterpret_cast<float4*>(Ab_ + ((tid >> 2) + 64 * i) * LDA + 4 * kq) = v;                    \
+    }                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < BL; ++i)                                                   \
+        if (b_store[i]) *reinterpret_cast<float4*>(Bb_ + b_loff[i]) = rb[i];                         \
+  }
 
   floatx16 acc[MT][NT];
 #pragma unroll
@@ -210,13 +208,16 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
 
   const int half = lane >> 5, l32 = lane & 31;
 
-  load_tile(0);
-  store_tile(0);
+  ADVOC_LOAD_TILE(0);
+  ADVOC_STORE_TILE(0);
   __syncthreads();
 
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
+    const bool more = kt + 1 < nkt;
+    // unconditional prefetch (the last iteration re-reads its own tile): keeps the prefetch
+    // registers out of a conditional region
+    ADVOC_LOAD_TILE(more ? kt + 1 : kt);
 
     const float* Ab = As + buf * C::A_TILE;
     const float* Bb = Bs + buf * C::B_TILE;
@@ -251,9 +252,11 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
 
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    if (more) ADVOC_STORE_TILE(buf ^ 1);
     __syncthreads();
   }
+#undef ADVOC_LOAD_TILE
+#undef ADVOC_STORE_TILE
 
   // ---- epilogue ----
   for (int r = tid; r < BM; r += 256) {
@@ -275,6 +278,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
   }
   __syncthreads();
 
+  const float gslope = act_slope(p.grad_act);   // act'(x) = x > 0 ? 1 : slope
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + (wn * NT + j) * 32 + l32;
@@ -290,10 +294,10 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
         const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         const int pix = s_pix[di * BM + row];
         if (pix < 0) continue;
-        const int64_t off = (int64_t)pix * d.c + ch;
+        const int off = pix * d.c + ch;
         float v = acc[i][j][r] + bias;
         if (p.y_mask) v *= p.y_mask[off] * p.y_mask_scale;
-        if (p.grad_act != ADVOC_ACT_NONE) v *= act_grad(d.xpre[off], p.grad_act);
+        if (p.grad_act != ADVOC_ACT_NONE) v *= d.xpre[off] > 0.f ? 1.f : gslope;
         if (d.accum) v += d.p[off];
         d.p[off] = v;
       }
@@ -338,8 +342,11 @@ int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
   if (ktot % BK || p.c0 % BK || p.n_total % 32 || p.n_split % 32) return ADVOC_ERR_UNSUPPORTED;
   if (p.nphase < 1 || p.nphase > kMaxPhases || p.ntaps < 1 || p.ntaps > kMaxTaps) return ADVOC_ERR_UNSUPPORTED;
   if (p.a_mask && p.c1) return ADVOC_ERR_UNSUPPORTED;
-  // 32-bit pixel indices in the epilogue
-  if ((int64_t)p.batch * p.out_h * (int64_t)(p.d[0].pitch > p.d[1].pitch ? p.d[0].pitch : p.d[1].pitch) > 0x7fffffffLL)
+  // the kernel indexes every tensor with 32-bit element offsets
+  const int64_t lim = 0x7fffffffLL;
+  if ((int64_t)p.batch * p.a_h * p.a0_pitch * p.c0 > lim || (int64_t)p.batch * p.a_h * p.a1_pitch * p.c1 > lim ||
+      (int64_t)p.batch * p.out_h * p.d[0].pitch * p.d[0].c > lim ||
+      (int64_t)p.batch * p.out_h * p.d[1].pitch * p.d[1].c > lim)
     return ADVOC_ERR_UNSUPPORTED;
   return b_kn ? dispatch<true>(p, stream, name_only) : dispatch<false>(p, stream, name_only);
 }

@@ -79,11 +79,38 @@ struct WCfg {
   static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (WK * LDP + WK * LDQ);
 };
 
+// float4 of `op` at a precomputed pixel index (img*h + y)*pitch + x per source, channels ch..ch+3
+__device__ __forceinline__ float4 load_op4_at(const Operand& op, int pix0, int pix1, int ch, float slope) {
+  const bool second = ch >= op.c0;
+  const float* src = second ? op.p1 : op.p0;
+  const int off = second ? pix1 * op.c1 + (ch - op.c0) : pix0 * op.c0 + ch;
+  float4 v = *reinterpret_cast<const float4*>(src + off);
+  if (op.scale) {
+    const float4 sc = *reinterpret_cast<const float4*>(op.scale + ch);
+    const float4 sh = *reinterpret_cast<const float4*>(op.shift + ch);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+  }
+  v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
+  v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
+  if (op.mask) {
+    const uchar4 mk = *reinterpret_cast<const uchar4*>(op.mask + off);
+    v.x *= mk.x * op.mask_scale; v.y *= mk.y * op.mask_scale;
+    v.z *= mk.z * op.mask_scale; v.w *= mk.w * op.mask_scale;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float slope_of(int act) {
+  return act == ADVOC_ACT_LRELU02 ? 0.2f : (act == ADVOC_ACT_RELU ? 0.f : 1.f);
+}
+
+// launch_bounds(256, 2): see igemm.hip -- keeps the prefetch registers out of scratch.
 template <int MT, int NT, int WGM, int WGN>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p, int tiles_n,
-                                                         int chunk) {
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p, int tiles_n,
+                                                            int chunk) {
   using C = WCfg<MT, NT, WGM, WGN>;
   constexpr int BM = C::BM, BN = C::BN;
+  constexpr int PL = C::P_LOADS, QL = C::Q_LOADS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ps = smem;                      // [2][WK][LDP]
   float* Qs = smem + 2 * WK * C::LDP;    // [2][WK][LDQ]
@@ -100,58 +127,76 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p, in
   const int64_t g_begin = (int64_t)blockIdx.z * chunk;
   const int64_t g_end = g_begin + chunk < M ? g_begin + chunk : M;
   const int nkt = (int)((g_end - g_begin + WK - 1) / WK);
+  const float pslope = slope_of(p.P.act), qslope = slope_of(p.Q.act);
 
-  // loader slots: slot i covers pixel (idx / (B/4)) of the K step, channel quad (idx % (B/4))
-  float4 rp[C::P_LOADS], rq[C::Q_LOADS];
+  // Loader slots.  Slot i of the P (Q) tile = pixel k_i of the K step, channel quad cq_i; the
+  // slot's grid point advances by WK per K step and is tracked incrementally (no divisions).
+  int p_k[PL], p_ch[PL], p_gx[PL], p_gy[PL], p_img[PL];
+  int q_k[QL], q_ch[QL], q_gx[QL], q_gy[QL], q_img[QL];
+  bool p_on[PL], q_on[QL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    const int idx = tid + 256 * i;
+    p_k[i] = idx / (BM / 4);
+    p_ch[i] = a0 + 4 * (idx % (BM / 4));
+    p_on[i] = p_k[i] < WK && p_ch[i] < ca;
+    const int64_t g = g_begin + (p_k[i] < WK ? p_k[i] : 0);
+    p_gx[i] = (int)(g % p.gw);
+    const int64_t t = g / p.gw;
+    p_gy[i] = (int)(t % p.gh);
+    p_img[i] = (int)(t / p.gh);
+  }
+#pragma unroll
+  for (int i = 0; i < QL; ++i) {
+    const int idx = tid + 256 * i;
+    q_k[i] = idx / (BN / 4);
+    q_ch[i] = b0 + 4 * (idx % (BN / 4));
+    q_on[i] = q_k[i] < WK && q_ch[i] < cb;
+    const int64_t g = g_begin + (q_k[i] < WK ? q_k[i] : 0);
+    q_gx[i] = (int)(g % p.gw);
+    const int64_t t = g / p.gw;
+    q_gy[i] = (int)(t % p.gh);
+    q_img[i] = (int)(t / p.gh);
+  }
 
-  auto load_tiles = [&](int kt) {
-    const int64_t gbase = g_begin + (int64_t)kt * WK;
-#pragma unroll
-    for (int i = 0; i < C::P_LOADS; ++i) {
-      const int idx = tid + 256 * i;
-      const int k = idx / (BM / 4), cq = idx % (BM / 4);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int64_t g = gbase + k;
-      if (k < WK && g < g_end) {
-        const int gx = (int)(g % p.gw);
-        const int64_t t = g / p.gw;
-        const int y = (int)(t % p.gh) * p.sy + dy, x = gx * p.sx + dx;
-        if ((unsigned)y < (unsigned)p.P.h && (unsigned)x < (unsigned)p.P.w && a0 + 4 * cq < ca)
-          v = load_op4(p.P, (int)(t / p.gh), y, x, a0 + 4 * cq);
-      }
-      rp[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < C::Q_LOADS; ++i) {
-      const int idx = tid + 256 * i;
-      const int k = idx / (BN / 4), cq = idx % (BN / 4);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int64_t g = gbase + k;
-      if (k < WK && g < g_end && b0 + 4 * cq < cb) {
-        const int gx = (int)(g % p.gw);
-        const int64_t t = g / p.gw;
-        v = load_op4(p.Q, (int)(t / p.gh), (int)(t % p.gh), gx, b0 + 4 * cq);
-      }
-      rq[i] = v;
-    }
-  };
+  float4 rp[PL], rq[QL];
 
-  auto store_tiles = [&](int buf) {
-    float* Pb = Ps + buf * WK * C::LDP;
-    float* Qb = Qs + buf * WK * C::LDQ;
-#pragma unroll
-    for (int i = 0; i < C::P_LOADS; ++i) {
-      const int idx = tid + 256 * i;
-      const int k = idx / (BM / 4), cq = idx % (BM / 4);
-      if (k < WK) *reinterpret_cast<float4*>(Pb + k * C::LDP + 4 * cq) = rp[i];
-    }
-#pragma unroll
-    for (int i = 0; i < C::Q_LOADS; ++i) {
-      const int idx = tid + 256 * i;
-      const int k = idx / (BN / 4), cq = idx % (BN / 4);
-      if (k < WK) *reinterpret_cast<float4*>(Qb + k * C::LDQ + 4 * cq) = rq[i];
-    }
-  };
+  // loads the slots' current grid points, then advances them by WK
+#define ADVOC_W_LOAD(KT)                                                                             \
+  {                                                                                                  \
+    const int64_t gb_ = g_begin + (int64_t)(KT) * WK;                                                \
+    _Pragma("unroll") for (int i = 0; i < PL; ++i) {                                                 \
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+      const int y = p_gy[i] * p.sy + dy, x = p_gx[i] * p.sx + dx;                                    \
+      if (p_on[i] && gb_ + p_k[i] < g_end && (unsigned)y < (unsigned)p.P.h && (unsigned)x < (unsigned)p.P.w) { \
+        const int row = p_img[i] * p.P.h + y;                                                        \
+        v = load_op4_at(p.P, row * p.P.pitch0 + x, row * p.P.pitch1 + x, p_ch[i], pslope);           \
+      }                                                                                              \
+      rp[i] = v;                                                                                     \
+      p_gx[i] += WK;                                                                                 \
+      while (p_gx[i] >= p.gw) { p_gx[i] -= p.gw; if (++p_gy[i] >= p.gh) { p_gy[i] = 0; ++p_img[i]; } } \
+    }                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < QL; ++i) {                                                 \
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+      if (q_on[i] && gb_ + q_k[i] < g_end) {                                                         \
+        const int row = q_img[i] * p.Q.h + q_gy[i];                                                  \
+        v = load_op4_at(p.Q, row * p.Q.pitch0 + q_gx[i], row * p.Q.pitch1 + q_gx[i], q_ch[i], qslope); \
+      }                                                                                              \
+      rq[i] = v;                                                                                     \
+      q_gx[i] += WK;                                                                                 \
+      while (q_gx[i] >= p.gw) { q_gx[i] -= p.gw; if (++q_gy[i] >= p.gh) { q_gy[i] = 0; ++q_img[i]; } } \
+    }                                                                                                \
+  }
+
+#define ADVOC_W_STORE(BUF)                                                                           \
+  {                                                                                                  \
+    float* Pb_ = Ps + (BUF) * WK * C::LDP;                                                           \
+    float* Qb_ = Qs + (BUF) * WK * C::LDQ;                                                           \
+    _Pragma("unroll") for (int i = 0; i < PL; ++i)                                                   \
+        if (p_k[i] < WK) *reinterpret_cast<float4*>(Pb_ + p_k[i] * C::LDP + (p_ch[i] - a0)) = rp[i]; \
+    _Pragma("unroll") for (int i = 0; i < QL; ++i)                                                   \
+        if (q_k[i] < WK) *reinterpret_cast<float4*>(Qb_ + q_k[i] * C::LDQ + (q_ch[i] - b0)) = rq[i]; \
+  }
 
   floatx16 acc[MT][NT];
 #pragma unroll
@@ -161,15 +206,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (nkt > 0) {
-    load_tiles(0);
-    store_tiles(0);
-  }
+  if (nkt == 0) return;
+  ADVOC_W_LOAD(0);
+  ADVOC_W_STORE(0);
   __syncthreads();
 
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tiles(kt + 1);
+    // unconditional prefetch; past the end every slot fails the g_end test and loads nothing
+    ADVOC_W_LOAD(kt + 1);
     const float* Pb = Ps + buf * WK * C::LDP;
     const float* Qb = Qs + buf * WK * C::LDQ;
 #pragma unroll
@@ -186,11 +231,12 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p, in
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nkt) store_tiles(buf ^ 1);
+    if (kt + 1 < nkt) ADVOC_W_STORE(buf ^ 1);
     __syncthreads();
   }
+#undef ADVOC_W_LOAD
+#undef ADVOC_W_STORE
 
-  if (nkt == 0) return;
   float* out = p.dw + (int64_t)wtap * ca * cb;
 #pragma unroll
   for (int i = 0; i < MT; ++i)

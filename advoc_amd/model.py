@@ -415,7 +415,7 @@ class Advoc(Model):
     if callable(x):
       self._feed = x
     else:
-      fixed = (x, target, x_wav, x_mel_spec)
+      fixed = tuple(x) if isinstance(x, (tuple, list)) else (x, target, x_wav, x_mel_spec)
       self._feed = lambda: fixed
     return self
 
