@@ -329,6 +329,10 @@ int launch_cfg(const GatherGemmParams& p, hipStream_t stream, const char** name_
 template <bool B_KN>
 int dispatch(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
   const int N = p.n_total;
+  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  // small grids (deep, narrow layers): 64 x 64 tiles put 4x more workgroups on the 256 CUs
+  if (N % 64 == 0 && ceil_div(M, 128) * ceil_div(N, 128) * p.nphase < 384)
+    return launch_cfg<1, 1, 2, 2, B_KN>(p, stream, name_only);                    // 64 x 64
   if (N % 128 == 0) return launch_cfg<2, 2, 2, 2, B_KN>(p, stream, name_only);   // 128 x 128
   if (N % 64 == 0) return launch_cfg<2, 1, 2, 2, B_KN>(p, stream, name_only);    // 128 x 64
   return launch_cfg<2, 1, 4, 1, B_KN>(p, stream, name_only);                     // 256 x 32

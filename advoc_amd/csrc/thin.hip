@@ -42,9 +42,15 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
 // thin_k_gemm
 // ---------------------------------------------------------------------------------------------
 // KP: padded contraction length (16 or 32); NT: 32-channel tiles per wave.
+// Per-slot gather constants and the weight tile live in LDS (read back with conflict-free
+// ds_read_b32), so a wave needs ~16 NT accumulator registers + KP/2 operands: 4-8 waves per SIMD
+// cover the HBM latency of this streaming kernel.
 template <int KP, int NT, bool B_KN>
 __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams p, int n_base_tiles) {
   __shared__ int s_pix[4][2][32];
+  __shared__ int s_delta[KP];     // element offset of slot k' relative to the row base of its source
+  __shared__ int s_info[KP];      // (dy & 0xff) | (dx & 0xff) << 8 | valid << 16 | second << 17 | ci << 18
+  __shared__ float s_w[KP][32 * NT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l32 = lane & 31;
   const int phase = blockIdx.z;
@@ -53,30 +59,28 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
   const int N = p.n_total;
   const int n0 = blockIdx.y * (32 * NT);
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  const float slope = p.in_act == ADVOC_ACT_LRELU02 ? 0.2f : (p.in_act == ADVOC_ACT_RELU ? 0.f : 1.f);
+  const float gslope = p.grad_act == ADVOC_ACT_LRELU02 ? 0.2f : (p.grad_act == ADVOC_ACT_RELU ? 0.f : 1.f);
 
-  // ---- per-lane K slots: slot s of this lane is k' = 2 s + half ----
-  int k_dy[KP / 2], k_dx[KP / 2];
-  unsigned k_valid = 0, k_second = 0;
-  float wreg[NT][KP / 2];
-#pragma unroll
-  for (int s = 0; s < KP / 2; ++s) {
-    const int kk = 2 * s + half;
+  for (int kk = threadIdx.x; kk < KP; kk += 256) {
     const bool ok = kk < kreal;
     const int t = ok ? kk / ktot : 0, ci = ok ? kk % ktot : 0;
     const int tp = p.tap[phase][t];
-    k_dy[s] = (int)(int8_t)(tp & 0xff);
-    k_dx[s] = (int)(int8_t)((tp >> 8) & 0xff);
-    const int wtap = tp >> 16;
-    if (ok) k_valid |= 1u << s;
-    if (ok && ci >= p.c0) k_second |= 1u << s;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + 32 * j + l32;
-      float w = 0.f;
-      if (ok && n < N)
-        w = B_KN ? p.w[((int64_t)wtap * ktot + ci) * N + n] : p.w[((int64_t)wtap * N + n) * ktot + ci];
-      wreg[j][s] = w;
+    const int dy = (int)(int8_t)(tp & 0xff), dx = (int)(int8_t)((tp >> 8) & 0xff);
+    const bool second = ok && ci >= p.c0;
+    s_delta[kk] = second ? (dy * p.a1_pitch + dx) * p.c1 + (ci - p.c0) : (dy * p.a0_pitch + dx) * p.c0 + ci;
+    s_info[kk] = (dy & 0xff) | ((dx & 0xff) << 8) | ((ok ? 1 : 0) << 16) | ((second ? 1 : 0) << 17) | (ci << 18);
+  }
+  for (int idx = threadIdx.x; idx < KP * 32 * NT; idx += 256) {
+    const int kk = idx / (32 * NT), nn = idx % (32 * NT);
+    const int n = n0 + nn;
+    float w = 0.f;
+    if (kk < kreal && n < N) {
+      const int t = kk / ktot, ci = kk % ktot;
+      const int wtap = p.tap[phase][t] >> 16;
+      w = B_KN ? p.w[((int64_t)wtap * ktot + ci) * N + n] : p.w[((int64_t)wtap * N + n) * ktot + ci];
     }
+    s_w[kk][nn] = w;
   }
   float bias[NT];
 #pragma unroll
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
     const int n = n0 + 32 * j + l32;
     bias[j] = (p.bias && n < N) ? p.bias[n] : 0.f;
   }
+  __syncthreads();
 
   const int64_t tiles = (M + 31) / 32;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
@@ -96,8 +101,7 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
       gy = (int)(t % p.gh);
       img = (int)(t / p.gh);
     }
-    // output pixel offsets of this wave's 32 rows (lanes 0-31 publish them)
-    if (half == 0) {
+    if (half == 0) {   // lanes 0-31 publish their row's output pixel
       int pix0 = -1, pix1 = -1;
       const int oy = gy * p.osy + p.ooy[phase], ox = gx * p.osx + p.oox[phase];
       if (live && oy < p.out_h && ox < p.out_w) {
@@ -107,24 +111,26 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
       s_pix[wave][0][l32] = pix0;
       s_pix[wave][1][l32] = pix1;
     }
-    // A operand: one gathered scalar per K slot
+    const int y0 = gy * p.sy, x0 = gx * p.sx;
+    const int base0 = ((img * p.a_h + y0) * p.a0_pitch + x0) * p.c0;
+    const int base1 = ((img * p.a_h + y0) * p.a1_pitch + x0) * p.c1;
+    // A operand: one gathered scalar per K slot (k' = 2 s + half)
     float a[KP / 2];
 #pragma unroll
     for (int s = 0; s < KP / 2; ++s) {
+      const int kk = 2 * s + half;
+      const int info = s_info[kk];
+      const int iy = y0 + (int)(int8_t)(info & 0xff), ix = x0 + (int)(int8_t)((info >> 8) & 0xff);
       float v = 0.f;
-      const int iy = gy * p.sy + k_dy[s], ix = gx * p.sx + k_dx[s];
-      if (live && ((k_valid >> s) & 1u) && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) {
-        const bool second = (k_second >> s) & 1u;
-        const float* src = second ? p.a1 : p.a0;
-        const int cs = second ? p.c1 : p.c0;
-        const int pitch = second ? p.a1_pitch : p.a0_pitch;
-        // with <= 2 channels per source the channel offset inside a source is k' % ktot - c0 or 0
-        const int kk = 2 * s + half;
-        const int ci = kk % ktot;
-        const int64_t off = (((int64_t)img * p.a_h + iy) * pitch + ix) * cs + (second ? ci - p.c0 : ci);
-        v = src[off];
-        if (p.in_scale) v = v * p.in_scale[ci] + p.in_shift[ci];
-        v = act_fwd(v, p.in_act);
+      if (live && ((info >> 16) & 1) && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) {
+        const bool second = (info >> 17) & 1;
+        const int off = (second ? base1 : base0) + s_delta[kk];
+        v = (second ? p.a1 : p.a0)[off];
+        if (p.in_scale) {
+          const int ci = info >> 18;
+          v = v * p.in_scale[ci] + p.in_shift[ci];
+        }
+        v = fmaxf(v, slope * v);
         if (p.a_mask) v *= p.a_mask[off] * p.a_mask_scale;
       }
       a[s] = v;
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
     for (int s = 0; s < KP / 2; ++s)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wreg[j][s], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], s_w[2 * s + half][32 * j + l32], acc[j], 0, 0, 0);
 
     wave_lds_sync();
 #pragma unroll
@@ -154,10 +160,10 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         const int pix = s_pix[wave][di][row];
         if (pix < 0) continue;
-        const int64_t off = (int64_t)pix * d.c + ch;
+        const int off = pix * d.c + ch;
         float v = acc[j][r] + bias[j];
         if (p.y_mask) v *= p.y_mask[off] * p.y_mask_scale;
-        if (p.grad_act != ADVOC_ACT_NONE) v *= act_bwd(d.xpre[off], p.grad_act);
+        if (p.grad_act != ADVOC_ACT_NONE) v *= d.xpre[off] > 0.f ? 1.f : gslope;
         if (d.accum) v += d.p[off];
         d.p[off] = v;
       }
@@ -197,8 +203,11 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
 // ---------------------------------------------------------------------------------------------
 // thin_wgrad
 // ---------------------------------------------------------------------------------------------
+// U MFMA steps (2 grid points each) are fetched together so a wave keeps U * (1 + NT) loads in
+// flight; with the loop-carried one-step version the kernel ran at memory latency, not bandwidth.
 template <int NT>
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, int chunk) {
+  constexpr int U = 8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l32 = lane & 31;
   const int ca = p.P.c0 + p.P.c1;            // 1 or 2
@@ -206,17 +215,33 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
   const int rows = p.ntaps * ca;             // <= 32 live rows of the A operand
   const int b0 = blockIdx.y * (32 * NT);
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  const float pslope = p.P.act == ADVOC_ACT_LRELU02 ? 0.2f : (p.P.act == ADVOC_ACT_RELU ? 0.f : 1.f);
+  const float qslope = p.Q.act == ADVOC_ACT_LRELU02 ? 0.2f : (p.Q.act == ADVOC_ACT_RELU ? 0.f : 1.f);
 
   // this lane's A row: (tap, a)
   const bool row_ok = l32 < rows;
   const int t = row_ok ? l32 / ca : 0, a = row_ok ? l32 % ca : 0;
   const int tp = p.tap[t];
-  const int dy = (int)(int8_t)(tp & 0xff), dx = (int)(int8_t)((tp >> 8) & 0xff), wtap = tp >> 16;
+  const int dy = (int)(int8_t)(tp & 0xff), dx = (int)(int8_t)((tp >> 8) & 0xff);
   const bool a_second = a >= p.P.c0;
   const float* psrc = a_second ? p.P.p1 : p.P.p0;
   const int pcs = a_second ? p.P.c1 : p.P.c0;
   const int ppitch = a_second ? p.P.pitch1 : p.P.pitch0;
   const int pch = a_second ? a - p.P.c0 : a;
+  // this lane's B columns
+  const float* qsrc[NT];
+  int qcs[NT], qpitch[NT], qch[NT];
+  bool q_ok[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int b = b0 + 32 * j + l32;
+    q_ok[j] = b < cb;
+    const bool second = b >= p.Q.c0;
+    qsrc[j] = second ? p.Q.p1 : p.Q.p0;
+    qcs[j] = second ? p.Q.c1 : p.Q.c0;
+    qpitch[j] = second ? p.Q.pitch1 : p.Q.pitch0;
+    qch[j] = second ? b - p.Q.c0 : b;
+  }
 
   // each wave owns a contiguous run of grid points, two per MFMA (lanes 0-31 / 32-63)
   const int64_t w_begin = ((int64_t)blockIdx.x * 4 + wave) * chunk;
@@ -236,64 +261,66 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  for (; g - half < w_end; g += 2) {
-    const bool live = g < w_end;
-    float av = 0.f;
-    float bv[NT];
+  for (; g - half < w_end; g += 2 * U) {
+    float av[U], bv[NT][U];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bv[j] = 0.f;
-    if (live) {
-      const int y = gy * p.sy + dy, x = gx * p.sx + dx;
-      if (row_ok && (unsigned)y < (unsigned)p.P.h && (unsigned)x < (unsigned)p.P.w) {
-        const int64_t off = (((int64_t)img * p.P.h + y) * ppitch + x) * pcs + pch;
-        float v = psrc[off];
-        if (p.P.scale) v = v * p.P.scale[a] + p.P.shift[a];
-        v = act_fwd(v, p.P.act);
-        if (p.P.mask) v *= p.P.mask[off] * p.P.mask_scale;
-        av = v;
-      }
+    for (int u = 0; u < U; ++u) {
+      const bool live = g + 2 * u < w_end;
+      av[u] = 0.f;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int b = b0 + 32 * j + l32;
-        if (b < cb) {
-          const bool second = b >= p.Q.c0;
-          const float* src = second ? p.Q.p1 : p.Q.p0;
-          const int cs = second ? p.Q.c1 : p.Q.c0;
-          const int pitch = second ? p.Q.pitch1 : p.Q.pitch0;
-          const int64_t off = (((int64_t)img * p.Q.h + gy) * pitch + gx) * cs + (second ? b - p.Q.c0 : b);
-          float v = src[off];
-          if (p.Q.scale) v = v * p.Q.scale[b] + p.Q.shift[b];
-          v = act_fwd(v, p.Q.act);
-          if (p.Q.mask) v *= p.Q.mask[off] * p.Q.mask_scale;
-          bv[j] = v;
+      for (int j = 0; j < NT; ++j) bv[j][u] = 0.f;
+      if (live) {
+        const int y = gy * p.sy + dy, x = gx * p.sx + dx;
+        if (row_ok && (unsigned)y < (unsigned)p.P.h && (unsigned)x < (unsigned)p.P.w) {
+          const int off = ((img * p.P.h + y) * ppitch + x) * pcs + pch;
+          float v = psrc[off];
+          if (p.P.scale) v = v * p.P.scale[a] + p.P.shift[a];
+          v = fmaxf(v, pslope * v);
+          if (p.P.mask) v *= p.P.mask[off] * p.P.mask_scale;
+          av[u] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (q_ok[j]) {
+            const int off = ((img * p.Q.h + gy) * qpitch[j] + gx) * qcs[j] + qch[j];
+            float v = qsrc[j][off];
+            if (p.Q.scale) v = v * p.Q.scale[b0 + 32 * j + l32] + p.Q.shift[b0 + 32 * j + l32];
+            v = fmaxf(v, qslope * v);
+            if (p.Q.mask) v *= p.Q.mask[off] * p.Q.mask_scale;
+            bv[j][u] = v;
+          }
         }
       }
+      gx += 2;   // this lane's next grid point
+      while (gx >= p.gw) {
+        gx -= p.gw;
+        if (++gy >= p.gh) { gy = 0; ++img; }
+      }
     }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j], 0, 0, 0);
-    // advance this lane's grid point by 2
-    gx += 2;
-    while (gx >= p.gw) {
-      gx -= p.gw;
-      if (++gy >= p.gh) { gy = 0; ++img; }
-    }
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[j][u], acc[j], 0, 0, 0);
   }
 
-  // acc[j][r]: row (r&3)+8(r>>2)+4*half = A row index (tap, a); column l32 = channel
+  // Combine the four waves of the block in LDS, then ONE atomic per output element per block:
+  // thousands of waves hammering the same <= 32 x cb addresses serialise in L2 otherwise.
+  __shared__ float s_red[4][NT][16][64];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int b = b0 + 32 * j + l32;
-    if (b >= cb) continue;
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (row >= rows) continue;
-      const int rt = row / ca, ra = row % ca;
-      const int rw = p.tap[rt] >> 16;
-      unsafeAtomicAdd(p.dw + ((int64_t)rw * ca + ra) * cb + b, acc[j][r]);
-    }
+    for (int r = 0; r < 16; ++r) s_red[wave][j][r][lane] = acc[j][r];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < NT * 16 * 64; idx += 256) {
+    const int ln = idx & 63, r = (idx >> 6) & 15, j = idx >> 10;
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);     // A row index (tap, a)
+    const int b = b0 + 32 * j + (ln & 31);
+    if (row >= rows || b >= cb) continue;
+    const float v = s_red[0][j][r][ln] + s_red[1][j][r][ln] + s_red[2][j][r][ln] + s_red[3][j][r][ln];
+    const int rt = row / ca, ra = row % ca;
+    unsafeAtomicAdd(p.dw + ((int64_t)(p.tap[rt] >> 16) * ca + ra) * cb + b, v);
   }
-  (void)wtap;
 }
 
 }  // namespace
@@ -322,7 +349,8 @@ int launch_wgrad_thin_mfma(const WgradParams& p, hipStream_t stream, const char*
   if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   const int by = cb / (32 * nt);
-  // ~2048 waves over the pixel axis (8 per CU) so HBM latency is covered by occupancy
+  // ~2048 waves over the pixel axis (2 blocks of 4 waves per CU); each wave keeps 8 x (1 + NT)
+  // loads in flight
   int64_t waves = 2048 / by;
   if (waves < 4) waves = 4;
   int64_t chunk = ceil_div(M, waves);

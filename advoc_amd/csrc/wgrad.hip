@@ -118,11 +118,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int half = lane >> 5, l32 = lane & 31;
+  // rows of the GEMM = (tap, channel of P): every tap shares the Q tile of a grid point
   const int a0 = (blockIdx.x / tiles_n) * BM;
   const int b0 = (blockIdx.x % tiles_n) * BN;
-  const int tp = p.tap[blockIdx.y];
-  const int dy = (int)(int8_t)(tp & 0xff), dx = (int)(int8_t)((tp >> 8) & 0xff), wtap = tp >> 16;
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
+  const int rows_total = p.ntaps * ca;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   const int64_t g_begin = (int64_t)blockIdx.z * chunk;
   const int64_t g_end = g_begin + chunk < M ? g_begin + chunk : M;
@@ -131,15 +131,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
 
   // Loader slots.  Slot i of the P (Q) tile = pixel k_i of the K step, channel quad cq_i; the
   // slot's grid point advances by WK per K step and is tracked incrementally (no divisions).
-  int p_k[PL], p_ch[PL], p_gx[PL], p_gy[PL], p_img[PL];
+  int p_k[PL], p_ch[PL], p_gx[PL], p_gy[PL], p_img[PL], p_dy[PL], p_dx[PL], p_col[PL];
   int q_k[QL], q_ch[QL], q_gx[QL], q_gy[QL], q_img[QL];
   bool p_on[PL], q_on[QL];
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
     const int idx = tid + 256 * i;
     p_k[i] = idx / (BM / 4);
-    p_ch[i] = a0 + 4 * (idx % (BM / 4));
-    p_on[i] = p_k[i] < WK && p_ch[i] < ca;
+    p_col[i] = 4 * (idx % (BM / 4));
+    const int row = a0 + p_col[i];
+    p_on[i] = p_k[i] < WK && row < rows_total;
+    const int t_ = p_on[i] ? row / ca : 0;
+    p_ch[i] = row - t_ * ca;
+    const int tp_ = p.tap[t_];
+    p_dy[i] = (int)(int8_t)(tp_ & 0xff);
+    p_dx[i] = (int)(int8_t)((tp_ >> 8) & 0xff);
     const int64_t g = g_begin + (p_k[i] < WK ? p_k[i] : 0);
     p_gx[i] = (int)(g % p.gw);
     const int64_t t = g / p.gw;
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
     const int64_t gb_ = g_begin + (int64_t)(KT) * WK;                                                \
     _Pragma("unroll") for (int i = 0; i < PL; ++i) {                                                 \
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
-      const int y = p_gy[i] * p.sy + dy, x = p_gx[i] * p.sx + dx;                                    \
+      const int y = p_gy[i] * p.sy + p_dy[i], x = p_gx[i] * p.sx + p_dx[i];                          \
       if (p_on[i] && gb_ + p_k[i] < g_end && (unsigned)y < (unsigned)p.P.h && (unsigned)x < (unsigned)p.P.w) { \
         const int row = p_img[i] * p.P.h + y;                                                        \
         v = load_op4_at(p.P, row * p.P.pitch0 + x, row * p.P.pitch1 + x, p_ch[i], pslope);           \
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
     float* Pb_ = Ps + (BUF) * WK * C::LDP;                                                           \
     float* Qb_ = Qs + (BUF) * WK * C::LDQ;                                                           \
     _Pragma("unroll") for (int i = 0; i < PL; ++i)                                                   \
-        if (p_k[i] < WK) *reinterpret_cast<float4*>(Pb_ + p_k[i] * C::LDP + (p_ch[i] - a0)) = rp[i]; \
+        if (p_k[i] < WK) *reinterpret_cast<float4*>(Pb_ + p_k[i] * C::LDP + p_col[i]) = rp[i];       \
     _Pragma("unroll") for (int i = 0; i < QL; ++i)                                                   \
         if (q_k[i] < WK) *reinterpret_cast<float4*>(Qb_ + q_k[i] * C::LDQ + (q_ch[i] - b0)) = rq[i]; \
   }
@@ -237,18 +243,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
 #undef ADVOC_W_LOAD
 #undef ADVOC_W_STORE
 
-  float* out = p.dw + (int64_t)wtap * ca * cb;
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < MT; ++i) {
+    // a 32-row MFMA tile never straddles a tap (ca % 32 == 0): one tap lookup per tile
+    const int row0 = a0 + (wm * MT + i) * 32;
+    if (row0 >= rows_total) continue;
+    const int t_ = row0 / ca;
+    float* out = p.dw + ((int64_t)(p.tap[t_] >> 16) * ca + (row0 - t_ * ca)) * cb;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int b = b0 + (wn * NT + j) * 32 + l32;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int a = a0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (a < ca && b < cb) unsafeAtomicAdd(out + (int64_t)a * cb + b, acc[i][j][r]);
+        const int a = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (b < cb) unsafeAtomicAdd(out + (int64_t)a * cb + b, acc[i][j][r]);
       }
     }
+  }
 }
 
 template <int MT, int NT, int WGM, int WGN>
@@ -267,10 +278,10 @@ int launch_wcfg(const WgradParams& p, hipStream_t stream, const char** name_only
     if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
   }
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
-  const int tiles_m = (ca + C::BM - 1) / C::BM, tiles_n = (cb + C::BN - 1) / C::BN;
+  const int tiles_m = (p.ntaps * ca + C::BM - 1) / C::BM, tiles_n = (cb + C::BN - 1) / C::BN;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   // split the pixel axis so the launch has ~1024 workgroups (4 per CU)
-  const int64_t tiles = (int64_t)tiles_m * tiles_n * p.ntaps;
+  const int64_t tiles = (int64_t)tiles_m * tiles_n;
   int64_t ksplit = ceil_div(1024, tiles);
   const int64_t max_split = ceil_div(M, 8 * WK);
   if (ksplit > max_split) ksplit = max_split;
@@ -278,7 +289,7 @@ int launch_wcfg(const WgradParams& p, hipStream_t stream, const char** name_only
   int64_t chunk = ceil_div(ceil_div(M, ksplit), WK) * WK;
   ksplit = ceil_div(M, chunk);
   if (chunk > 0x7fffffffLL || ksplit > 65535) return ADVOC_ERR_UNSUPPORTED;
-  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)p.ntaps, (unsigned)ksplit);
+  dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)ksplit);
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL((wgrad_mfma_kernel<MT, NT, WGM, WGN>), grid, dim3(256), C::LDS_BYTES, stream, p,
                      tiles_n, (int)chunk);
@@ -388,22 +399,12 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
 int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream, const char** name_only) {
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   if (ca % 32 || cb % 32 || p.P.c0 % 4 || p.Q.c0 % 4) return ADVOC_ERR_UNSUPPORTED;
-  if (p.P.c1 && p.P.c0 % 32) return ADVOC_ERR_UNSUPPORTED;  // a block's channel tile stays in one source
+  if (p.P.c1 && p.P.c0 % 32) return ADVOC_ERR_UNSUPPORTED;  // a 32-row MFMA tile stays in one source
   if (p.Q.c1 && p.Q.c0 % 32) return ADVOC_ERR_UNSUPPORTED;
-  // pick the tile with the least padded work (ties: the larger tile); edges are masked
-  const int bm[4] = {128, 64, 32, 128}, bn[4] = {128, 64, 128, 32};
-  int best = 0;
-  int64_t best_cost = -1;
-  for (int i = 0; i < 4; ++i) {
-    const int64_t cost = ceil_div(ca, bm[i]) * bm[i] * ceil_div(cb, bn[i]) * bn[i];
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = i; }
-  }
-  switch (best) {
-    case 0: return launch_wcfg<2, 2, 2, 2>(p, stream, name_only);
-    case 1: return launch_wcfg<1, 1, 2, 2>(p, stream, name_only);
-    case 2: return launch_wcfg<1, 1, 1, 4>(p, stream, name_only);
-    default: return launch_wcfg<1, 1, 4, 1>(p, stream, name_only);
-  }
+  // rows = taps x ca (>= 512): 128-row tiles; the column tile follows cb
+  if (cb % 128 == 0) return launch_wcfg<2, 2, 2, 2>(p, stream, name_only);   // 128 x 128
+  if (cb % 64 == 0) return launch_wcfg<2, 1, 2, 2>(p, stream, name_only);    // 128 x 64
+  return launch_wcfg<1, 1, 4, 1>(p, stream, name_only);                      // 128 x 32
 }
 
 int launch_wgrad_thin(const WgradParams& p, hipStream_t stream, const char** name_only) {
