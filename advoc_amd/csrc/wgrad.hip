@@ -359,12 +359,54 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const WgradParams p, in
 // ---------------------------------------------------------------------------------------------
 // bias gradient
 // ---------------------------------------------------------------------------------------------
+// Column sums with 16-byte loads: when c % 4 == 0 and rows are dense a thread owns 4 channels
+// and walks pixels; lanes of a wave cover consecutive 16-byte pieces (full 128-B lines).
+__global__ __launch_bounds__(256) void bias_grad_vec4_kernel(const float* __restrict__ dy,
+                                                             const uint8_t* __restrict__ mask,
+                                                             float mask_scale, int64_t npix, int c,
+                                                             float* __restrict__ db) {
+  __shared__ float4 red[256];
+  const int quads = c / 4;                        // float4 columns
+  const int lanes_q = quads < 256 ? quads : 256;  // quads is a power-of-two multiple of 8 here or < 256
+  const int groups = 256 / lanes_q;
+  const int tq = threadIdx.x % lanes_q, tg = threadIdx.x / lanes_q;
+  for (int qbase = 0; qbase < quads; qbase += lanes_q) {
+    const int q = qbase + tq;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tg < groups && q < quads) {
+      for (int64_t pix = (int64_t)blockIdx.x * groups + tg; pix < npix; pix += (int64_t)gridDim.x * groups) {
+        const int64_t off = pix * c + 4 * q;
+        float4 v = *reinterpret_cast<const float4*>(dy + off);
+        if (mask) {
+          const uchar4 mk = *reinterpret_cast<const uchar4*>(mask + off);
+          v.x *= mk.x * mask_scale; v.y *= mk.y * mask_scale; v.z *= mk.z * mask_scale; v.w *= mk.w * mask_scale;
+        }
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (tg == 0 && q < quads) {
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < groups; ++k) {
+        const float4 r = red[k * lanes_q + tq];
+        tot.x += r.x; tot.y += r.y; tot.z += r.z; tot.w += r.w;
+      }
+      unsafeAtomicAdd(db + 4 * q, tot.x);
+      unsafeAtomicAdd(db + 4 * q + 1, tot.y);
+      unsafeAtomicAdd(db + 4 * q + 2, tot.z);
+      unsafeAtomicAdd(db + 4 * q + 3, tot.w);
+    }
+    __syncthreads();
+  }
+}
+
+// generic fallback (any c, pitched rows): thread -> channel x pixel sub-group
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy,
                                                         const uint8_t* __restrict__ mask,
                                                         float mask_scale, int64_t rows, int w,
                                                         int pitch, int c, float* __restrict__ db) {
   __shared__ float red[256];
-  // thread -> channel (fast) x pixel sub-group; for c < 256 several pixels per pass
   const int lanes_c = c < 256 ? c : 256;
   const int groups = 256 / lanes_c;
   const int tc = threadIdx.x % lanes_c, tg = threadIdx.x / lanes_c;
@@ -437,14 +479,24 @@ int launch_bias_grad(const float* dy, const uint8_t* mask, float mask_scale, int
                      int pitch, int c, float* db, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)c, stream);
   if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
-  const int lanes_c = c < 256 ? c : 256;
-  const int groups = 256 / lanes_c;
-  int64_t blocks = ceil_div(rows * w, (int64_t)groups * 64);
-  if (blocks > 1024) blocks = 1024;
-  if (blocks < 1) blocks = 1;
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, mask,
-                     mask_scale, rows, w, pitch, c, db);
+  const int quads = c / 4;
+  if (c % 4 == 0 && pitch == w && 256 % (quads < 256 ? quads : 256) == 0) {
+    const int groups = 256 / (quads < 256 ? quads : 256);
+    int64_t blocks = ceil_div(rows * w, (int64_t)groups * 16);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bias_grad_vec4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, mask,
+                       mask_scale, rows * w, c, db);
+  } else {
+    const int lanes_c = c < 256 ? c : 256;
+    const int groups = 256 / lanes_c;
+    int64_t blocks = ceil_div(rows * w, (int64_t)groups * 64);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, mask,
+                       mask_scale, rows, w, pitch, c, db);
+  }
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }

@@ -1,0 +1,69 @@
+"""Vocoding inference path (scripts/spectrogram_advoc.py:15-22,80-94 semantics)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import advoc_torch as A
+from oracle import spectral_np as S
+
+gpu = pytest.mark.gpu
+
+
+def test_chunk_plan_always_adds_a_chunk():
+  from advoc_amd.infer import chunk_plan
+  assert chunk_plan(1, 256) == (256, 1)
+  assert chunk_plan(255, 256) == (256, 1)
+  assert chunk_plan(256, 256) == (512, 2)       # the reference pads a full extra chunk here
+  assert chunk_plan(600, 256) == (768, 3)
+  assert chunk_plan(64, 32) == (96, 3)
+
+
+def oracle_vocode(P, cfg, spec, masks):
+  Winv = S.create_inverse_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80)
+  X = S.tacotron_mel_to_mag(spec[:, :, 0], Winv)
+  T = X.shape[0]
+  L = cfg.subseq_len
+  target = int(T / L) * L + L
+  X = np.pad(X, ([0, target - T], [0, 0]), 'constant')
+  n = int(target / L)
+  chunks = torch.from_numpy(X.reshape(n, L, 513, 1).astype(np.float32))
+  gen = A.build_generator(P, chunks, cfg, masks)
+  return gen.reshape(target, 513, 1)[:T].numpy()
+
+
+@gpu
+@pytest.mark.parametrize('T', [70, 64])
+def test_vocode_matches_oracle(hip, T):
+  from advoc_amd.infer import vocode_melspec
+  from advoc_amd.model import AdvocSmall, Modes
+  L = 32
+  cfg = A.Config(small=True, subseq_len=L)
+  P = A.init_params(cfg, seed=3)
+  rng = np.random.default_rng(T)
+  spec = rng.uniform(0.2, 0.9, size=(T, 80, 1))
+  n = int(T / L) + 1
+  masks = A.make_dropout_masks(cfg, n, seed=4)
+  want = oracle_vocode(P, cfg, spec, masks)
+  m = AdvocSmall(Modes.INFER)
+  m.subseq_len = L
+  m.build(batch_size=n)
+  m.load_state_dict(P)
+  m.set_dropout_masks({k: v.to(torch.uint8) for k, v in masks.items()})
+  got = vocode_melspec(m, spec, chunk_batch=n)
+  assert got.shape == (T, 513, 1) and got.dtype == np.float32
+  assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-4
+
+
+@gpu
+def test_inference_is_stochastic_like_the_reference(hip):
+  """Dropout stays on at inference (advoc_model.py:145-149): two calls differ."""
+  from advoc_amd.infer import vocode_melspec
+  from advoc_amd.model import AdvocSmall, Modes
+  m = AdvocSmall(Modes.INFER)
+  m.subseq_len = 32
+  m.build(batch_size=2)
+  spec = np.random.default_rng(0).uniform(0.2, 0.9, size=(40, 80, 1))
+  a = vocode_melspec(m, spec, chunk_batch=2)
+  b = vocode_melspec(m, spec, chunk_batch=2)
+  assert a.shape == b.shape == (40, 513, 1) and np.isfinite(a).all()
+  assert not np.array_equal(a, b)
