@@ -47,8 +47,9 @@ PROTOTYPES = {
     'advoc_error_string': (ctypes.c_char_p, [ctypes.c_int]),
     'advoc_target_arch': (ctypes.c_char_p, []),
     'advoc_last_hip_error': (ctypes.c_char_p, []),
-    'advoc_stft_mag_f32': (ctypes.c_int, [_p, _i64, _i64, _p, _i32, _i32, _i64, _p, _p]),
-    'advoc_stft_c64': (ctypes.c_int, [_p, _i64, _i64, _p, _i32, _i32, _i64, _p, _p]),
+    'advoc_stft_mag_f32': (ctypes.c_int, [_p, _i64, _i64, _p, _p, _i32, _i32, _i64, _p, _p]),
+    'advoc_stft_c64': (ctypes.c_int, [_p, _i64, _i64, _p, _p, _i32, _i32, _i64, _p, _p]),
+    'advoc_stft_twiddle_host': (ctypes.c_int, [_p, _i32]),
     'advoc_matmul_nt_f32': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
     'advoc_mel_dbnorm_f32': (ctypes.c_int, [_p, _i64, _f32, _f32, _f32, _p]),
     'advoc_conv_forward': (ctypes.c_int, [_p, _p]),

@@ -17,6 +17,8 @@
 //   * the real-FFT split pairs Z[k] with Z[512-k] by one cross-lane permute per value, then
 //     each lane stores 8 magnitudes: 256 B contiguous per store instruction.
 // HBM-bound: algorithmic traffic is 256 new samples in + 513 floats out per frame.
+#include <math.h>
+
 #include "common.h"
 
 namespace {
@@ -26,7 +28,7 @@ using advoc::wave_lds_sync;
 constexpr int kNfft = 1024;
 constexpr int kBins = kNfft / 2 + 1;
 constexpr int kWaves = 4;
-constexpr int kFramesPerWave = 4;
+constexpr int kFramesPerWave = 2;
 constexpr int kFramesPerBlock = kWaves * kFramesPerWave;
 constexpr int kPlane = 576;  // 64 rows x 9 floats (8 + 1 pad): conflict-free transposes
 
@@ -69,8 +71,9 @@ __device__ __forceinline__ void dft8(float (&re)[8], float (&im)[8]) {
 
 template <bool kComplexOut>
 __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
-    const float* __restrict__ wav, int64_t nsamps, const float* __restrict__ window, int nhop,
-    int64_t nframes, float* __restrict__ out, int tiles_per_clip) {
+    const float* __restrict__ wav, int64_t nsamps, const float* __restrict__ window,
+    const float2* __restrict__ twiddle, int nhop, int64_t nframes, float* __restrict__ out,
+    int tiles_per_clip) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int span = (kFramesPerBlock - 1) * nhop + kNfft;
   float* stage = smem;
@@ -89,9 +92,14 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
   {
     const float* src = wav + clip * nsamps;
     const int64_t s0 = f0 * nhop;
-    for (int i = threadIdx.x; i < span; i += kWaves * 64) {
-      const int64_t s = s0 + i;
-      stage[i] = (s < nsamps) ? src[s] : 0.f;
+    if (((nsamps | nhop) & 3) == 0 && s0 + span <= nsamps) {   // interior tile, 16-byte aligned
+      for (int i = 4 * threadIdx.x; i < span; i += 4 * kWaves * 64)
+        *reinterpret_cast<float4*>(stage + i) = *reinterpret_cast<const float4*>(src + s0 + i);
+    } else {
+      for (int i = threadIdx.x; i < span; i += kWaves * 64) {
+        const int64_t s = s0 + i;
+        stage[i] = (s < nsamps) ? src[s] : 0.f;
+      }
     }
   }
 
@@ -104,15 +112,20 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
     w0[a] = w.x;
     w1[a] = w.y;
   }
+  // twiddles: cos/sin(2 pi e / 1024) from the 1024-entry table built once on the host in double
+  // precision (float2 {cos, sin} per entry, L2 resident): W_N^e = tw[e * 1024 / N] conjugated
   float t1r[8], t1i[8], t2r[8], t2i[8], tsn[8], tcs[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     // pass-1 twiddle W64^(b*p): lane = (b=hi, c=lo), p = j
-    sincospif(-(float)(hi * j) * (1.f / 32.f), &t1i[j], &t1r[j]);
+    const float2 a = twiddle[((hi * j) & 63) * 16];
+    t1r[j] = a.x; t1i[j] = -a.y;
     // pass-2 twiddle W512^(c*(p+8q)): lane = (p=hi, c=lo), q = j
-    sincospif(-(float)(lo * (hi + 8 * j)) * (1.f / 256.f), &t2i[j], &t2r[j]);
-    // split twiddle: theta = 2*pi*k/1024, k = lane + 64 j
-    sincospif((float)(lane + 64 * j) * (1.f / 512.f), &tsn[j], &tcs[j]);
+    const float2 b = twiddle[((lo * (hi + 8 * j)) & 511) * 2];
+    t2r[j] = b.x; t2i[j] = -b.y;
+    // split twiddle: theta = 2*pi*k/1024, k = lane + 64 j  (k <= 511)
+    const float2 c = twiddle[lane + 64 * j];
+    tcs[j] = c.x; tsn[j] = c.y;
   }
   const int partner = (64 - lane) & 63;
 
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
       if (kComplexOut) {
         *reinterpret_cast<float2*>(orow + 2 * k) = make_float2(xr, xi);
       } else {
-        orow[k] = sqrtf(xr * xr + xi * xi);
+        orow[k] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);   // v_sqrt_f32, <= 1 ulp
       }
     }
     if (lane == 0) {  // Nyquist bin: X[512] = Re Z0 - Im Z0
@@ -206,12 +219,14 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
   }
 }
 
-int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* window, int32_t nfft,
-                int32_t nhop, int64_t nframes, float* out, bool complex_out, hipStream_t stream) {
+int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* window,
+                const float* twiddle, int32_t nfft, int32_t nhop, int64_t nframes, float* out,
+                bool complex_out, hipStream_t stream) {
   if (batch < 0 || nsamps < 0 || nframes < 0 || nhop <= 0) return ADVOC_ERR_BAD_SHAPE;
   if (nfft != kNfft || (nhop & 1) || nhop > 4096) return ADVOC_ERR_UNSUPPORTED;
   if (batch == 0 || nframes == 0) return ADVOC_OK;  // empty output: nothing to touch
-  if (!wav || !window || !out) return ADVOC_ERR_NULL;
+  if (!wav || !window || !twiddle || !out) return ADVOC_ERR_NULL;
+  if (reinterpret_cast<uintptr_t>(wav) & 15) return ADVOC_ERR_UNSUPPORTED;   // float4 staging
   const int tiles = (int)advoc::ceil_div(nframes, kFramesPerBlock);
   const int64_t blocks = batch * tiles;
   if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
@@ -221,11 +236,11 @@ int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* wi
   if (complex_out) {
     ADVOC_CLEAR_LAUNCH_ERROR();
     hipLaunchKernelGGL(stft1024_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream,
-                       wav, nsamps, window, nhop, nframes, out, tiles);
+                       wav, nsamps, window, reinterpret_cast<const float2*>(twiddle), nhop, nframes, out, tiles);
   } else {
     ADVOC_CLEAR_LAUNCH_ERROR();
     hipLaunchKernelGGL(stft1024_kernel<false>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream,
-                       wav, nsamps, window, nhop, nframes, out, tiles);
+                       wav, nsamps, window, reinterpret_cast<const float2*>(twiddle), nhop, nframes, out, tiles);
   }
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
@@ -234,15 +249,28 @@ int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* wi
 }  // namespace
 
 extern "C" int advoc_stft_mag_f32(const float* wav, int64_t batch, int64_t nsamps,
-                                  const float* window, int32_t nfft, int32_t nhop, int64_t nframes,
-                                  float* mag, advoc_stream_t stream) {
-  return launch_stft(wav, batch, nsamps, window, nfft, nhop, nframes, mag, false,
+                                  const float* window, const float* twiddle, int32_t nfft,
+                                  int32_t nhop, int64_t nframes, float* mag, advoc_stream_t stream) {
+  return launch_stft(wav, batch, nsamps, window, twiddle, nfft, nhop, nframes, mag, false,
                      advoc::as_stream(stream));
 }
 
 extern "C" int advoc_stft_c64(const float* wav, int64_t batch, int64_t nsamps, const float* window,
-                              int32_t nfft, int32_t nhop, int64_t nframes, float* out,
-                              advoc_stream_t stream) {
-  return launch_stft(wav, batch, nsamps, window, nfft, nhop, nframes, out, true,
+                              const float* twiddle, int32_t nfft, int32_t nhop, int64_t nframes,
+                              float* out, advoc_stream_t stream) {
+  return launch_stft(wav, batch, nsamps, window, twiddle, nfft, nhop, nframes, out, true,
                      advoc::as_stream(stream));
+}
+
+// Fills the twiddle table the STFT kernels read: tw[2e] = cos(2 pi e / nfft), tw[2e+1] =
+// sin(2 pi e / nfft), e in [0, nfft), evaluated in double precision on the HOST.
+extern "C" int advoc_stft_twiddle_host(float* tw_host, int32_t nfft) {
+  if (!tw_host) return ADVOC_ERR_NULL;
+  if (nfft != kNfft) return ADVOC_ERR_UNSUPPORTED;
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int e = 0; e < nfft; ++e) {
+    tw_host[2 * e] = (float)cos(two_pi * e / nfft);
+    tw_host[2 * e + 1] = (float)sin(two_pi * e / nfft);
+  }
+  return ADVOC_OK;
 }

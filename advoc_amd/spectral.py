@@ -63,6 +63,16 @@ def _device_window(nfft, nhop):
   return _device_const(('win', nfft, nhop), lambda: lws_hann_default(nfft, nhop, torch.float32))
 
 
+def _device_twiddle(nfft):
+  def make():
+    import ctypes
+    host = torch.empty(2 * nfft, dtype=torch.float32)
+    _lib.check(_lib.load().advoc_stft_twiddle_host(ctypes.c_void_p(host.data_ptr()), nfft),
+               'advoc_stft_twiddle_host')
+    return host
+  return _device_const(('twiddle', nfft), make)
+
+
 def _slaney_hz_to_mel(hz):
   hz = np.atleast_1d(np.asarray(hz, dtype=np.float64))
   lin = hz * (3.0 / 200.0)
@@ -150,9 +160,11 @@ def _run_stft(wav2d, nfft, nhop, nframes, complex_out):
   shape = (clips, nframes, nbins, 2) if complex_out else (clips, nframes, nbins)
   out = torch.empty(shape, dtype=torch.float32, device=wav2d.device)
   fn = _lib.load().advoc_stft_c64 if complex_out else _lib.load().advoc_stft_mag_f32
+  if nframes == 0 or clips == 0:
+    return out
   win = _device_window(nfft, nhop)
-  _lib.check(fn(_lib.ptr(wav2d), clips, n, _lib.ptr(win), nfft, nhop, nframes, _lib.ptr(out),
-                _lib.stream()), 'advoc_stft')
+  _lib.check(fn(_lib.ptr(wav2d), clips, n, _lib.ptr(win), _lib.ptr(_device_twiddle(nfft)), nfft, nhop,
+                nframes, _lib.ptr(out), _lib.stream()), 'advoc_stft')
   return out
 
 

@@ -56,17 +56,23 @@ const char* advoc_target_arch(void);
  * via advoc/loader.py:116-128 (magspec branch).
  *   wav     [batch, nsamps]                 float32
  *   window  [nfft]                          float32  (lws sqrt-Hann, advoc/spectral.py:44-57)
+ *   twiddle [nfft, 2]                       float32  {cos, sin}(2 pi e / nfft), from
+ *                                           advoc_stft_twiddle_host (device copy owned by the caller)
  *   mag     [batch, nframes, nfft/2+1]      float32
  * Frame t covers samples [t*nhop, t*nhop+nfft); samples >= nsamps read as zero (pad_end).
- * nfft must be 1024 (the only size the reference's tensor path is used with). */
+ * nfft must be 1024 (the only size the reference's tensor path is used with); wav 16-byte aligned. */
 int advoc_stft_mag_f32(const float* wav, int64_t batch, int64_t nsamps, const float* window,
-                       int32_t nfft, int32_t nhop, int64_t nframes, float* mag,
+                       const float* twiddle, int32_t nfft, int32_t nhop, int64_t nframes, float* mag,
                        advoc_stream_t stream);
+
+/* Host helper: fills tw_host[2 * nfft] with the double-precision-evaluated twiddle table the
+ * STFT kernels expect (upload it once; it is read-only). */
+int advoc_stft_twiddle_host(float* tw_host, int32_t nfft);
 
 /* Complex STFT, interleaved (re, im) float32 pairs: out [batch, nframes, nfft/2+1, 2].
  * Replaces tf.contrib.signal.stft at advoc/spectral.py:79. */
 int advoc_stft_c64(const float* wav, int64_t batch, int64_t nsamps, const float* window,
-                   int32_t nfft, int32_t nhop, int64_t nframes, float* out,
+                   const float* twiddle, int32_t nfft, int32_t nhop, int64_t nframes, float* out,
                    advoc_stream_t stream);
 
 /* out[r, n] = sum_k x[r, k] * w[n, k]      (x @ w^T over the last dimension)

@@ -53,13 +53,22 @@ def test_code_object_is_gfx950_only():
 
 def test_null_and_shape_errors_need_no_gpu(lib):
   # argument validation happens before any HIP call
-  assert lib.advoc_stft_mag_f32(None, 1, 1024, None, 1024, 256, 4, None, None) == -4
-  assert lib.advoc_stft_mag_f32(None, 1, 700, None, 1024, 256, 0, None, None) == 0
+  assert lib.advoc_stft_mag_f32(None, 1, 1024, None, None, 1024, 256, 4, None, None) == -4
+  assert lib.advoc_stft_mag_f32(None, 1, 700, None, None, 1024, 256, 0, None, None) == 0
   assert lib.advoc_matmul_nt_f32(None, None, None, 1, 1, 1, None) == -4
   one = 1  # a non-null dummy address; never dereferenced on these paths
-  assert lib.advoc_stft_mag_f32(one, 1, 1024, one, 1000, 250, 4, one, None) == -2
-  assert lib.advoc_stft_mag_f32(one, -1, 1024, one, 1024, 256, 4, one, None) == -1
-  assert lib.advoc_stft_mag_f32(one, 0, 1024, one, 1024, 256, 4, one, None) == 0
+  assert lib.advoc_stft_mag_f32(one, 1, 1024, one, one, 1000, 250, 4, one, None) == -2
+  assert lib.advoc_stft_mag_f32(one, -1, 1024, one, one, 1024, 256, 4, one, None) == -1
+  assert lib.advoc_stft_mag_f32(one, 0, 1024, one, one, 1024, 256, 4, one, None) == 0
+  import ctypes
+  import numpy as np
+  tw = (ctypes.c_float * 2048)()
+  assert lib.advoc_stft_twiddle_host(tw, 1024) == 0
+  t = np.frombuffer(tw, dtype=np.float32).reshape(1024, 2)
+  e = np.arange(1024)
+  assert np.array_equal(t[:, 0], np.cos(2 * np.pi * e / 1024).astype(np.float32))
+  assert np.array_equal(t[:, 1], np.sin(2 * np.pi * e / 1024).astype(np.float32))
+  assert lib.advoc_stft_twiddle_host(tw, 512) == -2
   assert lib.advoc_matmul_nt_f32(one, one, one, 4, 0, 3, None) == -1
 
 
