@@ -19,6 +19,8 @@
 //     other LDS buffer after them: one s_barrier per K tile, HBM/L2 latency hidden under MFMA.
 //   * epilogue: bias, dropout mask, act'(x) gating, optional accumulate, split over two
 //     destinations (skip-connection gradients); 128 B contiguous per 32-lane store.
+#include <stdlib.h>
+
 #include <string>
 
 #include "common.h"
@@ -29,8 +31,8 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
-constexpr int LDA = 20;  // floats per LDS row of a [rows][16] tile (16 + 4 pad)
+// K tile depth BK (16 or 32) is a template parameter; LDS rows are BK + 4 floats (conflict-free
+// ds_write_b128 / ds_read_b128 for both depths).
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == ADVOC_ACT_LRELU02) return fmaxf(0.2f * v, v);
@@ -46,15 +48,17 @@ __device__ __forceinline__ float act_grad(float x, int act) {
   return 1.f;
 }
 
-template <int MT, int NT, int WGM, int WGN, bool B_KN>
+template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK>
 struct Cfg {
   static constexpr int BM = 32 * MT * WGM;
   static constexpr int BN = 32 * NT * WGN;
+  static constexpr int LDA = BK + 4;
+  static constexpr int QPR = BK / 4;                       // float4 per tile row
   static constexpr int LDB_KN = BN + 4;
   static constexpr int A_TILE = BM * LDA;
   static constexpr int B_TILE = B_KN ? BK * LDB_KN : BN * LDA;
-  static constexpr int A_LOADS = BM / 64;                  // float4 per thread per K tile
-  static constexpr int B_LOADS = (BN * 4 + 255) / 256;     // float4 per thread per K tile
+  static constexpr int A_LOADS = BM * QPR / 256;           // float4 per thread per K tile
+  static constexpr int B_LOADS = (BN * QPR + 255) / 256;   // float4 per thread per K tile
   static constexpr size_t LDS_BYTES =
       sizeof(float) * (2 * A_TILE + 2 * B_TILE) + sizeof(int) * (kMaxTaps + 2 * BM);
 };
@@ -67,11 +71,12 @@ __device__ __forceinline__ float act_slope(int act) {
 // launch_bounds(256, 2): budget registers for 2 waves per SIMD (<= 256 VGPR+AGPR).  With the
 // default bound hipcc chases a higher occupancy and spills the prefetch registers to scratch,
 // which serialises the global loads behind s_waitcnt vmcnt(0).
-template <int MT, int NT, int WGM, int WGN, bool B_KN>
+template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK>
 __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmParams p) {
-  using C = Cfg<MT, NT, WGM, WGN, B_KN>;
-  constexpr int BM = C::BM, BN = C::BN;
+  using C = Cfg<MT, NT, WGM, WGN, B_KN, BK>;
+  constexpr int BM = C::BM, BN = C::BN, LDA = C::LDA, QPR = C::QPR;
   constexpr int AL = C::A_LOADS, BL = C::B_LOADS;
+  constexpr int RPP = 256 / QPR;   // tile rows covered by one pass of the 256 loader threads
   static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -96,12 +101,12 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   if (tid < kMaxTaps) s_tap[tid] = p.tap[phase][tid];
 
   // ---- per-thread A rows (fixed for the whole K loop); 32-bit element offsets ----
-  const int kq = tid & 3;  // which float4 of the 16-wide K slice
+  const int kq = tid % QPR;  // which float4 of the BK-wide K slice
   int row_y[AL], row_x[AL], base0[AL], base1[AL];
   bool row_ok[AL];
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
-    const int64_t m = m0 + (tid >> 2) + 64 * i;
+    const int64_t m = m0 + tid / QPR + RPP * i;
     row_ok[i] = m < M;
     const int64_t mm = row_ok[i] ? m : 0;
     const int gx = (int)(mm % p.gw);
@@ -120,14 +125,14 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
 #pragma unroll
   for (int i = 0; i < BL; ++i) {
     const int idx = tid + 256 * i;
-    b_store[i] = idx < BN * 4;
-    const int id = b_store[i] ? idx : idx % (BN * 4);
+    b_store[i] = idx < BN * QPR;
+    const int id = b_store[i] ? idx : idx % (BN * QPR);
     if (B_KN) {
       const int k = id / (BN / 4), nq = id % (BN / 4);
       b_goff[i] = k * p.n_total + n0 + 4 * nq;           // + (wtap*ktot + k0) * N per tile
       b_loff[i] = k * C::LDB_KN + 4 * nq;
     } else {
-      const int n = id >> 2, q = id & 3;
+      const int n = id / QPR, q = id % QPR;
       b_goff[i] = (n0 + n) * ktot + 4 * q;                // + wtap*N*ktot + k0 per tile
       b_loff[i] = n * LDA + 4 * q;
     }
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
         v.x *= mk_.x * p.a_mask_scale; v.y *= mk_.y * p.a_mask_scale;                                \
         v.z *= mk_.z * p.a_mask_scale; v.w *= mk_.w * p.a_mask_scale;                                \
       }                                                                                              \
-      *reinterpret_cast<float4*>(Ab_ + ((tid >> 2) + 64 * i) * LDA + 4 * kq) = v;                    \
+      *reinterpret_cast<float4*>(Ab_ + (tid / QPR + RPP * i) * LDA + 4 * kq) = v;                    \
     }                                                                                                \
     _Pragma("unroll") for (int i = 0; i < BL; ++i)                                                   \
         if (b_store[i]) *reinterpret_cast<float4*>(Bb_ + b_loff[i]) = rb[i];                         \
@@ -221,31 +226,34 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
 
     const float* Ab = As + buf * C::A_TILE;
     const float* Bb = Bs + buf * C::B_TILE;
-    float a[MT][8], b[NT][8];
+    constexpr int KH = BK / 2;   // K slots per wave half: lanes 0-31 take [0, KH), lanes 32-63 [KH, BK)
+    float a[MT][KH], b[NT][KH];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const float* q = Ab + ((wm * MT + i) * 32 + l32) * LDA + half * 8;
-      const float4 v0 = *reinterpret_cast<const float4*>(q);
-      const float4 v1 = *reinterpret_cast<const float4*>(q + 4);
-      a[i][0] = v0.x; a[i][1] = v0.y; a[i][2] = v0.z; a[i][3] = v0.w;
-      a[i][4] = v1.x; a[i][5] = v1.y; a[i][6] = v1.z; a[i][7] = v1.w;
+      const float* q = Ab + ((wm * MT + i) * 32 + l32) * LDA + half * KH;
+#pragma unroll
+      for (int c = 0; c < KH / 4; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(q + 4 * c);
+        a[i][4 * c] = v.x; a[i][4 * c + 1] = v.y; a[i][4 * c + 2] = v.z; a[i][4 * c + 3] = v.w;
+      }
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = (wn * NT + j) * 32 + l32;
       if (B_KN) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) b[j][s] = Bb[(half * 8 + s) * C::LDB_KN + col];
+        for (int s = 0; s < KH; ++s) b[j][s] = Bb[(half * KH + s) * C::LDB_KN + col];
       } else {
-        const float* q = Bb + col * LDA + half * 8;
-        const float4 v0 = *reinterpret_cast<const float4*>(q);
-        const float4 v1 = *reinterpret_cast<const float4*>(q + 4);
-        b[j][0] = v0.x; b[j][1] = v0.y; b[j][2] = v0.z; b[j][3] = v0.w;
-        b[j][4] = v1.x; b[j][5] = v1.y; b[j][6] = v1.z; b[j][7] = v1.w;
+        const float* q = Bb + col * LDA + half * KH;
+#pragma unroll
+        for (int c = 0; c < KH / 4; ++c) {
+          const float4 v = *reinterpret_cast<const float4*>(q + 4 * c);
+          b[j][4 * c] = v.x; b[j][4 * c + 1] = v.y; b[j][4 * c + 2] = v.z; b[j][4 * c + 3] = v.w;
+        }
       }
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < KH; ++s)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -279,39 +287,63 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   __syncthreads();
 
   const float gslope = act_slope(p.grad_act);   // act'(x) = x > 0 ? 1 : slope
+  // Each 32x32 accumulator tile is transposed through a private LDS patch so that global
+  // traffic is 16 bytes per lane on full 128-byte channel rows (8 lanes per pixel): the MFMA C
+  // layout itself would give 4-byte stores, ~3x slower on the store-heavy narrow layers.
+  constexpr int LDT = 36;
+  float* T = smem + wave * (32 * LDT);          // the K-loop buffers are dead after the last barrier
+  const int trow = lane >> 3, tq = lane & 7;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int n = n0 + (wn * NT + j) * 32 + l32;
-    const int di = n >= p.n_split ? 1 : 0;   // uniform per 32-wide tile (n_split % 32 == 0)
+    const int nt0 = n0 + (wn * NT + j) * 32;    // first channel of this 32-wide tile
+    const int di = nt0 >= p.n_split ? 1 : 0;    // uniform: n_split % 32 == 0
     const GemmDest& d = p.d[di];
     if (d.p == nullptr) continue;
-    const int ch = di ? n - p.n_split : n;
-    const float bias = p.bias ? p.bias[n] : 0.f;
+    const int ch = (di ? nt0 - p.n_split : nt0) + 4 * tq;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + nt0 + 4 * tq);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int pix = s_pix[di * BM + row];
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * half) * LDT + l32] = acc[i][j][r];
+      wave_lds_sync();
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int row = trow + 8 * ps;
+        const int pix = s_pix[di * BM + (wm * MT + i) * 32 + row];
         if (pix < 0) continue;
         const int off = pix * d.c + ch;
-        float v = acc[i][j][r] + bias;
-        if (p.y_mask) v *= p.y_mask[off] * p.y_mask_scale;
-        if (p.grad_act != ADVOC_ACT_NONE) v *= d.xpre[off] > 0.f ? 1.f : gslope;
-        if (d.accum) v += d.p[off];
-        d.p[off] = v;
+        float4 v = *reinterpret_cast<const float4*>(T + row * LDT + 4 * tq);
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (p.y_mask) {
+          const uchar4 mk = *reinterpret_cast<const uchar4*>(p.y_mask + off);
+          v.x *= mk.x * p.y_mask_scale; v.y *= mk.y * p.y_mask_scale;
+          v.z *= mk.z * p.y_mask_scale; v.w *= mk.w * p.y_mask_scale;
+        }
+        if (p.grad_act != ADVOC_ACT_NONE) {
+          const float4 x = *reinterpret_cast<const float4*>(d.xpre + off);
+          v.x *= x.x > 0.f ? 1.f : gslope; v.y *= x.y > 0.f ? 1.f : gslope;
+          v.z *= x.z > 0.f ? 1.f : gslope; v.w *= x.w > 0.f ? 1.f : gslope;
+        }
+        if (d.accum) {
+          const float4 o = *reinterpret_cast<const float4*>(d.p + off);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *reinterpret_cast<float4*>(d.p + off) = v;
       }
+      wave_lds_sync();
     }
   }
 }
 
-template <int MT, int NT, int WGM, int WGN, bool B_KN>
+template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK>
 int launch_cfg(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
-  using C = Cfg<MT, NT, WGM, WGN, B_KN>;
+  using C = Cfg<MT, NT, WGM, WGN, B_KN, BK>;
   if (name_only) {
     static const std::string name = std::string("gather_gemm_kernel<") + std::to_string(MT) + ", " +
                                     std::to_string(NT) + ", " + std::to_string(WGM) + ", " +
-                                    std::to_string(WGN) + ", " + (B_KN ? "true" : "false") + ">";
+                                    std::to_string(WGN) + ", " + (B_KN ? "true" : "false") + ", " +
+                                    std::to_string(BK) + ">";
     *name_only = name.c_str();
     return ADVOC_OK;
   }
@@ -319,23 +351,43 @@ int launch_cfg(const GatherGemmParams& p, hipStream_t stream, const char** name_
   const int64_t gx = ceil_div(M, C::BM);
   if (gx > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
   dim3 grid((unsigned)gx, (unsigned)(p.n_total / C::BN), (unsigned)p.nphase);
-  auto kern = gather_gemm_kernel<MT, NT, WGM, WGN, B_KN>;
+  auto kern = gather_gemm_kernel<MT, NT, WGM, WGN, B_KN, BK>;
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, p);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }
 
-template <bool B_KN>
-int dispatch(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
+// K tile depth: 32 when every channel slice allows it (fewer barriers, full 128-B rows per
+// gather), overridable with ADVOC_IGEMM_BK=16|32 for A/B measurements.
+int preferred_bk() {
+  static const int v = [] {
+    const char* e = getenv("ADVOC_IGEMM_BK");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
+template <bool B_KN, int BK>
+int dispatch_bk(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
   const int N = p.n_total;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   // small grids (deep, narrow layers): 64 x 64 tiles put 4x more workgroups on the 256 CUs
   if (N % 64 == 0 && ceil_div(M, 128) * ceil_div(N, 128) * p.nphase < 384)
-    return launch_cfg<1, 1, 2, 2, B_KN>(p, stream, name_only);                    // 64 x 64
-  if (N % 128 == 0) return launch_cfg<2, 2, 2, 2, B_KN>(p, stream, name_only);   // 128 x 128
-  if (N % 64 == 0) return launch_cfg<2, 1, 2, 2, B_KN>(p, stream, name_only);    // 128 x 64
-  return launch_cfg<2, 1, 4, 1, B_KN>(p, stream, name_only);                     // 256 x 32
+    return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, stream, name_only);                    // 64 x 64
+  if (N % 128 == 0) return launch_cfg<2, 2, 2, 2, B_KN, BK>(p, stream, name_only);   // 128 x 128
+  if (N % 64 == 0) return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, stream, name_only);    // 128 x 64
+  return launch_cfg<2, 1, 4, 1, B_KN, BK>(p, stream, name_only);                     // 256 x 32
+}
+
+template <bool B_KN>
+int dispatch(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
+  const int ktot = p.c0 + p.c1;
+  const bool can32 = ktot % 32 == 0 && p.c0 % 32 == 0;
+  int bk = preferred_bk();
+  if (bk != 16 && bk != 32) bk = 16;
+  if (bk == 32 && can32) return dispatch_bk<B_KN, 32>(p, stream, name_only);
+  return dispatch_bk<B_KN, 16>(p, stream, name_only);
 }
 
 }  // namespace
@@ -343,7 +395,7 @@ int dispatch(const GatherGemmParams& p, hipStream_t stream, const char** name_on
 int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only) {
   const int ktot = p.c0 + p.c1;
   if (p.batch <= 0 || p.gh <= 0 || p.gw <= 0 || ktot <= 0 || p.n_total <= 0) return ADVOC_ERR_BAD_SHAPE;
-  if (ktot % BK || p.c0 % BK || p.n_total % 32 || p.n_split % 32) return ADVOC_ERR_UNSUPPORTED;
+  if (ktot % 16 || p.c0 % 16 || p.n_total % 32 || p.n_split % 32) return ADVOC_ERR_UNSUPPORTED;
   if (p.nphase < 1 || p.nphase > kMaxPhases || p.ntaps < 1 || p.ntaps > kMaxTaps) return ADVOC_ERR_UNSUPPORTED;
   if (p.a_mask && p.c1) return ADVOC_ERR_UNSUPPORTED;
   // the kernel indexes every tensor with 32-bit element offsets
