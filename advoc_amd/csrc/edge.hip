@@ -58,9 +58,9 @@ __device__ __forceinline__ void store_result(const GatherGemmParams& p, int phas
 // ---------------------------------------------------------------------------------------------
 template <int G>
 __global__ __launch_bounds__(256) void gather_dot_kernel(const GatherGemmParams p) {
-  __shared__ int s_tap[kMaxTaps];
-  const int phase = blockIdx.z;
-  if (threadIdx.x < kMaxTaps) s_tap[threadIdx.x] = p.tap[phase][threadIdx.x];
+  __shared__ int s_tap[kMaxPhases][kMaxTaps];
+  if (threadIdx.x < kMaxPhases * kMaxTaps) s_tap[threadIdx.x / kMaxTaps][threadIdx.x % kMaxTaps] =
+      p.tap[threadIdx.x / kMaxTaps][threadIdx.x % kMaxTaps];
   __syncthreads();
 
   constexpr int PTS = 256 / G;  // grid points per block
@@ -71,52 +71,58 @@ __global__ __launch_bounds__(256) void gather_dot_kernel(const GatherGemmParams 
   const GridPoint g = decompose(live ? m : 0, p.gh, p.gw);
   const int ktot = p.c0 + p.c1;
   const int N = p.n_total;
+  const float slope = p.in_act == ADVOC_ACT_LRELU02 ? 0.2f : (p.in_act == ADVOC_ACT_RELU ? 0.f : 1.f);
 
-  float acc0 = 0.f, acc1 = 0.f;
-  if (live) {
-    for (int t = 0; t < p.ntaps; ++t) {
-      const int tp = s_tap[t];
-      const int iy = g.gy * p.sy + (int)(int8_t)(tp & 0xff);
-      const int ix = g.gx * p.sx + (int)(int8_t)((tp >> 8) & 0xff);
-      if ((unsigned)iy >= (unsigned)p.in_h || (unsigned)ix >= (unsigned)p.in_w) continue;
-      const int wtap = tp >> 16;
-      for (int k = 4 * sub; k < ktot; k += 4 * G) {
-        const bool second = k >= p.c0;
-        const float* src = second ? p.a1 : p.a0;
-        const int cs = second ? p.c1 : p.c0;
-        const int pitch = second ? p.a1_pitch : p.a0_pitch;
-        const int64_t off = (((int64_t)g.img * p.a_h + iy) * pitch + ix) * cs + (second ? k - p.c0 : k);
-        float4 v = *reinterpret_cast<const float4*>(src + off);
-        if (p.in_scale) {
-          const float4 sc = *reinterpret_cast<const float4*>(p.in_scale + k);
-          const float4 sh = *reinterpret_cast<const float4*>(p.in_shift + k);
-          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-        }
-        v.x = act_fwd(v.x, p.in_act); v.y = act_fwd(v.y, p.in_act);
-        v.z = act_fwd(v.z, p.in_act); v.w = act_fwd(v.w, p.in_act);
-        if (p.a_mask) {
-          const uchar4 mk = *reinterpret_cast<const uchar4*>(p.a_mask + off);
-          v.x *= mk.x * p.a_mask_scale; v.y *= mk.y * p.a_mask_scale;
-          v.z *= mk.z * p.a_mask_scale; v.w *= mk.w * p.a_mask_scale;
-        }
-        // weights: N == 1 -> w[wtap*K + k]; N == 2 only in the [tap][N][K] layout
-        const float4 w0 = *reinterpret_cast<const float4*>(p.w + ((int64_t)wtap * N) * ktot + k);
-        acc0 = fmaf(v.x, w0.x, fmaf(v.y, w0.y, fmaf(v.z, w0.z, fmaf(v.w, w0.w, acc0))));
-        if (N > 1) {
-          const float4 w1 = *reinterpret_cast<const float4*>(p.w + ((int64_t)wtap * N + 1) * ktot + k);
-          acc1 = fmaf(v.x, w1.x, fmaf(v.y, w1.y, fmaf(v.z, w1.z, fmaf(v.w, w1.w, acc1))));
+  // All sub-pixel phases of a grid point are computed by the same lanes back to back: the 2x2-tap
+  // windows of the four phases overlap (9 distinct input pixels for 16 tap reads), so the
+  // re-reads hit this CU's L1 instead of going back to L2 from four different workgroups.
+  for (int phase = 0; phase < p.nphase; ++phase) {
+    float acc0 = 0.f, acc1 = 0.f;
+    if (live) {
+      for (int t = 0; t < p.ntaps; ++t) {
+        const int tp = s_tap[phase][t];
+        const int iy = g.gy * p.sy + (int)(int8_t)(tp & 0xff);
+        const int ix = g.gx * p.sx + (int)(int8_t)((tp >> 8) & 0xff);
+        if ((unsigned)iy >= (unsigned)p.in_h || (unsigned)ix >= (unsigned)p.in_w) continue;
+        const int wtap = tp >> 16;
+        for (int k = 4 * sub; k < ktot; k += 4 * G) {
+          const bool second = k >= p.c0;
+          const float* src = second ? p.a1 : p.a0;
+          const int cs = second ? p.c1 : p.c0;
+          const int pitch = second ? p.a1_pitch : p.a0_pitch;
+          const int64_t off = (((int64_t)g.img * p.a_h + iy) * pitch + ix) * cs + (second ? k - p.c0 : k);
+          float4 v = *reinterpret_cast<const float4*>(src + off);
+          if (p.in_scale) {
+            const float4 sc = *reinterpret_cast<const float4*>(p.in_scale + k);
+            const float4 sh = *reinterpret_cast<const float4*>(p.in_shift + k);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+          }
+          v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
+          v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
+          if (p.a_mask) {
+            const uchar4 mk = *reinterpret_cast<const uchar4*>(p.a_mask + off);
+            v.x *= mk.x * p.a_mask_scale; v.y *= mk.y * p.a_mask_scale;
+            v.z *= mk.z * p.a_mask_scale; v.w *= mk.w * p.a_mask_scale;
+          }
+          // weights: N == 1 -> w[wtap*K + k]; N == 2 only in the [tap][N][K] layout
+          const float4 w0 = *reinterpret_cast<const float4*>(p.w + ((int64_t)wtap * N) * ktot + k);
+          acc0 = fmaf(v.x, w0.x, fmaf(v.y, w0.y, fmaf(v.z, w0.z, fmaf(v.w, w0.w, acc0))));
+          if (N > 1) {
+            const float4 w1 = *reinterpret_cast<const float4*>(p.w + ((int64_t)wtap * N + 1) * ktot + k);
+            acc1 = fmaf(v.x, w1.x, fmaf(v.y, w1.y, fmaf(v.z, w1.z, fmaf(v.w, w1.w, acc1))));
+          }
         }
       }
     }
-  }
 #pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) {
-    acc0 += __shfl_xor(acc0, o, 64);
-    acc1 += __shfl_xor(acc1, o, 64);
-  }
-  if (live && sub == 0) {
-    store_result(p, phase, g, 0, acc0);
-    if (N > 1) store_result(p, phase, g, 1, acc1);
+    for (int o = G / 2; o > 0; o >>= 1) {
+      acc0 += __shfl_xor(acc0, o, 64);
+      acc1 += __shfl_xor(acc1, o, 64);
+    }
+    if (live && sub == 0) {
+      store_result(p, phase, g, 0, acc0);
+      if (N > 1) store_result(p, phase, g, 1, acc1);
+    }
   }
 }
 
@@ -180,7 +186,7 @@ int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream, 
   }
   const int64_t blocks = ceil_div(M, 256 / G);
   if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
-  dim3 grid((unsigned)blocks, 1, (unsigned)p.nphase);
+  dim3 grid((unsigned)blocks, 1, 1);      // phases are looped inside the kernel
   ADVOC_CLEAR_LAUNCH_ERROR();
   switch (G) {
     case 8: hipLaunchKernelGGL(gather_dot_kernel<8>, grid, dim3(256), 0, stream, p); break;
