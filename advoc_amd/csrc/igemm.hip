@@ -59,8 +59,10 @@ struct Cfg {
   static constexpr int B_TILE = B_KN ? BK * LDB_KN : BN * LDA;
   static constexpr int A_LOADS = BM * QPR / 256;           // float4 per thread per K tile
   static constexpr int B_LOADS = (BN * QPR + 255) / 256;   // float4 per thread per K tile
-  static constexpr size_t LDS_BYTES =
-      sizeof(float) * (2 * A_TILE + 2 * B_TILE) + sizeof(int) * (kMaxTaps + 2 * BM);
+  // Exactly the two double-buffered tiles: 40 KiB for 128x128 so FOUR workgroups fit a CU's
+  // 160 KiB.  The tap table lives in the (never written) pad words of the first A rows and the
+  // epilogue's pixel table / transpose patches reuse the tile buffers once the K loop is done.
+  static constexpr size_t LDS_BYTES = sizeof(float) * (2 * A_TILE + 2 * B_TILE);
 };
 
 // act(v) = max(v, slope * v): slope 1 -> identity, 0.2 -> leaky ReLU, 0 -> ReLU (branch-free)
@@ -82,8 +84,12 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                               // [2][BM][LDA]
   float* Bs = smem + 2 * C::A_TILE;               // [2][B_TILE]
-  int* s_tap = reinterpret_cast<int*>(Bs + 2 * C::B_TILE);  // [16]
-  int* s_pix = s_tap + kMaxTaps;                  // [2][BM]
+  // tap t -> pad word (column BK) of A row t: tile stores only touch columns [0, BK)
+  int* s_tapw = reinterpret_cast<int*>(smem) + BK;
+#define ADVOC_TAP(T) s_tapw[(T) * LDA]
+  // epilogue tables, carved from the tile buffers AFTER the last K-loop barrier:
+  //   [0, 4*32*36) floats  per-wave transpose patches;  then [2][BM] ints pixel table
+  int* s_pix = reinterpret_cast<int*>(smem + 4 * 32 * 36);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   const int nkt = kpt * p.ntaps;
   const float slope = act_slope(p.in_act);
 
-  if (tid < kMaxTaps) s_tap[tid] = p.tap[phase][tid];
+  if (tid < kMaxTaps) ADVOC_TAP(tid) = p.tap[phase][tid];
 
   // ---- per-thread A rows (fixed for the whole K loop); 32-bit element offsets ----
   const int kq = tid % QPR;  // which float4 of the BK-wide K slice
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   {                                                                                                  \
     const int ti_ = (KT) / kpt;                                                                      \
     const int k0_ = ((KT) - ti_ * kpt) * BK;                                                         \
-    const int tp_ = s_tap[ti_];                                                                      \
+    const int tp_ = ADVOC_TAP(ti_);                                                                  \
     const int dy_ = (int)(int8_t)(tp_ & 0xff), dx_ = (int)(int8_t)((tp_ >> 8) & 0xff);              \
     const int wtap_ = tp_ >> 16;                                                                     \
     const bool second_ = k0_ >= p.c0;                                                                \
@@ -265,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   }
 #undef ADVOC_LOAD_TILE
 #undef ADVOC_STORE_TILE
+#undef ADVOC_TAP
 
   // ---- epilogue ----
   for (int r = tid; r < BM; r += 256) {

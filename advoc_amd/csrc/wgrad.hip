@@ -280,9 +280,23 @@ int launch_wcfg(const WgradParams& p, hipStream_t stream, const char** name_only
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   const int tiles_m = (p.ntaps * ca + C::BM - 1) / C::BM, tiles_n = (cb + C::BN - 1) / C::BN;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
-  // split the pixel axis so the launch has ~1024 workgroups (4 per CU)
+  // Split the pixel axis so the launch is whole rounds of the chip: `resident` workgroups fit at
+  // once (occupancy query, cached per kernel instance); a launch of 1.33 x resident would run a
+  // 1/3-full second round.  Two rounds when the work allows it (shorter tail, same traffic).
+  static const int64_t resident = [] {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_mfma_kernel<MT, NT, WGM, WGN>, 256,
+                                                     C::LDS_BYTES) != hipSuccess || per_cu < 1)
+      per_cu = 3;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    (void)hipGetLastError();
+    return (int64_t)per_cu * cus;
+  }();
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
-  int64_t ksplit = ceil_div(1024, tiles);
+  int64_t ksplit = ceil_div(resident, tiles);
+  if (M / ksplit >= 4096) ksplit = ceil_div(2 * resident, tiles);
   const int64_t max_split = ceil_div(M, 8 * WK);
   if (ksplit > max_split) ksplit = max_split;
   if (ksplit < 1) ksplit = 1;
