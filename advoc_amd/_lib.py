@@ -37,6 +37,7 @@ class ConvLayer(ctypes.Structure):
       ('y', Tensor4),
       ('w', _p), ('b', _p),
       ('drop_mask', _p), ('drop_scale', _f32),
+      ('in_mask', _p), ('in_mask_scale', _f32),
   ]
 
 
@@ -54,8 +55,10 @@ PROTOTYPES = {
     'advoc_mel_dbnorm_f32': (ctypes.c_int, [_p, _i64, _f32, _f32, _f32, _p]),
     'advoc_conv_forward': (ctypes.c_int, [_p, _p]),
     'advoc_conv_backward_data': (ctypes.c_int, [_p, _p, _p, _p, _i32, _i32, _p]),
-    'advoc_conv_backward_weight': (ctypes.c_int, [_p, _p, _p, _p, _p]),
-    'advoc_conv_backward_bias': (ctypes.c_int, [_p, _p, _p, _p]),
+    'advoc_conv_backward_weight': (ctypes.c_int, [_p, _p, _p, _p, _i32, _p]),
+    'advoc_conv_backward_bias': (ctypes.c_int, [_p, _p, _p, _i32, _p]),
+    'advoc_bn_forward': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _f32, _p, _p, _p, _p, _p, _p]),
+    'advoc_bn_backward': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p]),
     'advoc_conv_kernel_name': (ctypes.c_int, [_p, _i32, ctypes.c_char_p, _i32]),
     'advoc_gan_d_loss': (ctypes.c_int, [_p, _p, _i64, _p, _p, _p, _p]),
     'advoc_gan_g_loss': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _f32, _f32, _p, _p, _i32, _p, _p]),

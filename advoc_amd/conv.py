@@ -76,7 +76,7 @@ class Layer(object):
 
   def __init__(self, kind, x0, y, weight, bias=None, x1=None, in_w=None, out_w=None, stride=(2, 2),
                pad=(1, 1), in_act=ACT_NONE, drop_mask=None, drop_scale=0., in_scale=None,
-               in_shift=None):
+               in_shift=None, in_mask=None, in_mask_scale=0.):
     kh, kw = int(weight.shape[0]), int(weight.shape[1])
     cin = x0.shape[3] + (x1.shape[3] if x1 is not None else 0)
     cout = y.shape[3]
@@ -85,13 +85,17 @@ class Layer(object):
       raise _lib.AdvocHipError('kernel shape {} != {}'.format(tuple(weight.shape), want))
     if bias is not None and tuple(bias.shape) != (cout,):
       raise _lib.AdvocHipError('bias shape {} != ({},)'.format(tuple(bias.shape), cout))
-    for t in (weight, bias, drop_mask, in_scale, in_shift):
+    for t in (weight, bias, drop_mask, in_scale, in_shift, in_mask):
       if t is not None:
         _lib.require_device(t)
+    if in_mask is not None and (in_mask.dtype != torch.uint8 or tuple(in_mask.shape) != tuple(x0.shape)):
+      raise _lib.AdvocHipError('input mask must be uint8 with the shape of x0')
+    if in_scale is not None and (tuple(in_scale.shape) != (cin,) or tuple(in_shift.shape) != (cin,)):
+      raise _lib.AdvocHipError('in_scale / in_shift must have one entry per input channel')
     if drop_mask is not None and (drop_mask.dtype != torch.uint8 or tuple(drop_mask.shape) != tuple(y.shape)):
       raise _lib.AdvocHipError('dropout mask must be uint8 with the shape of y')
     self.kind = kind
-    self.tensors = (x0, x1, y, weight, bias, drop_mask, in_scale, in_shift)
+    self.tensors = (x0, x1, y, weight, bias, drop_mask, in_scale, in_shift, in_mask)
     self.x0, self.x1, self.y, self.weight, self.bias = x0, x1, y, weight, bias
     s = _lib.ConvLayer()
     s.kind = kind
@@ -108,6 +112,8 @@ class Layer(object):
     s.b = _lib.ptr(bias)
     s.drop_mask = _lib.ptr(drop_mask)
     s.drop_scale = float(drop_scale)
+    s.in_mask = _lib.ptr(in_mask)
+    s.in_mask_scale = float(in_mask_scale)
     self.struct = s
     self._names = {}
     lw = s.x0.w
@@ -151,18 +157,19 @@ class Layer(object):
         ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dx0), _lib.ptr(dx1), int(accum0),
         int(accum1), _lib.stream()), 'advoc_conv_backward_data'))
 
-  def backward_weight(self, dy, dw, db=None):
+  def backward_weight(self, dy, dw, db=None, accumulate=False):
     _lib.require_device(dy)
     _lib.require_device(dw)
     if tuple(dw.shape) != tuple(self.weight.shape):
       raise _lib.AdvocHipError('dw shape mismatch')
     self._run(2, lambda: _lib.check(_lib.load().advoc_conv_backward_weight(
-        ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dw), None, _lib.stream()),
+        ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dw), None, int(accumulate), _lib.stream()),
         'advoc_conv_backward_weight'))
     if db is not None:
       _lib.require_device(db)
       call = lambda: _lib.check(_lib.load().advoc_conv_backward_bias(      # noqa: E731
-          ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(db), _lib.stream()), 'advoc_conv_backward_bias')
+          ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(db), int(accumulate), _lib.stream()),
+          'advoc_conv_backward_bias')
       prof = Layer.profiler
       if prof is None:
         call()

@@ -100,6 +100,7 @@ int build_forward(const advoc_conv_layer* L, GatherGemmParams& p, bool& b_kn) {
   p.a1 = L->x1.p; p.c1 = L->x1.p ? L->x1.c : 0; p.a1_pitch = L->x1.p ? L->x1.w_pitch : 0;
   p.a_h = L->x0.h; p.in_h = L->x0.h; p.in_w = L->x0.w;
   p.in_scale = L->in_scale; p.in_shift = L->in_shift; p.in_act = L->in_act;
+  p.a_mask = L->in_mask; p.a_mask_scale = L->in_mask_scale;
   p.batch = L->x0.n;
   p.w = L->w;
   p.n_total = p.n_split = L->y.c;
@@ -125,7 +126,6 @@ int build_forward(const advoc_conv_layer* L, GatherGemmParams& p, bool& b_kn) {
 // ---------------------------------------------------------------------------------------------
 int build_backward_data(const advoc_conv_layer* L, const float* dy, float* dx0, float* dx1, int accum0,
                         int accum1, GatherGemmParams& p, bool& b_kn) {
-  if (L->in_scale) return ADVOC_ERR_UNSUPPORTED;   // BN-folded prologue: backward not built yet
   p = GatherGemmParams{};
   p.a0 = dy; p.c0 = L->y.c; p.a0_pitch = L->y.w_pitch;
   p.a_h = L->y.h; p.in_h = L->y.h; p.in_w = L->y.w;
@@ -139,6 +139,10 @@ int build_backward_data(const advoc_conv_layer* L, const float* dy, float* dx0, 
   p.d[0].p = dx0; p.d[0].xpre = L->x0.p; p.d[0].pitch = L->x0.w_pitch; p.d[0].c = c0; p.d[0].accum = accum0;
   p.d[1].p = c1 ? dx1 : nullptr; p.d[1].xpre = L->x1.p; p.d[1].pitch = c1 ? L->x1.w_pitch : 0;
   p.d[1].c = c1; p.d[1].accum = accum1;
+  p.d[0].gscale = L->in_scale; p.d[0].gshift = L->in_shift;
+  p.d[0].gmask = L->in_mask; p.d[0].gmask_scale = L->in_mask_scale;
+  p.d[1].gscale = L->in_scale ? L->in_scale + c0 : nullptr;
+  p.d[1].gshift = L->in_shift ? L->in_shift + c0 : nullptr;
   p.out_h = L->x0.h; p.out_w = L->x0.w;
   p.grad_act = L->in_act;
   if (L->kind == ADVOC_DECONV) {
@@ -178,6 +182,7 @@ void operand_from_inputs(const advoc_conv_layer* L, Operand& o) {
   o.p1 = L->x1.p; o.c1 = L->x1.p ? L->x1.c : 0; o.pitch1 = L->x1.p ? L->x1.w_pitch : 0;
   o.h = L->x0.h; o.w = L->x0.w;
   o.act = L->in_act; o.scale = L->in_scale; o.shift = L->in_shift;
+  o.mask = L->in_mask; o.mask_scale = L->in_mask_scale;
 }
 
 void operand_from_dy(const advoc_conv_layer* L, const float* dy, Operand& o) {
@@ -260,14 +265,14 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
 }
 
 extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float* dy, float* dw,
-                                          float* db, advoc_stream_t stream) {
+                                          float* db, int32_t accumulate, advoc_stream_t stream) {
   int rc = validate_layer(L);
   if (rc != ADVOC_OK) return rc;
   if (!dy || !dw) return ADVOC_ERR_NULL;
-  if (L->in_scale) return ADVOC_ERR_UNSUPPORTED;
   WgradParams p;
   rc = build_backward_weight(L, dy, dw, p);
   if (rc != ADVOC_OK) return rc;
+  p.accumulate = accumulate;
   const int ca = p.P.c0 + p.P.c1;
   if (ca <= 2) {
     const int cb = p.Q.c0 + p.Q.c1;
@@ -279,17 +284,17 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
   if (rc != ADVOC_OK) return rc;
   if (db)
     rc = launch_bias_grad(dy, L->drop_mask, L->drop_scale, (int64_t)L->y.n * L->y.h, L->y.w,
-                          L->y.w_pitch, L->y.c, db, as_stream(stream));
+                          L->y.w_pitch, L->y.c, db, accumulate, as_stream(stream));
   return rc;
 }
 
 extern "C" int advoc_conv_backward_bias(const advoc_conv_layer* L, const float* dy, float* db,
-                                        advoc_stream_t stream) {
+                                        int32_t accumulate, advoc_stream_t stream) {
   const int rc = validate_layer(L);
   if (rc != ADVOC_OK) return rc;
   if (!dy || !db) return ADVOC_ERR_NULL;
   return launch_bias_grad(dy, L->drop_mask, L->drop_scale, (int64_t)L->y.n * L->y.h, L->y.w,
-                          L->y.w_pitch, L->y.c, db, as_stream(stream));
+                          L->y.w_pitch, L->y.c, db, accumulate, as_stream(stream));
 }
 
 extern "C" int advoc_conv_kernel_name(const advoc_conv_layer* L, int32_t direction, char* buf_host,

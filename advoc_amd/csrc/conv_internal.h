@@ -32,7 +32,7 @@ struct Operand {
   int act;
   const float* scale;  // optional per-channel affine before act
   const float* shift;
-  const uint8_t* mask; // optional {0,1} mask (single source only), indexed like p0
+  const uint8_t* mask; // optional {0,1} mask on the channels of source 0, indexed like p0
   float mask_scale;
 };
 
@@ -44,7 +44,8 @@ struct WgradParams {
   int sy, sx;
   int ntaps;
   int tap[kMaxTaps];   // (dy & 0xff) | (dx & 0xff) << 8 | wtap << 16
-  float* dw;           // zero-filled by the launcher, accumulated with atomics
+  float* dw;           // accumulated with atomics; zero-filled by the launcher unless `accumulate`
+  int accumulate;
 };
 
 int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream,
@@ -57,6 +58,6 @@ int launch_wgrad_thin_mfma(const WgradParams& p, hipStream_t stream,
 
 // db[c] = sum over pixels of dy[., c] (* mask * scale)
 int launch_bias_grad(const float* dy, const uint8_t* mask, float mask_scale, int64_t rows, int w,
-                     int pitch, int c, float* db, hipStream_t stream);
+                     int pitch, int c, float* db, int accumulate, hipStream_t stream);
 
 }  // namespace advoc

@@ -48,7 +48,12 @@ __device__ __forceinline__ void store_result(const GatherGemmParams& p, int phas
   const int64_t off = (((int64_t)g.img * p.out_h + oy) * d.pitch + ox) * d.c + ch;
   if (p.bias) v += p.bias[n];
   if (p.y_mask) v *= p.y_mask[off] * p.y_mask_scale;
-  if (p.grad_act != ADVOC_ACT_NONE) v *= act_bwd(d.xpre[off], p.grad_act);
+  if (p.grad_act != ADVOC_ACT_NONE) {
+    float x = d.xpre[off];
+    if (d.gscale) x = x * d.gscale[ch] + d.gshift[ch];
+    v *= act_bwd(x, p.grad_act);
+  }
+  if (d.gmask) v *= d.gmask[off] * d.gmask_scale;
   if (d.accum) v += d.p[off];
   d.p[off] = v;
 }
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256) void gather_dot_kernel(const GatherGemmParams 
           }
           v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
           v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
-          if (p.a_mask) {
+          if (p.a_mask && !second) {
             const uchar4 mk = *reinterpret_cast<const uchar4*>(p.a_mask + off);
             v.x *= mk.x * p.a_mask_scale; v.y *= mk.y * p.a_mask_scale;
             v.z *= mk.z * p.a_mask_scale; v.w *= mk.w * p.a_mask_scale;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256) void gather_outer_kernel(const GatherGemmParam
       float v = src[off];
       if (p.in_scale) v = v * p.in_scale[k] + p.in_shift[k];
       v = act_fwd(v, p.in_act);
-      if (p.a_mask) v *= p.a_mask[off] * p.a_mask_scale;
+      if (p.a_mask && !second) v *= p.a_mask[off] * p.a_mask_scale;
       const float w = B_KN ? p.w[((int64_t)wtap * ktot + k) * N + n] : p.w[((int64_t)wtap * N + n) * ktot + k];
       acc = fmaf(v, w, acc);
     }
@@ -175,7 +180,6 @@ int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream, 
   const int ktot = p.c0 + p.c1;
   if (p.n_total < 1 || p.n_total > 2 || ktot % 4 || p.c0 % 4) return ADVOC_ERR_UNSUPPORTED;
   if (p.n_total == 2 && b_kn) return ADVOC_ERR_UNSUPPORTED;
-  if (p.a_mask && p.c1) return ADVOC_ERR_UNSUPPORTED;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   int G = 8;
   while (G < 64 && G * 4 < ktot) G *= 2;
@@ -201,7 +205,6 @@ int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream, 
 int launch_gather_outer(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only) {
   const int ktot = p.c0 + p.c1;
   if (ktot < 1 || ktot > 2) return ADVOC_ERR_UNSUPPORTED;
-  if (p.a_mask && p.c1) return ADVOC_ERR_UNSUPPORTED;
   if (name_only) {
     *name_only = b_kn ? "gather_outer_kernel<true>" : "gather_outer_kernel<false>";
     return ADVOC_OK;

@@ -23,6 +23,13 @@ struct GemmDest {
   int pitch;
   int c;
   int accum;          // 1: add into destination
+  // act'(.) is evaluated at gscale * xpre + gshift (the BN affine the forward applied to this
+  // input, per channel of THIS destination; null = identity) and the result is multiplied by
+  // gmask * gmask_scale (the dropout mask the forward applied to this input; null = none)
+  const float* gscale;
+  const float* gshift;
+  const uint8_t* gmask;
+  float gmask_scale;
 };
 
 struct GatherGemmParams {
@@ -36,7 +43,7 @@ struct GatherGemmParams {
   const float* in_scale;   // optional per-channel affine applied before the activation
   const float* in_shift;
   int in_act;
-  const uint8_t* a_mask;   // optional {0,1} mask multiplied into A (indexed like a0), c1 must be 0
+  const uint8_t* a_mask;   // optional {0,1} mask multiplied into the channels of SOURCE 0 (indexed like a0)
   float a_mask_scale;
   // ---- grid / taps ----
   int batch, gh, gw;

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   float4 ra[AL], rb[BL];
   unsigned a_ok = 0;
   int a_chan = 0;
+  bool a_first = true;     // the staged A slice comes from source 0 (the only one a_mask covers)
   int a_moff[AL];
 
 #define ADVOC_LOAD_TILE(KT)                                                                          \
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
     const int delta_ = second_ ? (dy_ * p.a1_pitch + dx_) * p.c1 + (k0_ - p.c0)                      \
                                : (dy_ * p.a0_pitch + dx_) * p.c0 + k0_;                              \
     a_chan = k0_ + 4 * kq;                                                                           \
+    a_first = !second_;                                                                              \
     a_ok = 0;                                                                                        \
     _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                                 \
       const int iy_ = row_y[i] + dy_, ix_ = row_x[i] + dx_;                                          \
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
       v.z = fmaf(v.z, sc_.z, sh_.z * live_); v.w = fmaf(v.w, sc_.w, sh_.w * live_);                  \
       v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);                                  \
       v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);                                  \
-      if (p.a_mask) {                                                                                \
+      if (p.a_mask && a_first) {                                                                     \
         uchar4 mk_ = make_uchar4(0, 0, 0, 0);                                                        \
         if ((a_ok >> i) & 1u) mk_ = *reinterpret_cast<const uchar4*>(p.a_mask + a_moff[i]);          \
         v.x *= mk_.x * p.a_mask_scale; v.y *= mk_.y * p.a_mask_scale;                                \
@@ -328,9 +330,19 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
           v.z *= mk.z * p.y_mask_scale; v.w *= mk.w * p.y_mask_scale;
         }
         if (p.grad_act != ADVOC_ACT_NONE) {
-          const float4 x = *reinterpret_cast<const float4*>(d.xpre + off);
+          float4 x = *reinterpret_cast<const float4*>(d.xpre + off);
+          if (d.gscale) {
+            const float4 gs = *reinterpret_cast<const float4*>(d.gscale + ch);
+            const float4 gh = *reinterpret_cast<const float4*>(d.gshift + ch);
+            x.x = x.x * gs.x + gh.x; x.y = x.y * gs.y + gh.y; x.z = x.z * gs.z + gh.z; x.w = x.w * gs.w + gh.w;
+          }
           v.x *= x.x > 0.f ? 1.f : gslope; v.y *= x.y > 0.f ? 1.f : gslope;
           v.z *= x.z > 0.f ? 1.f : gslope; v.w *= x.w > 0.f ? 1.f : gslope;
+        }
+        if (d.gmask) {
+          const uchar4 mk = *reinterpret_cast<const uchar4*>(d.gmask + off);
+          v.x *= mk.x * d.gmask_scale; v.y *= mk.y * d.gmask_scale;
+          v.z *= mk.z * d.gmask_scale; v.w *= mk.w * d.gmask_scale;
         }
         if (d.accum) {
           const float4 o = *reinterpret_cast<const float4*>(d.p + off);
@@ -404,7 +416,6 @@ int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
   if (p.batch <= 0 || p.gh <= 0 || p.gw <= 0 || ktot <= 0 || p.n_total <= 0) return ADVOC_ERR_BAD_SHAPE;
   if (ktot % 16 || p.c0 % 16 || p.n_total % 32 || p.n_split % 32) return ADVOC_ERR_UNSUPPORTED;
   if (p.nphase < 1 || p.nphase > kMaxPhases || p.ntaps < 1 || p.ntaps > kMaxTaps) return ADVOC_ERR_UNSUPPORTED;
-  if (p.a_mask && p.c1) return ADVOC_ERR_UNSUPPORTED;
   // the kernel indexes every tensor with 32-bit element offsets
   const int64_t lim = 0x7fffffffLL;
   if ((int64_t)p.batch * p.a_h * p.a0_pitch * p.c0 > lim || (int64_t)p.batch * p.a_h * p.a1_pitch * p.c1 > lim ||

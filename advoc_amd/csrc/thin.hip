@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
           v = v * p.in_scale[ci] + p.in_shift[ci];
         }
         v = fmaxf(v, slope * v);
-        if (p.a_mask) v *= p.a_mask[off] * p.a_mask_scale;
+        if (p.a_mask && !second) v *= p.a_mask[off] * p.a_mask_scale;
       }
       a[s] = v;
     }
@@ -163,7 +163,12 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
         const int off = pix * d.c + ch;
         float v = acc[j][r] + bias[j];
         if (p.y_mask) v *= p.y_mask[off] * p.y_mask_scale;
-        if (p.grad_act != ADVOC_ACT_NONE) v *= d.xpre[off] > 0.f ? 1.f : gslope;
+        if (p.grad_act != ADVOC_ACT_NONE) {
+          float x = d.xpre[off];
+          if (d.gscale) x = x * d.gscale[ch] + d.gshift[ch];
+          v *= x > 0.f ? 1.f : gslope;
+        }
+        if (d.gmask) v *= d.gmask[off] * d.gmask_scale;
         if (d.accum) v += d.p[off];
         d.p[off] = v;
       }
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
           float v = psrc[off];
           if (p.P.scale) v = v * p.P.scale[a] + p.P.shift[a];
           v = fmaxf(v, pslope * v);
-          if (p.P.mask) v *= p.P.mask[off] * p.P.mask_scale;
+          if (p.P.mask && !a_second) v *= p.P.mask[off] * p.P.mask_scale;
           av[u] = v;
         }
 #pragma unroll
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
             float v = qsrc[j][off];
             if (p.Q.scale) v = v * p.Q.scale[b0 + 32 * j + l32] + p.Q.shift[b0 + 32 * j + l32];
             v = fmaxf(v, qslope * v);
-            if (p.Q.mask) v *= p.Q.mask[off] * p.Q.mask_scale;
+            if (p.Q.mask && qsrc[j] == p.Q.p0) v *= p.Q.mask[off] * p.Q.mask_scale;
             bv[j][u] = v;
           }
         }
@@ -328,7 +333,6 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
 int launch_thin_k_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only) {
   const int ktot = p.c0 + p.c1;
   if (ktot < 1 || ktot > 2 || p.c0 > 2 || p.n_total % 32) return ADVOC_ERR_UNSUPPORTED;
-  if (p.a_mask && p.c1) return ADVOC_ERR_UNSUPPORTED;
   const int kreal = p.ntaps * ktot;
   if (kreal > 32) return ADVOC_ERR_UNSUPPORTED;
   if ((int64_t)p.batch * p.out_h * (int64_t)(p.d[0].pitch > p.d[1].pitch ? p.d[0].pitch : p.d[1].pitch) > 0x7fffffffLL)
@@ -345,8 +349,10 @@ int launch_wgrad_thin_mfma(const WgradParams& p, hipStream_t stream, const char*
     *name_only = nt == 4 ? "thin_wgrad_kernel<4>" : (nt == 2 ? "thin_wgrad_kernel<2>" : "thin_wgrad_kernel<1>");
     return ADVOC_OK;
   }
-  hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
-  if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  if (!p.accumulate) {
+    hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
+    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  }
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   const int by = cb / (32 * nt);
   // ~2048 waves over the pixel axis (2 blocks of 4 waves per CU); each wave keeps 8 x (1 + NT)

@@ -42,7 +42,7 @@ __device__ __forceinline__ float4 load_op4(const Operand& op, int img, int y, in
   }
   v.x = act_fwd(v.x, op.act); v.y = act_fwd(v.y, op.act);
   v.z = act_fwd(v.z, op.act); v.w = act_fwd(v.w, op.act);
-  if (op.mask) {
+  if (op.mask && !second) {
     const uchar4 mk = *reinterpret_cast<const uchar4*>(op.mask + off);
     v.x *= mk.x * op.mask_scale; v.y *= mk.y * op.mask_scale;
     v.z *= mk.z * op.mask_scale; v.w *= mk.w * op.mask_scale;
@@ -59,7 +59,7 @@ __device__ __forceinline__ float load_op1(const Operand& op, int img, int y, int
   float v = src[off];
   if (op.scale) v = v * op.scale[ch] + op.shift[ch];
   v = act_fwd(v, op.act);
-  if (op.mask) v *= op.mask[off] * op.mask_scale;
+  if (op.mask && !second) v *= op.mask[off] * op.mask_scale;
   return v;
 }
 
@@ -92,7 +92,7 @@ __device__ __forceinline__ float4 load_op4_at(const Operand& op, int pix0, int p
   }
   v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
   v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
-  if (op.mask) {
+  if (op.mask && !second) {   // the mask covers source 0 only
     const uchar4 mk = *reinterpret_cast<const uchar4*>(op.mask + off);
     v.x *= mk.x * op.mask_scale; v.y *= mk.y * op.mask_scale;
     v.z *= mk.z * op.mask_scale; v.w *= mk.w * op.mask_scale;
@@ -272,7 +272,7 @@ int launch_wcfg(const WgradParams& p, hipStream_t stream, const char** name_only
     *name_only = name.c_str();
     return ADVOC_OK;
   }
-  {
+  if (!p.accumulate) {
     const int ca_ = p.P.c0 + p.P.c1, cb_ = p.Q.c0 + p.Q.c1;
     hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca_ * cb_, stream);
     if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
@@ -388,7 +388,32 @@ __global__ __launch_bounds__(256) void bias_grad_vec4_kernel(const float* __rest
     const int q = qbase + tq;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tg < groups && q < quads) {
-      for (int64_t pix = (int64_t)blockIdx.x * groups + tg; pix < npix; pix += (int64_t)gridDim.x * groups) {
+      const int64_t step = (int64_t)gridDim.x * groups;
+      int64_t pix = (int64_t)blockIdx.x * groups + tg;
+      // four independent 16-byte loads in flight per lane
+      float4 s1 = s, s2 = s, s3 = s;
+      for (; pix + 3 * step < npix; pix += 4 * step) {
+        const int64_t o0 = pix * c + 4 * q, o1 = o0 + step * c, o2 = o1 + step * c, o3 = o2 + step * c;
+        float4 v0 = *reinterpret_cast<const float4*>(dy + o0);
+        float4 v1 = *reinterpret_cast<const float4*>(dy + o1);
+        float4 v2 = *reinterpret_cast<const float4*>(dy + o2);
+        float4 v3 = *reinterpret_cast<const float4*>(dy + o3);
+        if (mask) {
+          const uchar4 m0 = *reinterpret_cast<const uchar4*>(mask + o0);
+          const uchar4 m1 = *reinterpret_cast<const uchar4*>(mask + o1);
+          const uchar4 m2 = *reinterpret_cast<const uchar4*>(mask + o2);
+          const uchar4 m3 = *reinterpret_cast<const uchar4*>(mask + o3);
+          v0.x *= m0.x * mask_scale; v0.y *= m0.y * mask_scale; v0.z *= m0.z * mask_scale; v0.w *= m0.w * mask_scale;
+          v1.x *= m1.x * mask_scale; v1.y *= m1.y * mask_scale; v1.z *= m1.z * mask_scale; v1.w *= m1.w * mask_scale;
+          v2.x *= m2.x * mask_scale; v2.y *= m2.y * mask_scale; v2.z *= m2.z * mask_scale; v2.w *= m2.w * mask_scale;
+          v3.x *= m3.x * mask_scale; v3.y *= m3.y * mask_scale; v3.z *= m3.z * mask_scale; v3.w *= m3.w * mask_scale;
+        }
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+        s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+        s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+        s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+      }
+      for (; pix < npix; pix += step) {
         const int64_t off = pix * c + 4 * q;
         float4 v = *reinterpret_cast<const float4*>(dy + off);
         if (mask) {
@@ -397,6 +422,8 @@ __global__ __launch_bounds__(256) void bias_grad_vec4_kernel(const float* __rest
         }
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
+      s.x += s1.x + s2.x + s3.x; s.y += s1.y + s2.y + s3.y;
+      s.z += s1.z + s2.z + s3.z; s.w += s1.w + s2.w + s3.w;
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -470,8 +497,10 @@ int launch_wgrad_thin(const WgradParams& p, hipStream_t stream, const char** nam
     *name_only = ca == 1 ? "wgrad_thin_kernel<1>" : "wgrad_thin_kernel<2>";
     return ADVOC_OK;
   }
-  hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
-  if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  if (!p.accumulate) {
+    hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
+    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  }
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   const int lanes_b = cb < 64 ? cb : 64;
   const int by = cb / lanes_b;
@@ -490,15 +519,17 @@ int launch_wgrad_thin(const WgradParams& p, hipStream_t stream, const char** nam
 }
 
 int launch_bias_grad(const float* dy, const uint8_t* mask, float mask_scale, int64_t rows, int w,
-                     int pitch, int c, float* db, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)c, stream);
-  if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+                     int pitch, int c, float* db, int accumulate, hipStream_t stream) {
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)c, stream);
+    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  }
   ADVOC_CLEAR_LAUNCH_ERROR();
   const int quads = c / 4;
   if (c % 4 == 0 && pitch == w && 256 % (quads < 256 ? quads : 256) == 0) {
     const int groups = 256 / (quads < 256 ? quads : 256);
     int64_t blocks = ceil_div(rows * w, (int64_t)groups * 16);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bias_grad_vec4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, mask,
                        mask_scale, rows * w, c, db);

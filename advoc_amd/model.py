@@ -147,8 +147,6 @@ class Advoc(Model):
                                 .format(self.generator_type))
     if self.separable_conv:
       raise NotImplementedError('separable_conv=True is a non-default ablation outside the hot path')
-    if self.use_batchnorm:
-      raise NotImplementedError('use_batchnorm=True is not built yet (default is False)')
     if self.subseq_len % (2 ** len(self._encoder_channels())):
       raise NotImplementedError('subseq_len must be a multiple of 2^#encoders; the (1,2)-stride '
                                 'layers of advoc_model.py:115-120 are outside the BASELINE configs')
@@ -174,12 +172,24 @@ class Advoc(Model):
       cin = 2 if i == 0 else chans[i - 1]
       d.append(('discriminator/layer_%d/conv2d' % (i + 1), (4, 4, cin, chans[i])))
 
+    def has_bn(scope):
+      # batchnorm follows encoder_2.., every decoder but decoder_1, and layer_2..4
+      # (advoc_model.py:118,142,194); never encoder_1 / decoder_1 / layer_1 / layer_5
+      if not self.use_batchnorm:
+        return False
+      name = scope.split('/')[1]
+      return name not in ('encoder_1', 'decoder_1', 'layer_1', 'layer_5')
+
     def expand(lst):
       out = []
       for scope, kshape in lst:
         cout = kshape[2] if 'transpose' in scope else kshape[3]
         out.append((scope + '/kernel', kshape))
         out.append((scope + '/bias', (cout,)))
+        if has_bn(scope):
+          base = scope.rsplit('/', 1)[0] + '/batch_normalization'
+          out.append((base + '/gamma', (cout,)))
+          out.append((base + '/beta', (cout,)))
       return out
     return expand(g), expand(d)
 
@@ -214,6 +224,8 @@ class Advoc(Model):
         for name, t in st[net + '_P'].items():
           if name.endswith('/kernel'):
             t.copy_(torch.randn(t.shape, generator=gen) * 0.02)
+          elif name.endswith('/gamma'):
+            t.fill_(1.0)
       st['g_t'] = st['d_t'] = 0
       st['sums'] = torch.zeros(4, dtype=torch.float32, device=dev)
     st['B'] = B
@@ -231,6 +243,20 @@ class Advoc(Model):
     enc_c = self._encoder_channels()
     dec = self._decoder_specs()
     P, G = st['g_P'], st['g_G']
+    bn_on = bool(self.use_batchnorm)
+    st['bn_on'] = bn_on
+
+    def new_bn(z, scope, PP, GG, scale=None, shift=None):
+      """Per-tensor batch-norm state: the affine (scale, shift) is written by advoc_bn_forward and
+      read by the CONSUMING layers' loads; scale/shift may alias a slice of a consumer's vector."""
+      c = z.shape[3]
+      base = scope + '/batch_normalization'
+      return dict(z=z, c=c, npix=z.numel() // c, gamma=PP[base + '/gamma'], beta=PP[base + '/beta'],
+                  dgamma=GG[base + '/gamma'], dbeta=GG[base + '/beta'],
+                  scale=scale if scale is not None else torch.ones(c, **f32),
+                  shift=shift if shift is not None else torch.zeros(c, **f32),
+                  mean=torch.zeros(c, **f32), invstd=torch.ones(c, **f32),
+                  work=torch.zeros(2 * c, **f32), copies=[])
 
     # ---- generator buffers ----
     st['x_in'] = torch.zeros(B, T, F, 1, **f32)
@@ -239,7 +265,6 @@ class Advoc(Model):
     st['d_target'] = torch.zeros(2 * B, T, F, 1, **f32)
     gen_out = st['d_target'][B:]
     st['gen_out'] = gen_out
-    st['g_gen_out'] = torch.zeros(B, T, F, 1, **f32)
     e, ge = [], []
     h, w = T, F
     for c in enc_c:
@@ -253,10 +278,43 @@ class Advoc(Model):
       hh = src.shape[1] * 2
       ww = (src.shape[2] if j == 0 else e[idx - 1].shape[2]) * 2
       d[idx] = torch.zeros(B, hh, ww, c, **f32)
-      gd[idx] = torch.zeros(B, hh, ww, c, **f32)     # trimmed column stays zero forever
+      gd[idx] = torch.zeros(B, hh, ww, c, **f32)     # trimmed column is never written by backward
       if drop > 0:
         masks[idx] = (torch.zeros(B, hh, ww, c, dtype=torch.uint8, device=dev), 1.0 - drop)
     st['dec'], st['g_dec'], st['masks'] = d, gd, masks
+
+    # ---- generator batch-norm state (use_batchnorm=True) ----
+    # encoder k >= 2 feeds encoder k+1 (alone) and decoder k (second half of a concat);
+    # decoder idx feeds the next decoder (first half of the concat).
+    gbn = collections.OrderedDict()
+    dec_aff = {}   # decoder name -> (scale_vec, shift_vec) over its concatenated input channels
+    if bn_on:
+      for j, (idx, c, drop) in enumerate(dec):
+        if j > 0:
+          cin = d[dec[j - 1][0]].shape[3] + e[idx - 1].shape[3]
+          dec_aff['decoder_%d' % idx] = (torch.ones(cin, **f32), torch.zeros(cin, **f32))
+      if dec:
+        cin = d[dec[-1][0]].shape[3] + e[0].shape[3]
+        dec_aff['decoder_1'] = (torch.ones(cin, **f32), torch.zeros(cin, **f32))
+      for i in range(1, len(enc_c)):
+        gbn['encoder_%d' % (i + 1)] = new_bn(e[i], 'generator/encoder_%d' % (i + 1), P, G)
+      for j, (idx, c, drop) in enumerate(dec):
+        # this decoder's consumer: the next decoder in the list, or decoder_1 for the last one
+        consumer = 'decoder_%d' % dec[j + 1][0] if j + 1 < len(dec) else 'decoder_1'
+        sc, sh = dec_aff[consumer]
+        gbn['decoder_%d' % idx] = new_bn(d[idx], 'generator/decoder_%d' % idx, P, G,
+                                         scale=sc[:c], shift=sh[:c])
+      # encoder outputs that are the second half of a decoder's concat: copy their affine over
+      for j, (idx, c, drop) in enumerate(dec):
+        if j > 0 and idx - 1 >= 1:
+          c0 = d[dec[j - 1][0]].shape[3]
+          sc, sh = dec_aff['decoder_%d' % idx]
+          gbn['encoder_%d' % idx]['copies'].append((sc[c0:], sh[c0:]))
+    st['g_bn'] = gbn
+
+    def aff_of(name_src):
+      b = gbn.get(name_src)
+      return (b['scale'], b['shift']) if b else (None, None)
 
     # ---- generator layers ----
     L = collections.OrderedDict()
@@ -266,28 +324,46 @@ class Advoc(Model):
       src = x if i == 0 else e[i - 1]
       pt, _ = C.same_pad(src.shape[1], 4, 2)
       pl, _ = C.same_pad(src.shape[2], 4, 2)
+      sc, sh = aff_of('encoder_%d' % i) if i > 0 else (None, None)
       L['encoder_%d' % (i + 1)] = C.Layer(C.CONV, src, e[i], P[s + '/kernel'], P[s + '/bias'],
                                           stride=(2, 2), pad=(pt, pl),
-                                          in_act=C.ACT_NONE if i == 0 else C.ACT_LRELU)
+                                          in_act=C.ACT_NONE if i == 0 else C.ACT_LRELU,
+                                          in_scale=sc, in_shift=sh)
     for j, (idx, c, drop) in enumerate(dec):
       s = 'generator/decoder_%d/conv2d_transpose' % idx
       if j == 0:
         x0, x1, in_w = e[-1], None, None
+        sc, sh = aff_of('encoder_%d' % len(enc_c))
+        src_mask = None
       else:
         x0, x1 = d[dec[j - 1][0]], e[idx - 1]
         in_w = x1.shape[2]                      # layers[-1][:, :, :-1, :]  (advoc_model.py:137)
+        sc, sh = dec_aff.get('decoder_%d' % idx, (None, None))
+        src_mask = masks.get(dec[j - 1][0])
       mk = masks.get(idx)
-      L['decoder_%d' % idx] = C.Layer(C.DECONV, x0, d[idx], P[s + '/kernel'], P[s + '/bias'], x1=x1,
-                                      in_w=in_w, stride=(2, 2), pad=(1, 1), in_act=C.ACT_RELU,
-                                      drop_mask=mk[0] if mk else None,
-                                      drop_scale=1.0 / mk[1] if mk else 0.)
+      # Without BN the producer applies its own dropout in its epilogue.  With BN dropout acts
+      # AFTER the normalisation (advoc_model.py:142-149), i.e. on the consumer's loads.
+      L['decoder_%d' % idx] = C.Layer(
+          C.DECONV, x0, d[idx], P[s + '/kernel'], P[s + '/bias'], x1=x1, in_w=in_w, stride=(2, 2),
+          pad=(1, 1), in_act=C.ACT_RELU,
+          drop_mask=mk[0] if (mk and not bn_on) else None, drop_scale=1.0 / mk[1] if (mk and not bn_on) else 0.,
+          in_scale=sc, in_shift=sh,
+          in_mask=src_mask[0] if (src_mask and bn_on) else None,
+          in_mask_scale=1.0 / src_mask[1] if (src_mask and bn_on) else 0.)
     s = 'generator/decoder_1/conv2d_transpose'
     last = d[dec[-1][0]] if dec else e[-1]
+    sc, sh = dec_aff.get('decoder_1', (None, None))
+    src_mask = masks.get(dec[-1][0]) if dec else None
     L['decoder_1'] = C.Layer(C.DECONV, last, gen_out, P[s + '/kernel'], P[s + '/bias'], x1=e[0],
-                             in_w=e[0].shape[2], out_w=F, stride=(2, 2), pad=(1, 1), in_act=C.ACT_RELU)
+                             in_w=e[0].shape[2], out_w=F, stride=(2, 2), pad=(1, 1), in_act=C.ACT_RELU,
+                             in_scale=sc, in_shift=sh,
+                             in_mask=src_mask[0] if (src_mask and bn_on) else None,
+                             in_mask_scale=1.0 / src_mask[1] if (src_mask and bn_on) else 0.)
     st['g_layers'] = L
 
-    # ---- discriminator buffers + layers: full 2B batch (D step) and fake half only (G step) ----
+    # ---- discriminator buffers + layers ----
+    # BN off: the D step runs [real ; fake] as ONE 2B batch; BN on: two B passes (each pass has its
+    # own batch statistics, as the reference's two build_discriminator calls do).
     chans = [self.ndf, self.ndf * 2, self.ndf * 4, self.ndf * 8, 1]
     strides = [2, 2, 2, 1, 1]
     a, ga = [], []
@@ -297,23 +373,54 @@ class Advoc(Model):
       a.append(torch.zeros(2 * B, h, w, c, **f32))
       ga.append(torch.zeros(2 * B, h, w, c, **f32))
     st['d_act'], st['g_d_act'] = a, ga
-    DP = st['d_P']
+    DP, DG = st['d_P'], st['d_G']
+    st['d_bn_scratch'] = (torch.zeros(max(chans), **f32), torch.zeros(max(chans), **f32))
 
-    def d_layers(lo):
+    def d_layers(lo, hi):
+      bns = {}
+      if bn_on:
+        for i in (1, 2, 3):
+          bns[i] = new_bn(a[i][lo:hi], 'discriminator/layer_%d' % (i + 1), DP, DG)
       out = []
       for i in range(5):
         s = 'discriminator/layer_%d/conv2d' % (i + 1)
         if i == 0:
-          lay = C.Layer(C.CONV, st['d_cond'][lo:], a[0][lo:], DP[s + '/kernel'], DP[s + '/bias'],
-                        x1=st['d_target'][lo:], stride=(2, 2), pad=(1, 1), in_act=C.ACT_NONE)
+          lay = C.Layer(C.CONV, st['d_cond'][lo:hi], a[0][lo:hi], DP[s + '/kernel'], DP[s + '/bias'],
+                        x1=st['d_target'][lo:hi], stride=(2, 2), pad=(1, 1), in_act=C.ACT_NONE)
         else:
-          lay = C.Layer(C.CONV, a[i - 1][lo:], a[i][lo:], DP[s + '/kernel'], DP[s + '/bias'],
-                        stride=(strides[i],) * 2, pad=(1, 1), in_act=C.ACT_LRELU)
+          b = bns.get(i - 1)
+          lay = C.Layer(C.CONV, a[i - 1][lo:hi], a[i][lo:hi], DP[s + '/kernel'], DP[s + '/bias'],
+                        stride=(strides[i],) * 2, pad=(1, 1), in_act=C.ACT_LRELU,
+                        in_scale=b['scale'] if b else None, in_shift=b['shift'] if b else None)
         out.append(lay)
-      return out
-    st['d_layers_2b'] = d_layers(0)
-    st['d_layers_fake'] = d_layers(B)
+      return out, bns
+    st['d_layers_fake'], st['d_bn_fake'] = d_layers(B, 2 * B)
+    if bn_on:
+      st['d_layers_real'], st['d_bn_real'] = d_layers(0, B)
+    else:
+      st['d_layers_2b'], _ = d_layers(0, 2 * B)
     st['g_d_target'] = torch.zeros(2 * B, T, F, 1, **f32)
+
+  # ------------------------------------------------------------------------------------------
+  # batch-norm plumbing
+  # ------------------------------------------------------------------------------------------
+  def _bn_forward(self, b):
+    _lib.check(_lib.load().advoc_bn_forward(
+        _lib.ptr(b['z']), b['npix'], b['c'], _lib.ptr(b['gamma']), _lib.ptr(b['beta']), 1e-5,
+        _lib.ptr(b['scale']), _lib.ptr(b['shift']), _lib.ptr(b['mean']), _lib.ptr(b['invstd']),
+        _lib.ptr(b['work']), _lib.stream()), 'advoc_bn_forward')
+    for sc, sh in b['copies']:
+      sc.copy_(b['scale'])
+      sh.copy_(b['shift'])
+
+  def _bn_backward(self, b, g, accumulate=False, discard_param_grads=False):
+    st = self._built
+    dg, db = (st['d_bn_scratch'][0][:b['c']], st['d_bn_scratch'][1][:b['c']]) if discard_param_grads \
+        else (b['dgamma'], b['dbeta'])
+    _lib.check(_lib.load().advoc_bn_backward(
+        _lib.ptr(b['z']), _lib.ptr(g), b['npix'], b['c'], _lib.ptr(b['gamma']), _lib.ptr(b['mean']),
+        _lib.ptr(b['invstd']), _lib.ptr(dg), _lib.ptr(db), int(accumulate), _lib.ptr(b['work']),
+        _lib.stream()), 'advoc_bn_backward')
 
   # ------------------------------------------------------------------------------------------
   # parameters in / out (TF variable names)
@@ -377,9 +484,18 @@ class Advoc(Model):
     if x.data_ptr() != st['x_in'].data_ptr():
       st['x_in'].copy_(x)
     self._refresh_masks(self._rank * st['B'])
-    for lay in st['g_layers'].values():
+    gbn = st['g_bn']
+    for name, lay in st['g_layers'].items():
       lay.forward()
+      if name in gbn:
+        self._bn_forward(gbn[name])
     return st['gen_out']
+
+  def _disc_forward(self, layers, bns):
+    for i, lay in enumerate(layers):
+      lay.forward()
+      if i in bns:
+        self._bn_forward(bns[i])
 
   def build_generator(self, x):
     """x: [B, subseq_len, 513, 1] float32 -> generated magnitude spectrogram, same shape
@@ -399,8 +515,7 @@ class Advoc(Model):
     B = st['B']
     st['d_cond'][B:].copy_(cond)
     st['d_target'][B:].copy_(tgt)
-    for lay in st['d_layers_fake']:
-      lay.forward()
+    self._disc_forward(st['d_layers_fake'], st['d_bn_fake'])
     return torch.sigmoid(st['d_act'][4][B:])
 
   # ------------------------------------------------------------------------------------------
@@ -442,16 +557,19 @@ class Advoc(Model):
     st['d_target'][:B].copy_(target)
 
   def d_step(self, batch):
-    """One discriminator update on `batch` (advoc_model.py:238,257): G forward, D over
-    [real ; fake] as one 2B batch, discrim_loss, D weight gradients, Adam."""
+    """One discriminator update on `batch` (advoc_model.py:238,257): G forward, D on real and on
+    fake (one 2B batch without BN, two B passes with BN), discrim_loss, D weight gradients, Adam."""
     st = self._built
     lib = _lib.load()
     B = st['B']
     self._load_batch(batch)
     self._gen_forward(st['x_in'])
-    Ld = st['d_layers_2b']
-    for lay in Ld:
-      lay.forward()
+    if st['bn_on']:
+      passes = [(st['d_layers_real'], st['d_bn_real'], 0, B), (st['d_layers_fake'], st['d_bn_fake'], B, 2 * B)]
+    else:
+      passes = [(st['d_layers_2b'], {}, 0, 2 * B)]
+    for layers, bns, lo, hi in passes:
+      self._disc_forward(layers, bns)
     logits = st['d_act'][4]
     glog = st['g_d_act'][4]
     n = logits[:B].numel()
@@ -459,11 +577,16 @@ class Advoc(Model):
                                     _lib.ptr(glog[B:]), _lib.ptr(st['sums'][0:1]), _lib.stream()),
                'advoc_gan_d_loss')
     DG = st['d_G']
-    for i in range(4, -1, -1):
-      s = 'discriminator/layer_%d/conv2d' % (i + 1)
-      Ld[i].backward_weight(st['g_d_act'][i], DG[s + '/kernel'], DG[s + '/bias'])
-      if i > 0:
-        Ld[i].backward_data(st['g_d_act'][i], st['g_d_act'][i - 1])
+    for k, (layers, bns, lo, hi) in enumerate(passes):
+      acc = k > 0        # the second pass adds to the first pass's parameter gradients
+      for i in range(4, -1, -1):
+        s = 'discriminator/layer_%d/conv2d' % (i + 1)
+        g = st['g_d_act'][i][lo:hi]
+        if i in bns:
+          self._bn_backward(bns[i], g, accumulate=acc)
+        layers[i].backward_weight(g, DG[s + '/kernel'], DG[s + '/bias'], accumulate=acc)
+        if i > 0:
+          layers[i].backward_data(g, st['g_d_act'][i - 1][lo:hi])
     self._adam('d')
     st['last_counts_d'] = n
 
@@ -479,22 +602,29 @@ class Advoc(Model):
     g_out = st['g_d_target'][B:]            # gradient w.r.t. the generator output
     logits = st['d_act'][4][B:]
     glog = st['g_d_act'][4][B:]
-    Lf = st['d_layers_fake']
+    Lf, bnf = st['d_layers_fake'], st['d_bn_fake']
     if use_gan:
-      for lay in Lf:
-        lay.forward()
+      self._disc_forward(Lf, bnf)
     _lib.check(lib.advoc_gan_g_loss(
         _lib.ptr(logits) if use_gan else None, logits.numel(), _lib.ptr(gen), _lib.ptr(st['d_target'][:B]),
         gen.numel(), float(self.gan_weight), float(self.l1_weight), _lib.ptr(glog) if use_gan else None,
         _lib.ptr(g_out), 0, _lib.ptr(st['sums'][1:3]), _lib.stream()), 'advoc_gan_g_loss')
     if use_gan:
       for i in range(4, 0, -1):
+        if i in bnf:   # through the discriminator's batch norm; its parameter gradients are not used here
+          self._bn_backward(bnf[i], st['g_d_act'][i][B:], discard_param_grads=True)
         Lf[i].backward_data(st['g_d_act'][i][B:], st['g_d_act'][i - 1][B:])
       Lf[0].backward_data(st['g_d_act'][0][B:], None, g_out, accum1=True)
     # generator backward: decoder_1 .. decoder_N, then encoder_N .. encoder_1
     GL, GG = st['g_layers'], st['g_G']
     dec = self._decoder_specs()
     e, ge, gd = st['enc'], st['g_enc'], st['g_dec']
+    gbn = st['g_bn']
+    if st['bn_on']:
+      # BN backward rewrites the whole gradient tensor in place, including the trimmed column the
+      # consumers never write: start every step from zero there
+      for t in gd.values():
+        t.zero_()
     s = 'generator/decoder_1/conv2d_transpose'
     GL['decoder_1'].backward_weight(g_out, GG[s + '/kernel'], GG[s + '/bias'])
     last_idx = dec[-1][0] if dec else None
@@ -503,6 +633,8 @@ class Advoc(Model):
       idx = dec[j][0]
       s = 'generator/decoder_%d/conv2d_transpose' % idx
       lay = GL['decoder_%d' % idx]
+      if 'decoder_%d' % idx in gbn:
+        self._bn_backward(gbn['decoder_%d' % idx], gd[idx])
       lay.backward_weight(gd[idx], GG[s + '/kernel'], GG[s + '/bias'])
       if j == 0:
         lay.backward_data(gd[idx], ge[-1])
@@ -511,6 +643,8 @@ class Advoc(Model):
     for i in range(len(e) - 1, -1, -1):
       s = 'generator/encoder_%d/conv2d' % (i + 1)
       lay = GL['encoder_%d' % (i + 1)]
+      if 'encoder_%d' % (i + 1) in gbn:
+        self._bn_backward(gbn['encoder_%d' % (i + 1)], ge[i])
       lay.backward_weight(ge[i], GG[s + '/kernel'], GG[s + '/bias'])
       if i > 0:
         lay.backward_data(ge[i], ge[i - 1], accum0=True)

@@ -108,8 +108,12 @@ typedef struct advoc_tensor4 {
 
 /* One conv / transposed-conv layer of the reference graph, with everything the reference
  * applies around it folded in:
- *   input  = act( scale * concat_c(x0, x1) + shift )      (x1.p may be NULL; scale/shift NULL = none)
+ *   input  = act( in_mask * in_mask_scale * (scale * concat_c(x0, x1) + shift) )
+ *            (x1.p may be NULL; scale/shift NULL = none; in_mask covers the channels of x0 only)
  *   y      = (conv(input, w) + b) * drop_mask * drop_scale   (drop_mask NULL = no dropout)
+ * scale/shift fold a batch normalisation of the PRODUCING layers into this layer's loads
+ * (advoc_model.py:78-84,118,142); in_mask is the producer's dropout when it has to act AFTER that
+ * normalisation (advoc_model.py:142-149) -- without BN the producer applies drop_mask itself.
  * ADVOC_CONV   : tf.layers.conv2d, kernel [kh,kw,cin,cout]  (advoc_model.py:25-32, 34-51);
  *                SAME padding is passed explicitly as pad_t/pad_l (bottom/right implied by y.h/y.w).
  * ADVOC_DECONV : tf.layers.conv2d_transpose, kernel [kh,kw,cout,cin], 4x4 stride 2 "same"
@@ -129,14 +133,17 @@ typedef struct advoc_conv_layer {
   const float* b;
   const uint8_t* drop_mask;
   float drop_scale;
+  const uint8_t* in_mask; /* uint8 {0,1}, indexed exactly like x0 */
+  float in_mask_scale;
 } advoc_conv_layer;
 
 /* Forward.  Replaces TF Conv2D / Conv2DBackpropInput(+BiasAdd, activations, concat, dropout)
  * built at advoc_model.py:89-158 (generator) and :184-202 (discriminator). */
 int advoc_conv_forward(const advoc_conv_layer* layer, advoc_stream_t stream);
 
-/* Gradient w.r.t. the layer's (pre-activation) inputs: dx0 / dx1 have the geometry of x0 / x1.
- *   dx = act'(x) * conv_backward_data(dy * drop_mask * drop_scale, w)
+/* Gradient w.r.t. the layer's inputs AFTER their (optional) scale/shift: dx0 / dx1 have the
+ * geometry of x0 / x1.
+ *   dx = in_mask * in_mask_scale * act'(scale * x + shift) * conv_backward_data(dy * drop_mask * drop_scale, w)
  * accum != 0 adds into the destination (an encoder output receives gradient from its next
  * encoder AND its skip decoder).  dx1 may be NULL when x1 is absent or its gradient is unwanted;
  * dx0 may be NULL likewise.  Pixels of dx0/dx1 at columns >= logical w are NOT written.
@@ -147,7 +154,7 @@ int advoc_conv_backward_data(const advoc_conv_layer* layer, const float* dy, flo
 
 /* Bias gradient alone: db[co] = sum over pixels of dy * drop_mask * drop_scale (BiasAddGrad). */
 int advoc_conv_backward_bias(const advoc_conv_layer* layer, const float* dy, float* db,
-                             advoc_stream_t stream);
+                             int32_t accumulate, advoc_stream_t stream);
 
 /* Diagnostics: name of the kernel template instance a call on `layer` launches, e.g.
  * "gather_gemm_kernel<2, 2, 2, 2, true>" -- the string rocprofv3 shows for it.
@@ -156,9 +163,29 @@ int advoc_conv_kernel_name(const advoc_conv_layer* layer, int32_t direction, cha
                            int32_t buf_len);
 
 /* Gradient w.r.t. kernel and bias: dw has the layout of layer->w, db is [cout] (NULL = skip).
- * Overwrites dw / db.  Replaces Conv2DBackpropFilter / BiasAddGrad. */
+ * accumulate == 0 overwrites dw / db, != 0 adds to them (a variable shared by two passes, e.g. the
+ * discriminator on real and on fake inputs).  Replaces Conv2DBackpropFilter / BiasAddGrad. */
 int advoc_conv_backward_weight(const advoc_conv_layer* layer, const float* dy, float* dw, float* db,
-                               advoc_stream_t stream);
+                               int32_t accumulate, advoc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batch normalisation (use_batchnorm=True; always batch statistics, advoc_model.py:77-84,173-177)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Statistics of z [npix, c] (dense NHWC, c % 4 == 0) and the affine a consuming conv folds into its
+ * loads:  mean, invstd = 1/sqrt(biased var + epsilon);  scale = gamma * invstd;
+ * shift = beta - mean * scale.   work: 2*c floats of scratch.  The normalised tensor itself is
+ * never materialised. */
+int advoc_bn_forward(const float* z, int64_t npix, int32_t c, const float* gamma, const float* beta,
+                     float epsilon, float* scale, float* shift, float* mean, float* invstd, float* work,
+                     advoc_stream_t stream);
+
+/* In place g: dL/dy -> dL/dz for y = gamma * (z - mean) * invstd + beta with batch statistics;
+ * dgamma = sum g * (z - mean) * invstd, dbeta = sum g (overwritten, or added to when
+ * accumulate != 0).  work: 2*c floats. */
+int advoc_bn_backward(const float* z, float* g, int64_t npix, int32_t c, const float* gamma,
+                      const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                      int32_t accumulate, float* work, advoc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Losses, optimiser, dropout masks
