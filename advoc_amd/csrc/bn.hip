@@ -17,8 +17,8 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ 
                                                       const float* __restrict__ b,
                                                       const float* __restrict__ pa,
                                                       const float* __restrict__ pb, int64_t npix,
-                                                      int c, float* __restrict__ s1,
-                                                      float* __restrict__ s2) {
+                                                      int c, double* __restrict__ s1,
+                                                      double* __restrict__ s2) {
   __shared__ float4 red1[256];
   __shared__ float4 red2[256];
   const int quads = c / 4;
@@ -55,31 +55,33 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ 
     red2[threadIdx.x] = v;
     __syncthreads();
     if (tg == 0 && q < quads) {
-      float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+      // cross-thread and cross-block combination in double: the per-channel sums feed gradients
+      // (d gamma = sum g * zhat) that cancel heavily; fp32 atomics made them order-dependent
+      double t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
       for (int k = 0; k < groups; ++k) {
         const float4 r1 = red1[k * lanes_q + tq], r2 = red2[k * lanes_q + tq];
-        t1.x += r1.x; t1.y += r1.y; t1.z += r1.z; t1.w += r1.w;
-        t2.x += r2.x; t2.y += r2.y; t2.z += r2.z; t2.w += r2.w;
+        t1[0] += r1.x; t1[1] += r1.y; t1[2] += r1.z; t1[3] += r1.w;
+        t2[0] += r2.x; t2[1] += r2.y; t2[2] += r2.z; t2[3] += r2.w;
       }
-      unsafeAtomicAdd(s1 + 4 * q, t1.x); unsafeAtomicAdd(s1 + 4 * q + 1, t1.y);
-      unsafeAtomicAdd(s1 + 4 * q + 2, t1.z); unsafeAtomicAdd(s1 + 4 * q + 3, t1.w);
-      unsafeAtomicAdd(s2 + 4 * q, t2.x); unsafeAtomicAdd(s2 + 4 * q + 1, t2.y);
-      unsafeAtomicAdd(s2 + 4 * q + 2, t2.z); unsafeAtomicAdd(s2 + 4 * q + 3, t2.w);
+      for (int k = 0; k < 4; ++k) {
+        unsafeAtomicAdd(s1 + 4 * q + k, t1[k]);
+        unsafeAtomicAdd(s2 + 4 * q + k, t2[k]);
+      }
     }
     __syncthreads();
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ pivot, const float* __restrict__ s1,
-                                   const float* __restrict__ s2, const float* __restrict__ gamma,
+__global__ void bn_finalize_kernel(const float* __restrict__ pivot, const double* __restrict__ s1,
+                                   const double* __restrict__ s2, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float inv_n, float eps, int c,
                                    float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean, float* __restrict__ invstd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c) return;
-  const float d = s1[i] * inv_n;                 // E[z - pivot]
-  const float var = fmaxf(s2[i] * inv_n - d * d, 0.f);
-  const float m = pivot[i] + d;
+  const double dd = s1[i] * (double)inv_n;       // E[z - pivot]
+  const float var = (float)fmax(s2[i] * (double)inv_n - dd * dd, 0.0);
+  const float m = (float)((double)pivot[i] + dd);
   const float is = 1.0f / sqrtf(var + eps);
   const float sc = gamma[i] * is;
   mean[i] = m;
@@ -92,7 +94,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ pivot, const float*
 __global__ __launch_bounds__(256) void bn_backward_apply_kernel(
     const float* __restrict__ z, float* __restrict__ g, int64_t total4, int c,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ s1, const float* __restrict__ s2, float inv_n) {
+    const double* __restrict__ s1, const double* __restrict__ s2, float inv_n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int quads = c / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
@@ -102,8 +104,8 @@ __global__ __launch_bounds__(256) void bn_backward_apply_kernel(
     const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * q);
     const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * q);
     const float4 is = *reinterpret_cast<const float4*>(invstd + 4 * q);
-    const float4 a1 = *reinterpret_cast<const float4*>(s1 + 4 * q);
-    const float4 a2 = *reinterpret_cast<const float4*>(s2 + 4 * q);
+    const float4 a1 = make_float4((float)s1[4 * q], (float)s1[4 * q + 1], (float)s1[4 * q + 2], (float)s1[4 * q + 3]);
+    const float4 a2 = make_float4((float)s2[4 * q], (float)s2[4 * q + 1], (float)s2[4 * q + 2], (float)s2[4 * q + 3]);
     gg.x = ga.x * is.x * (gg.x - a1.x * inv_n - (zz.x - mu.x) * is.x * is.x * a2.x * inv_n);
     gg.y = ga.y * is.y * (gg.y - a1.y * inv_n - (zz.y - mu.y) * is.y * is.y * a2.y * inv_n);
     gg.z = ga.z * is.z * (gg.z - a1.z * inv_n - (zz.z - mu.z) * is.z * is.z * a2.z * inv_n);
@@ -112,20 +114,20 @@ __global__ __launch_bounds__(256) void bn_backward_apply_kernel(
   }
 }
 
-__global__ void bn_param_grad_kernel(const float* __restrict__ s1, const float* __restrict__ s2,
+__global__ void bn_param_grad_kernel(const double* __restrict__ s1, const double* __restrict__ s2,
                                      const float* __restrict__ invstd, int c, int accumulate,
                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c) return;
-  const float dg = s2[i] * invstd[i], db = s1[i];
+  const float dg = (float)(s2[i] * (double)invstd[i]), db = (float)s1[i];
   dgamma[i] = accumulate ? dgamma[i] + dg : dg;
   dbeta[i] = accumulate ? dbeta[i] + db : db;
 }
 
 int launch_colsum2(const float* a, const float* b, const float* pa, const float* pb, int64_t npix, int c,
-                   float* s1, float* s2, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(s1, 0, sizeof(float) * (size_t)c, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(s2, 0, sizeof(float) * (size_t)c, stream);
+                   double* s1, double* s2, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(s1, 0, sizeof(double) * (size_t)c, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(s2, 0, sizeof(double) * (size_t)c, stream);
   if (e != hipSuccess) { advoc::note_hip_error(e); return ADVOC_ERR_HIP; }
   const int quads = c / 4;
   const int groups = 256 / (quads < 256 ? quads : 256);
@@ -155,11 +157,13 @@ extern "C" int advoc_bn_forward(const float* z, int64_t npix, int32_t c, const f
   if (npix <= 0 || c <= 0) return ADVOC_ERR_BAD_SHAPE;
   if (!bn_shape_ok(npix, c)) return ADVOC_ERR_UNSUPPORTED;
   // pivot = first pixel (row 0 of z): just a pointer
-  int rc = launch_colsum2(z, z, z, z, npix, c, work, work + c, as_stream(stream));
+  if (reinterpret_cast<uintptr_t>(work) & 7) return ADVOC_ERR_UNSUPPORTED;
+  double* w1 = reinterpret_cast<double*>(work);
+  int rc = launch_colsum2(z, z, z, z, npix, c, w1, w1 + c, as_stream(stream));
   if (rc != ADVOC_OK) return rc;
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), z, work,
-                     work + c, gamma, beta, 1.0f / (float)npix, epsilon, c, scale, shift, mean, invstd);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), z, w1,
+                     w1 + c, gamma, beta, 1.0f / (float)npix, epsilon, c, scale, shift, mean, invstd);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }
@@ -170,18 +174,20 @@ extern "C" int advoc_bn_backward(const float* z, float* g, int64_t npix, int32_t
   if (!z || !g || !gamma || !mean || !invstd || !dgamma || !dbeta || !work) return ADVOC_ERR_NULL;
   if (npix <= 0 || c <= 0) return ADVOC_ERR_BAD_SHAPE;
   if (!bn_shape_ok(npix, c)) return ADVOC_ERR_UNSUPPORTED;
-  int rc = launch_colsum2(g, z, nullptr, mean, npix, c, work, work + c, as_stream(stream));
+  if (reinterpret_cast<uintptr_t>(work) & 7) return ADVOC_ERR_UNSUPPORTED;
+  double* w1 = reinterpret_cast<double*>(work);
+  int rc = launch_colsum2(g, z, nullptr, mean, npix, c, w1, w1 + c, as_stream(stream));
   if (rc != ADVOC_OK) return rc;
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), work,
-                     work + c, invstd, c, accumulate, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), w1,
+                     w1 + c, invstd, c, accumulate, dgamma, dbeta);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   const int64_t total4 = npix * (c / 4);
   int64_t blocks = advoc::ceil_div(total4, 256 * 4);
   if (blocks > 4096) blocks = 4096;
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(bn_backward_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z,
-                     g, total4, c, gamma, mean, invstd, work, work + c, 1.0f / (float)npix);
+                     g, total4, c, gamma, mean, invstd, w1, w1 + c, 1.0f / (float)npix);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }

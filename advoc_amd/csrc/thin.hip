@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
   __shared__ int s_delta[KP];     // element offset of slot k' relative to the row base of its source
   __shared__ int s_info[KP];      // (dy & 0xff) | (dx & 0xff) << 8 | valid << 16 | second << 17 | ci << 18
   __shared__ float s_w[KP][32 * NT];
+  __shared__ __attribute__((aligned(16))) float s_T[4][32 * 36];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l32 = lane & 31;
   const int phase = blockIdx.z;
@@ -147,33 +148,55 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], s_w[2 * s + half][32 * j + l32], acc[j], 0, 0, 0);
 
     wave_lds_sync();
+    // transpose each 32x32 tile through a private LDS patch: 16-byte accesses on 128-byte rows
+    float* T = &s_T[wave][0];
+    const int trow = lane >> 3, tq = lane & 7;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int n = n0 + 32 * j + l32;
-      if (n >= N) continue;
-      const int di = n >= p.n_split ? 1 : 0;
+      const int nt0 = n0 + 32 * j;
+      if (nt0 >= N) continue;
+      const int di = nt0 >= p.n_split ? 1 : 0;
       const GemmDest& d = p.d[di];
       if (d.p == nullptr) continue;
-      const int ch = di ? n - p.n_split : n;
+      const int ch = (di ? nt0 - p.n_split : nt0) + 4 * tq;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l32] = acc[j][r] + bias[j];
+      wave_lds_sync();
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int row = trow + 8 * ps;
         const int pix = s_pix[wave][di][row];
         if (pix < 0) continue;
         const int off = pix * d.c + ch;
-        float v = acc[j][r] + bias[j];
-        if (p.y_mask) v *= p.y_mask[off] * p.y_mask_scale;
-        if (p.grad_act != ADVOC_ACT_NONE) {
-          float x = d.xpre[off];
-          if (d.gscale) x = x * d.gscale[ch] + d.gshift[ch];
-          v *= x > 0.f ? 1.f : gslope;
+        float4 v = *reinterpret_cast<const float4*>(T + row * 36 + 4 * tq);
+        if (p.y_mask) {
+          const uchar4 mk = *reinterpret_cast<const uchar4*>(p.y_mask + off);
+          v.x *= mk.x * p.y_mask_scale; v.y *= mk.y * p.y_mask_scale;
+          v.z *= mk.z * p.y_mask_scale; v.w *= mk.w * p.y_mask_scale;
         }
-        if (d.gmask) v *= d.gmask[off] * d.gmask_scale;
-        if (d.accum) v += d.p[off];
-        d.p[off] = v;
+        if (p.grad_act != ADVOC_ACT_NONE) {
+          float4 x = *reinterpret_cast<const float4*>(d.xpre + off);
+          if (d.gscale) {
+            const float4 gs = *reinterpret_cast<const float4*>(d.gscale + ch);
+            const float4 gh = *reinterpret_cast<const float4*>(d.gshift + ch);
+            x.x = x.x * gs.x + gh.x; x.y = x.y * gs.y + gh.y; x.z = x.z * gs.z + gh.z; x.w = x.w * gs.w + gh.w;
+          }
+          v.x *= x.x > 0.f ? 1.f : gslope; v.y *= x.y > 0.f ? 1.f : gslope;
+          v.z *= x.z > 0.f ? 1.f : gslope; v.w *= x.w > 0.f ? 1.f : gslope;
+        }
+        if (d.gmask) {
+          const uchar4 mk = *reinterpret_cast<const uchar4*>(d.gmask + off);
+          v.x *= mk.x * d.gmask_scale; v.y *= mk.y * d.gmask_scale;
+          v.z *= mk.z * d.gmask_scale; v.w *= mk.w * d.gmask_scale;
+        }
+        if (d.accum) {
+          const float4 o = *reinterpret_cast<const float4*>(d.p + off);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *reinterpret_cast<float4*>(d.p + off) = v;
       }
+      wave_lds_sync();
     }
-    wave_lds_sync();
   }
 }
 
@@ -208,11 +231,18 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
 // ---------------------------------------------------------------------------------------------
 // thin_wgrad
 // ---------------------------------------------------------------------------------------------
-// U MFMA steps (2 grid points each) are fetched together so a wave keeps U * (1 + NT) loads in
-// flight; with the loop-carried one-step version the kernel ran at memory latency, not bandwidth.
+// One wave streams a run of grid points 16 at a time (8 MFMA steps of 2 points).  The wide
+// operand Q is fetched with 16-byte loads (full 128-byte channel rows), parked in a wave-private
+// LDS tile [16 points][32 NT channels] and read back in MFMA layout; the next tile's loads are in
+// flight while the current one is multiplied.  The thin operand P (<= 2 channels) is gathered
+// with scalar loads (it is a small, cache-resident tensor).
 template <int NT>
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, int chunk) {
-  constexpr int U = 8;
+  constexpr int U = 8;                 // MFMA steps per tile
+  constexpr int PT = 2 * U;            // grid points per tile
+  constexpr int LDQ = 32 * NT + 4;
+  constexpr int QL = (PT * 8 * NT) / 64;   // float4 slots per lane per tile (= 2 NT)
+  __shared__ __attribute__((aligned(16))) float s_q[4][PT * LDQ];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l32 = lane & 31;
   const int ca = p.P.c0 + p.P.c1;            // 1 or 2
@@ -222,6 +252,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   const float pslope = p.P.act == ADVOC_ACT_LRELU02 ? 0.2f : (p.P.act == ADVOC_ACT_RELU ? 0.f : 1.f);
   const float qslope = p.Q.act == ADVOC_ACT_LRELU02 ? 0.2f : (p.Q.act == ADVOC_ACT_RELU ? 0.f : 1.f);
+  float* Qs = &s_q[wave][0];
 
   // this lane's A row: (tap, a)
   const bool row_ok = l32 < rows;
@@ -233,31 +264,63 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
   const int pcs = a_second ? p.P.c1 : p.P.c0;
   const int ppitch = a_second ? p.P.pitch1 : p.P.pitch0;
   const int pch = a_second ? a - p.P.c0 : a;
-  // this lane's B columns
-  const float* qsrc[NT];
-  int qcs[NT], qpitch[NT], qch[NT];
-  bool q_ok[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int b = b0 + 32 * j + l32;
-    q_ok[j] = b < cb;
-    const bool second = b >= p.Q.c0;
-    qsrc[j] = second ? p.Q.p1 : p.Q.p0;
-    qcs[j] = second ? p.Q.c1 : p.Q.c0;
-    qpitch[j] = second ? p.Q.pitch1 : p.Q.pitch0;
-    qch[j] = second ? b - p.Q.c0 : b;
-  }
 
-  // each wave owns a contiguous run of grid points, two per MFMA (lanes 0-31 / 32-63)
   const int64_t w_begin = ((int64_t)blockIdx.x * 4 + wave) * chunk;
   const int64_t w_end = w_begin + chunk < M ? w_begin + chunk : M;
-  int64_t g = w_begin + half;
-  int gx = 0, gy = 0, img = 0;
-  if (g < M) {
-    gx = (int)(g % p.gw);
-    const int64_t tt = g / p.gw;
-    gy = (int)(tt % p.gh);
-    img = (int)(tt / p.gh);
+
+  // P walker: this lane's grid point for step s of the current tile is g0 + 2 s + half
+  int64_t pg = w_begin + half;
+  int pgx = 0, pgy = 0, pimg = 0;
+  if (pg < M) {
+    pgx = (int)(pg % p.gw);
+    const int64_t tt = pg / p.gw;
+    pgy = (int)(tt % p.gh);
+    pimg = (int)(tt / p.gh);
+  }
+  // Q loader slots: slot i covers point qk[i] of the tile and channel quad qc[i]
+  int qk[QL], qch[QL], qgx[QL], qgy[QL], qimg[QL];
+  bool q_on[QL];
+#pragma unroll
+  for (int i = 0; i < QL; ++i) {
+    const int idx = lane + 64 * i;
+    qk[i] = idx / (8 * NT);
+    qch[i] = b0 + 4 * (idx % (8 * NT));
+    q_on[i] = qch[i] < cb;
+    const int64_t g = w_begin + qk[i];
+    const int64_t gg = g < M ? g : 0;
+    qgx[i] = (int)(gg % p.gw);
+    const int64_t tt = gg / p.gw;
+    qgy[i] = (int)(tt % p.gh);
+    qimg[i] = (int)(tt / p.gh);
+  }
+  float4 rq[QL];
+
+#define ADVOC_TQ_LOAD(G0)                                                                             \
+  _Pragma("unroll") for (int i = 0; i < QL; ++i) {                                                    \
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+    if (q_on[i] && (G0) + qk[i] < w_end) {                                                            \
+      const bool second = qch[i] >= p.Q.c0;                                                           \
+      const float* src = second ? p.Q.p1 : p.Q.p0;                                                    \
+      const int row = qimg[i] * p.Q.h + qgy[i];                                                       \
+      const int off = second ? (row * p.Q.pitch1 + qgx[i]) * p.Q.c1 + (qch[i] - p.Q.c0)               \
+                             : (row * p.Q.pitch0 + qgx[i]) * p.Q.c0 + qch[i];                         \
+      v = *reinterpret_cast<const float4*>(src + off);                                                \
+      if (p.Q.scale) {                                                                                \
+        const float4 sc = *reinterpret_cast<const float4*>(p.Q.scale + qch[i]);                       \
+        const float4 sh = *reinterpret_cast<const float4*>(p.Q.shift + qch[i]);                       \
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w; \
+      }                                                                                               \
+      v.x = fmaxf(v.x, qslope * v.x); v.y = fmaxf(v.y, qslope * v.y);                                 \
+      v.z = fmaxf(v.z, qslope * v.z); v.w = fmaxf(v.w, qslope * v.w);                                 \
+      if (p.Q.mask && !second) {                                                                      \
+        const uchar4 mk = *reinterpret_cast<const uchar4*>(p.Q.mask + off);                           \
+        v.x *= mk.x * p.Q.mask_scale; v.y *= mk.y * p.Q.mask_scale;                                   \
+        v.z *= mk.z * p.Q.mask_scale; v.w *= mk.w * p.Q.mask_scale;                                   \
+      }                                                                                               \
+    }                                                                                                 \
+    rq[i] = v;                                                                                        \
+    qgx[i] += PT;                                                                                     \
+    while (qgx[i] >= p.gw) { qgx[i] -= p.gw; if (++qgy[i] >= p.gh) { qgy[i] = 0; ++qimg[i]; } }       \
   }
 
   floatx16 acc[NT];
@@ -266,48 +329,39 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  for (; g - half < w_end; g += 2 * U) {
-    float av[U], bv[NT][U];
+  ADVOC_TQ_LOAD(w_begin);
+  for (int64_t g0 = w_begin; g0 < w_end; g0 += PT) {
+#pragma unroll
+    for (int i = 0; i < QL; ++i)
+      *reinterpret_cast<float4*>(Qs + qk[i] * LDQ + (qch[i] - b0)) = rq[i];
+    wave_lds_sync();
+    ADVOC_TQ_LOAD(g0 + PT);        // next tile in flight during this tile's gathers + MFMAs
+    float av[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool live = g + 2 * u < w_end;
       av[u] = 0.f;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bv[j][u] = 0.f;
-      if (live) {
-        const int y = gy * p.sy + dy, x = gx * p.sx + dx;
+      if (g0 + 2 * u + half < w_end) {
+        const int y = pgy * p.sy + dy, x = pgx * p.sx + dx;
         if (row_ok && (unsigned)y < (unsigned)p.P.h && (unsigned)x < (unsigned)p.P.w) {
-          const int off = ((img * p.P.h + y) * ppitch + x) * pcs + pch;
+          const int off = ((pimg * p.P.h + y) * ppitch + x) * pcs + pch;
           float v = psrc[off];
           if (p.P.scale) v = v * p.P.scale[a] + p.P.shift[a];
           v = fmaxf(v, pslope * v);
           if (p.P.mask && !a_second) v *= p.P.mask[off] * p.P.mask_scale;
           av[u] = v;
         }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          if (q_ok[j]) {
-            const int off = ((img * p.Q.h + gy) * qpitch[j] + gx) * qcs[j] + qch[j];
-            float v = qsrc[j][off];
-            if (p.Q.scale) v = v * p.Q.scale[b0 + 32 * j + l32] + p.Q.shift[b0 + 32 * j + l32];
-            v = fmaxf(v, qslope * v);
-            if (p.Q.mask && qsrc[j] == p.Q.p0) v *= p.Q.mask[off] * p.Q.mask_scale;
-            bv[j][u] = v;
-          }
-        }
       }
-      gx += 2;   // this lane's next grid point
-      while (gx >= p.gw) {
-        gx -= p.gw;
-        if (++gy >= p.gh) { gy = 0; ++img; }
-      }
+      pgx += 2;
+      while (pgx >= p.gw) { pgx -= p.gw; if (++pgy >= p.gh) { pgy = 0; ++pimg; } }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[j][u], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], Qs[(2 * u + half) * LDQ + 32 * j + l32], acc[j], 0, 0, 0);
+    wave_lds_sync();
   }
+#undef ADVOC_TQ_LOAD
 
   // Combine the four waves of the block in LDS, then ONE atomic per output element per block:
   // thousands of waves hammering the same <= 32 x cb addresses serialise in L2 otherwise.
@@ -360,7 +414,7 @@ int launch_wgrad_thin_mfma(const WgradParams& p, hipStream_t stream, const char*
   int64_t waves = 2048 / by;
   if (waves < 4) waves = 4;
   int64_t chunk = ceil_div(M, waves);
-  chunk = (chunk + 1) / 2 * 2;
+  chunk = (chunk + 15) / 16 * 16;      // whole 16-point tiles per wave
   if (chunk < 64) chunk = 64;
   const int64_t bx = ceil_div(ceil_div(M, chunk), 4);
   if (chunk > 0x7fffffffLL || bx > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;

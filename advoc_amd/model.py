@@ -256,7 +256,7 @@ class Advoc(Model):
                   scale=scale if scale is not None else torch.ones(c, **f32),
                   shift=shift if shift is not None else torch.zeros(c, **f32),
                   mean=torch.zeros(c, **f32), invstd=torch.ones(c, **f32),
-                  work=torch.zeros(2 * c, **f32), copies=[])
+                  work=torch.zeros(4 * c, **f32), copies=[])
 
     # ---- generator buffers ----
     st['x_in'] = torch.zeros(B, T, F, 1, **f32)

@@ -174,15 +174,15 @@ int advoc_conv_backward_weight(const advoc_conv_layer* layer, const float* dy, f
 
 /* Statistics of z [npix, c] (dense NHWC, c % 4 == 0) and the affine a consuming conv folds into its
  * loads:  mean, invstd = 1/sqrt(biased var + epsilon);  scale = gamma * invstd;
- * shift = beta - mean * scale.   work: 2*c floats of scratch.  The normalised tensor itself is
- * never materialised. */
+ * shift = beta - mean * scale.   work: 4*c floats of scratch (8-byte aligned; sums are combined in
+ * double).  The normalised tensor itself is never materialised. */
 int advoc_bn_forward(const float* z, int64_t npix, int32_t c, const float* gamma, const float* beta,
                      float epsilon, float* scale, float* shift, float* mean, float* invstd, float* work,
                      advoc_stream_t stream);
 
 /* In place g: dL/dy -> dL/dz for y = gamma * (z - mean) * invstd + beta with batch statistics;
  * dgamma = sum g * (z - mean) * invstd, dbeta = sum g (overwritten, or added to when
- * accumulate != 0).  work: 2*c floats. */
+ * accumulate != 0).  work: 4*c floats, 8-byte aligned. */
 int advoc_bn_backward(const float* z, float* g, int64_t npix, int32_t c, const float* gamma,
                       const float* mean, const float* invstd, float* dgamma, float* dbeta,
                       int32_t accumulate, float* work, advoc_stream_t stream);
