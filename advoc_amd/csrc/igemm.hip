@@ -97,8 +97,18 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   const int wm = wave / WGN, wn = wave % WGN;
   const int phase = blockIdx.z;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (each XCD has its own L2); remap so that
+  // an XCD walks a CONTIGUOUS run of tiles: neighbouring M tiles share input halo rows and the
+  // N tiles of one M tile share the whole A tile, so those re-reads hit the local L2.
+  const int ntn = p.n_total / BN;                       // N tiles
+  int tile;
+  {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, slot = b >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;   // bijective for any nb
+  }
+  const int64_t m0 = (int64_t)(tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
   const int ktot = p.c0 + p.c1;
   const int kpt = ktot / BK;         // K tiles per tap
   const int nkt = kpt * p.ntaps;
@@ -369,7 +379,8 @@ int launch_cfg(const GatherGemmParams& p, hipStream_t stream, const char** name_
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   const int64_t gx = ceil_div(M, C::BM);
   if (gx > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
-  dim3 grid((unsigned)gx, (unsigned)(p.n_total / C::BN), (unsigned)p.nphase);
+  if (gx * (p.n_total / C::BN) > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)(gx * (p.n_total / C::BN)), 1, (unsigned)p.nphase);
   auto kern = gather_gemm_kernel<MT, NT, WGM, WGN, B_KN, BK>;
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, p);
@@ -387,16 +398,25 @@ int preferred_bk() {
   return v;
 }
 
+// Tile choice (measured on MI355X, AdVoc layer shapes): 128x128 / 128x64 tiles reach ~108 / ~97
+// TFLOP/s once >= ~900 workgroups are in the launch (4 resident per CU); below that the chip is
+// under-filled (528 workgroups: ~70 TFLOP/s) and 64x64 tiles, which quarter the tile and double
+// the residency, win (~80-94 TFLOP/s on the same layers).  32 output channels: 256x32.
 template <bool B_KN, int BK>
 int dispatch_bk(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
   const int N = p.n_total;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
-  // small grids (deep, narrow layers): 64 x 64 tiles put 4x more workgroups on the 256 CUs
-  if (N % 64 == 0 && ceil_div(M, 128) * ceil_div(N, 128) * p.nphase < 384)
-    return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, stream, name_only);                    // 64 x 64
-  if (N % 128 == 0) return launch_cfg<2, 2, 2, 2, B_KN, BK>(p, stream, name_only);   // 128 x 128
-  if (N % 64 == 0) return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, stream, name_only);    // 128 x 64
-  return launch_cfg<2, 1, 4, 1, B_KN, BK>(p, stream, name_only);                     // 256 x 32
+  if (N % 64 != 0) return launch_cfg<2, 1, 4, 1, B_KN, BK>(p, stream, name_only);   // 256 x 32
+  const int bn = N % 128 == 0 ? 128 : 64;
+  const int64_t big_blocks = ceil_div(M, 128) * (N / bn) * p.nphase;
+  // ... and the big tiles only pay off on deep contractions: with taps x channels < 2048 (< 1024
+  // for a plain forward epilogue) the 64x64 kernel measured 5-15 % faster on every such layer.
+  const int k_total = p.ntaps * (p.c0 + p.c1);
+  const bool heavy_epilogue = p.grad_act != ADVOC_ACT_NONE || p.d[1].p != nullptr;
+  const bool deep = k_total >= (heavy_epilogue ? 2048 : 1024);
+  if (big_blocks < 900 || !deep) return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, stream, name_only);   // 64 x 64
+  if (bn == 128) return launch_cfg<2, 2, 2, 2, B_KN, BK>(p, stream, name_only);          // 128 x 128
+  return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, stream, name_only);                          // 128 x 64
 }
 
 template <bool B_KN>
