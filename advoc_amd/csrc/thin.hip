@@ -295,9 +295,15 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
   }
   float4 rq[QL];
 
+  int rq_off[QL];
+  unsigned rq_live = 0;
+  // raw loads only: the affine / activation / mask are applied when the tile is written to LDS,
+  // so these loads stay in flight across the previous tile's MFMAs
 #define ADVOC_TQ_LOAD(G0)                                                                             \
+  rq_live = 0;                                                                                        \
   _Pragma("unroll") for (int i = 0; i < QL; ++i) {                                                    \
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+    rq_off[i] = 0;                                                                                    \
     if (q_on[i] && (G0) + qk[i] < w_end) {                                                            \
       const bool second = qch[i] >= p.Q.c0;                                                           \
       const float* src = second ? p.Q.p1 : p.Q.p0;                                                    \
@@ -305,22 +311,33 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
       const int off = second ? (row * p.Q.pitch1 + qgx[i]) * p.Q.c1 + (qch[i] - p.Q.c0)               \
                              : (row * p.Q.pitch0 + qgx[i]) * p.Q.c0 + qch[i];                         \
       v = *reinterpret_cast<const float4*>(src + off);                                                \
-      if (p.Q.scale) {                                                                                \
-        const float4 sc = *reinterpret_cast<const float4*>(p.Q.scale + qch[i]);                       \
-        const float4 sh = *reinterpret_cast<const float4*>(p.Q.shift + qch[i]);                       \
-        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w; \
-      }                                                                                               \
-      v.x = fmaxf(v.x, qslope * v.x); v.y = fmaxf(v.y, qslope * v.y);                                 \
-      v.z = fmaxf(v.z, qslope * v.z); v.w = fmaxf(v.w, qslope * v.w);                                 \
-      if (p.Q.mask && !second) {                                                                      \
-        const uchar4 mk = *reinterpret_cast<const uchar4*>(p.Q.mask + off);                           \
-        v.x *= mk.x * p.Q.mask_scale; v.y *= mk.y * p.Q.mask_scale;                                   \
-        v.z *= mk.z * p.Q.mask_scale; v.w *= mk.w * p.Q.mask_scale;                                   \
-      }                                                                                               \
+      rq_off[i] = off;                                                                                \
+      rq_live |= 1u << i;                                                                             \
     }                                                                                                 \
     rq[i] = v;                                                                                        \
     qgx[i] += PT;                                                                                     \
     while (qgx[i] >= p.gw) { qgx[i] -= p.gw; if (++qgy[i] >= p.gh) { qgy[i] = 0; ++qimg[i]; } }       \
+  }
+
+#define ADVOC_TQ_STORE()                                                                              \
+  _Pragma("unroll") for (int i = 0; i < QL; ++i) {                                                    \
+    float4 v = rq[i];                                                                                 \
+    const bool live_ = (rq_live >> i) & 1u;                                                           \
+    if (p.Q.scale) {                                                                                  \
+      const float4 sc = *reinterpret_cast<const float4*>(p.Q.scale + qch[i]);                         \
+      const float4 sh = *reinterpret_cast<const float4*>(p.Q.shift + qch[i]);                         \
+      const float k_ = live_ ? 1.f : 0.f;                                                             \
+      v.x = v.x * sc.x + sh.x * k_; v.y = v.y * sc.y + sh.y * k_;                                     \
+      v.z = v.z * sc.z + sh.z * k_; v.w = v.w * sc.w + sh.w * k_;                                     \
+    }                                                                                                 \
+    v.x = fmaxf(v.x, qslope * v.x); v.y = fmaxf(v.y, qslope * v.y);                                   \
+    v.z = fmaxf(v.z, qslope * v.z); v.w = fmaxf(v.w, qslope * v.w);                                   \
+    if (p.Q.mask && live_ && qch[i] < p.Q.c0) {                                                       \
+      const uchar4 mk = *reinterpret_cast<const uchar4*>(p.Q.mask + rq_off[i]);                       \
+      v.x *= mk.x * p.Q.mask_scale; v.y *= mk.y * p.Q.mask_scale;                                     \
+      v.z *= mk.z * p.Q.mask_scale; v.w *= mk.w * p.Q.mask_scale;                                     \
+    }                                                                                                 \
+    *reinterpret_cast<float4*>(Qs + qk[i] * LDQ + (qch[i] - b0)) = v;                                 \
   }
 
   floatx16 acc[NT];
@@ -331,9 +348,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
 
   ADVOC_TQ_LOAD(w_begin);
   for (int64_t g0 = w_begin; g0 < w_end; g0 += PT) {
-#pragma unroll
-    for (int i = 0; i < QL; ++i)
-      *reinterpret_cast<float4*>(Qs + qk[i] * LDQ + (qch[i] - b0)) = rq[i];
+    ADVOC_TQ_STORE();
     wave_lds_sync();
     ADVOC_TQ_LOAD(g0 + PT);        // next tile in flight during this tile's gathers + MFMAs
     float av[U];
@@ -362,6 +377,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
     wave_lds_sync();
   }
 #undef ADVOC_TQ_LOAD
+#undef ADVOC_TQ_STORE
 
   // Combine the four waves of the block in LDS, then ONE atomic per output element per block:
   // thousands of waves hammering the same <= 32 x cb addresses serialise in L2 otherwise.

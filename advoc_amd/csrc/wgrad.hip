@@ -100,6 +100,33 @@ __device__ __forceinline__ float4 load_op4_at(const Operand& op, int pix0, int p
   return v;
 }
 
+// raw 16-byte load + the element offset it came from (transforms are applied later, at the
+// LDS-store stage, so that the load itself can stay in flight across the MFMA block)
+__device__ __forceinline__ float4 load_raw4_at(const Operand& op, int pix0, int pix1, int ch, int* off_out) {
+  const bool second = ch >= op.c0;
+  const float* src = second ? op.p1 : op.p0;
+  const int off = second ? pix1 * op.c1 + (ch - op.c0) : pix0 * op.c0 + ch;
+  *off_out = off;
+  return *reinterpret_cast<const float4*>(src + off);
+}
+
+__device__ __forceinline__ float4 transform4(const Operand& op, float4 v, int ch, int off, float slope, bool live) {
+  if (op.scale) {
+    const float4 sc = *reinterpret_cast<const float4*>(op.scale + ch);
+    const float4 sh = *reinterpret_cast<const float4*>(op.shift + ch);
+    const float k = live ? 1.f : 0.f;     // padding stays zero
+    v.x = v.x * sc.x + sh.x * k; v.y = v.y * sc.y + sh.y * k; v.z = v.z * sc.z + sh.z * k; v.w = v.w * sc.w + sh.w * k;
+  }
+  v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
+  v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
+  if (op.mask && ch < op.c0 && live) {
+    const uchar4 mk = *reinterpret_cast<const uchar4*>(op.mask + off);
+    v.x *= mk.x * op.mask_scale; v.y *= mk.y * op.mask_scale;
+    v.z *= mk.z * op.mask_scale; v.w *= mk.w * op.mask_scale;
+  }
+  return v;
+}
+
 __device__ __forceinline__ float slope_of(int act) {
   return act == ADVOC_ACT_LRELU02 ? 0.2f : (act == ADVOC_ACT_RELU ? 0.f : 1.f);
 }
@@ -131,22 +158,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
 
   // Loader slots.  Slot i of the P (Q) tile = pixel k_i of the K step, channel quad cq_i; the
   // slot's grid point advances by WK per K step and is tracked incrementally (no divisions).
-  int p_k[PL], p_ch[PL], p_gx[PL], p_gy[PL], p_img[PL], p_dy[PL], p_dx[PL], p_col[PL];
-  int q_k[QL], q_ch[QL], q_gx[QL], q_gy[QL], q_img[QL];
+  // (slot -> tile position is recomputed from tid where needed: registers are what keeps this
+  //  kernel at 3 workgroups per CU instead of 4)
+#define P_K(i) ((tid + 256 * (i)) / (BM / 4))
+#define P_COL(i) (4 * ((tid + 256 * (i)) % (BM / 4)))
+#define Q_K(i) ((tid + 256 * (i)) / (BN / 4))
+#define Q_COL(i) (4 * ((tid + 256 * (i)) % (BN / 4)))
+  int p_ch[PL], p_gx[PL], p_gy[PL], p_img[PL], p_dydx[PL];
+  int q_gx[QL], q_gy[QL], q_img[QL];
   bool p_on[PL], q_on[QL];
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
-    const int idx = tid + 256 * i;
-    p_k[i] = idx / (BM / 4);
-    p_col[i] = 4 * (idx % (BM / 4));
-    const int row = a0 + p_col[i];
-    p_on[i] = p_k[i] < WK && row < rows_total;
+    const int row = a0 + P_COL(i);
+    p_on[i] = P_K(i) < WK && row < rows_total;
     const int t_ = p_on[i] ? row / ca : 0;
     p_ch[i] = row - t_ * ca;
-    const int tp_ = p.tap[t_];
-    p_dy[i] = (int)(int8_t)(tp_ & 0xff);
-    p_dx[i] = (int)(int8_t)((tp_ >> 8) & 0xff);
-    const int64_t g = g_begin + (p_k[i] < WK ? p_k[i] : 0);
+    p_dydx[i] = p.tap[t_] & 0xffff;
+    const int64_t g = g_begin + (P_K(i) < WK ? P_K(i) : 0);
     p_gx[i] = (int)(g % p.gw);
     const int64_t t = g / p.gw;
     p_gy[i] = (int)(t % p.gh);
@@ -154,11 +182,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
   }
 #pragma unroll
   for (int i = 0; i < QL; ++i) {
-    const int idx = tid + 256 * i;
-    q_k[i] = idx / (BN / 4);
-    q_ch[i] = b0 + 4 * (idx % (BN / 4));
-    q_on[i] = q_k[i] < WK && q_ch[i] < cb;
-    const int64_t g = g_begin + (q_k[i] < WK ? q_k[i] : 0);
+    q_on[i] = Q_K(i) < WK && b0 + Q_COL(i) < cb;
+    const int64_t g = g_begin + (Q_K(i) < WK ? Q_K(i) : 0);
     q_gx[i] = (int)(g % p.gw);
     const int64_t t = g / p.gw;
     q_gy[i] = (int)(t % p.gh);
@@ -166,17 +191,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
   }
 
   float4 rp[PL], rq[QL];
+  int rp_off[PL], rq_off[QL];
+  unsigned rp_live = 0, rq_live = 0;
 
   // loads the slots' current grid points, then advances them by WK
 #define ADVOC_W_LOAD(KT)                                                                             \
   {                                                                                                  \
     const int64_t gb_ = g_begin + (int64_t)(KT) * WK;                                                \
+    rp_live = 0; rq_live = 0;                                                                        \
     _Pragma("unroll") for (int i = 0; i < PL; ++i) {                                                 \
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
-      const int y = p_gy[i] * p.sy + p_dy[i], x = p_gx[i] * p.sx + p_dx[i];                          \
-      if (p_on[i] && gb_ + p_k[i] < g_end && (unsigned)y < (unsigned)p.P.h && (unsigned)x < (unsigned)p.P.w) { \
+      rp_off[i] = 0;                                                                                 \
+      const int y = p_gy[i] * p.sy + (int)(int8_t)(p_dydx[i] & 0xff);                                \
+      const int x = p_gx[i] * p.sx + (int)(int8_t)(p_dydx[i] >> 8);                                  \
+      if (p_on[i] && gb_ + P_K(i) < g_end && (unsigned)y < (unsigned)p.P.h && (unsigned)x < (unsigned)p.P.w) { \
         const int row = p_img[i] * p.P.h + y;                                                        \
-        v = load_op4_at(p.P, row * p.P.pitch0 + x, row * p.P.pitch1 + x, p_ch[i], pslope);           \
+        v = load_raw4_at(p.P, row * p.P.pitch0 + x, row * p.P.pitch1 + x, p_ch[i], &rp_off[i]);     \
+        rp_live |= 1u << i;                                                                          \
       }                                                                                              \
       rp[i] = v;                                                                                     \
       p_gx[i] += WK;                                                                                 \
@@ -184,9 +215,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
     }                                                                                                \
     _Pragma("unroll") for (int i = 0; i < QL; ++i) {                                                 \
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
-      if (q_on[i] && gb_ + q_k[i] < g_end) {                                                         \
+      rq_off[i] = 0;                                                                                 \
+      if (q_on[i] && gb_ + Q_K(i) < g_end) {                                                         \
         const int row = q_img[i] * p.Q.h + q_gy[i];                                                  \
-        v = load_op4_at(p.Q, row * p.Q.pitch0 + q_gx[i], row * p.Q.pitch1 + q_gx[i], q_ch[i], qslope); \
+        v = load_raw4_at(p.Q, row * p.Q.pitch0 + q_gx[i], row * p.Q.pitch1 + q_gx[i], b0 + Q_COL(i), &rq_off[i]); \
+        rq_live |= 1u << i;                                                                          \
       }                                                                                              \
       rq[i] = v;                                                                                     \
       q_gx[i] += WK;                                                                                 \
@@ -199,9 +232,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
     float* Pb_ = Ps + (BUF) * WK * C::LDP;                                                           \
     float* Qb_ = Qs + (BUF) * WK * C::LDQ;                                                           \
     _Pragma("unroll") for (int i = 0; i < PL; ++i)                                                   \
-        if (p_k[i] < WK) *reinterpret_cast<float4*>(Pb_ + p_k[i] * C::LDP + p_col[i]) = rp[i];       \
+        if (P_K(i) < WK) *reinterpret_cast<float4*>(Pb_ + P_K(i) * C::LDP + P_COL(i)) =              \
+            transform4(p.P, rp[i], p_ch[i], rp_off[i], pslope, (rp_live >> i) & 1u);                 \
     _Pragma("unroll") for (int i = 0; i < QL; ++i)                                                   \
-        if (q_k[i] < WK) *reinterpret_cast<float4*>(Qb_ + q_k[i] * C::LDQ + (q_ch[i] - b0)) = rq[i]; \
+        if (Q_K(i) < WK) *reinterpret_cast<float4*>(Qb_ + Q_K(i) * C::LDQ + Q_COL(i)) =              \
+            transform4(p.Q, rq[i], b0 + Q_COL(i), rq_off[i], qslope, (rq_live >> i) & 1u);           \
   }
 
   floatx16 acc[MT][NT];
@@ -242,6 +277,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
   }
 #undef ADVOC_W_LOAD
 #undef ADVOC_W_STORE
+#undef P_K
+#undef P_COL
+#undef Q_K
+#undef Q_COL
 
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
