@@ -73,10 +73,19 @@ class Layer(object):
   """A bound conv layer: holds the ctypes struct and keeps every tensor it points at alive."""
 
   profiler = None   # set to a LaunchProfiler to time every launch
+  _workspaces = {}
+
+  @staticmethod
+  def _workspace_for(device, nbytes):
+    ws = Layer._workspaces.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+      ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+      Layer._workspaces[device] = ws
+    return ws
 
   def __init__(self, kind, x0, y, weight, bias=None, x1=None, in_w=None, out_w=None, stride=(2, 2),
                pad=(1, 1), in_act=ACT_NONE, drop_mask=None, drop_scale=0., in_scale=None,
-               in_shift=None, in_mask=None, in_mask_scale=0.):
+               in_shift=None, in_mask=None, in_mask_scale=0., workspace=True):
     kh, kw = int(weight.shape[0]), int(weight.shape[1])
     cin = x0.shape[3] + (x1.shape[3] if x1 is not None else 0)
     cout = y.shape[3]
@@ -114,7 +123,18 @@ class Layer(object):
     s.drop_scale = float(drop_scale)
     s.in_mask = _lib.ptr(in_mask)
     s.in_mask_scale = float(in_mask_scale)
+    s.workspace = None
+    s.workspace_bytes = 0
     self.struct = s
+    # scratch for the two-stage path of the 1-2 channel layers: one buffer per device, shared by
+    # all layers (launches are stream-ordered), grown on demand
+    need = max(_lib.load().advoc_conv_workspace_bytes(ctypes.byref(s), 0),
+               _lib.load().advoc_conv_workspace_bytes(ctypes.byref(s), 1))
+    if need > 0 and workspace:
+      ws = Layer._workspace_for(x0.device, need)
+      s.workspace = ws.data_ptr()
+      s.workspace_bytes = ws.numel() * 4
+      self.tensors = self.tensors + (ws,)
     self._names = {}
     lw = s.x0.w
     grid = (y.shape[1] * s.y.w) if kind == CONV else (x0.shape[1] * lw)

@@ -166,8 +166,44 @@ int build_backward_data(const advoc_conv_layer* L, const float* dy, float* dx0, 
   return subpixel_taps(p, L);
 }
 
-int run_gather(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only = nullptr) {
+// <= 2 output columns, wide K: S[pixel][tap * N + n] = sum_k A[pixel, k] w[tap][n][k] for every
+// input pixel ONCE (pointwise MFMA GEMM, taps become GEMM columns), then a gather-sum over taps.
+// The direct kernel re-reads each input pixel once per tap that touches it (4-16x).
+bool two_stage_ok(const GatherGemmParams& p) {
   const int K = p.c0 + p.c1, N = p.n_total;
+  const int wtaps = p.nphase * p.ntaps;          // distinct kernel taps (phases partition them)
+  return N <= 2 && K % 16 == 0 && p.c0 % 16 == 0 && (wtaps * N) % 4 == 0 && wtaps * N <= 32 && !p.y_mask;
+}
+
+int64_t two_stage_bytes(const GatherGemmParams& p) {
+  const int cols = p.nphase * p.ntaps * p.n_total;
+  return (int64_t)sizeof(float) * p.batch * p.in_h * p.in_w * cols;
+}
+
+int run_two_stage(const GatherGemmParams& p, float* ws, hipStream_t stream, const char** name_only) {
+  const int cols = p.nphase * p.ntaps * p.n_total;
+  GatherGemmParams g = {};
+  g.a0 = p.a0; g.a1 = p.a1; g.c0 = p.c0; g.c1 = p.c1; g.a0_pitch = p.a0_pitch; g.a1_pitch = p.a1_pitch;
+  g.a_h = p.a_h; g.in_h = p.in_h; g.in_w = p.in_w;
+  g.in_scale = p.in_scale; g.in_shift = p.in_shift; g.in_act = p.in_act;
+  g.a_mask = p.a_mask; g.a_mask_scale = p.a_mask_scale;
+  g.batch = p.batch; g.gh = p.in_h; g.gw = p.in_w; g.sy = g.sx = 1;
+  g.nphase = 1; g.ntaps = 1; g.tap[0][0] = 0;
+  g.w = p.w; g.n_total = 32; g.n_valid = cols; g.n_split = 32;
+  g.osy = g.osx = 1;
+  g.out_h = p.in_h; g.out_w = p.in_w;
+  g.d[0].p = ws; g.d[0].pitch = p.in_w; g.d[0].c = cols;
+  if (name_only) return launch_gather_gemm(g, /*b_kn=*/false, stream, name_only);
+  int rc = launch_gather_gemm(g, /*b_kn=*/false, stream, nullptr);
+  if (rc != ADVOC_OK) return rc;
+  return launch_tap_sum(p, ws, cols, stream);
+}
+
+int run_gather(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only = nullptr,
+               float* ws = nullptr, int64_t ws_bytes = 0) {
+  const int K = p.c0 + p.c1, N = p.n_total;
+  if (two_stage_ok(p) && ws && ws_bytes >= two_stage_bytes(p) && (b_kn ? N == 1 : true))
+    return run_two_stage(p, ws, stream, name_only);
   if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0)
     return launch_gather_gemm(p, b_kn, stream, name_only);
   if (N <= 2 && K % 4 == 0 && p.c0 % 4 == 0) return launch_gather_dot(p, b_kn, stream, name_only);
@@ -247,7 +283,18 @@ extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stre
   bool b_kn;
   rc = build_forward(L, p, b_kn);
   if (rc != ADVOC_OK) return rc;
-  return run_gather(p, b_kn, as_stream(stream));
+  return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
+}
+
+extern "C" int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* L, int32_t direction) {
+  if (validate_layer(L) != ADVOC_OK) return 0;
+  GatherGemmParams p;
+  bool b_kn;
+  float dummy = 0.f;
+  const int rc = direction == 0 ? build_forward(L, p, b_kn)
+                                : build_backward_data(L, &dummy, &dummy, L->x1.p ? &dummy : nullptr, 0, 0, p, b_kn);
+  if (rc != ADVOC_OK || !two_stage_ok(p) || (b_kn && p.n_total != 1)) return 0;
+  return two_stage_bytes(p);
 }
 
 extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* dy, float* dx0,
@@ -261,7 +308,7 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
   bool b_kn;
   rc = build_backward_data(L, dy, dx0, dx1, accum0, accum1, p, b_kn);
   if (rc != ADVOC_OK) return rc;
-  return run_gather(p, b_kn, as_stream(stream));
+  return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
 
 extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float* dy, float* dw,
@@ -310,7 +357,7 @@ extern "C" int advoc_conv_kernel_name(const advoc_conv_layer* L, int32_t directi
     rc = direction == 0 ? build_forward(L, p, b_kn)
                         : build_backward_data(L, &dummy, &dummy, L->x1.p ? &dummy : nullptr, 0, 0, p, b_kn);
     if (rc != ADVOC_OK) return rc;
-    rc = run_gather(p, b_kn, nullptr, &name);
+    rc = run_gather(p, b_kn, nullptr, &name, L->workspace, L->workspace_bytes);
   } else if (direction == 2) {
     WgradParams p;
     float dummy = 0.f;

@@ -16,6 +16,12 @@ int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
 int launch_gather_outer(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
                         const char** name_only = nullptr);
 
+// Second stage of the two-stage path for <= 2 output channels (edge.hip): out = bias + sum over
+// the taps of S[pixel @ tap][wtap * n_total + n], S being the per-pixel, per-tap partial dot
+// products a pointwise MFMA GEMM produced.  `p` is the ORIGINAL problem (taps, phases, epilogue).
+int launch_tap_sum(const GatherGemmParams& p, const float* S, int s_channels, hipStream_t stream,
+                   const char** name_only = nullptr);
+
 // MFMA versions of the thin kernels (thin.hip): K = c0 + c1 <= 2 and taps * K <= 32, N % 32 == 0
 int launch_thin_k_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
                        const char** name_only = nullptr);

@@ -174,7 +174,49 @@ __global__ __launch_bounds__(256) void gather_outer_kernel(const GatherGemmParam
   store_result(p, phase, g, n, acc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// tap_sum: out[g, n] = bias[n] + sum_t S[g*s + d_t][wtap_t * N + n]   (thread per grid point)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tap_sum_kernel(const GatherGemmParams p, const float* __restrict__ S,
+                                                      int sc) {
+  __shared__ int s_tap[kMaxPhases][kMaxTaps];
+  if (threadIdx.x < kMaxPhases * kMaxTaps) s_tap[threadIdx.x / kMaxTaps][threadIdx.x % kMaxTaps] =
+      p.tap[threadIdx.x / kMaxTaps][threadIdx.x % kMaxTaps];
+  __syncthreads();
+  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const GridPoint g = decompose(m, p.gh, p.gw);
+  const int N = p.n_total;
+  for (int phase = 0; phase < p.nphase; ++phase) {
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int tp = s_tap[phase][t];
+      const int iy = g.gy * p.sy + (int)(int8_t)(tp & 0xff);
+      const int ix = g.gx * p.sx + (int)(int8_t)((tp >> 8) & 0xff);
+      if ((unsigned)iy >= (unsigned)p.in_h || (unsigned)ix >= (unsigned)p.in_w) continue;
+      const float* row = S + (((int64_t)g.img * p.in_h + iy) * p.in_w + ix) * sc + (tp >> 16) * N;
+      acc0 += row[0];
+      if (N > 1) acc1 += row[1];
+    }
+    store_result(p, phase, g, 0, acc0);
+    if (N > 1) store_result(p, phase, g, 1, acc1);
+  }
+}
+
 }  // namespace
+
+int launch_tap_sum(const GatherGemmParams& p, const float* S, int s_channels, hipStream_t stream,
+                   const char** name_only) {
+  if (name_only) { *name_only = "tap_sum_kernel"; return ADVOC_OK; }
+  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  const int64_t blocks = ceil_div(M, 256);
+  if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(tap_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, S, s_channels);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
 
 int launch_gather_dot(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only) {
   const int ktot = p.c0 + p.c1;

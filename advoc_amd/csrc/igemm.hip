@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   // B_KN: slot = (k row, 4 consecutive n); else slot = (n row, 4 consecutive k).  Threads beyond
   // the tile (BN = 32) re-read slot 0..: harmless, they skip the LDS store.
   int b_goff[BL], b_loff[BL];
-  bool b_store[BL];
+  bool b_store[BL], b_live[BL];
+  const int n_valid = p.n_valid ? p.n_valid : p.n_total;
 #pragma unroll
   for (int i = 0; i < BL; ++i) {
     const int idx = tid + 256 * i;
@@ -147,10 +148,12 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
       const int k = id / (BN / 4), nq = id % (BN / 4);
       b_goff[i] = k * p.n_total + n0 + 4 * nq;           // + (wtap*ktot + k0) * N per tile
       b_loff[i] = k * C::LDB_KN + 4 * nq;
+      b_live[i] = n0 + 4 * nq < n_valid;
     } else {
       const int n = id / QPR, q = id % QPR;
       b_goff[i] = (n0 + n) * ktot + 4 * q;                // + wtap*N*ktot + k0 per tile
       b_loff[i] = n * LDA + 4 * q;
+      b_live[i] = n0 + n < n_valid;
     }
   }
   __syncthreads();
@@ -188,9 +191,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
       }                                                                                              \
     }                                                                                                \
     const float* wb_ = B_KN ? p.w + ((int64_t)wtap_ * ktot + k0_) * p.n_total                        \
-                            : p.w + (int64_t)wtap_ * p.n_total * ktot + k0_;                         \
-    _Pragma("unroll") for (int i = 0; i < BL; ++i)                                                   \
-        rb[i] = *reinterpret_cast<const float4*>(wb_ + b_goff[i]);                                   \
+                            : p.w + (int64_t)wtap_ * n_valid * ktot + k0_;                           \
+    _Pragma("unroll") for (int i = 0; i < BL; ++i) {                                                 \
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+      if (b_live[i]) rb[i] = *reinterpret_cast<const float4*>(wb_ + b_goff[i]);                      \
+    }                                                                                                \
   }
 
 #define ADVOC_STORE_TILE(BUF)                                                                        \
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
     const int nt0 = n0 + (wn * NT + j) * 32;    // first channel of this 32-wide tile
     const int di = nt0 >= p.n_split ? 1 : 0;    // uniform: n_split % 32 == 0
     const GemmDest& d = p.d[di];
-    if (d.p == nullptr) continue;
+    if (d.p == nullptr || nt0 >= n_valid) continue;
     const int ch = (di ? nt0 - p.n_split : nt0) + 4 * tq;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + nt0 + 4 * tq);
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
       for (int ps = 0; ps < 4; ++ps) {
         const int row = trow + 8 * ps;
         const int pix = s_pix[di * BM + (wm * MT + i) * 32 + row];
-        if (pix < 0) continue;
+        if (pix < 0 || nt0 + 4 * tq >= n_valid) continue;
         const int off = pix * d.c + ch;
         float4 v = *reinterpret_cast<const float4*>(T + row * LDT + 4 * tq);
         v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;

@@ -135,7 +135,16 @@ typedef struct advoc_conv_layer {
   float drop_scale;
   const uint8_t* in_mask; /* uint8 {0,1}, indexed exactly like x0 */
   float in_mask_scale;
+  /* optional scratch (caller-owned, 16-byte aligned).  Layers with <= 2 output channels (forward)
+   * or <= 2 input channels (backward-data) run as a pointwise MFMA GEMM into this buffer followed
+   * by a tap gather-sum when it holds at least advoc_conv_workspace_bytes(); without it they
+   * use the slower direct kernel. */
+  float* workspace;
+  int64_t workspace_bytes;
 } advoc_conv_layer;
+
+/* Scratch the layer can use for `direction` (0 forward, 1 backward-data); 0 when it needs none. */
+int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* layer, int32_t direction);
 
 /* Forward.  Replaces TF Conv2D / Conv2DBackpropInput(+BiasAdd, activations, concat, dropout)
  * built at advoc_model.py:89-158 (generator) and :184-202 (discriminator). */

@@ -97,9 +97,32 @@ def build_case(case, seed=0):
               mask=mask, keep=0.5, out_w=ow, dy=dy, oh=oh)
 
 
+THIN = [c for c in CASES if c[0] in ('dec1_cout1', 'dec1_cout1_big', 'd1_cin2', 'd5_cout1')]
+
+
+@gpu
+@pytest.mark.parametrize('case', THIN, ids=[c[0] for c in THIN])
+def test_layer_all_directions_without_workspace(hip, case):
+  """The 1-2 channel layers have a direct kernel for callers that pass no scratch buffer."""
+  test_layer_all_directions(hip, case, workspace=False)
+
+
+@gpu
+def test_two_stage_path_is_selected(hip):
+  from advoc_amd import conv
+  dev = torch.device('cuda')
+  c = build_case(CASES[8])
+  x0, x1, w = c['x0'].to(dev), c['x1'].to(dev), c['w'].to(dev)
+  y = torch.empty(x0.shape[0], c['oh'], c['out_w'], 1, device=dev)
+  with_ws = conv.Layer(1, x0, y, w, None, x1=x1, in_w=c['in_w'], in_act=2)
+  without = conv.Layer(1, x0, y, w, None, x1=x1, in_w=c['in_w'], in_act=2, workspace=False)
+  assert 'gather_gemm' in with_ws.kernel_name(0)
+  assert 'gather_dot' in without.kernel_name(0)
+
+
 @gpu
 @pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
-def test_layer_all_directions(hip, case):
+def test_layer_all_directions(hip, case, workspace=True):
   from advoc_amd import conv
   c = build_case(case)
   dev = torch.device('cuda')
@@ -113,7 +136,8 @@ def test_layer_all_directions(hip, case):
   y = torch.full((x0.shape[0], c['oh'], c['out_w'], w.shape[3] if c['kind'] == 0 else w.shape[2]),
                  float('nan'), device=dev)
   L = conv.Layer(c['kind'], x0, y, w, b, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'],
-                 in_act=c['act'], drop_mask=mask, drop_scale=1 / c['keep'] if mask is not None else 0.)
+                 in_act=c['act'], drop_mask=mask, drop_scale=1 / c['keep'] if mask is not None else 0.,
+                 workspace=workspace)
   L.forward()
   assert torch.isfinite(y).all()
   assert rel(y, y_o) < TOL, ('fwd', rel(y, y_o))
