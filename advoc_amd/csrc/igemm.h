@@ -53,6 +53,7 @@ struct GatherGemmParams {
   // ---- B operand ----
   const float* w;
   int n_total;
+  int k_order;             // 0: channel slices inner, taps outer; 1: taps inner
   int n_valid;             // 0 = n_total; else only the first n_valid columns exist in w / are stored
   // ---- output ----
   int osy, osx;

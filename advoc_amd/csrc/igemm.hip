@@ -164,10 +164,21 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   bool a_first = true;     // the staged A slice comes from source 0 (the only one a_mask covers)
   int a_moff[AL];
 
+  // K order: the loader walks (tap, channel slice) pairs incrementally.  taps_inner: all taps of
+  // one BK-channel slice before the next slice -- a workgroup then re-touches the same input
+  // pixels on consecutive K tiles (L2 hits) instead of once per pass over the channels.
+  int ld_tap = 0, ld_k0 = 0;
+  const bool taps_inner = p.k_order != 0;
 #define ADVOC_LOAD_TILE(KT)                                                                          \
   {                                                                                                  \
-    const int ti_ = (KT) / kpt;                                                                      \
-    const int k0_ = ((KT) - ti_ * kpt) * BK;                                                         \
+    const int ti_ = ld_tap;                                                                          \
+    const int k0_ = ld_k0;                                                                           \
+    if (taps_inner) {                                                                                \
+      if (++ld_tap == p.ntaps) { ld_tap = 0; ld_k0 += BK; if (ld_k0 == ktot) ld_k0 = 0; }            \
+    } else {                                                                                         \
+      ld_k0 += BK;                                                                                   \
+      if (ld_k0 == ktot) { ld_k0 = 0; if (++ld_tap == p.ntaps) ld_tap = 0; }                         \
+    }                                                                                                \
     const int tp_ = ADVOC_TAP(ti_);                                                                  \
     const int dy_ = (int)(int8_t)(tp_ & 0xff), dx_ = (int)(int8_t)((tp_ >> 8) & 0xff);              \
     const int wtap_ = tp_ >> 16;                                                                     \
@@ -243,9 +254,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     const bool more = kt + 1 < nkt;
-    // unconditional prefetch (the last iteration re-reads its own tile): keeps the prefetch
-    // registers out of a conditional region
-    ADVOC_LOAD_TILE(more ? kt + 1 : kt);
+    // unconditional prefetch (the last iteration wraps round to tile 0 and drops it): keeps the
+    // prefetch registers out of a conditional region
+    ADVOC_LOAD_TILE(kt + 1);
 
     const float* Ab = As + buf * C::A_TILE;
     const float* Bb = Bs + buf * C::B_TILE;
@@ -447,7 +458,10 @@ int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
       (int64_t)p.batch * p.out_h * p.d[0].pitch * p.d[0].c > lim ||
       (int64_t)p.batch * p.out_h * p.d[1].pitch * p.d[1].c > lim)
     return ADVOC_ERR_UNSUPPORTED;
-  return b_kn ? dispatch<true>(p, stream, name_only) : dispatch<false>(p, stream, name_only);
+  static const int k_order = [] { const char* e = getenv("ADVOC_IGEMM_KORDER"); return e ? atoi(e) : 0; }();
+  GatherGemmParams q = p;
+  q.k_order = k_order;
+  return b_kn ? dispatch<true>(q, stream, name_only) : dispatch<false>(q, stream, name_only);
 }
 
 }  // namespace advoc
