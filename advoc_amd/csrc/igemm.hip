@@ -167,8 +167,13 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   // K order: the loader walks (tap, channel slice) pairs incrementally.  taps_inner: all taps of
   // one BK-channel slice before the next slice -- a workgroup then re-touches the same input
   // pixels on consecutive K tiles (L2 hits) instead of once per pass over the channels.
-  int ld_tap = 0, ld_k0 = 0;
+  // split-K: blockIdx.y owns K tiles [kt_begin, kt_end); partial results are combined with
+  // hardware fp32 atomics in the epilogue (launch_cfg zeroes the destination first)
+  const int kt_begin = (int)((int64_t)nkt * blockIdx.y / gridDim.y);
+  const int kt_end = (int)((int64_t)nkt * (blockIdx.y + 1) / gridDim.y);
   const bool taps_inner = p.k_order != 0;
+  int ld_tap = taps_inner ? kt_begin % p.ntaps : kt_begin / kpt;
+  int ld_k0 = (taps_inner ? kt_begin / p.ntaps : kt_begin % kpt) * BK;
 #define ADVOC_LOAD_TILE(KT)                                                                          \
   {                                                                                                  \
     const int ti_ = ld_tap;                                                                          \
@@ -247,13 +252,13 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
 
   const int half = lane >> 5, l32 = lane & 31;
 
-  ADVOC_LOAD_TILE(0);
+  ADVOC_LOAD_TILE(kt_begin);
   ADVOC_STORE_TILE(0);
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < nkt;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
     // unconditional prefetch (the last iteration wraps round to tile 0 and drops it): keeps the
     // prefetch registers out of a conditional region
     ADVOC_LOAD_TILE(kt + 1);
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
     if (d.p == nullptr || nt0 >= n_valid) continue;
     const int ch = (di ? nt0 - p.n_split : nt0) + 4 * tq;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + nt0 + 4 * tq);
+    if (p.bias && blockIdx.y == 0) bias4 = *reinterpret_cast<const float4*>(p.bias + nt0 + 4 * tq);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -370,6 +375,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
           v.x *= mk.x * d.gmask_scale; v.y *= mk.y * d.gmask_scale;
           v.z *= mk.z * d.gmask_scale; v.w *= mk.w * d.gmask_scale;
         }
+        if (gridDim.y > 1) {   // every epilogue factor above is linear in the accumulator
+          unsafeAtomicAdd(d.p + off, v.x); unsafeAtomicAdd(d.p + off + 1, v.y);
+          unsafeAtomicAdd(d.p + off + 2, v.z); unsafeAtomicAdd(d.p + off + 3, v.w);
+          continue;
+        }
         if (d.accum) {
           const float4 o = *reinterpret_cast<const float4*>(d.p + off);
           v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -379,6 +389,14 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
       wave_lds_sync();
     }
   }
+}
+
+// ADVOC_IGEMM_SPLITK=0 keeps every launch on one K pass (bitwise run-to-run reproducible results;
+// split-K combines partial sums with atomics, whose order varies).  Read per launch so a test
+// can toggle it.
+bool split_k_allowed() {
+  const char* e = getenv("ADVOC_IGEMM_SPLITK");
+  return e ? atoi(e) != 0 : true;
 }
 
 template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK>
@@ -396,7 +414,29 @@ int launch_cfg(const GatherGemmParams& p, hipStream_t stream, const char** name_
   const int64_t gx = ceil_div(M, C::BM);
   if (gx > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
   if (gx * (p.n_total / C::BN) > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
-  dim3 grid((unsigned)(gx * (p.n_total / C::BN)), 1, (unsigned)p.nphase);
+  // Small pixel grids with deep contractions (encoder_5.., decoder_5.. and their gradients) would
+  // put < 2 workgroups on a CU, each walking hundreds of K tiles alone: split K until the launch
+  // holds ~4 workgroups per CU, keeping >= 16 K tiles per split.
+  const int64_t tiles = gx * (p.n_total / C::BN) * p.nphase;
+  const int nkt = (p.c0 + p.c1) / BK * p.ntaps;
+  int ksplit = 1;
+  if (tiles < 512 && split_k_allowed()) {
+    ksplit = (int)ceil_div((int64_t)1024, tiles);
+    if (ksplit > nkt / 16) ksplit = nkt / 16;
+    if (ksplit > 16) ksplit = 16;
+    if (ksplit < 1) ksplit = 1;
+  }
+  if (ksplit > 1) {
+    for (int i = 0; i < 2; ++i) {
+      const GemmDest& d = p.d[i];
+      if (d.p == nullptr || d.accum) continue;
+      // logical region only: columns beyond out_w (pitch padding) stay untouched
+      hipError_t e = hipMemset2DAsync(d.p, sizeof(float) * (size_t)d.pitch * d.c, 0,
+                                      sizeof(float) * (size_t)p.out_w * d.c, (size_t)p.batch * p.out_h, stream);
+      if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    }
+  }
+  dim3 grid((unsigned)(gx * (p.n_total / C::BN)), (unsigned)ksplit, (unsigned)p.nphase);
   auto kern = gather_gemm_kernel<MT, NT, WGM, WGN, B_KN, BK>;
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, p);
@@ -461,7 +501,8 @@ int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
   // taps-inner K order by default: same speed as taps-outer on MI355X but ~9x less L2-miss traffic
   // on the stride-1 backward-data of discriminator layer_4 (rocprofv3 FETCH_SIZE 1039 -> 117 MB);
   // ADVOC_IGEMM_KORDER=0 restores the other order for A/B runs.
-  static const int k_order = [] { const char* e = getenv("ADVOC_IGEMM_KORDER"); return e ? atoi(e) : 1; }();
+  const char* ko = getenv("ADVOC_IGEMM_KORDER");
+  const int k_order = ko ? atoi(ko) : 1;
   GatherGemmParams q = p;
   q.k_order = k_order;
   return b_kn ? dispatch<true>(q, stream, name_only) : dispatch<false>(q, stream, name_only);

@@ -429,28 +429,31 @@ __global__ __launch_bounds__(256) void bias_grad_vec4_kernel(const float* __rest
     if (tg < groups && q < quads) {
       const int64_t step = (int64_t)gridDim.x * groups;
       int64_t pix = (int64_t)blockIdx.x * groups + tg;
-      // four independent 16-byte loads in flight per lane
-      float4 s1 = s, s2 = s, s3 = s;
-      for (; pix + 3 * step < npix; pix += 4 * step) {
-        const int64_t o0 = pix * c + 4 * q, o1 = o0 + step * c, o2 = o1 + step * c, o3 = o2 + step * c;
-        float4 v0 = *reinterpret_cast<const float4*>(dy + o0);
-        float4 v1 = *reinterpret_cast<const float4*>(dy + o1);
-        float4 v2 = *reinterpret_cast<const float4*>(dy + o2);
-        float4 v3 = *reinterpret_cast<const float4*>(dy + o3);
-        if (mask) {
-          const uchar4 m0 = *reinterpret_cast<const uchar4*>(mask + o0);
-          const uchar4 m1 = *reinterpret_cast<const uchar4*>(mask + o1);
-          const uchar4 m2 = *reinterpret_cast<const uchar4*>(mask + o2);
-          const uchar4 m3 = *reinterpret_cast<const uchar4*>(mask + o3);
-          v0.x *= m0.x * mask_scale; v0.y *= m0.y * mask_scale; v0.z *= m0.z * mask_scale; v0.w *= m0.w * mask_scale;
-          v1.x *= m1.x * mask_scale; v1.y *= m1.y * mask_scale; v1.z *= m1.z * mask_scale; v1.w *= m1.w * mask_scale;
-          v2.x *= m2.x * mask_scale; v2.y *= m2.y * mask_scale; v2.z *= m2.z * mask_scale; v2.w *= m2.w * mask_scale;
-          v3.x *= m3.x * mask_scale; v3.y *= m3.y * mask_scale; v3.z *= m3.z * mask_scale; v3.w *= m3.w * mask_scale;
+      // eight independent 16-byte loads in flight per lane (HBM latency x bandwidth wants
+      // ~16 MB in flight across the chip)
+      float4 acc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (; pix + 7 * step < npix; pix += 8 * step) {
+        float4 v[8];
+        int64_t o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          o[u] = (pix + u * step) * c + 4 * q;
+          v[u] = *reinterpret_cast<const float4*>(dy + o[u]);
         }
-        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
-        s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
-        s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
-        s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+        if (mask) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const uchar4 m = *reinterpret_cast<const uchar4*>(mask + o[u]);
+            v[u].x *= m.x * mask_scale; v[u].y *= m.y * mask_scale;
+            v[u].z *= m.z * mask_scale; v[u].w *= m.w * mask_scale;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w;
+        }
       }
       for (; pix < npix; pix += step) {
         const int64_t off = pix * c + 4 * q;
@@ -461,8 +464,8 @@ __global__ __launch_bounds__(256) void bias_grad_vec4_kernel(const float* __rest
         }
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
-      s.x += s1.x + s2.x + s3.x; s.y += s1.y + s2.y + s3.y;
-      s.z += s1.z + s2.z + s3.z; s.w += s1.w + s2.w + s3.w;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += acc[u].x; s.y += acc[u].y; s.z += acc[u].z; s.w += acc[u].w; }
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -568,7 +571,7 @@ int launch_bias_grad(const float* dy, const uint8_t* mask, float mask_scale, int
   if (c % 4 == 0 && pitch == w && 256 % (quads < 256 ? quads : 256) == 0) {
     const int groups = 256 / (quads < 256 ? quads : 256);
     int64_t blocks = ceil_div(rows * w, (int64_t)groups * 16);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bias_grad_vec4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, mask,
                        mask_scale, rows * w, c, db);

@@ -20,6 +20,14 @@ Extra objects on the JSON line:
   roofline      the kernel instance with the largest total time in the timed region, timed per
                 launch with HIP events on the launch stream: algorithmic flops / measured time
                 against the dense fp32 MFMA peak (157.3 TFLOP/s).
+                `traffic` = L2-miss bytes per launch of that kernel from the committed rocprofv3
+                counter passes of this same command (profiles/r01_traffic.json; FETCH_SIZE
+                doubled per the gfx950 correction + WRITE_SIZE), null when not recorded.
+  extractor     the HBM-bound leg: waveform -> |STFT| (stft1024_kernel) timed per launch with HIP
+                events; algorithmic bytes = 790 528 per clip against 8 TB/s.
+  inference     vocoded clips/s: mel -> pseudo-inverse -> generator forward on 256-frame chunks
+                (scripts/spectrogram_advoc.py:80-94 semantics, batched; phase estimation not
+                included).  Measured after the timed region; not part of `value`.
   cpu_baseline  the torch-CPU restatement of the reference graph (oracle/, "port") timed on this
                 box's host cores on a bounded sample (rank 0, N = 1 only).
 """
@@ -84,6 +92,60 @@ def cpu_baseline(model_small=True, budget_s=20.0):
               kind='port',
               sample='%d train_loop iterations (1 D + 1 G update each) of AdVoc-small at batch %d, '
                      'STFT/mel in numpy, convs in torch-CPU fp32' % (n, B))
+
+
+def extractor_leg(torch, spectral, wav, launches=30):
+  """waveform -> |STFT| alone: GB/s of algorithmic traffic (read wav once, write |X| once)."""
+  B = wav.shape[0]
+  for _ in range(3):
+    spectral.stft_magnitude(wav, 1024, 256, pad_end=False)
+  evs = []
+  for _ in range(launches):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    spectral.stft_magnitude(wav, 1024, 256, pad_end=False)
+    e1.record()
+    evs.append((e0, e1))
+  torch.cuda.synchronize()
+  ms = sum(a.elapsed_time(b) for a, b in evs) / launches
+  nbytes = B * (CLIP_SAMPLES * 4 + CLIP_FRAMES * 513 * 4)
+  gbs = nbytes / (ms * 1e-3) / 1e9
+  return dict(kernel='stft1024_kernel<false>', bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
+              frac=gbs / HBM_PEAK_GBS, clips_per_launch=B, bytes_per_launch=nbytes, avg_launch_ms=ms,
+              frames_per_s=B * CLIP_FRAMES / (ms * 1e-3),
+              note='includes the output allocation of the Python wrapper; clips of one training batch')
+
+
+def inference_leg(torch, model_cls, Modes, su, mel, iters=10):
+  """clips/s of mel -> magnitude through the generator (INFER mode, dropout active as in the
+  reference), batch = the training batch."""
+  m = model_cls(Modes.INFER)
+  B = mel.shape[0]
+  m.build(batch_size=B, seed=0)
+  for _ in range(2):
+    m.build_generator(su.mel_linear_to_mag_spec(mel))
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(iters):
+    m.build_generator(su.mel_linear_to_mag_spec(mel))
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  return dict(value=B * iters / dt, unit='vocoded 256-frame clips/s', batch=B, ms_per_batch=dt / iters * 1e3,
+              note='mel -> pinv projection -> generator forward; no phase estimation (LWS is a later row)')
+
+
+def recorded_traffic(kernel, model, batch):
+  """L2-miss bytes per launch from the committed counter passes (tools/pmc_summary.py), if they
+  were taken on this workload."""
+  fp = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+  if not os.path.exists(fp):
+    return None
+  rec = json.load(open(fp))
+  meta = rec.get('_workload', {})
+  if meta.get('model') != model or meta.get('batch') != batch:
+    return None
+  row = rec.get(kernel)
+  return row['traffic_bytes'] if row else None
 
 
 def main():
@@ -161,14 +223,17 @@ def main():
     if mfma:
       achieved = r['flops'] / (r['ms'] * 1e-3) / 1e12
       roofline = dict(bound='mfma', kernel=name, achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS,
-                      unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=None,
+                      unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS,
+                      traffic=recorded_traffic(name, args.model, B),
+                      algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
                       launches=r['launches'], avg_launch_ms=r['ms'] / r['launches'],
                       flops_per_launch=r['flops'] / r['launches'],
                       share_of_step=r['ms'] / (elapsed * 1e3))
     else:
       achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
       roofline = dict(bound='hbm', kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                      frac=achieved / HBM_PEAK_GBS, traffic=None, launches=r['launches'],
+                      frac=achieved / HBM_PEAK_GBS, traffic=recorded_traffic(name, args.model, B),
+                      launches=r['launches'],
                       avg_launch_ms=r['ms'] / r['launches'], share_of_step=r['ms'] / (elapsed * 1e3))
     if dp.rank == 0 and os.environ.get('ADVOC_BENCH_VERBOSE'):
       tot = sum(v['ms'] for v in rows.values())
@@ -178,6 +243,13 @@ def main():
             k, v['launches'], v['ms'], 100 * v['ms'] / tot, tf, v['bytes'] / max(v['ms'], 1e-9) / 1e6),
             file=sys.stderr)
       print('  conv-stack launches total %.2f ms of %.2f ms wall' % (tot, elapsed * 1e3), file=sys.stderr)
+
+  extractor = inference = None
+  if dp.rank == 0:
+    extractor = extractor_leg(torch, spectral, pool[0])
+    mel0 = su.mag_to_mel_linear_spec(spectral.stft_magnitude(pool[0], 1024, 256, pad_end=False))
+    inference = inference_leg(torch, AdvocSmall if args.model == 'small' else Advoc, Modes, su, mel0)
+  dp.barrier()
 
   cpu = None
   if dp.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
@@ -210,6 +282,8 @@ def main():
         'per_gpu_value': value / dp.world_size,
         'losses': losses,
         'roofline': roofline,
+        'extractor': extractor,
+        'inference': inference,
         'cpu_baseline': cpu,
     }
     print(json.dumps(out))

@@ -107,6 +107,35 @@ def test_layer_all_directions_without_workspace(hip, case):
   test_layer_all_directions(hip, case, workspace=False)
 
 
+SPLITK = [c for c in CASES if c[0] in ('enc_same_wide', 'enc_n256', 'dec_first_drop', 'dec_skip_drop', 'd4_s1')]
+
+
+@gpu
+@pytest.mark.parametrize('case', SPLITK, ids=[c[0] for c in SPLITK])
+def test_layer_single_k_pass(hip, case, monkeypatch):
+  """Small pixel grids split the contraction over workgroups (atomics) by default; with
+  ADVOC_IGEMM_SPLITK=0 the same layers run one K pass.  Both must meet the bar, and the single-pass
+  result must be bitwise reproducible."""
+  import os
+  from advoc_amd import conv
+  monkeypatch.setenv('ADVOC_IGEMM_SPLITK', '0')
+  os.environ['ADVOC_IGEMM_SPLITK'] = '0'
+  test_layer_all_directions(hip, case)
+  c = build_case(case)
+  dev = torch.device('cuda')
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w = c['w'].to(dev)
+  cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+  ys = []
+  for _ in range(2):
+    y = torch.zeros(x0.shape[0], c['oh'], c['out_w'], cout, device=dev)
+    conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'],
+               in_act=c['act']).forward()
+    ys.append(y)
+  assert torch.equal(ys[0], ys[1])
+
+
 @gpu
 def test_two_stage_path_is_selected(hip):
   from advoc_amd import conv

@@ -38,6 +38,7 @@ def main():
     out[k] = dict(launches=len(fetch[k]), fetch_kib_raw=f, write_kib=w, traffic_bytes=traffic)
     print('| `%s` | %d | %.2f | %.2f | %.1f |' % (k, len(fetch[k]), f / 1024, w / 1024, traffic / 1e6))
   if '--json' in sys.argv:
+    out['_workload'] = dict(model='small', batch=32, command='python bench.py --steps 3 --warmup 1')
     json.dump(out, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1, sort_keys=True)
 
 
