@@ -47,7 +47,7 @@ def test_override_model_attrs():
 
 def test_unsupported_ablations_fail_loudly():
   from advoc_amd.model import Advoc, Modes
-  for ov in ('generator_type=linear', 'separable_conv=True', 'use_batchnorm=True', 'subseq_len=100'):
+  for ov in ('generator_type=linear', 'separable_conv=True', 'subseq_len=100'):
     from advoc_amd.model import override_model_attrs
     m, _ = override_model_attrs(Advoc(Modes.TRAIN), ov)
     with pytest.raises(NotImplementedError):
