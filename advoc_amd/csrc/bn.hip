@@ -132,7 +132,7 @@ int launch_colsum2(const float* a, const float* b, const float* pa, const float*
   const int quads = c / 4;
   const int groups = 256 / (quads < 256 ? quads : 256);
   int64_t blocks = advoc::ceil_div(npix, (int64_t)groups * 16);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 256) blocks = 256;   // one per CU: the same-address atomics at the end cost ~40 ns per block
   if (blocks < 1) blocks = 1;
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(colsum2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, b, pa, pb, npix, c,

@@ -429,29 +429,28 @@ __global__ __launch_bounds__(256) void bias_grad_vec4_kernel(const float* __rest
     if (tg < groups && q < quads) {
       const int64_t step = (int64_t)gridDim.x * groups;
       int64_t pix = (int64_t)blockIdx.x * groups + tg;
-      // eight independent 16-byte loads in flight per lane (HBM latency x bandwidth wants
-      // ~16 MB in flight across the chip)
-      float4 acc[8];
+      // four independent 16-byte loads in flight per lane
+      float4 acc[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (; pix + 7 * step < npix; pix += 8 * step) {
-        float4 v[8];
-        int64_t o[8];
+      for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (; pix + 3 * step < npix; pix += 4 * step) {
+        float4 v[4];
+        int64_t o[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4; ++u) {
           o[u] = (pix + u * step) * c + 4 * q;
           v[u] = *reinterpret_cast<const float4*>(dy + o[u]);
         }
         if (mask) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < 4; ++u) {
             const uchar4 m = *reinterpret_cast<const uchar4*>(mask + o[u]);
             v[u].x *= m.x * mask_scale; v[u].y *= m.y * mask_scale;
             v[u].z *= m.z * mask_scale; v[u].w *= m.w * mask_scale;
           }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4; ++u) {
           acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w;
         }
       }
@@ -465,7 +464,7 @@ __global__ __launch_bounds__(256) void bias_grad_vec4_kernel(const float* __rest
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { s.x += acc[u].x; s.y += acc[u].y; s.z += acc[u].z; s.w += acc[u].w; }
+      for (int u = 0; u < 4; ++u) { s.x += acc[u].x; s.y += acc[u].y; s.z += acc[u].z; s.w += acc[u].w; }
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -570,8 +569,11 @@ int launch_bias_grad(const float* dy, const uint8_t* mask, float mask_scale, int
   const int quads = c / 4;
   if (c % 4 == 0 && pitch == w && 256 % (quads < 256 ? quads : 256) == 0) {
     const int groups = 256 / (quads < 256 ? quads : 256);
+    // ONE workgroup per CU: 256 workgroups already stream at ~5.5 TB/s (tools/micro/colsum_bw.hip),
+    // and every extra workgroup costs ~40 ns of serialised same-address atomics at the end
+    // (1024 workgroups: 81 us, 256: 49 us for a 268 MB tensor).
     int64_t blocks = ceil_div(rows * w, (int64_t)groups * 16);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bias_grad_vec4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, mask,
                        mask_scale, rows * w, c, db);
