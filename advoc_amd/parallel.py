@@ -21,12 +21,19 @@ class DataParallel(object):
     self.rank = 0
     self.local_rank = 0
     self.enabled = False
+    self.backend = None
 
   def init_from_env(self, backend=None):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run)."""
     self.world_size = int(os.environ.get('WORLD_SIZE', '1'))
     self.rank = int(os.environ.get('RANK', '0'))
     self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # ADVOC_DP_BACKEND=gloo / ADVOC_DP_DEVICE=<index>: run the N-rank code path on a box with fewer
+    # GPUs than ranks (wiring check only -- RCCL refuses two ranks on one device, so collectives go
+    # through host memory there)
+    backend = backend or os.environ.get('ADVOC_DP_BACKEND')
+    if 'ADVOC_DP_DEVICE' in os.environ:
+      self.local_rank = int(os.environ['ADVOC_DP_DEVICE'])
     if self.world_size > 1:
       os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
       if backend is None:
@@ -35,6 +42,7 @@ class DataParallel(object):
         torch.cuda.set_device(self.local_rank)
       if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+      self.backend = dist.get_backend()
       self.enabled = True
     elif torch.cuda.is_available():
       torch.cuda.set_device(self.local_rank)
@@ -46,8 +54,17 @@ class DataParallel(object):
       return flat
     n = flat.numel()
     for lo in range(0, n, self.bucket_elems):
-      dist.all_reduce(flat[lo:min(n, lo + self.bucket_elems)], op=dist.ReduceOp.SUM)
+      self._collective(dist.all_reduce, flat[lo:min(n, lo + self.bucket_elems)], op=dist.ReduceOp.SUM)
     return flat
+
+  def _collective(self, fn, t, **kw):
+    """RCCL works on device tensors directly; gloo (CPU tests, wiring checks) goes through host memory."""
+    if self.backend == 'gloo' and t.is_cuda:
+      host = t.cpu()
+      fn(host, **kw)
+      t.copy_(host)
+    else:
+      fn(t, **kw)
 
   def attach(self, model):
     """Makes `model` (advoc_amd.model.Advoc) average gradients across ranks before Adam."""
@@ -62,16 +79,19 @@ class DataParallel(object):
       return
     st = model._built
     for k in ('g_param', 'd_param', 'g_m', 'g_v', 'd_m', 'd_v'):
-      dist.broadcast(st[k], src=0)
+      self._collective(dist.broadcast, st[k], src=0)
 
   def barrier(self):
     if self.enabled:
-      dist.barrier()
+      if self.backend == 'nccl':
+        dist.barrier(device_ids=[self.local_rank])
+      else:
+        dist.barrier()
 
   def max_over_ranks(self, value):
     if not self.enabled:
       return value
-    dev = torch.device('cuda', self.local_rank) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    dev = torch.device('cuda', self.local_rank) if self.backend == 'nccl' else torch.device('cpu')
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
