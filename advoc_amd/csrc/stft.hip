@@ -219,6 +219,143 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Inverse: one wavefront = one frame.  irfft(1024) runs as the SAME 512-point complex transform
+// (IDFT(Z) = conj(DFT(conj(Z))) / 512) after undoing the real-FFT split:
+//   Ze[k] = (X[k] + conj(X[512-k])) / 2,  Zo[k] = (X[k] - conj(X[512-k])) / 2 * W1024^-k,
+//   Z[k] = Ze[k] + i Zo[k];   x[2n] + i x[2n+1] = IDFT512(Z)[n].
+// The frame is multiplied by the synthesis window and written to `frames` ([batch, T, 1024]);
+// ola_kernel then sums the <= nfft/hop frames that cover each output sample (a gather: no atomics).
+// Replaces lws.istft reached from advoc/spectral.py:300-309,320-321.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWaves * 64) void istft1024_frames_kernel(
+    const float2* __restrict__ spec, const float* __restrict__ window, const float2* __restrict__ twiddle,
+    int64_t total_frames, float* __restrict__ frames) {
+  __shared__ float planes[kWaves][2 * kPlane];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* xr_plane = &planes[wave][0];
+  float* xi_plane = xr_plane + kPlane;
+  const int hi = lane >> 3, lo = lane & 7;
+  float w0[8], w1[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const float2 w = *reinterpret_cast<const float2*>(window + 128 * a + 2 * lane);
+    w0[a] = w.x;
+    w1[a] = w.y;
+  }
+  float t1r[8], t1i[8], t2r[8], t2i[8], tsn[8], tcs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float2 a = twiddle[((hi * j) & 63) * 16];
+    t1r[j] = a.x; t1i[j] = -a.y;
+    const float2 b = twiddle[((lo * (hi + 8 * j)) & 511) * 2];
+    t2r[j] = b.x; t2i[j] = -b.y;
+    const float2 c = twiddle[lane + 64 * j];
+    tcs[j] = c.x; tsn[j] = c.y;
+  }
+  for (int64_t f = (int64_t)blockIdx.x * kWaves + wave; f < total_frames; f += (int64_t)gridDim.x * kWaves) {
+    const float2* X = spec + f * kBins;
+    float re[8], im[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int k = 64 * a + lane;
+      float2 xk = X[k];
+      float2 xm = X[512 - k];
+      if (k == 0) { xk.y = 0.f; xm.y = 0.f; }      // irfft ignores Im X[0] and Im X[N/2]
+      const float er = 0.5f * (xk.x + xm.x), ei = 0.5f * (xk.y - xm.y);      // Ze
+      const float dr = 0.5f * (xk.x - xm.x), di = 0.5f * (xk.y + xm.y);      // (X[k] - conj X[m]) / 2
+      const float zor = dr * tcs[a] - di * tsn[a], zoi = dr * tsn[a] + di * tcs[a];   // * e^{+i theta_k}
+      re[a] = er - zoi;                 // Z = Ze + i Zo
+      im[a] = -(ei + zor);              // conjugated for the forward machinery
+    }
+    dft8(re, im);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const float r = re[p] * t1r[p] - im[p] * t1i[p];
+      const float i = re[p] * t1i[p] + im[p] * t1r[p];
+      const int addr = (8 * p + hi) * 9 + lo;
+      xr_plane[addr] = r;
+      xi_plane[addr] = i;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int addr = (8 * hi + b) * 9 + lo;
+      re[b] = xr_plane[addr];
+      im[b] = xi_plane[addr];
+    }
+    wave_lds_sync();
+    dft8(re, im);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float r = re[q] * t2r[q] - im[q] * t2i[q];
+      const float i = re[q] * t2i[q] + im[q] * t2r[q];
+      const int addr = (8 * q + hi) * 9 + lo;
+      xr_plane[addr] = r;
+      xi_plane[addr] = i;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int addr = lane * 9 + c;
+      re[c] = xr_plane[addr];
+      im[c] = xi_plane[addr];
+    }
+    wave_lds_sync();
+    dft8(re, im);
+    // lane holds conj(z[n]) * 512 for n = lane + 64 r:  x[2n] = re / 512, x[2n+1] = -im / 512
+    float* orow = frames + f * kNfft;
+    const float sc = 1.0f / 512.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      *reinterpret_cast<float2*>(orow + 128 * r + 2 * lane) = make_float2(re[r] * sc * w0[r], -im[r] * sc * w1[r]);
+  }
+}
+
+// out[clip][s] = sum over frames f with f*hop <= s < f*hop + nfft of frames[clip][f][s - f*hop]
+__global__ __launch_bounds__(256) void ola_kernel(const float* __restrict__ frames, int64_t batch, int64_t nframes,
+                                                  int nhop, int64_t out_len, float* __restrict__ out) {
+  const int64_t quads = out_len / 4;     // out_len = (T-1)*hop + 1024, hop % 4 == 0
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= batch * quads) return;
+  const int64_t clip = i / quads;
+  const int64_t s = (i - clip * quads) * 4;
+  int64_t f_hi = s / nhop;
+  if (f_hi > nframes - 1) f_hi = nframes - 1;
+  int64_t f_lo = (s - kNfft + nhop) / nhop;      // smallest f with f*hop + nfft > s  (s+3 shares it: hop % 4 == 0)
+  if (s - kNfft + nhop < 0) f_lo = 0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* base = frames + clip * nframes * kNfft;
+  for (int64_t f = f_lo; f <= f_hi; ++f) {
+    const float4 v = *reinterpret_cast<const float4*>(base + f * kNfft + (s - f * nhop));
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *reinterpret_cast<float4*>(out + clip * out_len + s) = acc;
+}
+
+// spec <- mag * spec / |spec|  (|spec| == 0 -> phase 0, as np.angle(0) == 0)   advoc/spectral.py:306-307
+__global__ __launch_bounds__(256) void phase_project_kernel(float2* __restrict__ spec, const float* __restrict__ mag,
+                                                            int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float2 x = spec[i];
+  const float m = fabsf(mag[i]);
+  const float a = sqrtf(x.x * x.x + x.y * x.y);
+  spec[i] = a > 0.f ? make_float2(m * (x.x / a), m * (x.y / a)) : make_float2(m, 0.f);
+}
+
+// spec = |mag| * exp(2 pi i u)   advoc/spectral.py:301-304
+__global__ __launch_bounds__(256) void polar_kernel(const float* __restrict__ mag, const float* __restrict__ u,
+                                                    float2* __restrict__ spec, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float sn, cs;
+  sincospif(2.0f * u[i], &sn, &cs);
+  const float m = fabsf(mag[i]);
+  spec[i] = make_float2(m * cs, m * sn);
+}
+
 int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* window,
                 const float* twiddle, int32_t nfft, int32_t nhop, int64_t nframes, float* out,
                 bool complex_out, hipStream_t stream) {
@@ -260,6 +397,60 @@ extern "C" int advoc_stft_c64(const float* wav, int64_t batch, int64_t nsamps, c
                               float* out, advoc_stream_t stream) {
   return launch_stft(wav, batch, nsamps, window, twiddle, nfft, nhop, nframes, out, true,
                      advoc::as_stream(stream));
+}
+
+extern "C" int advoc_istft_f32(const float* spec, int64_t batch, int64_t nframes, const float* window,
+                               const float* twiddle, int32_t nfft, int32_t nhop, float* frames_work,
+                               float* wav, advoc_stream_t stream_) {
+  hipStream_t stream = advoc::as_stream(stream_);
+  if (batch < 0 || nframes < 0 || nhop <= 0) return ADVOC_ERR_BAD_SHAPE;
+  if (nfft != kNfft || (nhop & 3) || nhop > kNfft) return ADVOC_ERR_UNSUPPORTED;
+  if (batch == 0 || nframes == 0) return ADVOC_OK;
+  if (!spec || !window || !twiddle || !frames_work || !wav) return ADVOC_ERR_NULL;
+  const int64_t total = batch * nframes;
+  int64_t blocks = advoc::ceil_div(total, kWaves);
+  if (blocks > 4096) blocks = 4096;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(istft1024_frames_kernel, dim3((unsigned)blocks), dim3(kWaves * 64), 0, stream,
+                     reinterpret_cast<const float2*>(spec), window, reinterpret_cast<const float2*>(twiddle),
+                     total, frames_work);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  const int64_t out_len = (nframes - 1) * nhop + kNfft;
+  const int64_t threads = batch * (out_len / 4);
+  const int64_t ob = advoc::ceil_div(threads, 256);
+  if (ob > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(ola_kernel, dim3((unsigned)ob), dim3(256), 0, stream, frames_work, batch, nframes, nhop,
+                     out_len, wav);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+extern "C" int advoc_phase_project_c64(float* spec, const float* mag, int64_t n, advoc_stream_t stream) {
+  if (n < 0) return ADVOC_ERR_BAD_SHAPE;
+  if (n == 0) return ADVOC_OK;
+  if (!spec || !mag) return ADVOC_ERR_NULL;
+  const int64_t blocks = advoc::ceil_div(n, 256);
+  if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(phase_project_kernel, dim3((unsigned)blocks), dim3(256), 0, advoc::as_stream(stream),
+                     reinterpret_cast<float2*>(spec), mag, n);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+extern "C" int advoc_polar_c64(const float* mag, const float* unit_phase, float* spec, int64_t n,
+                               advoc_stream_t stream) {
+  if (n < 0) return ADVOC_ERR_BAD_SHAPE;
+  if (n == 0) return ADVOC_OK;
+  if (!spec || !mag || !unit_phase) return ADVOC_ERR_NULL;
+  const int64_t blocks = advoc::ceil_div(n, 256);
+  if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(polar_kernel, dim3((unsigned)blocks), dim3(256), 0, advoc::as_stream(stream), mag,
+                     unit_phase, reinterpret_cast<float2*>(spec), n);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
 }
 
 // Fills the twiddle table the STFT kernels read: tw[2e] = cos(2 pi e / nfft), tw[2e+1] =

@@ -348,26 +348,87 @@ def waveform_to_r9y9_melspec_tf(x, fs=22050):
 
 
 # ---------------------------------------------------------------------------------------------
-# inversion -- the step after this path, not built yet
+# inversion: the step after the generator (reference spectral.py:294-405)
 # ---------------------------------------------------------------------------------------------
-def _not_yet(name):
-  raise NotImplementedError(
-      name + ': phase reconstruction (lws / Griffin-Lim + iSTFT) follows the MI355X hot path '
-      'and is not implemented yet (SURVEY.md §8f-1)')
+def _synthesis_window(nfft, nhop):
+  """lws.synthwindow(awin, hop) = awin / sum_q awin^2[k + q*hop]; the denominator is 1 for the
+  lws sqrt-Hann default at hop = nfft/4, so this equals the analysis window there."""
+  def make():
+    awin = _lws_window_f64(nfft, nhop)
+    q = -(-nfft // nhop)
+    sq = np.zeros(q * nhop, dtype=np.float64)
+    sq[:nfft] = awin * awin
+    den = np.tile(sq.reshape(q, nhop).sum(axis=0), q)[:nfft]
+    return torch.from_numpy((awin / den).astype(np.float32))
+  return _device_const(('swin', nfft, nhop), make)
+
+
+def istft_batch(spec, nfft, nhop):
+  """lws istft (perfectrec=False) of a batch: complex64 [clips, T, nfft//2+1] in HBM ->
+  float32 [clips, (T-1)*nhop + nfft]."""
+  _lib.require_device(spec)
+  if spec.dtype != torch.complex64 or spec.dim() != 3 or spec.shape[2] != nfft // 2 + 1:
+    raise ValueError('expected complex64 [clips, T, nfft//2+1]')
+  spec = spec.contiguous()
+  clips, T = spec.shape[0], spec.shape[1]
+  n = (T - 1) * nhop + nfft if T > 0 else 0
+  wav = torch.empty(clips, n, dtype=torch.float32, device=spec.device)
+  if clips == 0 or T == 0:
+    return wav
+  work = torch.empty(clips, T, nfft, dtype=torch.float32, device=spec.device)
+  _lib.check(_lib.load().advoc_istft_f32(
+      _lib.ptr(torch.view_as_real(spec)), clips, T, _lib.ptr(_synthesis_window(nfft, nhop)),
+      _lib.ptr(_device_twiddle(nfft)), nfft, nhop, _lib.ptr(work), _lib.ptr(wav), _lib.stream()),
+      'advoc_istft_f32')
+  return wav
+
+
+def griffin_lim_batch(mag, nfft, nhop, ngl, unit_phase):
+  """Griffin-Lim on a batch of equally long magnitude spectrograms, all on the GPU.
+  mag, unit_phase: float32 [clips, T, bins] in HBM (unit_phase = the U[0,1) draw the reference
+  takes from np.random.rand).  Returns float32 [clips, (T-1)*nhop + nfft]."""
+  lib = _lib.load()
+  mag = mag.contiguous()
+  unit_phase = unit_phase.contiguous()
+  clips, T, bins = mag.shape
+  spec = torch.empty(clips, T, bins, 2, dtype=torch.float32, device=mag.device)
+  if mag.numel():
+    _lib.check(lib.advoc_polar_c64(_lib.ptr(mag), _lib.ptr(unit_phase), _lib.ptr(spec), mag.numel(),
+                                   _lib.stream()), 'advoc_polar_c64')
+  wav = istft_batch(torch.view_as_complex(spec), nfft, nhop)
+  for _ in range(ngl):
+    # lws.stft of the (T-1)*hop + nfft samples gives T frames again (no padding)
+    spec = _run_stft(wav, nfft, nhop, T, complex_out=True)
+    if mag.numel():
+      _lib.check(lib.advoc_phase_project_c64(_lib.ptr(spec), _lib.ptr(mag), mag.numel(), _lib.stream()),
+                 'advoc_phase_project_c64')
+    wav = istft_batch(torch.view_as_complex(spec), nfft, nhop)
+  return wav
 
 
 def magspec_to_waveform_griffin_lim(X_mag, nfft, nhop, ngl=60):
+  """Reference spectral.py:294-311.  X_mag: nd-array [T, bins, 1] -> nd-array float32
+  [(T-1)*nhop + nfft, 1, 1].  Initial phases come from numpy's global generator, exactly as in
+  the reference (np.random.seed controls them); the iterations run in fp32 on the GPU (the
+  reference iterates in float64 on the host)."""
   nsamps, nbins, nch = X_mag.shape
   if nch != 1:
     raise NotImplementedError('Can only invert monaural signals')
-  _not_yet('magspec_to_waveform_griffin_lim')
+  X_mag = np.asarray(X_mag)[:, :, 0]
+  u = np.random.rand(*X_mag.shape)
+  mag = _to_device_f32(np.abs(X_mag).astype(np.float32))[None]
+  wav = griffin_lim_batch(mag, nfft, nhop, ngl, _to_device_f32(u.astype(np.float32))[None])
+  return wav[0].cpu().numpy()[:, np.newaxis, np.newaxis].astype(np.float32)
 
 
 def magspec_to_waveform_lws(X_mag, nfft, nhop):
   nsamps, nbins, nch = X_mag.shape
   if nch != 1:
     raise NotImplementedError('Can only invert monaural signals')
-  _not_yet('magspec_to_waveform_lws')
+  raise NotImplementedError(
+      'magspec_to_waveform_lws: Local Weighted Sums phase reconstruction is the third-party lws 1.2 '
+      'C++ library (not part of /root/reference); use phase_estimation="gl60" (Griffin-Lim runs on '
+      'the GPU) until it is restated (SURVEY.md §8f-1)')
 
 
 def melspec_to_waveform(
@@ -381,16 +442,50 @@ def melspec_to_waveform(
     norm_ref_level_db=20,
     phase_estimation='lws',
     waveform_len=None):
+  """Approximately inverts a dB-normalised mel spectrogram to a waveform (reference
+  spectral.py:330-395): de-normalise, pseudo-inverse mel basis, clamp at 0, phase estimation.
+
+  Args:
+    X_mel_dbnorm: nd-array float64 [?, mel_num_bins, 1].
+    phase_estimation: 'gl<N>' (Griffin-Lim, N iterations) or 'lws' (not built yet).
+    waveform_len: pad or clip the output to this length.
+  Returns:
+    nd-array float32 [waveform_len, 1, 1].
+  """
   if X_mel_dbnorm.dtype != np.float64:
     raise ValueError()
   nsamps, mel_num_bins, nch = X_mel_dbnorm.shape
   if nch != 1:
     raise NotImplementedError('Can only invert monaural signals')
-  if phase_estimation != 'lws' and phase_estimation[:2] != 'gl':
+  X_mel_dbnorm = X_mel_dbnorm[:, :, 0]
+  # host float64, as in the reference (:367-373): a [T,80]x[80,513] product, done once per utterance
+  X_mel_db = (X_mel_dbnorm * -norm_min_level_db) + norm_min_level_db
+  X_mel = np.power(10, (X_mel_db + norm_ref_level_db) / 20)
+  inv_mel_filterbank = create_inverse_mel_filterbank(
+      fs, nfft, fmin=mel_min, fmax=mel_max, n_mels=mel_num_bins)
+  X_mag = np.dot(X_mel, inv_mel_filterbank.T)
+  X_mag = np.maximum(0., X_mag)
+  X_mag = X_mag[:, :, np.newaxis]
+  if phase_estimation == 'lws':
+    x = magspec_to_waveform_lws(X_mag, nfft, nhop)
+  elif phase_estimation[:2] == 'gl':
+    try:
+      ngl = int(phase_estimation[2:])
+    except Exception:
+      raise ValueError()
+    x = magspec_to_waveform_griffin_lim(X_mag, nfft, nhop, ngl)
+  else:
     raise ValueError()
-  _not_yet('melspec_to_waveform')
+  if waveform_len is not None:
+    x_len = x.shape[0]
+    if x_len < waveform_len:
+      x = np.pad(x, [[0, waveform_len - x_len], [0, 0], [0, 0]], 'constant')
+    elif x_len > waveform_len:
+      x = x[:waveform_len]
+  return x.astype(np.float32)
 
 
 def r9y9_melspec_to_waveform(X_mel_dbnorm, fs=22050, phase_estimation='lws', waveform_len=None):
+  """Reference spectral.py:398-420."""
   return melspec_to_waveform(X_mel_dbnorm, fs=fs, nfft=1024, nhop=256,
                              phase_estimation=phase_estimation, waveform_len=waveform_len)

@@ -65,6 +65,25 @@ int advoc_stft_mag_f32(const float* wav, int64_t batch, int64_t nsamps, const fl
                        const float* twiddle, int32_t nfft, int32_t nhop, int64_t nframes, float* mag,
                        advoc_stream_t stream);
 
+/* Inverse STFT, lws(nfft, nhop, perfectrec=False).istft reached from advoc/spectral.py:300-309,
+ * 320-321: irfft of every frame, synthesis window, overlap-add.
+ *   spec        [batch, nframes, nfft/2+1] complex64 (interleaved re, im)
+ *   window      [nfft] synthesis window (equal to the analysis window for the lws default)
+ *   frames_work [batch, nframes, nfft] float32 scratch, caller-owned
+ *   wav         [batch, (nframes-1)*nhop + nfft] float32, fully overwritten
+ * nfft must be 1024, nhop a multiple of 4 and <= nfft. */
+int advoc_istft_f32(const float* spec, int64_t batch, int64_t nframes, const float* window,
+                    const float* twiddle, int32_t nfft, int32_t nhop, float* frames_work, float* wav,
+                    advoc_stream_t stream);
+
+/* Griffin-Lim projection step (advoc/spectral.py:306-307): spec[i] <- |mag[i]| * spec[i] / |spec[i]|,
+ * phase 0 where spec[i] == 0 (numpy: angle(0) == 0).  n complex elements, in place. */
+int advoc_phase_project_c64(float* spec, const float* mag, int64_t n, advoc_stream_t stream);
+
+/* Griffin-Lim initialisation (advoc/spectral.py:301-304): spec[i] = |mag[i]| * exp(2 pi i * unit_phase[i]),
+ * unit_phase in [0, 1). */
+int advoc_polar_c64(const float* mag, const float* unit_phase, float* spec, int64_t n, advoc_stream_t stream);
+
 /* Host helper: fills tw_host[2 * nfft] with the double-precision-evaluated twiddle table the
  * STFT kernels expect (upload it once; it is read-only). */
 int advoc_stft_twiddle_host(float* tw_host, int32_t nfft);

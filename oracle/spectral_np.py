@@ -265,3 +265,58 @@ def tacotron_mel_to_mag(X_mel_dbnorm, invmeltrans):
   X_mel_db = (X_mel_dbnorm * -norm_min_level_db) + norm_min_level_db
   X_mel = np.power(10, (X_mel_db + norm_ref_level_db) / 20)
   return np.dot(X_mel, invmeltrans.T)
+
+
+# ----------------------------------------------------------------------------
+# inversion: iSTFT + Griffin-Lim  (advoc/spectral.py:294-311; lws 1.2 istft restated)
+# ----------------------------------------------------------------------------
+def synth_window(awin, nhop):
+  """lws.synthwindow: swin = awin / sum_q (awin * awin)[k + q*hop] -- the synthesis window that
+  makes overlap-add of analysis-windowed frames the identity.  For the lws default
+  sqrt(hann * 2*hop/nfft) with hop = nfft/4 the denominator is exactly 1 (swin == awin)."""
+  awin = np.asarray(awin, dtype=np.float64)
+  n = awin.shape[0]
+  q = -(-n // nhop)
+  sq = np.zeros(q * nhop, dtype=np.float64)
+  sq[:n] = awin * awin
+  den = np.tile(sq.reshape(q, nhop).sum(axis=0), q)[:n]
+  return awin / den
+
+
+def istft(X, nfft, nhop):
+  """lws(nfft, nhop, perfectrec=False).istft: X [T, nfft//2+1] complex -> [(T-1)*hop + nfft]
+  float64 (irfft per frame, synthesis window, overlap-add; no boundary trimming)."""
+  X = np.asarray(X)
+  T = X.shape[0]
+  if T == 0:
+    return np.zeros(0, dtype=np.float64)
+  swin = synth_window(lws_hann_default(nfft, nhop, np.float64), nhop)
+  frames = np.fft.irfft(X.astype(np.complex128), n=nfft, axis=1) * swin[None, :]
+  out = np.zeros((T - 1) * nhop + nfft, dtype=np.float64)
+  for t in range(T):
+    out[t * nhop:t * nhop + nfft] += frames[t]
+  return out
+
+
+def _stft_lws_1d(x, nfft, nhop):
+  T = num_frames_lws(x.shape[0], nfft, nhop)
+  frames = _frame(x.astype(np.float64), T, nfft, nhop) * lws_hann_default(nfft, nhop, np.float64)[None, :]
+  return np.fft.rfft(frames, n=nfft, axis=1)
+
+
+def magspec_to_waveform_griffin_lim(X_mag, nfft, nhop, ngl=60, angles0=None):
+  """advoc/spectral.py:294-311.  X_mag [T, bins, 1] -> float32 [(T-1)*hop + nfft, 1, 1].
+  The reference draws the initial phases from numpy's GLOBAL generator
+  (np.random.rand(*X_mag.shape)); `angles0` (uniform [0,1) array) overrides that for tests."""
+  nsamps, nbins, nch = X_mag.shape
+  if nch != 1:
+    raise NotImplementedError('Can only invert monaural signals')
+  X_mag = X_mag[:, :, 0]
+  u = np.random.rand(*X_mag.shape) if angles0 is None else np.asarray(angles0, dtype=np.float64)
+  angles = np.exp(2j * np.pi * u)
+  X_complex = np.abs(X_mag).astype(np.complex128)
+  x_gl = istft(X_complex * angles, nfft, nhop)
+  for _ in range(ngl):
+    angles = np.exp(1j * np.angle(_stft_lws_1d(x_gl, nfft, nhop)))
+    x_gl = istft(X_complex * angles, nfft, nhop)
+  return x_gl[:, np.newaxis, np.newaxis].astype(np.float32)

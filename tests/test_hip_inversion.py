@@ -1,0 +1,158 @@
+"""iSTFT + Griffin-Lim on MI355X (through the C ABI) vs the numpy oracle, and the oracle itself vs
+the reference's Griffin-Lim known answers (reference tests/test_spectral.py:178-206).
+
+Status of the pin: the reference constants were produced from mono.wav resampled to 22.05 kHz by
+librosa/resampy, which is not available here; with scipy's polyphase resampler standing in, the
+restated algorithm (np.random.seed(0) phases, lws sqrt-Hann analysis = synthesis window, overlap-
+add without trimming) reproduces them to 0.1 % -- tight enough to exclude every other window /
+normalisation convention, not tight enough for their 8 decimals."""
+import os
+
+import numpy as np
+import pytest
+import scipy.signal
+import torch
+
+from oracle import spectral_np as O
+
+gpu = pytest.mark.gpu
+REF_GL0_L1 = 0.0232695210048     # reference tests/test_spectral.py:200
+REF_GL60_L1 = 0.0310892466788    # :202
+
+
+def rel_l2(a, b):
+  a = np.asarray(a, dtype=np.float64)
+  b = np.asarray(b, dtype=np.float64)
+  return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope='module')
+def mono22(golden_dir):
+  from advoc_amd.audioio import decode_audio
+  fs, x = decode_audio(os.path.join(golden_dir, 'mono.wav'), fastwav=True)
+  assert fs == 44100
+  x22 = scipy.signal.resample_poly(x[:, 0, 0].astype(np.float64), 1, 2).astype(np.float32)
+  assert x22.shape == (82432,)                       # reference :179
+  return x22[:, None, None]
+
+
+# ------------------------------------------------------------------------------------------------
+# oracle (CPU)
+# ------------------------------------------------------------------------------------------------
+def test_oracle_istft_inverts_stft(mono22):
+  X = O.stft(mono22, 1024, 256, pad_end=False)
+  assert X.shape == (319, 513, 1)                    # reference :183
+  x = O.istft(X[:, :, 0], 1024, 256)
+  assert x.shape == (82432,)
+  assert np.abs(x[1024:-1024] - mono22[1024:-1024, 0, 0]).max() < 1e-12
+  w = O.lws_hann_default(1024, 256, np.float64)
+  assert np.abs(O.synth_window(w, 256) - w).max() < 1e-15   # the lws default is its own synthesis window
+
+
+def test_oracle_griffin_lim_reference_known_answers(mono22):
+  X_mag = np.abs(O.stft(mono22, 1024, 256, pad_end=False))
+  np.random.seed(0)                                  # reference :186
+  x0 = O.magspec_to_waveform_griffin_lim(X_mag, 1024, 256, ngl=0)
+  x60 = O.magspec_to_waveform_griffin_lim(X_mag, 1024, 256, ngl=60)
+  assert x0.shape == (82432, 1, 1) and x0.dtype == np.float32
+  assert abs(np.mean(np.abs(x0 - mono22)) / REF_GL0_L1 - 1) < 5e-3
+  assert abs(np.mean(np.abs(x60 - mono22)) / REF_GL60_L1 - 1) < 5e-3
+  # a different synthesis normalisation (e.g. no 2*hop/nfft factor: x2) would be off by >> 0.5 %
+  assert abs(np.mean(np.abs(2 * x0 - mono22)) / REF_GL0_L1 - 1) > 0.2
+
+
+# ------------------------------------------------------------------------------------------------
+# HIP
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def S(hip):
+  from advoc_amd import spectral
+  return spectral
+
+
+@gpu
+@pytest.mark.parametrize('clips,T,hop', [(3, 37, 256), (1, 1, 256), (2, 5, 128), (1, 9, 512), (1, 4, 1024)])
+def test_istft_matches_oracle(S, clips, T, hop):
+  rng = np.random.default_rng(T)
+  X = (rng.standard_normal((clips, T, 513)) + 1j * rng.standard_normal((clips, T, 513))).astype(np.complex64)
+  got = S.istft_batch(torch.from_numpy(X).cuda(), 1024, hop).cpu().numpy()
+  assert got.shape == (clips, (T - 1) * hop + 1024)
+  for c in range(clips):
+    want = O.istft(X[c], 1024, hop)                  # Im X[0], Im X[512] ignored, as numpy's irfft does
+    assert rel_l2(got[c], want) < 2e-6
+
+
+@gpu
+def test_istft_empty_and_errors(S):
+  z = torch.zeros(2, 0, 513, dtype=torch.complex64, device='cuda')
+  assert tuple(S.istft_batch(z, 1024, 256).shape) == (2, 0)
+  with pytest.raises(ValueError):
+    S.istft_batch(torch.zeros(2, 3, 512, dtype=torch.complex64, device='cuda'), 1024, 256)
+
+
+@gpu
+def test_stft_istft_round_trip(S, mono22):
+  x = torch.from_numpy(mono22[:, 0, 0]).cuda()[None]
+  X = torch.view_as_complex(S._run_stft(x, 1024, 256, 319, complex_out=True))
+  y = S.istft_batch(X, 1024, 256)[0].cpu().numpy()
+  assert np.abs(y[1024:-1024] - mono22[1024:-1024, 0, 0]).max() < 2e-6
+
+
+@gpu
+def test_griffin_lim_matches_oracle_on_same_phases(S):
+  rng = np.random.default_rng(3)
+  T = 40
+  mag = np.abs(rng.standard_normal((T, 513))) * np.linspace(1, 0.01, 513)[None, :]
+  mag[5, 7] = 0.0
+  u = rng.random((T, 513))
+  for ngl, bar in ((0, 3e-6), (3, 2e-4)):
+    want = O.magspec_to_waveform_griffin_lim(mag[:, :, None], 1024, 256, ngl=ngl, angles0=u)[:, 0, 0]
+    got = S.griffin_lim_batch(torch.from_numpy(mag.astype(np.float32)).cuda()[None], 1024, 256, ngl,
+                              torch.from_numpy(u.astype(np.float32)).cuda()[None])[0].cpu().numpy()
+    assert got.shape == want.shape
+    assert rel_l2(got, want) < bar, (ngl, rel_l2(got, want))
+
+
+@gpu
+def test_griffin_lim_reference_known_answers_and_convergence(S, mono22):
+  """reference tests/test_spectral.py:178-203 against the HIP path (same seed, fp32 iterations)."""
+  X_mag = np.abs(S.stft(mono22, 1024, 256, pad_end=False))
+  assert X_mag.shape == (319, 513, 1)
+  np.random.seed(0)
+  x0 = S.magspec_to_waveform_griffin_lim(X_mag, 1024, 256, ngl=0)
+  x60 = S.magspec_to_waveform_griffin_lim(X_mag, 1024, 256, ngl=60)
+  for x in (x0, x60):
+    assert x.shape == (82432, 1, 1) and x.dtype == np.float32
+  assert abs(np.mean(np.abs(x0 - mono22)) / REF_GL0_L1 - 1) < 5e-3
+  assert abs(np.mean(np.abs(x60 - mono22)) / REF_GL60_L1 - 1) < 1e-2
+
+  def inconsistency(x):   # || |STFT(x)| - X_mag || / ||X_mag||: what Griffin-Lim minimises
+    return rel_l2(np.abs(S.stft(x, 1024, 256, pad_end=False)), X_mag)
+  assert inconsistency(x60) < 0.5 * inconsistency(x0)
+
+
+@gpu
+def test_melspec_to_waveform_surface(S, mono22):
+  mel = S.waveform_to_r9y9_melspec(mono22)
+  assert mel.dtype == np.float64 and mel.shape[1:] == (80, 1)
+  np.random.seed(0)
+  y = S.r9y9_melspec_to_waveform(mel, phase_estimation='gl10', waveform_len=82432)    # reference :163
+  assert y.shape == mono22.shape and y.dtype == np.float32
+  short = S.r9y9_melspec_to_waveform(mel, phase_estimation='gl0', waveform_len=1000)
+  assert short.shape == (1000, 1, 1)
+  long_ = S.r9y9_melspec_to_waveform(mel, phase_estimation='gl0', waveform_len=90000)
+  assert long_.shape == (90000, 1, 1) and float(np.abs(long_[85000:]).max()) == 0.0
+  # envelope of the reconstruction follows the original (reference :166-176 checks the same statistic)
+  env = np.abs(scipy.signal.hilbert(mono22[:, 0, 0]))
+  env_y = np.abs(scipy.signal.hilbert(y[:, 0, 0]))
+  assert abs(np.mean(np.abs(env - env_y)) / 0.01686 - 1) < 0.15                       # reference :176
+  with pytest.raises(ValueError):
+    S.melspec_to_waveform(mel.astype(np.float32), 22050, 1024, 256)
+  with pytest.raises(ValueError):
+    S.melspec_to_waveform(mel, 22050, 1024, 256, phase_estimation='nope')
+  with pytest.raises(ValueError):
+    S.melspec_to_waveform(mel, 22050, 1024, 256, phase_estimation='glx')
+  with pytest.raises(NotImplementedError):
+    S.melspec_to_waveform(np.zeros((4, 80, 2)), 22050, 1024, 256)
+  with pytest.raises(NotImplementedError):
+    S.melspec_to_waveform(mel, 22050, 1024, 256, phase_estimation='lws')
