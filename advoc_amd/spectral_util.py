@@ -70,6 +70,14 @@ class SpectralUtil(object):
     mel = torch.from_numpy(X_mel.astype(np.float32)).to(_lib.device())
     return spectral.matmul_last(mel, self.invmeltrans)
 
-  def audio_from_mag_spec(self, mag_spec):
-    raise NotImplementedError('LWS phase reconstruction is the step after the MI355X hot path '
-                              '(SURVEY.md §8f-1); not implemented yet')
+  def audio_from_mag_spec(self, mag_spec, phase_estimation='gl60'):
+    """Magnitude spectrogram [T, 513, 1] -> waveform float32 [n, 1, 1] (spectral_util.py:45-50).
+    The reference runs lws.run_lws here (third-party C++, not restated); this build estimates
+    phase with Griffin-Lim on the GPU (`gl<N>`), the reference's own alternative
+    (advoc/spectral.py:294-311)."""
+    if phase_estimation == 'lws':
+      return spectral.magspec_to_waveform_lws(np.asarray(mag_spec), self.NFFT, self.NHOP)
+    if phase_estimation[:2] != 'gl':
+      raise ValueError()
+    return spectral.magspec_to_waveform_griffin_lim(np.asarray(mag_spec, dtype=np.float64), self.NFFT, self.NHOP,
+                                                    int(phase_estimation[2:]))

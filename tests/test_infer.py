@@ -67,3 +67,34 @@ def test_inference_is_stochastic_like_the_reference(hip):
   b = vocode_melspec(m, spec, chunk_batch=2)
   assert a.shape == b.shape == (40, 513, 1) and np.isfinite(a).all()
   assert not np.array_equal(a, b)
+
+
+@gpu
+def test_vocoding_script_writes_wavs(hip, tmp_path):
+  """scripts/spectrogram_advoc.py end to end in its checkpoint-free (pseudo-inverse) mode and
+  SpectralUtil.audio_from_mag_spec: mel .npy in, PCM16 .wav out (reference :75-97)."""
+  import os
+  import subprocess
+  import sys
+  from advoc_amd.audioio import decode_audio
+  from advoc_amd.spectral_util import SpectralUtil
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec_dir, out_dir = tmp_path / 'specs', tmp_path / 'out'
+  spec_dir.mkdir()
+  rng = np.random.default_rng(0)
+  np.save(spec_dir / 'utt0.npy', rng.uniform(0.3, 0.8, size=(50, 80, 1)))
+  np.save(spec_dir / 'utt1.npy', rng.uniform(0.3, 0.8, size=(7, 80, 1)))
+  r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'spectrogram_advoc.py'), '--spec_dir', str(spec_dir),
+                      '--out_dir', str(out_dir), '--phase_estimation', 'gl5'], capture_output=True, text=True)
+  assert r.returncode == 0, r.stderr[-2000:]
+  for name, T in (('utt0', 50), ('utt1', 7)):
+    fs, wav = decode_audio(str(out_dir / (name + '.wav')), fastwav=True)
+    assert fs == 22050 and wav.shape == ((T - 1) * 256 + 1024, 1, 1)
+    assert np.isfinite(wav).all() and float(np.abs(wav).max()) > 0
+  su = SpectralUtil()
+  mag = np.abs(rng.standard_normal((12, 513, 1))).astype(np.float32)
+  np.random.seed(1)
+  x = su.audio_from_mag_spec(mag, phase_estimation='gl2')
+  assert x.shape == (11 * 256 + 1024, 1, 1) and x.dtype == np.float32
+  with pytest.raises(NotImplementedError):
+    su.audio_from_mag_spec(mag, phase_estimation='lws')
