@@ -345,6 +345,14 @@ __global__ __launch_bounds__(256) void phase_project_kernel(float2* __restrict__
   spec[i] = a > 0.f ? make_float2(m * (x.x / a), m * (x.y / a)) : make_float2(m, 0.f);
 }
 
+// out[i] = |spec[i]|  (tf.abs of a complex64 tensor, advoc/loader.py:128 / spectral.py:203)
+__global__ __launch_bounds__(256) void cabs_kernel(const float2* __restrict__ spec, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float2 x = spec[i];
+  out[i] = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);
+}
+
 // spec = |mag| * exp(2 pi i u)   advoc/spectral.py:301-304
 __global__ __launch_bounds__(256) void polar_kernel(const float* __restrict__ mag, const float* __restrict__ u,
                                                     float2* __restrict__ spec, int64_t n) {
@@ -435,6 +443,19 @@ extern "C" int advoc_phase_project_c64(float* spec, const float* mag, int64_t n,
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(phase_project_kernel, dim3((unsigned)blocks), dim3(256), 0, advoc::as_stream(stream),
                      reinterpret_cast<float2*>(spec), mag, n);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+extern "C" int advoc_cabs_f32(const float* spec, float* out, int64_t n, advoc_stream_t stream) {
+  if (n < 0) return ADVOC_ERR_BAD_SHAPE;
+  if (n == 0) return ADVOC_OK;
+  if (!spec || !out) return ADVOC_ERR_NULL;
+  const int64_t blocks = advoc::ceil_div(n, 256);
+  if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(cabs_kernel, dim3((unsigned)blocks), dim3(256), 0, advoc::as_stream(stream),
+                     reinterpret_cast<const float2*>(spec), out, n);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }

@@ -162,9 +162,43 @@ def _run_stft(wav2d, nfft, nhop, nframes, complex_out):
   fn = _lib.load().advoc_stft_c64 if complex_out else _lib.load().advoc_stft_mag_f32
   if nframes == 0 or clips == 0:
     return out
+  if nfft != 1024:
+    return _run_stft_generic(wav2d, nfft, nhop, nframes, complex_out, out)
   win = _device_window(nfft, nhop)
   _lib.check(fn(_lib.ptr(wav2d), clips, n, _lib.ptr(win), _lib.ptr(_device_twiddle(nfft)), nfft, nhop,
                 nframes, _lib.ptr(out), _lib.stream()), 'advoc_stft')
+  return out
+
+
+def _dft_basis(nfft, nhop):
+  """[2*bins, nfft] float32: rows (2k, 2k+1) = window * (cos, -sin)(2 pi k n / nfft), float64 on the host."""
+  def make():
+    n = np.arange(nfft, dtype=np.float64)
+    k = np.arange(nfft // 2 + 1, dtype=np.float64)
+    ang = 2.0 * np.pi * np.outer(k, n) / nfft
+    w = _lws_window_f64(nfft, nhop).astype(np.float32).astype(np.float64)     # the fp32 window, as TF applies it
+    basis = np.empty((2 * k.shape[0], nfft), dtype=np.float64)
+    basis[0::2] = np.cos(ang) * w[None, :]
+    basis[1::2] = -np.sin(ang) * w[None, :]
+    return torch.from_numpy(basis.astype(np.float32))
+  return _device_const(('dft', nfft, nhop), make)
+
+
+def _run_stft_generic(wav2d, nfft, nhop, nframes, complex_out, out):
+  """Any frame length (the Tacotron-2 preset uses nfft 1200 / hop 300, spectral.py:241-247): the
+  windowed DFT is one [frames, nfft] x [nfft, 2*bins] product on advoc_matmul_nt_f32.  Not a hot
+  path -- training and vocoding run the fused 1024-point kernel."""
+  clips, n = wav2d.shape
+  need = (nframes - 1) * nhop + nfft
+  if need > n:
+    wav2d = torch.nn.functional.pad(wav2d, (0, need - n))
+  frames = wav2d.unfold(1, nfft, nhop)[:, :nframes].contiguous()          # data movement only
+  spec = matmul_last(frames, _dft_basis(nfft, nhop))                       # [clips, T, 2*bins]
+  if complex_out:
+    out.copy_(spec.reshape(out.shape))
+    return out
+  _lib.check(_lib.load().advoc_cabs_f32(_lib.ptr(spec), _lib.ptr(out), out.numel(), _lib.stream()),
+             'advoc_cabs_f32')
   return out
 
 

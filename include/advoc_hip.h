@@ -80,6 +80,10 @@ int advoc_istft_f32(const float* spec, int64_t batch, int64_t nframes, const flo
  * phase 0 where spec[i] == 0 (numpy: angle(0) == 0).  n complex elements, in place. */
 int advoc_phase_project_c64(float* spec, const float* mag, int64_t n, advoc_stream_t stream);
 
+/* out[i] = |spec[i]| for n complex64 elements (tf.abs, advoc/loader.py:128).  Used by the generic-nfft
+ * STFT path (DFT as a matmul through advoc_matmul_nt_f32); the 1024-point kernel fuses it. */
+int advoc_cabs_f32(const float* spec, float* out, int64_t n, advoc_stream_t stream);
+
 /* Griffin-Lim initialisation (advoc/spectral.py:301-304): spec[i] = |mag[i]| * exp(2 pi i * unit_phase[i]),
  * unit_phase in [0, 1). */
 int advoc_polar_c64(const float* mag, const float* unit_phase, float* spec, int64_t n, advoc_stream_t stream);

@@ -221,3 +221,33 @@ def test_error_behaviour(S):
     S.waveform_to_melspec_tf(np.zeros((1, 2048, 1, 1), np.float32), 22050, 1024, 256,
                              norm_allow_clipping=False)
   assert tuple(S.stft_tf(np.zeros((2, 0, 1, 1), np.float32), 1024, 256).shape) == (2, 0, 513, 1)
+
+
+@gpu
+@pytest.mark.parametrize('nfft,nhop', [(1200, 300), (512, 128), (2048, 512)])
+def test_other_frame_lengths_via_dft_matmul(S, nfft, nhop):
+  """nfft != 1024 (the Tacotron-2 preset, reference spectral.py:241-247) runs the windowed DFT as a
+  matmul; same framing rules, same bar."""
+  rng = np.random.default_rng(nfft)
+  x = (0.3 * rng.standard_normal((2, 5000, 1, 1))).astype(np.float32)
+  for pad_end in (True, False):
+    got = S.stft_tf(x, nfft, nhop, pad_end=pad_end).cpu().numpy()
+    want = O.stft_tf(x, nfft, nhop, pad_end=pad_end)
+    assert got.shape == want.shape and got.dtype == np.complex64
+    assert rel_l2(got, want) < 1e-5
+    mag = S.stft_magnitude(x, nfft, nhop, pad_end=pad_end).cpu().numpy()
+    assert rel_l2(mag, O.stft_mag_f64(x, nfft, nhop, pad_end=pad_end)) < REL_L2 / 10
+  x1 = x[0, :, :, :]
+  X = S.stft(x1, nfft, nhop)
+  Xo = O.stft(x1, nfft, nhop)
+  assert X.shape == Xo.shape and X.dtype == np.complex128 and rel_l2(X, Xo) < 1e-5
+
+
+@gpu
+def test_tacotron2_preset(S):
+  rng = np.random.default_rng(9)
+  x = (0.2 * rng.standard_normal((24000, 1, 1))).astype(np.float32)
+  got = S.waveform_to_tacotron2_melspec(x)
+  want = O.waveform_to_tacotron2_melspec(x)
+  assert got.shape == want.shape == (80, 80, 1) and got.dtype == np.float64     # 24000 / 300 frames
+  assert np.abs(got - want).max() < 1e-4
