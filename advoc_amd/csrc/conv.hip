@@ -33,9 +33,12 @@ int validate_layer(const advoc_conv_layer* L) {
     if ((int64_t)(y.h - 1) * L->sh - L->pad_t >= x0.h || (int64_t)(y.w - 1) * L->sw - L->pad_l >= x0.w)
       return ADVOC_ERR_BAD_SHAPE;
   } else {
-    if (L->kh != 4 || L->kw != 4 || L->sh != 2 || L->sw != 2 || L->pad_t != 1 || L->pad_l != 1)
+    // strides (2,2), and (1,2) for the layers the reference builds once the time axis has
+    // shrunk to 1 (advoc_model.py:109-116,139-142)
+    if (L->kh != 4 || L->kw != 4 || L->sh < 1 || L->sh > 2 || L->sw < 1 || L->sw > 2 || L->pad_t != 1 ||
+        L->pad_l != 1)
       return ADVOC_ERR_UNSUPPORTED;
-    if (y.h != 2 * x0.h || y.w > 2 * x0.w || y.w < 2 * x0.w - 1) return ADVOC_ERR_BAD_SHAPE;
+    if (y.h != L->sh * x0.h || y.w > L->sw * x0.w || y.w < L->sw * x0.w - 1) return ADVOC_ERR_BAD_SHAPE;
   }
   return ADVOC_OK;
 }
@@ -44,16 +47,16 @@ namespace {
 
 int cin_of(const advoc_conv_layer* L) { return L->x0.c + (L->x1.p ? L->x1.c : 0); }
 
-// taps of one sub-pixel phase of a stride-2 transposed gather:
-//   out index o = 2 g + par reads in index g + d for every k with (par + pad - k) even,
-//   d = (par + pad - k) / 2
-int phase_taps(int par, int pad, int ksize, int* ks, int* ds) {
+// taps of one sub-pixel phase of a stride-s transposed gather (s = 1 or 2):
+//   out index o = s g + par reads in index g + d for every k with s | (par + pad - k),
+//   d = (par + pad - k) / s
+int phase_taps(int par, int pad, int ksize, int s, int* ks, int* ds) {
   int n = 0;
   for (int k = 0; k < ksize; ++k) {
     const int t = par + pad - k;
-    if ((t & 1) == 0) {
+    if (s == 1 || (t & 1) == 0) {
       ks[n] = k;
-      ds[n] = t / 2;   // t even: exact for negatives too
+      ds[n] = t / s;   // exact (t even when s == 2), also for negatives
       ++n;
     }
   }
@@ -71,16 +74,18 @@ void dense_taps(GatherGemmParams& p, const advoc_conv_layer* L, bool flipped) {
 }
 
 int subpixel_taps(GatherGemmParams& p, const advoc_conv_layer* L) {
+  if (L->sh > 2 || L->sw > 2) return ADVOC_ERR_UNSUPPORTED;
   p.sy = p.sx = 1;
-  p.osy = p.osx = 2;
-  p.nphase = 4;
-  for (int py = 0; py < 2; ++py)
-    for (int px = 0; px < 2; ++px) {
+  p.osy = L->sh;
+  p.osx = L->sw;
+  p.nphase = L->sh * L->sw;
+  for (int py = 0; py < L->sh; ++py)
+    for (int px = 0; px < L->sw; ++px) {
       int kys[kMaxTaps], dys[kMaxTaps], kxs[kMaxTaps], dxs[kMaxTaps];
-      const int ny = phase_taps(py, L->pad_t, L->kh, kys, dys);
-      const int nx = phase_taps(px, L->pad_l, L->kw, kxs, dxs);
-      if (ny * 2 != L->kh || nx * 2 != L->kw) return ADVOC_ERR_UNSUPPORTED;  // even kernels only
-      const int ph = py * 2 + px;
+      const int ny = phase_taps(py, L->pad_t, L->kh, L->sh, kys, dys);
+      const int nx = phase_taps(px, L->pad_l, L->kw, L->sw, kxs, dxs);
+      if (ny * L->sh != L->kh || nx * L->sw != L->kw) return ADVOC_ERR_UNSUPPORTED;  // same tap count in every phase
+      const int ph = py * L->sw + px;
       p.ntaps = ny * nx;
       for (int a = 0; a < ny; ++a)
         for (int b = 0; b < nx; ++b)
@@ -115,7 +120,7 @@ int build_forward(const advoc_conv_layer* L, GatherGemmParams& p, bool& b_kn) {
     b_kn = true;    // kernel [kh,kw,ci,co]: K rows, N contiguous
     return ADVOC_OK;
   }
-  // transposed conv, stride 2: four dense sub-pixel phases over the INPUT grid
+  // transposed conv: sh x sw dense sub-pixel phases over the INPUT grid
   p.gh = L->x0.h; p.gw = L->x0.w;
   b_kn = false;     // kernel [kh,kw,co,ci]: N rows, K contiguous
   return subpixel_taps(p, L);
@@ -161,8 +166,7 @@ int build_backward_data(const advoc_conv_layer* L, const float* dy, float* dx0, 
     dense_taps(p, L, true);
     return ADVOC_OK;
   }
-  if (L->sh != 2 || L->sw != 2) return ADVOC_ERR_UNSUPPORTED;
-  p.gh = (L->x0.h + 1) / 2; p.gw = (L->x0.w + 1) / 2;
+  p.gh = (L->x0.h + L->sh - 1) / L->sh; p.gw = (L->x0.w + L->sw - 1) / L->sw;
   return subpixel_taps(p, L);
 }
 

@@ -147,9 +147,33 @@ class Advoc(Model):
                                 .format(self.generator_type))
     if self.separable_conv:
       raise NotImplementedError('separable_conv=True is a non-default ablation outside the hot path')
-    if self.subseq_len % (2 ** len(self._encoder_channels())):
-      raise NotImplementedError('subseq_len must be a multiple of 2^#encoders; the (1,2)-stride '
-                                'layers of advoc_model.py:115-120 are outside the BASELINE configs')
+    # the skip concats only line up when halving (SAME: ceil) and doubling retrace each other;
+    # the reference's TF graph fails to build otherwise (tf.concat shape error)
+    h, hs = int(self.subseq_len), []
+    for sh, _ in self._encoder_strides():
+      h = -(-h // sh)
+      hs.append(h)
+    hd = hs[-1]
+    n1 = sum(1 for st in self._encoder_strides() if st == (1, 2))
+    for j in range(len(hs) - 1):
+      hd *= 1 if j < n1 else 2
+      if hd != hs[len(hs) - 2 - j]:
+        raise ValueError('subseq_len {}: decoder heights do not match the encoder skips'.format(self.subseq_len))
+    if 2 * hs[0] != int(self.subseq_len):
+      raise ValueError('subseq_len must be even')
+
+  def _encoder_strides(self):
+    """advoc_model.py:90-116: (2,2) while the reference's running `n_time` (halved as a float per
+    layer) is > 1, then (1,2): the time axis has collapsed, only frequency is down-sampled."""
+    n_time = self.subseq_len / 2
+    out = [(2, 2)]
+    for _ in range(len(self._encoder_channels()) - 1):
+      if n_time > 1:
+        out.append((2, 2))
+        n_time /= 2
+      else:
+        out.append((1, 2))
+    return out
 
   def variable_specs(self):
     """TF variable names and shapes.  Generator entries are ordered decoder_1 .. decoder_N,
@@ -267,15 +291,18 @@ class Advoc(Model):
     st['gen_out'] = gen_out
     e, ge = [], []
     h, w = T, F
-    for c in enc_c:
-      h, w = -(-h // 2), -(-w // 2)
+    enc_s = self._encoder_strides()
+    n_stride1 = sum(1 for st_ in enc_s if st_ == (1, 2))
+    dec_s = [(1, 2) if j < n_stride1 else (2, 2) for j in range(len(dec))]     # advoc_model.py:139-142
+    for c, (sh_, sw_) in zip(enc_c, enc_s):
+      h, w = -(-h // sh_), -(-w // sw_)
       e.append(torch.zeros(B, h, w, c, **f32))
       ge.append(torch.zeros(B, h, w, c, **f32))
     st['enc'], st['g_enc'] = e, ge
     d, gd, masks = {}, {}, {}
     for j, (idx, c, drop) in enumerate(dec):
       src = e[-1] if j == 0 else d[dec[j - 1][0]]
-      hh = src.shape[1] * 2
+      hh = src.shape[1] * dec_s[j][0]
       ww = (src.shape[2] if j == 0 else e[idx - 1].shape[2]) * 2
       d[idx] = torch.zeros(B, hh, ww, c, **f32)
       gd[idx] = torch.zeros(B, hh, ww, c, **f32)     # trimmed column is never written by backward
@@ -322,11 +349,11 @@ class Advoc(Model):
     for i, c in enumerate(enc_c):
       s = 'generator/encoder_%d/conv2d' % (i + 1)
       src = x if i == 0 else e[i - 1]
-      pt, _ = C.same_pad(src.shape[1], 4, 2)
-      pl, _ = C.same_pad(src.shape[2], 4, 2)
+      pt, _ = C.same_pad(src.shape[1], 4, enc_s[i][0])
+      pl, _ = C.same_pad(src.shape[2], 4, enc_s[i][1])
       sc, sh = aff_of('encoder_%d' % i) if i > 0 else (None, None)
       L['encoder_%d' % (i + 1)] = C.Layer(C.CONV, src, e[i], P[s + '/kernel'], P[s + '/bias'],
-                                          stride=(2, 2), pad=(pt, pl),
+                                          stride=enc_s[i], pad=(pt, pl),
                                           in_act=C.ACT_NONE if i == 0 else C.ACT_LRELU,
                                           in_scale=sc, in_shift=sh)
     for j, (idx, c, drop) in enumerate(dec):
@@ -344,7 +371,7 @@ class Advoc(Model):
       # Without BN the producer applies its own dropout in its epilogue.  With BN dropout acts
       # AFTER the normalisation (advoc_model.py:142-149), i.e. on the consumer's loads.
       L['decoder_%d' % idx] = C.Layer(
-          C.DECONV, x0, d[idx], P[s + '/kernel'], P[s + '/bias'], x1=x1, in_w=in_w, stride=(2, 2),
+          C.DECONV, x0, d[idx], P[s + '/kernel'], P[s + '/bias'], x1=x1, in_w=in_w, stride=dec_s[j],
           pad=(1, 1), in_act=C.ACT_RELU,
           drop_mask=mk[0] if (mk and not bn_on) else None, drop_scale=1.0 / mk[1] if (mk and not bn_on) else 0.,
           in_scale=sc, in_shift=sh,

@@ -159,10 +159,27 @@ def gen_conv(x, kernel, bias, strides=(2, 2)):
   return _nhwc(F.conv2d(xp, kernel.permute(3, 2, 0, 1).contiguous(), bias, stride=strides))
 
 
-def gen_deconv(x, kernel, bias):
-  # SAME, stride (2,2): output exactly 2x input == torch padding 1
-  return _nhwc(F.conv_transpose2d(_nchw(x), kernel.permute(3, 2, 0, 1).contiguous(), bias, stride=2,
-                                  padding=1))
+def gen_deconv(x, kernel, bias, strides=(2, 2)):
+  # tf.layers.conv2d_transpose(k=4, 'same') is the input-gradient of a SAME conv: output = stride x
+  # input, and the (k - s) implicit padding puts 1 row/column BEFORE (the smaller share, as SAME
+  # does) for s = 2 and for s = 1 alike.  Full transposed conv, then crop [1, 1 + s*n).
+  full = F.conv_transpose2d(_nchw(x), kernel.permute(3, 2, 0, 1).contiguous(), bias, stride=strides, padding=0)
+  oh, ow = strides[0] * x.shape[1], strides[1] * x.shape[2]
+  return _nhwc(full[:, :, 1:1 + oh, 1:1 + ow])
+
+
+def encoder_strides(cfg):
+  """advoc_model.py:90-116: encoder_1 always strides (2,2); later encoders stride (2,2) while the
+  running n_time (a float: `n_time /= 2`) is > 1, then (1,2).  Returns the list for encoder_1..N."""
+  n_time = cfg.subseq_len / 2
+  out = [(2, 2)]
+  for _ in range(cfg.num_enc_layers):
+    if n_time > 1:
+      out.append((2, 2))
+      n_time /= 2
+    else:
+      out.append((1, 2))
+  return out
 
 
 def discrim_conv(x, kernel, bias, stride):
@@ -188,12 +205,14 @@ def dropout_shapes(cfg, batch):
   shapes = {}
   enc = cfg.encoder_channels()
   h, w = cfg.subseq_len, cfg.nbins
-  for _ in enc:
-    h, w = -(-h // 2), -(-w // 2)
+  es = encoder_strides(cfg)
+  n_stride1 = sum(1 for st in es if st == (1, 2))
+  for sh, sw in es:
+    h, w = -(-h // sh), -(-w // sw)
   for j, (idx, c, drop) in enumerate(cfg.decoder_specs()):
     if j > 0:
       w -= 1
-    h, w = h * 2, w * 2
+    h, w = h * (1 if j < n_stride1 else 2), w * 2
     if drop > 0:
       shapes['decoder_%d' % idx] = (batch, h, w, c)
   return shapes
@@ -206,8 +225,8 @@ def make_dropout_masks(cfg, batch, seed, dtype=torch.float32):
 
 
 def build_generator(P, x, cfg, masks, collect=None):
-  if cfg.subseq_len < 2 ** (1 + cfg.num_enc_layers):
-    raise NotImplementedError('(1,2)-stride layers (advoc_model.py:115-120) are outside BASELINE configs')
+  es = encoder_strides(cfg)
+  n_stride1 = sum(1 for st in es if st == (1, 2))
   bnorm = (lambda t, s: batchnorm(t, P[s + '/batch_normalization/gamma'],
                                   P[s + '/batch_normalization/beta'])) if cfg.use_batchnorm else (lambda t, s: t)
   layers = []
@@ -215,12 +234,13 @@ def build_generator(P, x, cfg, masks, collect=None):
   layers.append(gen_conv(x, P[s + '/conv2d/kernel'], P[s + '/conv2d/bias']))
   for i in range(1, 1 + cfg.num_enc_layers):
     s = 'generator/encoder_%d' % (i + 1)
-    out = gen_conv(lrelu(layers[-1]), P[s + '/conv2d/kernel'], P[s + '/conv2d/bias'])
+    out = gen_conv(lrelu(layers[-1]), P[s + '/conv2d/kernel'], P[s + '/conv2d/bias'], strides=es[i])
     layers.append(bnorm(out, s))
   for j, (idx, c, drop) in enumerate(cfg.decoder_specs()):
     s = 'generator/decoder_%d' % idx
     inp = layers[-1] if j == 0 else torch.cat([layers[-1][:, :, :-1, :], layers[idx - 1]], dim=3)
-    out = gen_deconv(torch.relu(inp), P[s + '/conv2d_transpose/kernel'], P[s + '/conv2d_transpose/bias'])
+    out = gen_deconv(torch.relu(inp), P[s + '/conv2d_transpose/kernel'], P[s + '/conv2d_transpose/bias'],
+                     strides=(1, 2) if j < n_stride1 else (2, 2))       # advoc_model.py:139-142
     out = bnorm(out, s)
     if drop > 0:
       out = dropout(out, masks['decoder_%d' % idx], 1 - drop)

@@ -47,11 +47,21 @@ def test_override_model_attrs():
 
 def test_unsupported_ablations_fail_loudly():
   from advoc_amd.model import Advoc, Modes
-  for ov in ('generator_type=linear', 'separable_conv=True', 'subseq_len=100'):
-    from advoc_amd.model import override_model_attrs
+  from advoc_amd.model import override_model_attrs
+  for ov in ('generator_type=linear', 'separable_conv=True'):
     m, _ = override_model_attrs(Advoc(Modes.TRAIN), ov)
     with pytest.raises(NotImplementedError):
       m._check_supported()
+  # a clip length whose halvings and doublings do not retrace each other cannot be built in the
+  # reference either (tf.concat shape error at advoc_model.py:137)
+  m, _ = override_model_attrs(Advoc(Modes.TRAIN), 'subseq_len=100')
+  with pytest.raises(ValueError):
+    m._check_supported()
+  # shorter power-of-two clips use the (1,2)-stride layers (advoc_model.py:109-116): supported
+  for n, want in ((64, 2), (32, 3), (256, 0)):
+    m, _ = override_model_attrs(Advoc(Modes.TRAIN), 'subseq_len=%d' % n)
+    m._check_supported()
+    assert sum(1 for st in m._encoder_strides() if st == (1, 2)) == want
 
 
 @gpu

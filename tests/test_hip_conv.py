@@ -44,7 +44,7 @@ def oracle_layer(kind, x0, x1, in_w, w, b, stride, pad, act, mask, keep, out_w, 
     y = torch.nn.functional.conv2d(xp, w.permute(3, 2, 0, 1).contiguous(), b, stride=stride).permute(0, 2, 3, 1)
     y = y[:, :oh, :ow]
   else:
-    y = A.gen_deconv(inp, w, b)[:, :, :out_w, :]
+    y = A.gen_deconv(inp, w, b, strides=stride)[:, :, :out_w, :]
   if mask is not None:
     y = (y / keep) * mask.double()[:, :, :out_w]
   g = torch.autograd.grad(y, [x0, w, b] + ([x1] if x1 is not None else []), dy.double()[:, :, :out_w])
@@ -67,6 +67,11 @@ CASES = [
     ('d2_even',        0, (2, 16, 32), 32, 0, 64, 0, (2, 2), (1, 1), 1, False, 0),
     ('d4_s1',          0, (2, 9, 12), 64, 0, 128, 0, (1, 1), (1, 1), 1, False, 0),
     ('d5_cout1',       0, (2, 9, 11), 128, 0, 1, 0, (1, 1), (1, 1), 1, False, 0),
+    # time axis collapsed (subseq_len 64 with 8 encoders, advoc_model.py:109-116,139-142): strides (1,2)
+    ('enc_s12_h1',     0, (3, 1, 9), 64, 0, 64, 0, (1, 2), None, 1, False, 0),
+    ('enc_s12_h2',     0, (2, 2, 17), 32, 0, 64, 0, (1, 2), None, 1, False, 0),
+    ('dec_s12_first',  1, (3, 1, 5), 64, 0, 64, 0, (1, 2), (1, 1), 2, True, 0),
+    ('dec_s12_skip',   1, (2, 1, 9), 64, 64, 32, 1, (1, 2), (1, 1), 2, False, 0),
 ]
 
 
@@ -88,7 +93,7 @@ def build_case(case, seed=0):
     w = torch.randn(4, 4, cin, cout, generator=g) * 0.05
   else:
     pt, pl = 1, 1
-    oh, ow = 2 * H, 2 * W - clip
+    oh, ow = stride[0] * H, stride[1] * W - clip
     w = torch.randn(4, 4, cout, cin, generator=g) * 0.05
   b = torch.randn(cout, generator=g) * 0.1
   mask = (torch.rand(B, oh, ow, cout, generator=g) >= 0.5).to(torch.uint8) if drop else None

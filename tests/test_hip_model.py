@@ -61,7 +61,10 @@ def dev_masks(masks):
 
 @gpu
 @pytest.mark.parametrize('small,T,B,bn', [(True, 32, 2, False), (True, 64, 1, False), (False, 256, 1, False),
-                                          (True, 32, 2, True), (True, 64, 3, True)])
+                                          (True, 32, 2, True), (True, 64, 3, True),
+                                          # (1,2)-stride layers: encoder_7/8 + decoder_8/7 of the full model at 64
+                                          # frames (the SC09 setting, models/advoc/melspecVocoder.py:114)
+                                          (False, 64, 1, False), (False, 64, 2, True)])
 def test_forward_losses_and_gradients(hip, small, T, B, bn):
   cfg, P, m = make(small, T, B, bn=bn)
   x, target = batch(B, T, 5)
@@ -95,8 +98,11 @@ def test_forward_losses_and_gradients(hip, small, T, B, bn):
   m._lr = 0.0           # freeze parameters: inspect raw gradients
   m.d_step((xb, tb))
   assert abs(m.losses()['disc_loss'] - float(LD['d_loss'])) < 1e-4 * max(1, abs(float(LD['d_loss'])))
+  gD32, _ = A.grads(P, x, target, cfg, masks, 'D')
   for k, v in gD.items():
-    assert close(st['d_G'][k], v, GRAD_BAR), (k, rel(st['d_G'][k], v))
+    # judged like the G gradients below: against the bar, or against what plain fp32 evaluation of the
+    # same graph achieves where a leaky-ReLU gate sits within round-off of 0 (batch-norm cases)
+    assert close(st['d_G'][k], v, max(GRAD_BAR, 3 * rel(gD32[k], v))), (k, rel(st['d_G'][k], v), rel(gD32[k], v))
 
   # G step gradients + losses
   gG, LG = A.grads(P64, x.double(), target.double(), cfg, m64, 'G')
