@@ -175,27 +175,56 @@ __global__ __launch_bounds__(256) void gather_outer_kernel(const GatherGemmParam
 }
 
 // ---------------------------------------------------------------------------------------------
-// tap_sum: out[g, n] = bias[n] + sum_t S[g*s + d_t][wtap_t * N + n]   (thread per grid point)
+// tap_sum: out[g, n] = bias[n] + sum_t S[g*s + d_t][wtap_t * N + n]
+// A workgroup owns a TY x TX patch of grid points of one image.  The S rows/columns its taps can
+// reach are staged in LDS ONCE with coalesced 16-byte loads (zeros outside the image), pixel
+// stride SC + 1 words so that the per-lane gathers are bank-conflict free; every S value is used
+// by exactly one (phase, tap) of one grid point, so HBM sees S once.
 // ---------------------------------------------------------------------------------------------
+constexpr int kTsTX = 64, kTsTY = 4;
+
 __global__ __launch_bounds__(256) void tap_sum_kernel(const GatherGemmParams p, const float* __restrict__ S,
-                                                      int sc) {
+                                                      int sc, int dy_min, int dx_min, int ry, int rx,
+                                                      int tiles_y, int tiles_x) {
+  extern __shared__ __attribute__((aligned(16))) float s_patch[];   // [ry][rx][sc + 1]
   __shared__ int s_tap[kMaxPhases][kMaxTaps];
   if (threadIdx.x < kMaxPhases * kMaxTaps) s_tap[threadIdx.x / kMaxTaps][threadIdx.x % kMaxTaps] =
       p.tap[threadIdx.x / kMaxTaps][threadIdx.x % kMaxTaps];
+  int b = blockIdx.x;
+  const int tx_i = b % tiles_x; b /= tiles_x;
+  const int ty_i = b % tiles_y;
+  const int img = b / tiles_y;
+  const int gy0 = ty_i * kTsTY, gx0 = tx_i * kTsTX;
+  const int iy0 = gy0 * p.sy + dy_min, ix0 = gx0 * p.sx + dx_min;
+  const int ld = sc + 1;
+  const int quads = sc / 4;
+  // stage: one float4 of one pixel per thread per step
+  for (int i = threadIdx.x; i < ry * rx * quads; i += 256) {
+    const int q = i % quads;
+    const int pix = i / quads;
+    const int px = pix % rx, py = pix / rx;
+    const int iy = iy0 + py, ix = ix0 + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w)
+      v = *reinterpret_cast<const float4*>(S + (((int64_t)img * p.in_h + iy) * p.in_w + ix) * sc + 4 * q);
+    float* dst = s_patch + pix * ld + 4 * q;
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+  }
   __syncthreads();
-  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
-  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
-  const GridPoint g = decompose(m, p.gh, p.gw);
+  GridPoint g;
+  g.img = img;
+  g.gy = gy0 + threadIdx.x / kTsTX;
+  g.gx = gx0 + threadIdx.x % kTsTX;
+  if (g.gy >= p.gh || g.gx >= p.gw) return;
+  const int ly = (g.gy - gy0) * p.sy - dy_min, lx = (g.gx - gx0) * p.sx - dx_min;
   const int N = p.n_total;
   for (int phase = 0; phase < p.nphase; ++phase) {
     float acc0 = 0.f, acc1 = 0.f;
     for (int t = 0; t < p.ntaps; ++t) {
       const int tp = s_tap[phase][t];
-      const int iy = g.gy * p.sy + (int)(int8_t)(tp & 0xff);
-      const int ix = g.gx * p.sx + (int)(int8_t)((tp >> 8) & 0xff);
-      if ((unsigned)iy >= (unsigned)p.in_h || (unsigned)ix >= (unsigned)p.in_w) continue;
-      const float* row = S + (((int64_t)g.img * p.in_h + iy) * p.in_w + ix) * sc + (tp >> 16) * N;
+      const int py = ly + (int)(int8_t)(tp & 0xff);
+      const int px = lx + (int)(int8_t)((tp >> 8) & 0xff);
+      const float* row = s_patch + (py * rx + px) * ld + (tp >> 16) * N;
       acc0 += row[0];
       if (N > 1) acc1 += row[1];
     }
@@ -209,11 +238,29 @@ __global__ __launch_bounds__(256) void tap_sum_kernel(const GatherGemmParams p, 
 int launch_tap_sum(const GatherGemmParams& p, const float* S, int s_channels, hipStream_t stream,
                    const char** name_only) {
   if (name_only) { *name_only = "tap_sum_kernel"; return ADVOC_OK; }
-  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
-  const int64_t blocks = ceil_div(M, 256);
+  if (s_channels % 4) return ADVOC_ERR_UNSUPPORTED;
+  int dy_min = 127, dy_max = -128, dx_min = 127, dx_max = -128;
+  for (int ph = 0; ph < p.nphase; ++ph)
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int dy = (int)(int8_t)(p.tap[ph][t] & 0xff), dx = (int)(int8_t)((p.tap[ph][t] >> 8) & 0xff);
+      dy_min = dy < dy_min ? dy : dy_min; dy_max = dy > dy_max ? dy : dy_max;
+      dx_min = dx < dx_min ? dx : dx_min; dx_max = dx > dx_max ? dx : dx_max;
+    }
+  const int ry = (kTsTY - 1) * p.sy + (dy_max - dy_min) + 1;
+  const int rx = (kTsTX - 1) * p.sx + (dx_max - dx_min) + 1;
+  const size_t lds = sizeof(float) * (size_t)ry * rx * (s_channels + 1);
+  if (lds > 150 * 1024) return ADVOC_ERR_UNSUPPORTED;
+  const int tiles_y = (int)ceil_div(p.gh, kTsTY), tiles_x = (int)ceil_div(p.gw, kTsTX);
+  const int64_t blocks = (int64_t)p.batch * tiles_y * tiles_x;
   if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_sum_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }
+  }
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(tap_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, S, s_channels);
+  hipLaunchKernelGGL(tap_sum_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, p, S, s_channels, dy_min,
+                     dx_min, ry, rx, tiles_y, tiles_x);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }
