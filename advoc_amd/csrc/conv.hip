@@ -211,7 +211,10 @@ int run_gather(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const c
   if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0)
     return launch_gather_gemm(p, b_kn, stream, name_only);
   if (N <= 2 && K % 4 == 0 && p.c0 % 4 == 0) return launch_gather_dot(p, b_kn, stream, name_only);
-  if (K <= 2 && N % 32 == 0 && p.ntaps * K <= 32) return launch_thin_k_gemm(p, b_kn, stream, name_only);
+  if (K <= 2 && N % 32 == 0 && p.ntaps * K <= 32) {
+    const int rc = launch_thin_k_gemm(p, b_kn, stream, name_only);
+    if (rc != ADVOC_ERR_UNSUPPORTED) return rc;     // tap span beyond the LDS patch: direct kernel below
+  }
   if (K <= 2) return launch_gather_outer(p, b_kn, stream, name_only);
   return ADVOC_ERR_UNSUPPORTED;
 }

@@ -45,13 +45,26 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
 // Per-slot gather constants and the weight tile live in LDS (read back with conflict-free
 // ds_read_b32), so a wave needs ~16 NT accumulator registers + KP/2 operands: 4-8 waves per SIMD
 // cover the HBM latency of this streaming kernel.
-template <int KP, int NT, bool B_KN>
-__global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams p, int n_base_tiles) {
+constexpr int kThinPatchRows = 4;                       // tap rows a tile can reach
+constexpr int kThinPatchCols = 31 * 2 + 4;              // 32 grid points at stride <= 2 + tap span
+constexpr int kThinPatch = kThinPatchRows * kThinPatchCols * 2;   // x up to 2 channels
+
+// PL: patch elements per lane (ceil(pr * pc * ktot / 64)); a template parameter because the fetch
+// registers (value + mask factor + coordinates per element) decide the occupancy of the wide-N cases
+template <int KP, int NT, bool B_KN, int PL>
+__global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams p, int dy_min, int dx_min,
+                                                          int pr, int pc, int tiles_x) {
   __shared__ int s_pix[4][2][32];
-  __shared__ int s_delta[KP];     // element offset of slot k' relative to the row base of its source
-  __shared__ int s_info[KP];      // (dy & 0xff) | (dx & 0xff) << 8 | valid << 16 | second << 17 | ci << 18
+  __shared__ int s_delta[KP];     // LDS-patch offset of slot k' relative to the lane's column origin
+  __shared__ int s_info[KP];      // valid << 16 | ci << 18
   __shared__ float s_w[KP][32 * NT];
   __shared__ __attribute__((aligned(16))) float s_T[4][32 * 36];
+  // The 1-2 channel input a tile of 32 grid points (one grid row) reads: pr tap rows x pc columns
+  // x ktot channels, staged per wave with coalesced loads (zeros outside the image, affine /
+  // activation / mask applied once here), so the 16-32 operand gathers per lane are ds_reads at
+  // tile-invariant offsets.  Gathering them from global memory made this kernel latency-bound
+  // (213 -> 88 us on discriminator layer_1 with the loads stubbed out).
+  __shared__ float s_patch[4][kThinPatch];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l32 = lane & 31;
   const int phase = blockIdx.z;
@@ -59,7 +72,6 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
   const int kreal = p.ntaps * ktot;
   const int N = p.n_total;
   const int n0 = blockIdx.y * (32 * NT);
-  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   const float slope = p.in_act == ADVOC_ACT_LRELU02 ? 0.2f : (p.in_act == ADVOC_ACT_RELU ? 0.f : 1.f);
   const float gslope = p.grad_act == ADVOC_ACT_LRELU02 ? 0.2f : (p.grad_act == ADVOC_ACT_RELU ? 0.f : 1.f);
 
@@ -68,9 +80,8 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
     const int t = ok ? kk / ktot : 0, ci = ok ? kk % ktot : 0;
     const int tp = p.tap[phase][t];
     const int dy = (int)(int8_t)(tp & 0xff), dx = (int)(int8_t)((tp >> 8) & 0xff);
-    const bool second = ok && ci >= p.c0;
-    s_delta[kk] = second ? (dy * p.a1_pitch + dx) * p.c1 + (ci - p.c0) : (dy * p.a0_pitch + dx) * p.c0 + ci;
-    s_info[kk] = (dy & 0xff) | ((dx & 0xff) << 8) | ((ok ? 1 : 0) << 16) | ((second ? 1 : 0) << 17) | (ci << 18);
+    s_delta[kk] = ((dy - dy_min) * pc + (dx - dx_min)) * ktot + ci;
+    s_info[kk] = ((ok ? 1 : 0) << 16) | (ci << 18);
   }
   for (int idx = threadIdx.x; idx < KP * 32 * NT; idx += 256) {
     const int kk = idx / (32 * NT), nn = idx % (32 * NT);
@@ -89,19 +100,61 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
     const int n = n0 + 32 * j + l32;
     bias[j] = (p.bias && n < N) ? p.bias[n] : 0.f;
   }
+  // patch elements this lane stages every tile: element e = lane + 64 i -> (row, col, channel)
+  const int patch_elems = pr * pc * ktot;
+  int pe_row[PL], pe_col[PL], pe_ci[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    const int e = lane + 64 * i;
+    const int ee = e < patch_elems ? e : 0;
+    pe_ci[i] = ee % ktot;
+    const int px = ee / ktot;
+    pe_col[i] = px % pc;
+    pe_row[i] = e < patch_elems ? px / pc : -1;
+  }
   __syncthreads();
+  // this lane's K slots (k' = 2 s + half): LDS offsets relative to the tile's patch, decoded once
+  int sl_off[KP / 2];
+#pragma unroll
+  for (int s = 0; s < KP / 2; ++s) {
+    const int kk = 2 * s + half;
+    sl_off[s] = ((s_info[kk] >> 16) & 1) ? s_delta[kk] + l32 * p.sx * ktot : -1;
+  }
+  float* patch = &s_patch[wave][0];
 
-  const int64_t tiles = (M + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t m = tile * 32 + l32;
-    const bool live = m < M;
-    int img = 0, gy = 0, gx = 0;
-    if (live) {
-      gx = (int)(m % p.gw);
-      const int64_t t = m / p.gw;
-      gy = (int)(t % p.gh);
-      img = (int)(t / p.gh);
-    }
+  // tile = 32 consecutive grid points of ONE grid row (32-bit arithmetic: launch checks the range)
+  const int tiles = p.batch * p.gh * tiles_x;
+  float pv[PL], pm[PL];
+  // loads the patch of `TILE` into registers (the NEXT tile's loads fly during this tile's MFMAs
+  // and stores: a wave has no other way to overlap its own memory latency)
+#define ADVOC_THIN_FETCH(TILE)                                                                        \
+  {                                                                                                   \
+    const int rowid_ = (TILE) / tiles_x;                                                              \
+    const int gx0_ = ((TILE) - rowid_ * tiles_x) * 32;                                                \
+    const int img_ = rowid_ / p.gh, gy_ = rowid_ - img_ * p.gh;                                       \
+    const int iy0_ = gy_ * p.sy + dy_min, ix0_ = gx0_ * p.sx + dx_min;                                \
+    _Pragma("unroll") for (int i = 0; i < PL; ++i) {                                     \
+      const int iy = iy0_ + pe_row[i], ix = ix0_ + pe_col[i];                                         \
+      float v = 0.f, mk = 1.f;                                                                        \
+      if (pe_row[i] >= 0 && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) {     \
+        const bool second = pe_ci[i] >= p.c0;                                                         \
+        const int off = second ? ((img_ * p.a_h + iy) * p.a1_pitch + ix) * p.c1 + (pe_ci[i] - p.c0)   \
+                               : ((img_ * p.a_h + iy) * p.a0_pitch + ix) * p.c0 + pe_ci[i];           \
+        v = (second ? p.a1 : p.a0)[off];                                                              \
+        if (p.a_mask && !second) mk = p.a_mask[off] * p.a_mask_scale;                                 \
+      }                                                                                               \
+      pv[i] = v;                                                                                      \
+      pm[i] = mk;                                                                                     \
+    }                                                                                                 \
+  }
+  const int tile0 = blockIdx.x * 4 + wave;
+  if (tile0 < tiles) ADVOC_THIN_FETCH(tile0);
+  for (int tile = tile0; tile < tiles; tile += gridDim.x * 4) {
+    const int rowid = tile / tiles_x;
+    const int gx0 = (tile - rowid * tiles_x) * 32;
+    const int img = rowid / p.gh, gy = rowid - img * p.gh;
+    const int gx = gx0 + l32;
+    const bool live = gx < p.gw;
     if (half == 0) {   // lanes 0-31 publish their row's output pixel
       int pix0 = -1, pix1 = -1;
       const int oy = gy * p.osy + p.ooy[phase], ox = gx * p.osx + p.oox[phase];
@@ -112,30 +165,29 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
       s_pix[wave][0][l32] = pix0;
       s_pix[wave][1][l32] = pix1;
     }
-    const int y0 = gy * p.sy, x0 = gx * p.sx;
-    const int base0 = ((img * p.a_h + y0) * p.a0_pitch + x0) * p.c0;
-    const int base1 = ((img * p.a_h + y0) * p.a1_pitch + x0) * p.c1;
-    // A operand: one gathered scalar per K slot (k' = 2 s + half)
+    // ---- park the fetched patch in LDS (affine + activation here; zero padding stays zero) ----
+    {
+      const int iy0 = gy * p.sy + dy_min, ix0 = gx0 * p.sx + dx_min;
+#pragma unroll
+      for (int i = 0; i < PL; ++i) {
+        if (pe_row[i] < 0) continue;
+        float v = pv[i];
+        const int iy = iy0 + pe_row[i], ix = ix0 + pe_col[i];
+        const bool inb = (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
+        if (p.in_scale) v = inb ? v * p.in_scale[pe_ci[i]] + p.in_shift[pe_ci[i]] : 0.f;
+        v = fmaxf(v, slope * v);
+        patch[lane + 64 * i] = v * pm[i];
+      }
+    }
+    wave_lds_sync();
+    {
+      const int next = tile + gridDim.x * 4;
+      if (next < tiles) ADVOC_THIN_FETCH(next);
+    }
+    // A operand: one scalar per K slot from the patch
     float a[KP / 2];
 #pragma unroll
-    for (int s = 0; s < KP / 2; ++s) {
-      const int kk = 2 * s + half;
-      const int info = s_info[kk];
-      const int iy = y0 + (int)(int8_t)(info & 0xff), ix = x0 + (int)(int8_t)((info >> 8) & 0xff);
-      float v = 0.f;
-      if (live && ((info >> 16) & 1) && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) {
-        const bool second = (info >> 17) & 1;
-        const int off = (second ? base1 : base0) + s_delta[kk];
-        v = (second ? p.a1 : p.a0)[off];
-        if (p.in_scale) {
-          const int ci = info >> 18;
-          v = v * p.in_scale[ci] + p.in_shift[ci];
-        }
-        v = fmaxf(v, slope * v);
-        if (p.a_mask && !second) v *= p.a_mask[off] * p.a_mask_scale;
-      }
-      a[s] = v;
-    }
+    for (int s = 0; s < KP / 2; ++s) a[s] = (live && sl_off[s] >= 0) ? patch[sl_off[s]] : 0.f;
     floatx16 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -213,17 +265,42 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
     *name_only = names[i].c_str();
     return ADVOC_OK;
   }
-  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
-  const int64_t tiles = ceil_div(M, 32);
+  int dy_min = 127, dy_max = -128, dx_min = 127, dx_max = -128;
+  for (int ph = 0; ph < p.nphase; ++ph)
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int dy = (int)(int8_t)(p.tap[ph][t] & 0xff), dx = (int)(int8_t)((p.tap[ph][t] >> 8) & 0xff);
+      dy_min = dy < dy_min ? dy : dy_min; dy_max = dy > dy_max ? dy : dy_max;
+      dx_min = dx < dx_min ? dx : dx_min; dx_max = dx > dx_max ? dx : dx_max;
+    }
+  const int pr = dy_max - dy_min + 1, pc = 31 * p.sx + (dx_max - dx_min) + 1;
+  if (pr > kThinPatchRows || pc > kThinPatchCols) return ADVOC_ERR_UNSUPPORTED;
+  const int tiles_x = (p.gw + 31) / 32;
+  const int64_t tiles = (int64_t)p.batch * p.gh * tiles_x;
+  if (tiles > 0x7fffffffLL / 64) return ADVOC_ERR_UNSUPPORTED;
   int64_t bx = ceil_div(tiles, 4);
   const int by = (N + 32 * nt - 1) / (32 * nt);
-  const int64_t cap = 2048 / (by * p.nphase) > 0 ? 2048 / (by * p.nphase) : 1;
-  if (bx > cap) bx = cap;       // grid-stride over row tiles: weights stay in registers
+  // whole rounds of the chip: `resident` workgroups fit at once (occupancy query, cached)
+  const int pl = (pr * pc * (p.c0 + p.c1) + 63) / 64;
+  // ~6 workgroups per CU fit (LDS): launch whole rounds of the chip, grid-stride over the tiles
+  const int resident = 6 * 256;
+  const int64_t cap = resident / (by * p.nphase) > 0 ? resident / (by * p.nphase) : 1;
+  if (bx > cap) bx = cap;
   dim3 grid((unsigned)bx, (unsigned)by, (unsigned)p.nphase);
   ADVOC_CLEAR_LAUNCH_ERROR();
-  if (nt == 4) hipLaunchKernelGGL((thin_k_gemm_kernel<KP, 4, B_KN>), grid, dim3(256), 0, stream, p, 0);
-  else if (nt == 2) hipLaunchKernelGGL((thin_k_gemm_kernel<KP, 2, B_KN>), grid, dim3(256), 0, stream, p, 0);
-  else hipLaunchKernelGGL((thin_k_gemm_kernel<KP, 1, B_KN>), grid, dim3(256), 0, stream, p, 0);
+#define ADVOC_THIN_LAUNCH(NT_, PL_)                                                                   \
+  hipLaunchKernelGGL((thin_k_gemm_kernel<KP, NT_, B_KN, PL_>), grid, dim3(256), 0, stream, p, dy_min, dx_min, pr, \
+                     pc, tiles_x)
+#define ADVOC_THIN_LAUNCH_PL(NT_)                                                                     \
+  {                                                                                                   \
+    if (pl <= 3) ADVOC_THIN_LAUNCH(NT_, 3);                                                           \
+    else if (pl <= 5) ADVOC_THIN_LAUNCH(NT_, 5);                                                      \
+    else ADVOC_THIN_LAUNCH(NT_, 9);                                                                   \
+  }
+  if (nt == 4) ADVOC_THIN_LAUNCH_PL(4)
+  else if (nt == 2) ADVOC_THIN_LAUNCH_PL(2)
+  else ADVOC_THIN_LAUNCH_PL(1)
+#undef ADVOC_THIN_LAUNCH_PL
+#undef ADVOC_THIN_LAUNCH
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }
