@@ -330,8 +330,8 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
   const int ca = p.P.c0 + p.P.c1;
   if (ca <= 2) {
     const int cb = p.Q.c0 + p.Q.c1;
-    rc = (cb % 32 == 0 && p.ntaps * ca <= 32) ? launch_wgrad_thin_mfma(p, as_stream(stream))
-                                              : launch_wgrad_thin(p, as_stream(stream));
+    rc = (cb % 32 == 0 && p.ntaps * ca <= 32) ? launch_wgrad_thin_mfma(p, as_stream(stream)) : ADVOC_ERR_UNSUPPORTED;
+    if (rc == ADVOC_ERR_UNSUPPORTED) rc = launch_wgrad_thin(p, as_stream(stream));   // odd channel counts / wide tap spans
   } else {
     rc = launch_wgrad_mfma(p, as_stream(stream));
   }

@@ -313,49 +313,57 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
 // LDS tile [16 points][32 NT channels] and read back in MFMA layout; the next tile's loads are in
 // flight while the current one is multiplied.  The thin operand P (<= 2 channels) is gathered
 // with scalar loads (it is a small, cache-resident tensor).
-template <int NT>
-__global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, int chunk) {
+constexpr int kWgPatchCols = 15 * 2 + 4;               // 16 grid points at stride <= 2 + tap span
+constexpr int kWgPatch = kThinPatchRows * kWgPatchCols * 2;
+
+// PL: P-patch elements per lane, ceil(pr * pc * ca / 64)
+template <int NT, int PL>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, int chunk_tiles, int tiles_x,
+                                                         int dy_min, int dx_min, int pr, int pc) {
   constexpr int U = 8;                 // MFMA steps per tile
-  constexpr int PT = 2 * U;            // grid points per tile
+  constexpr int PT = 2 * U;            // grid points per tile (one grid row, 16 consecutive columns)
   constexpr int LDQ = 32 * NT + 4;
   constexpr int QL = (PT * 8 * NT) / 64;   // float4 slots per lane per tile (= 2 NT)
   __shared__ __attribute__((aligned(16))) float s_q[4][PT * LDQ];
+  // the thin operand a tile reads (pr tap rows x pc columns x ca channels), staged per wave with
+  // coalesced loads; the per-step operand gathers are ds_reads at tile-invariant offsets
+  __shared__ float s_patch[4][kWgPatch];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l32 = lane & 31;
   const int ca = p.P.c0 + p.P.c1;            // 1 or 2
   const int cb = p.Q.c0 + p.Q.c1;
   const int rows = p.ntaps * ca;             // <= 32 live rows of the A operand
   const int b0 = blockIdx.y * (32 * NT);
-  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   const float pslope = p.P.act == ADVOC_ACT_LRELU02 ? 0.2f : (p.P.act == ADVOC_ACT_RELU ? 0.f : 1.f);
   const float qslope = p.Q.act == ADVOC_ACT_LRELU02 ? 0.2f : (p.Q.act == ADVOC_ACT_RELU ? 0.f : 1.f);
   float* Qs = &s_q[wave][0];
+  float* patch = &s_patch[wave][0];
 
-  // this lane's A row: (tap, a)
+  // this lane's A row (tap, a): patch offset of grid point 0 of the tile; step u adds (2u + half) sx ca
   const bool row_ok = l32 < rows;
-  const int t = row_ok ? l32 / ca : 0, a = row_ok ? l32 % ca : 0;
-  const int tp = p.tap[t];
-  const int dy = (int)(int8_t)(tp & 0xff), dx = (int)(int8_t)((tp >> 8) & 0xff);
-  const bool a_second = a >= p.P.c0;
-  const float* psrc = a_second ? p.P.p1 : p.P.p0;
-  const int pcs = a_second ? p.P.c1 : p.P.c0;
-  const int ppitch = a_second ? p.P.pitch1 : p.P.pitch0;
-  const int pch = a_second ? a - p.P.c0 : a;
-
-  const int64_t w_begin = ((int64_t)blockIdx.x * 4 + wave) * chunk;
-  const int64_t w_end = w_begin + chunk < M ? w_begin + chunk : M;
-
-  // P walker: this lane's grid point for step s of the current tile is g0 + 2 s + half
-  int64_t pg = w_begin + half;
-  int pgx = 0, pgy = 0, pimg = 0;
-  if (pg < M) {
-    pgx = (int)(pg % p.gw);
-    const int64_t tt = pg / p.gw;
-    pgy = (int)(tt % p.gh);
-    pimg = (int)(tt / p.gh);
+  int a_off = -1;
+  if (row_ok) {
+    const int t = l32 / ca, a = l32 % ca;
+    const int tp = p.tap[t];
+    const int dy = (int)(int8_t)(tp & 0xff), dx = (int)(int8_t)((tp >> 8) & 0xff);
+    a_off = ((dy - dy_min) * pc + (dx - dx_min) + half * p.sx) * ca + a;
   }
-  // Q loader slots: slot i covers point qk[i] of the tile and channel quad qc[i]
-  int qk[QL], qch[QL], qgx[QL], qgy[QL], qimg[QL];
+  const int a_step = 2 * p.sx * ca;
+
+  // patch elements this lane stages: e = lane + 64 i -> (row, col, channel)
+  const int patch_elems = pr * pc * ca;
+  int pe_row[PL], pe_col[PL], pe_ci[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    const int e = lane + 64 * i;
+    const int ee = e < patch_elems ? e : 0;
+    pe_ci[i] = ee % ca;
+    const int px = ee / ca;
+    pe_col[i] = px % pc;
+    pe_row[i] = e < patch_elems ? px / pc : -1;
+  }
+  // Q loader slots: slot i covers point qk of the tile and channel quad qch
+  int qk[QL], qch[QL];
   bool q_on[QL];
 #pragma unroll
   for (int i = 0; i < QL; ++i) {
@@ -363,40 +371,57 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
     qk[i] = idx / (8 * NT);
     qch[i] = b0 + 4 * (idx % (8 * NT));
     q_on[i] = qch[i] < cb;
-    const int64_t g = w_begin + qk[i];
-    const int64_t gg = g < M ? g : 0;
-    qgx[i] = (int)(gg % p.gw);
-    const int64_t tt = gg / p.gw;
-    qgy[i] = (int)(tt % p.gh);
-    qimg[i] = (int)(tt / p.gh);
   }
-  float4 rq[QL];
 
+  const int total_tiles = p.batch * p.gh * tiles_x;
+  const int t_begin = (blockIdx.x * 4 + wave) * chunk_tiles;
+  const int t_end = t_begin + chunk_tiles < total_tiles ? t_begin + chunk_tiles : total_tiles;
+
+  float4 rq[QL];
   int rq_off[QL];
   unsigned rq_live = 0;
-  // raw loads only: the affine / activation / mask are applied when the tile is written to LDS,
-  // so these loads stay in flight across the previous tile's MFMAs
-#define ADVOC_TQ_LOAD(G0)                                                                             \
-  rq_live = 0;                                                                                        \
-  _Pragma("unroll") for (int i = 0; i < QL; ++i) {                                                    \
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
-    rq_off[i] = 0;                                                                                    \
-    if (q_on[i] && (G0) + qk[i] < w_end) {                                                            \
-      const bool second = qch[i] >= p.Q.c0;                                                           \
-      const float* src = second ? p.Q.p1 : p.Q.p0;                                                    \
-      const int row = qimg[i] * p.Q.h + qgy[i];                                                       \
-      const int off = second ? (row * p.Q.pitch1 + qgx[i]) * p.Q.c1 + (qch[i] - p.Q.c0)               \
-                             : (row * p.Q.pitch0 + qgx[i]) * p.Q.c0 + qch[i];                         \
-      v = *reinterpret_cast<const float4*>(src + off);                                                \
-      rq_off[i] = off;                                                                                \
-      rq_live |= 1u << i;                                                                             \
+  float pv[PL], pm[PL];
+  // Raw loads of tile `TILE` (both operands) into registers; the affine / activation / mask are
+  // applied when the tile is parked in LDS, so these stay in flight across the previous MFMAs.
+#define ADVOC_TW_FETCH(TILE)                                                                          \
+  {                                                                                                   \
+    const int rowid_ = (TILE) / tiles_x;                                                              \
+    const int gx0_ = ((TILE) - rowid_ * tiles_x) * PT;                                                \
+    const int img_ = rowid_ / p.gh, gy_ = rowid_ - img_ * p.gh;                                       \
+    rq_live = 0;                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < QL; ++i) {                                                  \
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
+      rq_off[i] = 0;                                                                                  \
+      const int gx = gx0_ + qk[i];                                                                    \
+      if (q_on[i] && gx < p.gw) {                                                                     \
+        const bool second = qch[i] >= p.Q.c0;                                                         \
+        const float* src = second ? p.Q.p1 : p.Q.p0;                                                  \
+        const int row = img_ * p.Q.h + gy_;                                                           \
+        const int off = second ? (row * p.Q.pitch1 + gx) * p.Q.c1 + (qch[i] - p.Q.c0)                 \
+                               : (row * p.Q.pitch0 + gx) * p.Q.c0 + qch[i];                           \
+        v = *reinterpret_cast<const float4*>(src + off);                                              \
+        rq_off[i] = off;                                                                              \
+        rq_live |= 1u << i;                                                                           \
+      }                                                                                               \
+      rq[i] = v;                                                                                      \
     }                                                                                                 \
-    rq[i] = v;                                                                                        \
-    qgx[i] += PT;                                                                                     \
-    while (qgx[i] >= p.gw) { qgx[i] -= p.gw; if (++qgy[i] >= p.gh) { qgy[i] = 0; ++qimg[i]; } }       \
+    const int iy0_ = gy_ * p.sy + dy_min, ix0_ = gx0_ * p.sx + dx_min;                                \
+    _Pragma("unroll") for (int i = 0; i < PL; ++i) {                                                  \
+      const int iy = iy0_ + pe_row[i], ix = ix0_ + pe_col[i];                                         \
+      float v = 0.f, mk = 0.f;     /* mk doubles as the in-bounds flag: 0 outside the image */        \
+      if (pe_row[i] >= 0 && (unsigned)iy < (unsigned)p.P.h && (unsigned)ix < (unsigned)p.P.w) {       \
+        const bool second = pe_ci[i] >= p.P.c0;                                                       \
+        const int off = second ? ((img_ * p.P.h + iy) * p.P.pitch1 + ix) * p.P.c1 + (pe_ci[i] - p.P.c0) \
+                               : ((img_ * p.P.h + iy) * p.P.pitch0 + ix) * p.P.c0 + pe_ci[i];         \
+        v = (second ? p.P.p1 : p.P.p0)[off];                                                          \
+        mk = (p.P.mask && !second) ? p.P.mask[off] * p.P.mask_scale : 1.f;                            \
+      }                                                                                               \
+      pv[i] = v;                                                                                      \
+      pm[i] = mk;                                                                                     \
+    }                                                                                                 \
   }
 
-#define ADVOC_TQ_STORE()                                                                              \
+#define ADVOC_TW_PARK()                                                                               \
   _Pragma("unroll") for (int i = 0; i < QL; ++i) {                                                    \
     float4 v = rq[i];                                                                                 \
     const bool live_ = (rq_live >> i) & 1u;                                                           \
@@ -414,7 +439,14 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
       v.x *= mk.x * p.Q.mask_scale; v.y *= mk.y * p.Q.mask_scale;                                     \
       v.z *= mk.z * p.Q.mask_scale; v.w *= mk.w * p.Q.mask_scale;                                     \
     }                                                                                                 \
-    *reinterpret_cast<float4*>(Qs + qk[i] * LDQ + (qch[i] - b0)) = v;                                 \
+    if (q_on[i]) *reinterpret_cast<float4*>(Qs + qk[i] * LDQ + (qch[i] - b0)) = v;                    \
+  }                                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < PL; ++i) {                                                    \
+    if (pe_row[i] < 0) continue;                                                                      \
+    float v = pv[i];                                                                                  \
+    if (p.P.scale) v = pm[i] != 0.f ? v * p.P.scale[pe_ci[i]] + p.P.shift[pe_ci[i]] : 0.f;            \
+    v = fmaxf(v, pslope * v);                                                                         \
+    patch[lane + 64 * i] = v * pm[i];                                                                 \
   }
 
   floatx16 acc[NT];
@@ -423,29 +455,14 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  ADVOC_TQ_LOAD(w_begin);
-  for (int64_t g0 = w_begin; g0 < w_end; g0 += PT) {
-    ADVOC_TQ_STORE();
+  if (t_begin < t_end) ADVOC_TW_FETCH(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    ADVOC_TW_PARK();
     wave_lds_sync();
-    ADVOC_TQ_LOAD(g0 + PT);        // next tile in flight during this tile's gathers + MFMAs
+    if (tile + 1 < t_end) ADVOC_TW_FETCH(tile + 1);     // next tile in flight during this tile's MFMAs
     float av[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      av[u] = 0.f;
-      if (g0 + 2 * u + half < w_end) {
-        const int y = pgy * p.sy + dy, x = pgx * p.sx + dx;
-        if (row_ok && (unsigned)y < (unsigned)p.P.h && (unsigned)x < (unsigned)p.P.w) {
-          const int off = ((pimg * p.P.h + y) * ppitch + x) * pcs + pch;
-          float v = psrc[off];
-          if (p.P.scale) v = v * p.P.scale[a] + p.P.shift[a];
-          v = fmaxf(v, pslope * v);
-          if (p.P.mask && !a_second) v *= p.P.mask[off] * p.P.mask_scale;
-          av[u] = v;
-        }
-      }
-      pgx += 2;
-      while (pgx >= p.gw) { pgx -= p.gw; if (++pgy >= p.gh) { pgy = 0; ++pimg; } }
-    }
+    for (int u = 0; u < U; ++u) av[u] = row_ok ? patch[a_off + u * a_step] : 0.f;
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -453,8 +470,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], Qs[(2 * u + half) * LDQ + 32 * j + l32], acc[j], 0, 0, 0);
     wave_lds_sync();
   }
-#undef ADVOC_TQ_LOAD
-#undef ADVOC_TQ_STORE
+#undef ADVOC_TW_FETCH
+#undef ADVOC_TW_PARK
 
   // Combine the four waves of the block in LDS, then ONE atomic per output element per block:
   // thousands of waves hammering the same <= 32 x cb addresses serialise in L2 otherwise.
@@ -500,22 +517,42 @@ int launch_wgrad_thin_mfma(const WgradParams& p, hipStream_t stream, const char*
     hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
     if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
   }
-  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  int dy_min = 127, dy_max = -128, dx_min = 127, dx_max = -128;
+  for (int t = 0; t < p.ntaps; ++t) {
+    const int dy = (int)(int8_t)(p.tap[t] & 0xff), dx = (int)(int8_t)((p.tap[t] >> 8) & 0xff);
+    dy_min = dy < dy_min ? dy : dy_min; dy_max = dy > dy_max ? dy : dy_max;
+    dx_min = dx < dx_min ? dx : dx_min; dx_max = dx > dx_max ? dx : dx_max;
+  }
+  const int pr = dy_max - dy_min + 1, pc = 15 * p.sx + (dx_max - dx_min) + 1;
+  if (pr > kThinPatchRows || pc > kWgPatchCols) return ADVOC_ERR_UNSUPPORTED;
+  const int pl = (pr * pc * ca + 63) / 64;
+  const int tiles_x = (p.gw + 15) / 16;
+  const int64_t tiles = (int64_t)p.batch * p.gh * tiles_x;
+  if (tiles > 0x7fffffffLL / 64) return ADVOC_ERR_UNSUPPORTED;
   const int by = cb / (32 * nt);
-  // ~2048 waves over the pixel axis (2 blocks of 4 waves per CU); each wave keeps 8 x (1 + NT)
-  // loads in flight
+  // ~2048 waves over the tile axis (2 blocks of 4 waves per CU); each wave keeps one tile of loads in
+  // flight while it multiplies the previous one
   int64_t waves = 2048 / by;
   if (waves < 4) waves = 4;
-  int64_t chunk = ceil_div(M, waves);
-  chunk = (chunk + 15) / 16 * 16;      // whole 16-point tiles per wave
-  if (chunk < 64) chunk = 64;
-  const int64_t bx = ceil_div(ceil_div(M, chunk), 4);
-  if (chunk > 0x7fffffffLL || bx > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  int64_t chunk = ceil_div(tiles, waves);
+  if (chunk < 4) chunk = 4;
+  const int64_t bx = ceil_div(ceil_div(tiles, chunk), 4);
   dim3 grid((unsigned)bx, (unsigned)by);
   ADVOC_CLEAR_LAUNCH_ERROR();
-  if (nt == 4) hipLaunchKernelGGL(thin_wgrad_kernel<4>, grid, dim3(256), 0, stream, p, (int)chunk);
-  else if (nt == 2) hipLaunchKernelGGL(thin_wgrad_kernel<2>, grid, dim3(256), 0, stream, p, (int)chunk);
-  else hipLaunchKernelGGL(thin_wgrad_kernel<1>, grid, dim3(256), 0, stream, p, (int)chunk);
+#define ADVOC_TW_LAUNCH(NT_, PL_)                                                                     \
+  hipLaunchKernelGGL((thin_wgrad_kernel<NT_, PL_>), grid, dim3(256), 0, stream, p, (int)chunk, tiles_x, dy_min, dx_min, \
+                     pr, pc)
+#define ADVOC_TW_LAUNCH_PL(NT_)                                                                       \
+  {                                                                                                   \
+    if (pl <= 2) ADVOC_TW_LAUNCH(NT_, 2);                                                             \
+    else if (pl <= 3) ADVOC_TW_LAUNCH(NT_, 3);                                                        \
+    else ADVOC_TW_LAUNCH(NT_, 5);                                                                     \
+  }
+  if (nt == 4) ADVOC_TW_LAUNCH_PL(4)
+  else if (nt == 2) ADVOC_TW_LAUNCH_PL(2)
+  else ADVOC_TW_LAUNCH_PL(1)
+#undef ADVOC_TW_LAUNCH_PL
+#undef ADVOC_TW_LAUNCH
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }
