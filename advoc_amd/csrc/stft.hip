@@ -5,18 +5,22 @@
 // lws sqrt-Hann window, real FFT, |.|.
 //
 // Mapping to the hardware
-//   * one workgroup (4 wavefronts) = 16 consecutive frames of one clip.  The
-//     (16-1)*hop+1024 sample span is read from HBM once, coalesced, into LDS: the 75 %
-//     overlap between neighbouring frames is served from LDS, not re-fetched.
-//   * one wavefront = one frame at a time.  The 1024-point real FFT is a 512-point complex
-//     FFT (z[n] = x[2n] + i x[2n+1]) held 8 complex values per lane, computed as three
-//     radix-8 passes (512 = 8*8*8); the two inter-pass transposes go through a private,
-//     bank-conflict-free LDS plane per wave (no workgroup barrier inside the frame loop).
-//   * twiddles and the window live in registers for the life of the kernel (they depend only
-//     on the lane), evaluated once with sincospif.
+//   * one wavefront = TWO consecutive frames of one clip at a time, carried in the two halves of
+//     2-wide fp32 vectors so that every butterfly / twiddle multiply is one packed instruction
+//     (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) for both frames: the kernel is bound by VALU
+//     issue (a 1024-point FFT per 3 KB of traffic), not by HBM, so halving the instruction count
+//     per frame is what moves it up the bandwidth roofline.
+//   * The 1024-point real FFT is a 512-point complex FFT (z[n] = x[2n] + i x[2n+1]) held 8 complex
+//     values per lane, computed as three radix-8 passes (512 = 8*8*8); the two inter-pass
+//     transposes go through a private, bank-conflict-free LDS plane per wave (no workgroup
+//     barrier anywhere).
+//   * samples are read straight from global memory, 8 bytes per lane on 512-byte rows; the 75 %
+//     overlap between neighbouring frames is served by L1/L2.
+//   * twiddles and the window live in registers for the life of the wave (they depend only on
+//     the lane) and a wave grid-strides over many frame pairs, so that set-up is amortised.
 //   * the real-FFT split pairs Z[k] with Z[512-k] by one cross-lane permute per value, then
-//     each lane stores 8 magnitudes: 256 B contiguous per store instruction.
-// HBM-bound: algorithmic traffic is 256 new samples in + 513 floats out per frame.
+//     each lane stores 8 magnitudes per frame: 256 B contiguous per store instruction.
+// Algorithmic traffic is 256 new samples in + 513 floats out per frame.
 #include <math.h>
 
 #include "common.h"
@@ -28,15 +32,16 @@ using advoc::wave_lds_sync;
 constexpr int kNfft = 1024;
 constexpr int kBins = kNfft / 2 + 1;
 constexpr int kWaves = 4;
-constexpr int kFramesPerWave = 2;
-constexpr int kFramesPerBlock = kWaves * kFramesPerWave;
-constexpr int kPlane = 576;  // 64 rows x 9 floats (8 + 1 pad): conflict-free transposes
+constexpr int kPlane = 576;  // 64 rows x 9 elements (8 + 1 pad): conflict-free transposes
+
+typedef float f2 __attribute__((ext_vector_type(2)));   // .x = first frame of the pair, .y = second
 
 // forward 8-point DFT in place: v[p] = sum_a v[a] * exp(-2*pi*i*a*p/8)
-__device__ __forceinline__ void dft8(float (&re)[8], float (&im)[8]) {
+template <typename T>
+__device__ __forceinline__ void dft8(T (&re)[8], T (&im)[8]) {
   const float h = 0.70710678118654752440f;
   // radix-2 DIF stage: sums feed even outputs, twiddled differences feed odd outputs
-  float sr[4], si[4], dr[4], di[4];
+  T sr[4], si[4], dr[4], di[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
     sr[n] = re[n] + re[n + 4];
@@ -46,22 +51,22 @@ __device__ __forceinline__ void dft8(float (&re)[8], float (&im)[8]) {
   }
   // d[n] *= W8^n
   {
-    float r1 = (dr[1] + di[1]) * h, i1 = (di[1] - dr[1]) * h;  // * (1 - i)/sqrt2
+    T r1 = (dr[1] + di[1]) * h, i1 = (di[1] - dr[1]) * h;  // * (1 - i)/sqrt2
     dr[1] = r1; di[1] = i1;
-    float r2 = di[2], i2 = -dr[2];                             // * (-i)
+    T r2 = di[2], i2 = -dr[2];                             // * (-i)
     dr[2] = r2; di[2] = i2;
-    float r3 = (di[3] - dr[3]) * h, i3 = -(dr[3] + di[3]) * h; // * (-1 - i)/sqrt2
+    T r3 = (di[3] - dr[3]) * h, i3 = -(dr[3] + di[3]) * h; // * (-1 - i)/sqrt2
     dr[3] = r3; di[3] = i3;
   }
   // 4-point DFT of s -> even bins, of d -> odd bins
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    float* xr = half ? dr : sr;
-    float* xi = half ? di : si;
-    float b0r = xr[0] + xr[2], b0i = xi[0] + xi[2];
-    float b2r = xr[0] - xr[2], b2i = xi[0] - xi[2];
-    float b1r = xr[1] + xr[3], b1i = xi[1] + xi[3];
-    float b3r = xi[1] - xi[3], b3i = -(xr[1] - xr[3]);  // (x1 - x3) * (-i)
+    T* xr = half ? dr : sr;
+    T* xi = half ? di : si;
+    T b0r = xr[0] + xr[2], b0i = xi[0] + xi[2];
+    T b2r = xr[0] - xr[2], b2i = xi[0] - xi[2];
+    T b1r = xr[1] + xr[3], b1i = xi[1] + xi[3];
+    T b3r = xi[1] - xi[3], b3i = -(xr[1] - xr[3]);  // (x1 - x3) * (-i)
     re[0 + half] = b0r + b1r; im[0 + half] = b0i + b1i;
     re[4 + half] = b0r - b1r; im[4 + half] = b0i - b1i;
     re[2 + half] = b2r + b3r; im[2 + half] = b2i + b3i;
@@ -73,85 +78,91 @@ template <bool kComplexOut>
 __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
     const float* __restrict__ wav, int64_t nsamps, const float* __restrict__ window,
     const float2* __restrict__ twiddle, int nhop, int64_t nframes, float* __restrict__ out,
-    int tiles_per_clip) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int span = (kFramesPerBlock - 1) * nhop + kNfft;
-  float* stage = smem;
-  const int span_pad = (span + 3) & ~3;
-
+    int pairs_per_clip, int64_t total_pairs) {
+  __shared__ f2 planes[kWaves][2 * kPlane];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int64_t clip = blockIdx.x / tiles_per_clip;
-  const int tile = blockIdx.x % tiles_per_clip;
-  const int64_t f0 = (int64_t)tile * kFramesPerBlock;
-
-  float* xr_plane = smem + span_pad + wave * (2 * kPlane);
-  float* xi_plane = xr_plane + kPlane;
-
-  // ---- stage the sample span (zero beyond the end of the clip: pad_end) ----
-  {
-    const float* src = wav + clip * nsamps;
-    const int64_t s0 = f0 * nhop;
-    if (((nsamps | nhop) & 3) == 0 && s0 + span <= nsamps) {   // interior tile, 16-byte aligned
-      for (int i = 4 * threadIdx.x; i < span; i += 4 * kWaves * 64)
-        *reinterpret_cast<float4*>(stage + i) = *reinterpret_cast<const float4*>(src + s0 + i);
-    } else {
-      for (int i = threadIdx.x; i < span; i += kWaves * 64) {
-        const int64_t s = s0 + i;
-        stage[i] = (s < nsamps) ? src[s] : 0.f;
-      }
-    }
-  }
+  f2* xr_plane = &planes[wave][0];
+  f2* xi_plane = xr_plane + kPlane;
 
   // ---- per-lane constants ----
+  // They depend on the lane only.  The split twiddles stay in registers; the window and the
+  // pass-1 / pass-2 twiddles sit in LDS ([j][lane], conflict-free 8-byte reads) -- holding all 64
+  // of them in registers next to two frames of data left room for only 2 waves per SIMD.
+  __shared__ float2 s_win[8][64], s_t1[8][64], s_t2[8][64];
   const int hi = lane >> 3, lo = lane & 7;
-  float w0[8], w1[8];
-#pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    const float2 w = *reinterpret_cast<const float2*>(window + 128 * a + 2 * lane);
-    w0[a] = w.x;
-    w1[a] = w.y;
-  }
   // twiddles: cos/sin(2 pi e / 1024) from the 1024-entry table built once on the host in double
   // precision (float2 {cos, sin} per entry, L2 resident): W_N^e = tw[e * 1024 / N] conjugated
-  float t1r[8], t1i[8], t2r[8], t2i[8], tsn[8], tcs[8];
+  float tsn[8], tcs[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    // pass-1 twiddle W64^(b*p): lane = (b=hi, c=lo), p = j
-    const float2 a = twiddle[((hi * j) & 63) * 16];
-    t1r[j] = a.x; t1i[j] = -a.y;
-    // pass-2 twiddle W512^(c*(p+8q)): lane = (p=hi, c=lo), q = j
-    const float2 b = twiddle[((lo * (hi + 8 * j)) & 511) * 2];
-    t2r[j] = b.x; t2i[j] = -b.y;
+    if (wave == 0) {
+      s_win[j][lane] = *reinterpret_cast<const float2*>(window + 128 * j + 2 * lane);
+      // pass-1 twiddle W64^(b*p): lane = (b=hi, c=lo), p = j
+      const float2 a = twiddle[((hi * j) & 63) * 16];
+      s_t1[j][lane] = make_float2(a.x, -a.y);
+      // pass-2 twiddle W512^(c*(p+8q)): lane = (p=hi, c=lo), q = j
+      const float2 b = twiddle[((lo * (hi + 8 * j)) & 511) * 2];
+      s_t2[j][lane] = make_float2(b.x, -b.y);
+    }
     // split twiddle: theta = 2*pi*k/1024, k = lane + 64 j  (k <= 511)
     const float2 c = twiddle[lane + 64 * j];
     tcs[j] = c.x; tsn[j] = c.y;
   }
-  const int partner = (64 - lane) & 63;
-
   __syncthreads();
+  const int partner = (64 - lane) & 63;
+  const bool aligned = ((nsamps | nhop) & 1) == 0;     // float2 loads stay 8-byte aligned
 
-  for (int fi = 0; fi < kFramesPerWave; ++fi) {
-    const int fl = wave * kFramesPerWave + fi;
-    const int64_t f = f0 + fl;
-    if (f >= nframes) break;  // wave-uniform
+  // raw samples of a frame pair: x[2n], x[2n+1] for n = 64 a + lane, zero beyond the end of the clip
+  // (pad_end).  Fetched one pair AHEAD: a wave has nothing else to overlap its own load latency with.
+  float2 raw0[8], raw1[8];
+#define ADVOC_STFT_FETCH(PAIR)                                                                        \
+  {                                                                                                   \
+    const int64_t clip_ = (PAIR) / pairs_per_clip;                                                    \
+    const int64_t f_ = ((PAIR) - clip_ * pairs_per_clip) * 2;                                         \
+    const bool two_ = f_ + 1 < nframes;                                                               \
+    const float* src_ = wav + clip_ * nsamps;                                                         \
+    const int64_t s0_ = f_ * nhop;                                                                    \
+    if (aligned && s0_ + nhop + kNfft <= nsamps) {                                                    \
+      _Pragma("unroll") for (int a = 0; a < 8; ++a) {                                                 \
+        raw0[a] = *reinterpret_cast<const float2*>(src_ + s0_ + 128 * a + 2 * lane);                  \
+        raw1[a] = *reinterpret_cast<const float2*>(src_ + s0_ + nhop + 128 * a + 2 * lane);           \
+      }                                                                                               \
+    } else {                                                                                          \
+      _Pragma("unroll") for (int a = 0; a < 8; ++a) {                                                 \
+        const int64_t i0 = s0_ + 128 * a + 2 * lane, i1 = i0 + nhop;                                  \
+        raw0[a].x = i0 < nsamps ? src_[i0] : 0.f;                                                     \
+        raw0[a].y = i0 + 1 < nsamps ? src_[i0 + 1] : 0.f;                                             \
+        raw1[a].x = (two_ && i1 < nsamps) ? src_[i1] : 0.f;                                           \
+        raw1[a].y = (two_ && i1 + 1 < nsamps) ? src_[i1 + 1] : 0.f;                                   \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+  const int64_t pair0 = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t pstride = (int64_t)gridDim.x * kWaves;
+  if (pair0 < total_pairs) ADVOC_STFT_FETCH(pair0);
+  for (int64_t pair = pair0; pair < total_pairs; pair += pstride) {
+    const int64_t clip = pair / pairs_per_clip;
+    const int64_t f = (pair - clip * pairs_per_clip) * 2;     // frames f and f + 1
+    const bool two = f + 1 < nframes;
 
-    float re[8], im[8];
-    // z[n] = x[2n] w[2n] + i x[2n+1] w[2n+1], n = 64 a + lane
-    const float* fs = stage + fl * nhop;
+    f2 re[8], im[8];
+    // z[n] = x[2n] w[2n] + i x[2n+1] w[2n+1]
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-      const float2 v = *reinterpret_cast<const float2*>(fs + 128 * a + 2 * lane);
-      re[a] = v.x * w0[a];
-      im[a] = v.y * w1[a];
+      const float2 w = s_win[a][lane];
+      re[a] = f2{raw0[a].x, raw1[a].x} * w.x;
+      im[a] = f2{raw0[a].y, raw1[a].y} * w.y;
     }
+    if (pair + pstride < total_pairs) ADVOC_STFT_FETCH(pair + pstride);
 
     // pass 1: DFT over a -> p, twiddle, transpose (b,c | p) -> (p,c | b)
     dft8(re, im);
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      const float r = re[p] * t1r[p] - im[p] * t1i[p];
-      const float i = re[p] * t1i[p] + im[p] * t1r[p];
+      const float2 t = s_t1[p][lane];
+      const f2 r = re[p] * t.x - im[p] * t.y;
+      const f2 i = re[p] * t.y + im[p] * t.x;
       const int addr = (8 * p + hi) * 9 + lo;
       xr_plane[addr] = r;
       xi_plane[addr] = i;
@@ -169,8 +180,9 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
     dft8(re, im);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const float r = re[q] * t2r[q] - im[q] * t2i[q];
-      const float i = re[q] * t2i[q] + im[q] * t2r[q];
+      const float2 t = s_t2[q][lane];
+      const f2 r = re[q] * t.x - im[q] * t.y;
+      const f2 i = re[q] * t.y + im[q] * t.x;
       const int addr = (8 * q + hi) * 9 + lo;
       xr_plane[addr] = r;
       xi_plane[addr] = i;
@@ -188,35 +200,43 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
     dft8(re, im);
 
     // real-FFT split: X[k] = ((Zk + conj(Zm)) - i W1024^k (Zk - conj(Zm))) / 2, m = 512 - k
-    float* orow = out + ((clip * nframes + f) * kBins) * (kComplexOut ? 2 : 1);
+    float* orow0 = out + ((clip * nframes + f) * kBins) * (kComplexOut ? 2 : 1);
+    float* orow1 = orow0 + kBins * (kComplexOut ? 2 : 1);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      float c = __shfl(re[7 - r], partner, 64);
-      float d = __shfl(im[7 - r], partner, 64);
+      f2 c, d;
+      c.x = __shfl(re[7 - r].x, partner, 64); c.y = __shfl(re[7 - r].y, partner, 64);
+      d.x = __shfl(im[7 - r].x, partner, 64); d.y = __shfl(im[7 - r].y, partner, 64);
       if (lane == 0) {  // k = 64 r pairs with 512 - 64 r = 64 (8 - r) on the same lane
         c = re[(8 - r) & 7];
         d = im[(8 - r) & 7];
       }
-      const float a = re[r], b = im[r];
-      const float sr = a + c, si = b - d, dr = a - c, di = b + d;
-      const float xr = 0.5f * (sr - (tsn[r] * dr - tcs[r] * di));
-      const float xi = 0.5f * (si - (tsn[r] * di + tcs[r] * dr));
+      const f2 a = re[r], b = im[r];
+      const f2 sr = a + c, si = b - d, dr = a - c, di = b + d;
+      const f2 xr = 0.5f * (sr - (tsn[r] * dr - tcs[r] * di));
+      const f2 xi = 0.5f * (si - (tsn[r] * di + tcs[r] * dr));
       const int k = lane + 64 * r;
       if (kComplexOut) {
-        *reinterpret_cast<float2*>(orow + 2 * k) = make_float2(xr, xi);
+        *reinterpret_cast<float2*>(orow0 + 2 * k) = make_float2(xr.x, xi.x);
+        if (two) *reinterpret_cast<float2*>(orow1 + 2 * k) = make_float2(xr.y, xi.y);
       } else {
-        orow[k] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);   // v_sqrt_f32, <= 1 ulp
+        const f2 m2 = xr * xr + xi * xi;
+        orow0[k] = __builtin_amdgcn_sqrtf(m2.x);   // v_sqrt_f32, <= 1 ulp
+        if (two) orow1[k] = __builtin_amdgcn_sqrtf(m2.y);
       }
     }
     if (lane == 0) {  // Nyquist bin: X[512] = Re Z0 - Im Z0
-      const float xn = re[0] - im[0];
+      const f2 xn = re[0] - im[0];
       if (kComplexOut) {
-        *reinterpret_cast<float2*>(orow + 2 * (kBins - 1)) = make_float2(xn, 0.f);
+        *reinterpret_cast<float2*>(orow0 + 2 * (kBins - 1)) = make_float2(xn.x, 0.f);
+        if (two) *reinterpret_cast<float2*>(orow1 + 2 * (kBins - 1)) = make_float2(xn.y, 0.f);
       } else {
-        orow[kBins - 1] = fabsf(xn);
+        orow0[kBins - 1] = fabsf(xn.x);
+        if (two) orow1[kBins - 1] = fabsf(xn.y);
       }
     }
   }
+#undef ADVOC_STFT_FETCH
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,21 +391,24 @@ int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* wi
   if (nfft != kNfft || (nhop & 1) || nhop > 4096) return ADVOC_ERR_UNSUPPORTED;
   if (batch == 0 || nframes == 0) return ADVOC_OK;  // empty output: nothing to touch
   if (!wav || !window || !twiddle || !out) return ADVOC_ERR_NULL;
-  if (reinterpret_cast<uintptr_t>(wav) & 15) return ADVOC_ERR_UNSUPPORTED;   // float4 staging
-  const int tiles = (int)advoc::ceil_div(nframes, kFramesPerBlock);
-  const int64_t blocks = batch * tiles;
-  if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
-  const int span = (kFramesPerBlock - 1) * nhop + kNfft;
-  const size_t lds = sizeof(float) * (((span + 3) & ~3) + kWaves * 2 * kPlane);
-  if (lds > 160 * 1024) return ADVOC_ERR_UNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(wav) & 7) return ADVOC_ERR_UNSUPPORTED;    // 8-byte sample loads
+  const int64_t pairs_per_clip = (nframes + 1) / 2;
+  const int64_t total_pairs = batch * pairs_per_clip;
+  if (pairs_per_clip > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  // a wave keeps ~64 constant registers (window + twiddles): grid-stride so that set-up is
+  // amortised; 8 workgroups per CU is more than the register file holds at once
+  int64_t blocks = advoc::ceil_div(total_pairs, kWaves);
+  if (blocks > 2048) blocks = 2048;
   if (complex_out) {
     ADVOC_CLEAR_LAUNCH_ERROR();
-    hipLaunchKernelGGL(stft1024_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream,
-                       wav, nsamps, window, reinterpret_cast<const float2*>(twiddle), nhop, nframes, out, tiles);
+    hipLaunchKernelGGL(stft1024_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), 0, stream, wav, nsamps,
+                       window, reinterpret_cast<const float2*>(twiddle), nhop, nframes, out, (int)pairs_per_clip,
+                       total_pairs);
   } else {
     ADVOC_CLEAR_LAUNCH_ERROR();
-    hipLaunchKernelGGL(stft1024_kernel<false>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream,
-                       wav, nsamps, window, reinterpret_cast<const float2*>(twiddle), nhop, nframes, out, tiles);
+    hipLaunchKernelGGL(stft1024_kernel<false>, dim3((unsigned)blocks), dim3(kWaves * 64), 0, stream, wav, nsamps,
+                       window, reinterpret_cast<const float2*>(twiddle), nhop, nframes, out, (int)pairs_per_clip,
+                       total_pairs);
   }
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
