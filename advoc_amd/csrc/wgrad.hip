@@ -133,7 +133,7 @@ __device__ __forceinline__ float slope_of(int act) {
 
 // launch_bounds(256, 2): see igemm.hip -- keeps the prefetch registers out of scratch.
 template <int MT, int NT, int WGM, int WGN>
-__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p, int tiles_n,
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p, int tiles_n, int tiles,
                                                             int chunk) {
   using C = WCfg<MT, NT, WGM, WGN>;
   constexpr int BM = C::BM, BN = C::BN;
@@ -145,13 +145,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int half = lane >> 5, l32 = lane & 31;
+  // XCD-aware block order.  Workgroup b runs on XCD b % 8, each with its own L2; the `tiles` blocks
+  // of one pixel chunk read the SAME P and Q pixels (different taps / channel tiles), so an XCD
+  // walks a contiguous run of (chunk, tile) pairs and those re-reads hit its L2 instead of being
+  // fetched once per XCD.
+  int vblock;
+  {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, slot = b >> 3;
+    vblock = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;   // bijective for any nb
+  }
+  const int zchunk = vblock / tiles;
+  const int tile_id = vblock - zchunk * tiles;
   // rows of the GEMM = (tap, channel of P): every tap shares the Q tile of a grid point
-  const int a0 = (blockIdx.x / tiles_n) * BM;
-  const int b0 = (blockIdx.x % tiles_n) * BN;
+  const int a0 = (tile_id / tiles_n) * BM;
+  const int b0 = (tile_id % tiles_n) * BN;
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   const int rows_total = p.ntaps * ca;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
-  const int64_t g_begin = (int64_t)blockIdx.z * chunk;
+  const int64_t g_begin = (int64_t)zchunk * chunk;
   const int64_t g_end = g_begin + chunk < M ? g_begin + chunk : M;
   const int nkt = (int)((g_end - g_begin + WK - 1) / WK);
   const float pslope = slope_of(p.P.act), qslope = slope_of(p.Q.act);
@@ -341,11 +353,11 @@ int launch_wcfg(const WgradParams& p, hipStream_t stream, const char** name_only
   if (ksplit < 1) ksplit = 1;
   int64_t chunk = ceil_div(ceil_div(M, ksplit), WK) * WK;
   ksplit = ceil_div(M, chunk);
-  if (chunk > 0x7fffffffLL || ksplit > 65535) return ADVOC_ERR_UNSUPPORTED;
-  dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)ksplit);
+  if (chunk > 0x7fffffffLL || tiles * ksplit > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)(tiles * ksplit), 1, 1);
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL((wgrad_mfma_kernel<MT, NT, WGM, WGN>), grid, dim3(256), C::LDS_BYTES, stream, p,
-                     tiles_n, (int)chunk);
+                     tiles_n, (int)tiles, (int)chunk);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }
