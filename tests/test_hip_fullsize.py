@@ -1,0 +1,130 @@
+"""Size-independent properties at BASELINE.json's full sizes (AdVoc-small, 32 clips of 256 x 513 per
+GPU; the discriminator's 2B = 64 batch), where the CPU oracle would take minutes per layer:
+
+  * adjointness  <dy, conv(x)> == <conv_backward_data(dy), x> == <conv_backward_weight(dy), w>
+    for every distinct layer shape of the two networks (bias 0, identity activation: the three
+    directions are then three views of ONE trilinear form, so each inner product must agree to
+    fp32 round-off whatever the kernels' tiling, split-K or two-stage paths do),
+  * positive homogeneity of the fused leaky-ReLU prologue, conv(2x) - b == 2 (conv(x) - b),
+  * iSTFT(STFT(x)) == x away from the clip ends for a full training batch of waveforms,
+  * the Philox dropout stream does not depend on how a batch is sharded.
+The small-shape oracle comparisons live in test_hip_conv.py / test_hip_model.py."""
+import pytest
+import torch
+
+gpu = pytest.mark.gpu
+B = 32
+
+# name, kind, (batch, H, W), c0, c1, cout, trim, stride, pad
+LAYERS = [
+    ('encoder_1', 0, (B, 256, 513), 1, 0, 32, 0, (2, 2), (1, 1)),
+    ('encoder_2', 0, (B, 128, 257), 32, 0, 64, 0, (2, 2), (1, 1)),
+    ('encoder_3', 0, (B, 64, 129), 64, 0, 128, 0, (2, 2), (1, 1)),
+    ('encoder_4', 0, (B, 32, 65), 128, 0, 256, 0, (2, 2), (1, 1)),
+    ('encoder_5', 0, (B, 16, 33), 256, 0, 256, 0, (2, 2), (1, 1)),
+    ('decoder_5', 1, (B, 8, 17), 256, 0, 256, 0, (2, 2), (1, 1)),
+    ('decoder_4', 1, (B, 16, 33), 256, 256, 128, 1, (2, 2), (1, 1)),
+    ('decoder_3', 1, (B, 32, 65), 128, 128, 64, 1, (2, 2), (1, 1)),
+    ('decoder_2', 1, (B, 64, 129), 64, 64, 32, 1, (2, 2), (1, 1)),
+    ('decoder_1', 1, (B, 128, 257), 32, 32, 1, 1, (2, 2), (1, 1)),
+    ('layer_1', 0, (2 * B, 256, 513), 1, 1, 32, 0, (2, 2), (1, 1)),
+    ('layer_2', 0, (2 * B, 128, 256), 32, 0, 64, 0, (2, 2), (1, 1)),
+    ('layer_3', 0, (2 * B, 64, 128), 64, 0, 128, 0, (2, 2), (1, 1)),
+    ('layer_4', 0, (2 * B, 32, 64), 128, 0, 256, 0, (1, 1), (1, 1)),
+    ('layer_5', 0, (2 * B, 31, 63), 256, 0, 1, 0, (1, 1), (1, 1)),
+]
+
+
+def dot(a, b):
+  return float((a.double() * b.double()).sum())
+
+
+def build(case, act):
+  from advoc_amd import conv
+  name, kind, (n, H, W), c0, c1, cout, trim, stride, pad = case
+  dev = torch.device('cuda')
+  g = torch.Generator(device='cuda').manual_seed(sum(ord(ch) for ch in name))
+  x0 = torch.randn(n, H, W + trim, c0, device=dev, generator=g)
+  x1 = torch.randn(n, H, W, c1, device=dev, generator=g) if c1 else None
+  if kind == 0:
+    oh = (H + 2 * pad[0] - 4) // stride[0] + 1 if name.startswith('layer') else -(-H // stride[0])
+    ow = (W + 2 * pad[1] - 4) // stride[1] + 1 if name.startswith('layer') else -(-W // stride[1])
+    w = torch.randn(4, 4, c0 + c1, cout, device=dev, generator=g) * 0.05
+    clip = 0
+  else:
+    clip = 1 if cout == 1 else 0
+    oh, ow = 2 * H, 2 * W - clip
+    w = torch.randn(4, 4, cout, c0 + c1, device=dev, generator=g) * 0.05
+  y = torch.zeros(n, oh, ow, cout, device=dev)
+  b = torch.zeros(cout, device=dev)
+  L = conv.Layer(kind, x0, y, w, b, x1=x1, in_w=W, stride=stride, pad=pad, in_act=act)
+  dy = torch.randn(n, oh, ow, cout, device=dev, generator=g)
+  return L, x0, x1, w, b, y, dy, W
+
+
+@gpu
+@pytest.mark.parametrize('case', LAYERS, ids=[c[0] for c in LAYERS])
+def test_three_directions_are_one_trilinear_form(hip, case):
+  L, x0, x1, w, b, y, dy, W = build(case, act=0)
+  L.forward()
+  lhs = dot(dy, y)
+  dx0 = torch.zeros_like(x0)
+  dx1 = torch.zeros_like(x1) if x1 is not None else None
+  L.backward_data(dy, dx0, dx1)
+  via_x = dot(dx0[:, :, :W], x0[:, :, :W]) + (dot(dx1, x1) if x1 is not None else 0.0)
+  dw = torch.zeros_like(w)
+  db = torch.zeros_like(b)
+  L.backward_weight(dy, dw, db)
+  via_w = dot(dw, w)
+  scale = float(dy.double().norm() * y.double().norm())
+  assert abs(lhs - via_x) < 2e-6 * scale, (lhs, via_x)
+  assert abs(lhs - via_w) < 2e-6 * scale, (lhs, via_w)
+  # bias gradient = column sums of dy
+  want_db = dy.double().sum(dim=(0, 1, 2))
+  assert float((db.double() - want_db).norm()) < 1e-5 * float(want_db.norm() + dy.double().norm())
+
+
+@gpu
+@pytest.mark.parametrize('case', [LAYERS[1], LAYERS[7], LAYERS[13]], ids=['encoder_2', 'decoder_3', 'layer_4'])
+def test_leaky_relu_prologue_is_positively_homogeneous(hip, case):
+  L, x0, x1, w, b, y, dy, W = build(case, act=1)
+  b.copy_(torch.randn_like(b))
+  L.forward()
+  y1 = y.clone()
+  x0.mul_(2.0)
+  if x1 is not None:
+    x1.mul_(2.0)
+  L.forward()
+  lhs, rhs = (y - b).double(), 2.0 * (y1 - b).double()
+  assert float((lhs - rhs).norm() / rhs.norm()) < 1e-6
+
+
+@gpu
+def test_stft_istft_round_trip_full_batch(hip):
+  from advoc_amd import spectral
+  g = torch.Generator(device='cuda').manual_seed(5)
+  n = 255 * 256 + 1024
+  x = torch.rand(B, n, device='cuda', generator=g) - 0.5
+  X = torch.view_as_complex(spectral._run_stft(x, 1024, 256, 256, complex_out=True))
+  assert tuple(X.shape) == (B, 256, 513)
+  y = spectral.istft_batch(X, 1024, 256)
+  assert tuple(y.shape) == (B, n)
+  assert float((y[:, 1024:-1024] - x[:, 1024:-1024]).abs().max()) < 3e-6
+  # |X| from the fused magnitude kernel equals |.| of the complex kernel
+  mag = spectral._run_stft(x, 1024, 256, 256, complex_out=False)
+  assert float((mag - X.abs()).abs().max()) < 1e-4 * float(mag.abs().max())
+
+
+@gpu
+def test_dropout_stream_is_shard_invariant_at_full_size(hip):
+  from advoc_amd import _lib
+  lib = _lib.load()
+  per_clip = 16 * 34 * 256                      # decoder_5 output of one clip
+  whole = torch.empty(B * per_clip, dtype=torch.uint8, device='cuda')
+  _lib.check(lib.advoc_dropout_mask_u8(_lib.ptr(whole), whole.numel(), 12345, 0, 0.5, _lib.stream()), 'mask')
+  half = torch.empty(B // 2 * per_clip, dtype=torch.uint8, device='cuda')
+  _lib.check(lib.advoc_dropout_mask_u8(_lib.ptr(half), half.numel(), 12345, B // 2 * per_clip, 0.5, _lib.stream()),
+             'mask')
+  assert torch.equal(whole[B // 2 * per_clip:], half)
+  keep = float(whole.float().mean())
+  assert abs(keep - 0.5) < 2e-3
