@@ -53,6 +53,7 @@ PROTOTYPES = {
     'advoc_stft_c64': (ctypes.c_int, [_p, _i64, _i64, _p, _p, _i32, _i32, _i64, _p, _p]),
     'advoc_stft_twiddle_host': (ctypes.c_int, [_p, _i32]),
     'advoc_istft_f32': (ctypes.c_int, [_p, _i64, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
+    'advoc_istft_project_f32': (ctypes.c_int, [_p, _p, _i64, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     'advoc_phase_project_c64': (ctypes.c_int, [_p, _p, _i64, _p]),
     'advoc_cabs_f32': (ctypes.c_int, [_p, _p, _i64, _p]),
     'advoc_polar_c64': (ctypes.c_int, [_p, _p, _p, _i64, _p]),

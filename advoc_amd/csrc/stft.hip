@@ -248,9 +248,12 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
 // ola_kernel then sums the <= nfft/hop frames that cover each output sample (a gather: no atomics).
 // Replaces lws.istft reached from advoc/spectral.py:300-309,320-321.
 // ---------------------------------------------------------------------------------------------
+// kProject: the Griffin-Lim projection fused into the loads -- every bin is replaced by
+// |mag| * X / |X| (phase 0 where X == 0) on its way in, so the projected spectrum never exists in HBM.
+template <bool kProject>
 __global__ __launch_bounds__(kWaves * 64) void istft1024_frames_kernel(
-    const float2* __restrict__ spec, const float* __restrict__ window, const float2* __restrict__ twiddle,
-    int64_t total_frames, float* __restrict__ frames) {
+    const float2* __restrict__ spec, const float* __restrict__ mag, const float* __restrict__ window,
+    const float2* __restrict__ twiddle, int64_t total_frames, float* __restrict__ frames) {
   __shared__ float planes[kWaves][2 * kPlane];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -282,6 +285,12 @@ __global__ __launch_bounds__(kWaves * 64) void istft1024_frames_kernel(
       const int k = 64 * a + lane;
       float2 xk = X[k];
       float2 xm = X[512 - k];
+      if (kProject) {
+        const float mk = fabsf(mag[f * kBins + k]), mm = fabsf(mag[f * kBins + 512 - k]);
+        const float ak = sqrtf(xk.x * xk.x + xk.y * xk.y), am = sqrtf(xm.x * xm.x + xm.y * xm.y);
+        xk = ak > 0.f ? make_float2(mk * (xk.x / ak), mk * (xk.y / ak)) : make_float2(mk, 0.f);
+        xm = am > 0.f ? make_float2(mm * (xm.x / am), mm * (xm.y / am)) : make_float2(mm, 0.f);
+      }
       if (k == 0) { xk.y = 0.f; xm.y = 0.f; }      // irfft ignores Im X[0] and Im X[N/2]
       const float er = 0.5f * (xk.x + xm.x), ei = 0.5f * (xk.y - xm.y);      // Ze
       const float dr = 0.5f * (xk.x - xm.x), di = 0.5f * (xk.y + xm.y);      // (X[k] - conj X[m]) / 2
@@ -430,10 +439,10 @@ extern "C" int advoc_stft_c64(const float* wav, int64_t batch, int64_t nsamps, c
                      advoc::as_stream(stream));
 }
 
-extern "C" int advoc_istft_f32(const float* spec, int64_t batch, int64_t nframes, const float* window,
-                               const float* twiddle, int32_t nfft, int32_t nhop, float* frames_work,
-                               float* wav, advoc_stream_t stream_) {
-  hipStream_t stream = advoc::as_stream(stream_);
+namespace {
+int launch_istft(const float* spec, const float* mag, int64_t batch, int64_t nframes, const float* window,
+                 const float* twiddle, int32_t nfft, int32_t nhop, float* frames_work, float* wav,
+                 hipStream_t stream) {
   if (batch < 0 || nframes < 0 || nhop <= 0) return ADVOC_ERR_BAD_SHAPE;
   if (nfft != kNfft || (nhop & 3) || nhop > kNfft) return ADVOC_ERR_UNSUPPORTED;
   if (batch == 0 || nframes == 0) return ADVOC_OK;
@@ -442,9 +451,14 @@ extern "C" int advoc_istft_f32(const float* spec, int64_t batch, int64_t nframes
   int64_t blocks = advoc::ceil_div(total, kWaves);
   if (blocks > 4096) blocks = 4096;
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(istft1024_frames_kernel, dim3((unsigned)blocks), dim3(kWaves * 64), 0, stream,
-                     reinterpret_cast<const float2*>(spec), window, reinterpret_cast<const float2*>(twiddle),
-                     total, frames_work);
+  if (mag)
+    hipLaunchKernelGGL(istft1024_frames_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), 0, stream,
+                       reinterpret_cast<const float2*>(spec), mag, window, reinterpret_cast<const float2*>(twiddle),
+                       total, frames_work);
+  else
+    hipLaunchKernelGGL(istft1024_frames_kernel<false>, dim3((unsigned)blocks), dim3(kWaves * 64), 0, stream,
+                       reinterpret_cast<const float2*>(spec), mag, window, reinterpret_cast<const float2*>(twiddle),
+                       total, frames_work);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   const int64_t out_len = (nframes - 1) * nhop + kNfft;
   const int64_t threads = batch * (out_len / 4);
@@ -455,6 +469,22 @@ extern "C" int advoc_istft_f32(const float* spec, int64_t batch, int64_t nframes
                      out_len, wav);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
+}
+}  // namespace
+
+extern "C" int advoc_istft_f32(const float* spec, int64_t batch, int64_t nframes, const float* window,
+                               const float* twiddle, int32_t nfft, int32_t nhop, float* frames_work,
+                               float* wav, advoc_stream_t stream) {
+  return launch_istft(spec, nullptr, batch, nframes, window, twiddle, nfft, nhop, frames_work, wav,
+                      advoc::as_stream(stream));
+}
+
+extern "C" int advoc_istft_project_f32(const float* spec, const float* mag, int64_t batch, int64_t nframes,
+                                       const float* window, const float* twiddle, int32_t nfft, int32_t nhop,
+                                       float* frames_work, float* wav, advoc_stream_t stream) {
+  if (!mag && batch > 0 && nframes > 0) return ADVOC_ERR_NULL;
+  return launch_istft(spec, mag, batch, nframes, window, twiddle, nfft, nhop, frames_work, wav,
+                      advoc::as_stream(stream));
 }
 
 extern "C" int advoc_phase_project_c64(float* spec, const float* mag, int64_t n, advoc_stream_t stream) {

@@ -420,23 +420,44 @@ def istft_batch(spec, nfft, nhop):
 def griffin_lim_batch(mag, nfft, nhop, ngl, unit_phase):
   """Griffin-Lim on a batch of equally long magnitude spectrograms, all on the GPU.
   mag, unit_phase: float32 [clips, T, bins] in HBM (unit_phase = the U[0,1) draw the reference
-  takes from np.random.rand).  Returns float32 [clips, (T-1)*nhop + nfft]."""
+  takes from np.random.rand).  Returns float32 [clips, (T-1)*nhop + nfft].
+
+  One iteration is three launches on static buffers (STFT; inverse FFT with the magnitude
+  projection fused into its loads; overlap-add).  Replaying the iteration from a HIP graph was
+  measured and bought nothing: at 32 clips the loop is bound by the kernels, not by launches."""
   lib = _lib.load()
   mag = mag.contiguous()
   unit_phase = unit_phase.contiguous()
   clips, T, bins = mag.shape
-  spec = torch.empty(clips, T, bins, 2, dtype=torch.float32, device=mag.device)
-  if mag.numel():
-    _lib.check(lib.advoc_polar_c64(_lib.ptr(mag), _lib.ptr(unit_phase), _lib.ptr(spec), mag.numel(),
-                                   _lib.stream()), 'advoc_polar_c64')
-  wav = istft_batch(torch.view_as_complex(spec), nfft, nhop)
+  dev = mag.device
+  n = (T - 1) * nhop + nfft if T > 0 else 0
+  wav = torch.empty(clips, n, dtype=torch.float32, device=dev)
+  if clips == 0 or T == 0:
+    return wav
+  if nfft != 1024:
+    raise _lib.AdvocHipError('Griffin-Lim runs on the 1024-point kernels only (nfft={})'.format(nfft))
+  spec = torch.empty(clips, T, bins, 2, dtype=torch.float32, device=dev)
+  work = torch.empty(clips, T, nfft, dtype=torch.float32, device=dev)
+  awin, swin, tw = _device_window(nfft, nhop), _synthesis_window(nfft, nhop), _device_twiddle(nfft)
+
+  def inverse():
+    _lib.check(lib.advoc_istft_f32(_lib.ptr(spec), clips, T, _lib.ptr(swin), _lib.ptr(tw), nfft, nhop,
+                                   _lib.ptr(work), _lib.ptr(wav), _lib.stream()), 'advoc_istft_f32')
+
+  def iteration():
+    # lws.stft of the (T-1)*hop + nfft samples gives T frames again (no padding); the projection
+    # onto the given magnitudes is fused into the inverse transform's loads
+    _lib.check(lib.advoc_stft_c64(_lib.ptr(wav), clips, n, _lib.ptr(awin), _lib.ptr(tw), nfft, nhop, T,
+                                  _lib.ptr(spec), _lib.stream()), 'advoc_stft_c64')
+    _lib.check(lib.advoc_istft_project_f32(_lib.ptr(spec), _lib.ptr(mag), clips, T, _lib.ptr(swin), _lib.ptr(tw),
+                                           nfft, nhop, _lib.ptr(work), _lib.ptr(wav), _lib.stream()),
+               'advoc_istft_project_f32')
+
+  _lib.check(lib.advoc_polar_c64(_lib.ptr(mag), _lib.ptr(unit_phase), _lib.ptr(spec), mag.numel(),
+                                 _lib.stream()), 'advoc_polar_c64')
+  inverse()
   for _ in range(ngl):
-    # lws.stft of the (T-1)*hop + nfft samples gives T frames again (no padding)
-    spec = _run_stft(wav, nfft, nhop, T, complex_out=True)
-    if mag.numel():
-      _lib.check(lib.advoc_phase_project_c64(_lib.ptr(spec), _lib.ptr(mag), mag.numel(), _lib.stream()),
-                 'advoc_phase_project_c64')
-    wav = istft_batch(torch.view_as_complex(spec), nfft, nhop)
+    iteration()
   return wav
 
 

@@ -76,6 +76,13 @@ int advoc_istft_f32(const float* spec, int64_t batch, int64_t nframes, const flo
                     const float* twiddle, int32_t nfft, int32_t nhop, float* frames_work, float* wav,
                     advoc_stream_t stream);
 
+/* One Griffin-Lim half step (advoc/spectral.py:306-307): the inverse STFT of |mag| * spec / |spec|
+ * (phase 0 where spec == 0), the projection applied while the bins are loaded.  mag: [batch, nframes,
+ * nfft/2+1] float32; everything else as advoc_istft_f32. */
+int advoc_istft_project_f32(const float* spec, const float* mag, int64_t batch, int64_t nframes,
+                            const float* window, const float* twiddle, int32_t nfft, int32_t nhop,
+                            float* frames_work, float* wav, advoc_stream_t stream);
+
 /* Griffin-Lim projection step (advoc/spectral.py:306-307): spec[i] <- |mag[i]| * spec[i] / |spec[i]|,
  * phase 0 where spec[i] == 0 (numpy: angle(0) == 0).  n complex elements, in place. */
 int advoc_phase_project_c64(float* spec, const float* mag, int64_t n, advoc_stream_t stream);

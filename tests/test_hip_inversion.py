@@ -156,3 +156,36 @@ def test_melspec_to_waveform_surface(S, mono22):
     S.melspec_to_waveform(np.zeros((4, 80, 2)), 22050, 1024, 256)
   with pytest.raises(NotImplementedError):
     S.melspec_to_waveform(mel, 22050, 1024, 256, phase_estimation='lws')
+
+
+@gpu
+def test_projection_and_polar_entry_points(S):
+  """advoc_phase_project_c64 / advoc_polar_c64 on their own (Griffin-Lim itself uses the projection
+  fused into advoc_istft_project_f32)."""
+  from advoc_amd import _lib
+  lib = _lib.load()
+  rng = np.random.default_rng(11)
+  X = (rng.standard_normal((7, 513)) + 1j * rng.standard_normal((7, 513))).astype(np.complex64)
+  X[2, 5] = 0
+  mag = rng.random((7, 513)).astype(np.float32)
+  spec = torch.view_as_real(torch.from_numpy(X).cuda()).contiguous()
+  m = torch.from_numpy(mag).cuda()
+  _lib.check(lib.advoc_phase_project_c64(_lib.ptr(spec), _lib.ptr(m), X.size, _lib.stream()), 'project')
+  want = mag * np.exp(1j * np.angle(X.astype(np.complex128)))
+  assert rel_l2(torch.view_as_complex(spec).cpu().numpy(), want) < 1e-6
+  u = rng.random((7, 513)).astype(np.float32)
+  out = torch.empty(7, 513, 2, device='cuda')
+  _lib.check(lib.advoc_polar_c64(_lib.ptr(m), _lib.ptr(torch.from_numpy(u).cuda()), _lib.ptr(out), X.size,
+                                 _lib.stream()), 'polar')
+  assert rel_l2(torch.view_as_complex(out).cpu().numpy(), mag * np.exp(2j * np.pi * u.astype(np.float64))) < 1e-6
+  # fused projection + inverse == projection, then inverse
+  wav_a = torch.empty(1, 6 * 256 + 1024, device='cuda')
+  wav_b = torch.empty_like(wav_a)
+  work = torch.empty(1, 7, 1024, device='cuda')
+  spec2 = torch.view_as_real(torch.from_numpy(X).cuda()).contiguous()
+  win, tw = S._synthesis_window(1024, 256), S._device_twiddle(1024)
+  _lib.check(lib.advoc_istft_project_f32(_lib.ptr(spec2), _lib.ptr(m), 1, 7, _lib.ptr(win), _lib.ptr(tw), 1024, 256,
+                                         _lib.ptr(work), _lib.ptr(wav_a), _lib.stream()), 'istft_project')
+  _lib.check(lib.advoc_istft_f32(_lib.ptr(spec), 1, 7, _lib.ptr(win), _lib.ptr(tw), 1024, 256, _lib.ptr(work),
+                                 _lib.ptr(wav_b), _lib.stream()), 'istft')
+  assert rel_l2(wav_a.cpu().numpy(), wav_b.cpu().numpy()) < 1e-6
