@@ -247,3 +247,28 @@ def test_adam_matches_tf_formula(hip):
     vr = 0.999 * vr + 0.001 * gd * gd
     pr = pr - lr_t * mr / (vr.sqrt() + 1e-8)
   assert rel(p.cpu() - p0, (pr - p0.double())) < 1e-5
+
+
+@gpu
+def test_short_training_run_reduces_l1(hip):
+  """80 train_loop iterations on one fixed synthetic batch: every loss stays finite and the L1 term
+  (weight 10 of the generator objective, advoc_model.py:243-245) falls well below its starting value.
+  A sanity check of the whole optimisation loop over many steps, not a parity test."""
+  from advoc_amd.model import AdvocSmall, Modes
+  m = AdvocSmall(Modes.TRAIN)
+  m.subseq_len = 32
+  m.train_batch_size = 4
+  m.build(batch_size=4, seed=3)
+  x, target = batch(4, 32, 77)
+  dev = torch.device('cuda')
+  m((x.to(dev), target.to(dev)))
+  m.train_loop()
+  first = m.losses()
+  hist = []
+  for _ in range(80):
+    m.train_loop()
+    ls = m.losses()
+    assert all(np.isfinite(v) for v in ls.values()), ls
+    hist.append(ls['gen_loss_L1'])
+  assert m.step == 81
+  assert np.mean(hist[-5:]) < 0.6 * first['gen_loss_L1'], (first, hist[-5:])
