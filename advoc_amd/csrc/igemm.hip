@@ -472,6 +472,14 @@ int dispatch_bk(const GatherGemmParams& p, hipStream_t stream, const char** name
   const int k_total = p.ntaps * (p.c0 + p.c1);
   const bool heavy_epilogue = p.grad_act != ADVOC_ACT_NONE || p.d[1].p != nullptr;
   const bool deep = k_total >= (heavy_epilogue ? 2048 : 1024);
+  {
+    const char* e = getenv("ADVOC_IGEMM_TILE");
+    const int force = e ? atoi(e) : 0;
+    if (force == 1) return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, stream, name_only);
+    if (force == 2) return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, stream, name_only);
+    if (force == 3 && bn == 128) return launch_cfg<2, 2, 2, 2, B_KN, BK>(p, stream, name_only);
+    if (force == 3) return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, stream, name_only);
+  }
   if (big_blocks < 900 || !deep) return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, stream, name_only);   // 64 x 64
   if (bn == 128) return launch_cfg<2, 2, 2, 2, B_KN, BK>(p, stream, name_only);          // 128 x 128
   return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, stream, name_only);                          // 128 x 64
