@@ -129,6 +129,7 @@ class Advoc(Model):
     self._world_size = 1
     self._rank = 0
     self._allreduce = None
+    self._reduce_async = None      # (start(flat, lo, hi), finish(), bucket_elems) from parallel.DataParallel
 
   # ------------------------------------------------------------------------------------------
   # structure helpers
@@ -567,7 +568,12 @@ class Advoc(Model):
     t = st[net + '_t']
     lr_t = self._lr * math.sqrt(1 - self._beta2 ** t) / (1 - self._beta1 ** t)
     flat = st[net + '_grad']
-    if self._allreduce is not None:
+    if net == 'g' and self._reduce_async is not None:
+      start, finish, _ = self._reduce_async
+      start(flat, st.get('g_sent', 0), flat.numel())     # whatever the backward pass has not sent yet
+      finish()
+      st['g_sent'] = 0
+    elif self._allreduce is not None:
       self._allreduce(flat)
     _lib.check(_lib.load().advoc_adam_tf_f32(
         _lib.ptr(st[net + '_param']), _lib.ptr(flat), _lib.ptr(st[net + '_m']), _lib.ptr(st[net + '_v']),
@@ -617,6 +623,29 @@ class Advoc(Model):
     self._adam('d')
     st['last_counts_d'] = n
 
+  def _last_param_of(self, scope):
+    """Name of the arena entry that ends `scope`'s block of parameters."""
+    names = [k for k in self._built['g_arena'].offsets if k.startswith(scope + '/')]
+    return names[-1]
+
+  def _g_grads_ready(self, last_name):
+    """Called when the generator backward has finished every parameter up to and including
+    `last_name` (arena order = backward-completion order): starts the cross-rank sum of the newly
+    completed arena range once it is at least one bucket long."""
+    if self._reduce_async is None:
+      return
+    st = self._built
+    start, _, bucket = self._reduce_async
+    off, shape = st['g_arena'].offsets[last_name]
+    n = 1
+    for d_ in shape:
+      n *= d_
+    hi = (off + n + 3) // 4 * 4
+    lo = st.get('g_sent', 0)
+    if hi - lo >= bucket:
+      start(st['g_grad'], lo, hi)
+      st['g_sent'] = hi
+
   def g_step(self, batch):
     """One generator update on `batch` (advoc_model.py:239-245,254-255): G forward, D(fake)
     forward, gen_loss, backward through D to the generator output, G backward, Adam."""
@@ -653,7 +682,9 @@ class Advoc(Model):
       for t in gd.values():
         t.zero_()
     s = 'generator/decoder_1/conv2d_transpose'
+    st['g_sent'] = 0
     GL['decoder_1'].backward_weight(g_out, GG[s + '/kernel'], GG[s + '/bias'])
+    self._g_grads_ready(self._last_param_of('generator/decoder_1'))
     last_idx = dec[-1][0] if dec else None
     GL['decoder_1'].backward_data(g_out, gd[last_idx] if dec else ge[-1], ge[0])
     for j in range(len(dec) - 1, -1, -1):
@@ -663,6 +694,7 @@ class Advoc(Model):
       if 'decoder_%d' % idx in gbn:
         self._bn_backward(gbn['decoder_%d' % idx], gd[idx])
       lay.backward_weight(gd[idx], GG[s + '/kernel'], GG[s + '/bias'])
+      self._g_grads_ready(self._last_param_of('generator/decoder_%d' % idx))
       if j == 0:
         lay.backward_data(gd[idx], ge[-1])
       else:
@@ -673,6 +705,7 @@ class Advoc(Model):
       if 'encoder_%d' % (i + 1) in gbn:
         self._bn_backward(gbn['encoder_%d' % (i + 1)], ge[i])
       lay.backward_weight(ge[i], GG[s + '/kernel'], GG[s + '/bias'])
+      self._g_grads_ready(self._last_param_of('generator/encoder_%d' % (i + 1)))
       if i > 0:
         lay.backward_data(ge[i], ge[i - 1], accum0=True)
     self._adam('g')

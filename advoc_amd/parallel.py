@@ -4,8 +4,10 @@ The reference has no multi-GPU code; this is new functionality
 contract: an N-GPU step on a global batch equals the 1-GPU step on the same global batch.
 Each rank owns batch/N clips; after each backward pass the network's flat gradient arena
 (advoc_amd.model) is summed across ranks with a few large all-reduces -- xGMI is
-point-to-point, ring all-reduce is per-link bound, so buckets are big (default 64 MiB) -- and the
-fused Adam kernel applies 1/N.  Dropout masks are Philox streams keyed by the GLOBAL clip index,
+point-to-point, ring all-reduce is per-link bound, so buckets are big (default 8 MiB) -- and the
+fused Adam kernel applies 1/N.  The generator's arena is laid out in backward-completion order
+and its buckets are reduced asynchronously as soon as the backward pass has filled them, next to
+the remaining backward kernels; the (small) discriminator arena is reduced in one go.  Dropout masks are Philox streams keyed by the GLOBAL clip index,
 so sharding does not change them.
 """
 import os
@@ -15,13 +17,14 @@ import torch.distributed as dist
 
 
 class DataParallel(object):
-  def __init__(self, bucket_bytes=64 << 20):
+  def __init__(self, bucket_bytes=8 << 20):
     self.bucket_elems = max(1, bucket_bytes // 4)
     self.world_size = 1
     self.rank = 0
     self.local_rank = 0
     self.enabled = False
     self.backend = None
+    self._pending = []
 
   def init_from_env(self, backend=None):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run)."""
@@ -57,6 +60,28 @@ class DataParallel(object):
       self._collective(dist.all_reduce, flat[lo:min(n, lo + self.bucket_elems)], op=dist.ReduceOp.SUM)
     return flat
 
+  # ---- overlapped reduction: ranges of a flat gradient arena are reduced as soon as the backward
+  # pass has produced them (the arena is laid out in backward-completion order) ----
+  def reduce_range_async(self, flat, lo, hi):
+    """Starts the sum of flat[lo:hi] across ranks.  RCCL: asynchronous on its own stream -- it waits
+    for the work already enqueued on the compute stream (the kernels that wrote this range) and runs
+    next to the kernels enqueued afterwards.  Completion is joined by `finish_reductions`."""
+    if not self.enabled or hi <= lo:
+      return
+    n = hi
+    for a in range(lo, n, self.bucket_elems):
+      piece = flat[a:min(n, a + self.bucket_elems)]
+      if self.backend == 'gloo' and piece.is_cuda:
+        self._collective(dist.all_reduce, piece, op=dist.ReduceOp.SUM)      # host-staged, synchronous
+      else:
+        self._pending.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+
+  def finish_reductions(self):
+    """Makes the current stream (RCCL) / the host (gloo) wait for every reduction started above."""
+    for w in self._pending:
+      w.wait()
+    self._pending = []
+
   def _collective(self, fn, t, **kw):
     """RCCL works on device tensors directly; gloo (CPU tests, wiring checks) goes through host memory."""
     if self.backend == 'gloo' and t.is_cuda:
@@ -71,6 +96,8 @@ class DataParallel(object):
     model._world_size = self.world_size
     model._rank = self.rank
     model._allreduce = self.allreduce_ if self.enabled else None
+    # generator gradients: reduce arena ranges while the rest of the backward pass still runs
+    model._reduce_async = (self.reduce_range_async, self.finish_reductions, self.bucket_elems) if self.enabled else None
     return model
 
   def broadcast_parameters(self, model):

@@ -42,7 +42,15 @@ def _worker(rank, world, port, out_dir):
   grads, _ = A.grads(P, x[lo:hi], target[lo:hi], cfg, local_masks, 'G')
   flat = torch.cat([v.reshape(-1) for v in grads.values()])
   assert flat.numel() * 4 > 4 * dp.bucket_elems            # several buckets
+  # the overlapped path: ranges of the arena reduced asynchronously as the "backward pass" completes them
+  flat2 = flat.clone()
+  n = flat2.numel()
+  cuts = [0, n // 5, n // 2, n]
+  for a, b in zip(cuts[:-1], cuts[1:]):
+    dp.reduce_range_async(flat2, a, b)
+  dp.finish_reductions()
   dp.allreduce_(flat)
+  assert torch.equal(flat, flat2)
   flat /= world                                             # what the fused Adam's grad_scale applies
   if rank == 0:
     full, _ = A.grads(P, x, target, cfg, masks, 'G')
