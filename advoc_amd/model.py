@@ -148,6 +148,9 @@ class Advoc(Model):
                                 .format(self.generator_type))
     if self.separable_conv:
       raise NotImplementedError('separable_conv=True is a non-default ablation outside the hot path')
+    if self.ngf % 32 or self.ndf % 32:
+      raise NotImplementedError('ngf / ndf must be multiples of 32: the gfx950 MFMA kernels tile channels '
+                                'by 32 (reference defaults: 64, small model: 32)')
     # the skip concats only line up when halving (SAME: ceil) and doubling retrace each other;
     # the reference's TF graph fails to build otherwise (tf.concat shape error)
     h, hs = int(self.subseq_len), []

@@ -48,7 +48,7 @@ def test_override_model_attrs():
 def test_unsupported_ablations_fail_loudly():
   from advoc_amd.model import Advoc, Modes
   from advoc_amd.model import override_model_attrs
-  for ov in ('generator_type=linear', 'separable_conv=True'):
+  for ov in ('generator_type=linear', 'separable_conv=True', 'ngf=48', 'ndf=16'):
     m, _ = override_model_attrs(Advoc(Modes.TRAIN), ov)
     with pytest.raises(NotImplementedError):
       m._check_supported()

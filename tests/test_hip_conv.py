@@ -250,3 +250,32 @@ def test_abi_rejects_bad_layers(hip):
     conv.Layer(0, x, y, torch.zeros(4, 4, 32, 24, device=dev), None)
   with pytest.raises(_lib.AdvocHipError):
     conv.Layer(0, torch.zeros(1, 8, 8, 32), y, torch.zeros(4, 4, 32, 32, device=dev), None)
+
+
+ODD = [
+    ('c1_to_24', 0, (2, 16, 33), 1, 0, 24, 0, (2, 2), None, 0, False, 0),
+    ('c24_to_1', 0, (2, 9, 11), 24, 0, 1, 0, (1, 1), (1, 1), 1, False, 0),
+]
+
+
+@gpu
+@pytest.mark.parametrize('case', ODD, ids=[c[0] for c in ODD])
+def test_channel_counts_outside_the_mfma_kernels(hip, case):
+  """The AdVoc nets only have channel counts that are multiples of 32 (or 1-2 at the edges).  Other
+  counts run forward and backward-data on the direct kernels (edge.hip) with the same parity, and
+  the weight gradient reports ADVOC_ERR_UNSUPPORTED instead of computing something else."""
+  from advoc_amd import _lib, conv
+  c = build_case(case)
+  dev = torch.device('cuda')
+  y_o, dx0_o, _, _, _ = oracle_layer(c['kind'], c['x0'], c['x1'], c['in_w'], c['w'], c['b'], c['stride'], c['pad'],
+                                     c['act'], c['mask'], c['keep'], c['out_w'], c['dy'])
+  x0, w, b, dy = c['x0'].to(dev), c['w'].to(dev), c['b'].to(dev), c['dy'].to(dev)
+  y = torch.zeros(x0.shape[0], c['oh'], c['out_w'], w.shape[3], device=dev)
+  L = conv.Layer(c['kind'], x0, y, w, b, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
+  L.forward()
+  assert rel(y, y_o) < TOL
+  dx0 = torch.zeros_like(x0)
+  L.backward_data(dy, dx0)
+  assert rel(dx0, dx0_o) < TOL
+  with pytest.raises(_lib.AdvocHipError, match='unsupported'):
+    L.backward_weight(dy, torch.zeros_like(w), torch.zeros_like(b))
