@@ -613,8 +613,11 @@ class Advoc(Model):
                                     _lib.ptr(glog[B:]), _lib.ptr(st['sums'][0:1]), _lib.stream()),
                'advoc_gan_d_loss')
     DG = st['d_G']
+    # one fill of the whole gradient arena instead of one small memset per kernel / bias / BN vector
+    # (every weight-gradient kernel accumulates with atomics into zeroed memory anyway)
+    st['d_grad'].zero_()
     for k, (layers, bns, lo, hi) in enumerate(passes):
-      acc = k > 0        # the second pass adds to the first pass's parameter gradients
+      acc = True
       for i in range(4, -1, -1):
         s = 'discriminator/layer_%d/conv2d' % (i + 1)
         g = st['g_d_act'][i][lo:hi]
@@ -686,7 +689,8 @@ class Advoc(Model):
         t.zero_()
     s = 'generator/decoder_1/conv2d_transpose'
     st['g_sent'] = 0
-    GL['decoder_1'].backward_weight(g_out, GG[s + '/kernel'], GG[s + '/bias'])
+    st['g_grad'].zero_()       # one fill for the whole arena; the kernels below accumulate into it
+    GL['decoder_1'].backward_weight(g_out, GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
     self._g_grads_ready(self._last_param_of('generator/decoder_1'))
     last_idx = dec[-1][0] if dec else None
     GL['decoder_1'].backward_data(g_out, gd[last_idx] if dec else ge[-1], ge[0])
@@ -695,8 +699,8 @@ class Advoc(Model):
       s = 'generator/decoder_%d/conv2d_transpose' % idx
       lay = GL['decoder_%d' % idx]
       if 'decoder_%d' % idx in gbn:
-        self._bn_backward(gbn['decoder_%d' % idx], gd[idx])
-      lay.backward_weight(gd[idx], GG[s + '/kernel'], GG[s + '/bias'])
+        self._bn_backward(gbn['decoder_%d' % idx], gd[idx], accumulate=True)
+      lay.backward_weight(gd[idx], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
       self._g_grads_ready(self._last_param_of('generator/decoder_%d' % idx))
       if j == 0:
         lay.backward_data(gd[idx], ge[-1])
@@ -706,8 +710,8 @@ class Advoc(Model):
       s = 'generator/encoder_%d/conv2d' % (i + 1)
       lay = GL['encoder_%d' % (i + 1)]
       if 'encoder_%d' % (i + 1) in gbn:
-        self._bn_backward(gbn['encoder_%d' % (i + 1)], ge[i])
-      lay.backward_weight(ge[i], GG[s + '/kernel'], GG[s + '/bias'])
+        self._bn_backward(gbn['encoder_%d' % (i + 1)], ge[i], accumulate=True)
+      lay.backward_weight(ge[i], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
       self._g_grads_ready(self._last_param_of('generator/encoder_%d' % (i + 1)))
       if i > 0:
         lay.backward_data(ge[i], ge[i - 1], accum0=True)
