@@ -42,9 +42,17 @@ def latest_checkpoint(train_dir):
   idx = os.path.join(train_dir, 'checkpoint')
   if not os.path.isfile(idx):
     return None
-  name = open(idx).read().strip()
-  fp = os.path.join(train_dir, name)
-  return fp if os.path.isfile(fp) else None
+  text = open(idx).read().strip()
+  name = text
+  if 'model_checkpoint_path' in text:        # TensorFlow's CheckpointState text proto
+    import re
+    m = re.search(r'model_checkpoint_path:\s*"([^"]+)"', text)
+    name = m.group(1) if m else text
+  fp = name if os.path.isabs(name) else os.path.join(train_dir, name)
+  from advoc_amd import tf_checkpoint
+  if os.path.isfile(fp) or tf_checkpoint.is_tf_checkpoint(fp):
+    return fp
+  return None
 
 
 def save_checkpoint(train_dir, model, generator_only=False, name=None):
@@ -67,6 +75,18 @@ def save_checkpoint(train_dir, model, generator_only=False, name=None):
 
 
 def restore_checkpoint(fp, model, with_optimizer=True):
+  """Restores a checkpoint written by save_checkpoint, or a TensorFlow checkpoint prefix
+  (`model.ckpt-N` with `.index` / `.data-*` next to it, e.g. the reference's published vocoders):
+  variables are matched by their TF names; TF Adam slots are not imported."""
+  from advoc_amd import tf_checkpoint
+  if not os.path.isfile(fp) and tf_checkpoint.is_tf_checkpoint(fp):
+    model.build()
+    loaded, missing, step = tf_checkpoint.load_into_model(fp, model)
+    if missing:
+      print('TF checkpoint {}: {} variables not found (left at their initial values): {}'.format(
+          fp, len(missing), ', '.join(missing[:4]) + (' ...' if len(missing) > 4 else '')))
+    model.step = step
+    return model.step
   state = torch.load(fp, map_location='cpu')
   model.load_state_dict(state['model'])
   model.step = int(state.get('step', 0))
