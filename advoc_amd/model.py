@@ -19,7 +19,9 @@ Semantics kept: TF SAME padding, kernel layouts and variable names, N(0, 0.02) i
 dropout 0.5 in every mode, D update on one batch then G update on the NEXT batch, TF Adam.
 """
 import collections
+import contextlib
 import math
+import os
 
 import torch
 
@@ -257,6 +259,9 @@ class Advoc(Model):
       st['g_t'] = st['d_t'] = 0
       st['sums'] = torch.zeros(4, dtype=torch.float32, device=dev)
     st['B'] = B
+    if 'side_stream' not in st:
+      st['side_stream'] = torch.cuda.Stream(device=dev)
+      st['side_on'] = os.environ.get('ADVOC_WGRAD_STREAM', '1') != '0'
     self._bind(st, B, dev)
     self._built = st
     if not hasattr(self, 'step'):
@@ -623,11 +628,29 @@ class Advoc(Model):
         g = st['g_d_act'][i][lo:hi]
         if i in bns:
           self._bn_backward(bns[i], g, accumulate=acc)
-        layers[i].backward_weight(g, DG[s + '/kernel'], DG[s + '/bias'], accumulate=acc)
+        with self._wgrad_ctx():
+          layers[i].backward_weight(g, DG[s + '/kernel'], DG[s + '/bias'], accumulate=acc)
         if i > 0:
           layers[i].backward_data(g, st['g_d_act'][i - 1][lo:hi])
+    self._join_wgrad()
     self._adam('d')
     st['last_counts_d'] = n
+
+  def _wgrad_ctx(self):
+    """Weight / bias gradients are off the critical path of the backward pass (nothing downstream
+    reads them before Adam): they run on a side stream so that their launches fill the tail of the
+    backward-data kernels and vice versa.  Returns a context manager; `_join_wgrad` re-joins."""
+    st = self._built
+    if not st.get('side_on', False):
+      return contextlib.nullcontext()
+    side = st['side_stream']
+    side.wait_stream(torch.cuda.current_stream())       # everything enqueued so far (dy is ready)
+    return torch.cuda.stream(side)
+
+  def _join_wgrad(self):
+    st = self._built
+    if st.get('side_on', False):
+      torch.cuda.current_stream().wait_stream(st['side_stream'])
 
   def _last_param_of(self, scope):
     """Name of the arena entry that ends `scope`'s block of parameters."""
@@ -690,8 +713,9 @@ class Advoc(Model):
     s = 'generator/decoder_1/conv2d_transpose'
     st['g_sent'] = 0
     st['g_grad'].zero_()       # one fill for the whole arena; the kernels below accumulate into it
-    GL['decoder_1'].backward_weight(g_out, GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
-    self._g_grads_ready(self._last_param_of('generator/decoder_1'))
+    with self._wgrad_ctx():
+      GL['decoder_1'].backward_weight(g_out, GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
+      self._g_grads_ready(self._last_param_of('generator/decoder_1'))
     last_idx = dec[-1][0] if dec else None
     GL['decoder_1'].backward_data(g_out, gd[last_idx] if dec else ge[-1], ge[0])
     for j in range(len(dec) - 1, -1, -1):
@@ -700,8 +724,9 @@ class Advoc(Model):
       lay = GL['decoder_%d' % idx]
       if 'decoder_%d' % idx in gbn:
         self._bn_backward(gbn['decoder_%d' % idx], gd[idx], accumulate=True)
-      lay.backward_weight(gd[idx], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
-      self._g_grads_ready(self._last_param_of('generator/decoder_%d' % idx))
+      with self._wgrad_ctx():
+        lay.backward_weight(gd[idx], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
+        self._g_grads_ready(self._last_param_of('generator/decoder_%d' % idx))
       if j == 0:
         lay.backward_data(gd[idx], ge[-1])
       else:
@@ -711,10 +736,12 @@ class Advoc(Model):
       lay = GL['encoder_%d' % (i + 1)]
       if 'encoder_%d' % (i + 1) in gbn:
         self._bn_backward(gbn['encoder_%d' % (i + 1)], ge[i], accumulate=True)
-      lay.backward_weight(ge[i], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
-      self._g_grads_ready(self._last_param_of('generator/encoder_%d' % (i + 1)))
+      with self._wgrad_ctx():
+        lay.backward_weight(ge[i], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
+        self._g_grads_ready(self._last_param_of('generator/encoder_%d' % (i + 1)))
       if i > 0:
         lay.backward_data(ge[i], ge[i - 1], accum0=True)
+    self._join_wgrad()
     self._adam('g')
     self.step += 1
     st['last_counts_g'] = (logits.numel(), gen.numel())
