@@ -261,7 +261,7 @@ class Advoc(Model):
     st['B'] = B
     if 'side_stream' not in st:
       st['side_stream'] = torch.cuda.Stream(device=dev)
-      st['side_on'] = os.environ.get('ADVOC_WGRAD_STREAM', '1') != '0'
+      st['side_on'] = os.environ.get('ADVOC_WGRAD_STREAM', '0') == '1'
     self._bind(st, B, dev)
     self._built = st
     if not hasattr(self, 'step'):
@@ -638,8 +638,10 @@ class Advoc(Model):
 
   def _wgrad_ctx(self):
     """Weight / bias gradients are off the critical path of the backward pass (nothing downstream
-    reads them before Adam): they run on a side stream so that their launches fill the tail of the
-    backward-data kernels and vice versa.  Returns a context manager; `_join_wgrad` re-joins."""
+    reads them before Adam): with ADVOC_WGRAD_STREAM=1 they run on a side stream so that their
+    launches fill the tail of the backward-data kernels and vice versa (measured -1.7 % step time).
+    Off by default: concurrent kernels share the CUs, which makes per-kernel durations -- and every
+    roofline figure derived from them -- uninterpretable.  Returns a context manager."""
     st = self._built
     if not st.get('side_on', False):
       return contextlib.nullcontext()

@@ -2,7 +2,7 @@
 """Per-layer / per-direction kernel timing of one AdVoc train_loop (HIP events).
     python tools/layer_times.py [small|regular] [batch]"""
 import os, sys
-os.environ.setdefault('ADVOC_WGRAD_STREAM', '0')   # per-kernel times: no concurrent side-stream kernels
+os.environ['ADVOC_WGRAD_STREAM'] = '0'   # per-kernel times: no concurrent side-stream kernels
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from advoc_amd import conv
