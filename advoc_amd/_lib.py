@@ -58,6 +58,7 @@ PROTOTYPES = {
     'advoc_cabs_f32': (ctypes.c_int, [_p, _p, _i64, _p]),
     'advoc_polar_c64': (ctypes.c_int, [_p, _p, _p, _i64, _p]),
     'advoc_matmul_nt_f32': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
+    'advoc_tanh_affine_f32': (ctypes.c_int, [_p, _p, _i64, _f32, _f32, _p]),
     'advoc_mel_dbnorm_f32': (ctypes.c_int, [_p, _i64, _f32, _f32, _f32, _p]),
     'advoc_conv_workspace_bytes': (_i64, [_p, _i32]),
     'advoc_conv_forward': (ctypes.c_int, [_p, _p]),

@@ -24,7 +24,10 @@ int validate_layer(const advoc_conv_layer* L) {
     if (x1.n != x0.n || x1.h != x0.h || x1.w != x0.w || x1.c <= 0 || x1.w_pitch < x1.w)
       return ADVOC_ERR_BAD_SHAPE;
   }
-  if (L->kh < 1 || L->kw < 1 || L->kh * L->kw > kMaxTaps || L->sh < 1 || L->sw < 1) return ADVOC_ERR_UNSUPPORTED;
+  // dense tap lists hold kMaxTaps entries; a transposed conv is run phase by phase (<= ceil(k/s)^2 taps
+  // each), so its forward direction also takes 5x5 kernels (MelspecGAN, models/melspecgan/conv2d.py:17-53)
+  const int max_taps = L->kind == ADVOC_DECONV ? 25 : kMaxTaps;
+  if (L->kh < 1 || L->kw < 1 || L->kh * L->kw > max_taps || L->sh < 1 || L->sw < 1) return ADVOC_ERR_UNSUPPORTED;
   if (L->pad_t < 0 || L->pad_l < 0 || L->pad_t >= L->kh || L->pad_l >= L->kw) return ADVOC_ERR_UNSUPPORTED;
   if (L->in_act < ADVOC_ACT_NONE || L->in_act > ADVOC_ACT_RELU) return ADVOC_ERR_UNSUPPORTED;
   if ((L->in_scale == nullptr) != (L->in_shift == nullptr)) return ADVOC_ERR_NULL;
@@ -35,8 +38,8 @@ int validate_layer(const advoc_conv_layer* L) {
   } else {
     // strides (2,2), and (1,2) for the layers the reference builds once the time axis has
     // shrunk to 1 (advoc_model.py:109-116,139-142)
-    if (L->kh != 4 || L->kw != 4 || L->sh < 1 || L->sh > 2 || L->sw < 1 || L->sw > 2 || L->pad_t != 1 ||
-        L->pad_l != 1)
+    if (L->kh < 4 || L->kh > 5 || L->kw != L->kh || L->sh < 1 || L->sh > 2 || L->sw < 1 || L->sw > 2 ||
+        L->pad_t != 1 || L->pad_l != 1)
       return ADVOC_ERR_UNSUPPORTED;
     if (y.h != L->sh * x0.h || y.w > L->sw * x0.w || y.w < L->sw * x0.w - 1) return ADVOC_ERR_BAD_SHAPE;
   }
@@ -79,19 +82,31 @@ int subpixel_taps(GatherGemmParams& p, const advoc_conv_layer* L) {
   p.osy = L->sh;
   p.osx = L->sw;
   p.nphase = L->sh * L->sw;
+  int counts[kMaxPhases] = {0, 0, 0, 0};
+  int most = 0;
   for (int py = 0; py < L->sh; ++py)
     for (int px = 0; px < L->sw; ++px) {
       int kys[kMaxTaps], dys[kMaxTaps], kxs[kMaxTaps], dxs[kMaxTaps];
       const int ny = phase_taps(py, L->pad_t, L->kh, L->sh, kys, dys);
       const int nx = phase_taps(px, L->pad_l, L->kw, L->sw, kxs, dxs);
-      if (ny * L->sh != L->kh || nx * L->sw != L->kw) return ADVOC_ERR_UNSUPPORTED;  // same tap count in every phase
+      if (ny * nx > kMaxTaps) return ADVOC_ERR_UNSUPPORTED;
       const int ph = py * L->sw + px;
-      p.ntaps = ny * nx;
+      counts[ph] = ny * nx;
+      most = ny * nx > most ? ny * nx : most;
       for (int a = 0; a < ny; ++a)
         for (int b = 0; b < nx; ++b)
           p.tap[ph][a * nx + b] = pack_tap(dys[a], dxs[b], kys[a] * L->kw + kxs[b]);
       p.ooy[ph] = py;
       p.oox[ph] = px;
+    }
+  p.ntaps = most;
+  // Odd kernels give the phases different tap counts (5x5, stride 2: 9 / 6 / 6 / 4).  The kernels walk
+  // ONE count, so the short phases are padded with taps that read 128 rows AND columns before the
+  // grid point -- outside any input this is accepted for, i.e. they contribute exactly zero.
+  for (int ph = 0; ph < p.nphase; ++ph)
+    for (int t = counts[ph]; t < most; ++t) {
+      if (p.in_h > 128 && p.in_w > 128) return ADVOC_ERR_UNSUPPORTED;
+      p.tap[ph][t] = pack_tap(-128, -128, 0);
     }
   return ADVOC_OK;
 }
@@ -150,6 +165,7 @@ int build_backward_data(const advoc_conv_layer* L, const float* dy, float* dx0, 
   p.d[1].gshift = L->in_shift ? L->in_shift + c0 : nullptr;
   p.out_h = L->x0.h; p.out_w = L->x0.w;
   p.grad_act = L->in_act;
+  if (L->kh * L->kw > kMaxTaps) return ADVOC_ERR_UNSUPPORTED;   // 5x5 transposed convs: forward (inference) only
   if (L->kind == ADVOC_DECONV) {
     // dIn[iy,ix,ci] = sum dOut[2 iy - pad + ky, 2 ix - pad + kx, co] * w[ky,kx,co,ci]
     p.gh = L->x0.h; p.gw = L->x0.w;
@@ -176,6 +192,9 @@ int build_backward_data(const advoc_conv_layer* L, const float* dy, float* dx0, 
 bool two_stage_ok(const GatherGemmParams& p) {
   const int K = p.c0 + p.c1, N = p.n_total;
   const int wtaps = p.nphase * p.ntaps;          // distinct kernel taps (phases partition them)
+  for (int ph = 0; ph < p.nphase; ++ph)
+    for (int t = 0; t < p.ntaps; ++t)
+      if ((int)(int8_t)(p.tap[ph][t] & 0xff) == -128) return false;     // padded phases (odd kernels): direct kernel
   return N <= 2 && K % 16 == 0 && p.c0 % 16 == 0 && (wtaps * N) % 4 == 0 && wtaps * N <= 32 && !p.y_mask;
 }
 
@@ -243,6 +262,7 @@ void operand_from_dy(const advoc_conv_layer* L, const float* dy, Operand& o) {
 // dw[tap][ci][0] = sum_in x[in][ci] * dY[in + pad - k].
 int build_backward_weight(const advoc_conv_layer* L, const float* dy, float* dw, WgradParams& p) {
   p = WgradParams{};
+  if (L->kh * L->kw > kMaxTaps) return ADVOC_ERR_UNSUPPORTED;
   p.batch = L->x0.n;
   p.dw = dw;
   p.ntaps = L->kh * L->kw;

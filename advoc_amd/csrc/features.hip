@@ -77,7 +77,28 @@ __global__ __launch_bounds__(256) void mel_dbnorm_kernel(float* __restrict__ v, 
   }
 }
 
+// y = tanh(x) * scale + shift: the MelspecGAN generator's output non-linearity fused with
+// feats_denorm (models/melspecgan/conv2d.py:139, util.py:11-12)
+__global__ __launch_bounds__(256) void tanh_affine_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          int64_t n, float scale, float shift) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = tanhf(x[i]) * scale + shift;
+}
+
 }  // namespace
+
+extern "C" int advoc_tanh_affine_f32(const float* x, float* y, int64_t n, float scale, float shift,
+                                     advoc_stream_t stream) {
+  if (n < 0) return ADVOC_ERR_BAD_SHAPE;
+  if (n == 0) return ADVOC_OK;
+  if (!x || !y) return ADVOC_ERR_NULL;
+  const int64_t blocks = advoc::ceil_div(n, 256);
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(tanh_affine_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0,
+                     advoc::as_stream(stream), x, y, n, scale, shift);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
 
 extern "C" int advoc_matmul_nt_f32(const float* x, const float* w, float* out, int64_t rows,
                                    int32_t k, int32_t n, advoc_stream_t stream) {

@@ -39,6 +39,39 @@ def vocode_melspec(model, spec, spectral_util=None, chunk_batch=16):
   return gen.cpu().numpy()
 
 
+def vocode_batch(model, specs, spectral_util=None, phase_estimation='gl60', chunk_batch=64, unit_phase=None):
+  """Equally long mel spectrograms -> waveforms, all on the GPU: nd-array / tensor float [n, T, n_mels, 1]
+  (dB-normalised, e.g. MelspecGAN samples) -> (magnitudes float32 [n, T, 513] in HBM, waveforms float32
+  [n, (T-1)*256 + 1024] in HBM or None).  Per sample exactly what scripts/spectrogram_advoc.py:80-95 /
+  models/advoc/melspecVocoder.py:57-83 do (pseudo-inverse, padding to int(T/L)*L + L frames -- a whole
+  extra zero chunk when T is a multiple of L --, generator, trim), with every chunk of every sample
+  in one generator batch and Griffin-Lim over all samples at once.  phase_estimation: 'gl<N>' or None."""
+  from advoc_amd import spectral
+  su = spectral_util or SpectralUtil(n_mels=model.n_mels, fs=model.audio_fs)
+  specs = torch.as_tensor(np.asarray(specs) if not isinstance(specs, torch.Tensor) else specs)
+  n, T = specs.shape[0], specs.shape[1]
+  L = model.subseq_len
+  mel_host = specs[:, :, :, 0].reshape(n * T, -1).detach().cpu().numpy()
+  X_mag = su.tacotron_mel_to_mag(mel_host).reshape(n, T, -1)                     # [n, T, 513] in HBM
+  target, per = chunk_plan(T, L)
+  padded = torch.zeros(n, target, X_mag.shape[2], dtype=torch.float32, device=X_mag.device)
+  padded[:, :T] = X_mag
+  chunks = padded.reshape(n * per, L, X_mag.shape[2], 1)
+  outs = []
+  for lo in range(0, n * per, chunk_batch):
+    outs.append(model.build_generator(chunks[lo:lo + chunk_batch]))
+  gen = torch.cat(outs, dim=0).reshape(n, target, X_mag.shape[2])[:, :T].contiguous()
+  if phase_estimation is None:
+    return gen, None
+  if phase_estimation[:2] != 'gl':
+    raise NotImplementedError('only Griffin-Lim phase estimation (gl<N>) is built; LWS is third-party')
+  if unit_phase is None:
+    unit_phase = torch.rand(gen.shape, device=gen.device)
+  wav = spectral.griffin_lim_batch(gen.abs(), SpectralUtil.NFFT, SpectralUtil.NHOP, int(phase_estimation[2:]),
+                                   unit_phase)
+  return gen, wav
+
+
 def load_generator(ckpt_fp, model_type='regular', subseq_len=256, fs=22050):
   """Builds an INFER-mode model and restores generator weights from a train_evaluate.py checkpoint."""
   from advoc_amd.model import Advoc, AdvocSmall, Modes

@@ -28,7 +28,8 @@ Extra objects on the JSON line:
                 events; algorithmic bytes = 790 528 per clip against 8 TB/s.
   inference     vocoded clips/s: mel -> pseudo-inverse -> generator forward on 256-frame chunks
                 (scripts/spectrogram_advoc.py:80-94 semantics, batched; phase estimation not
-                included).  Measured after the timed region; not part of `value`.
+                included), plus `joint_sc09`: z -> MelspecGAN -> AdVoc -> Griffin-Lim waveform
+                (BASELINE configs[4] on one GPU).  Measured after the timed region; not part of `value`.
   cpu_baseline  the torch-CPU restatement of the reference graph (oracle/, "port") timed on this
                 box's host cores on a bounded sample (rank 0, N = 1 only).
 """
@@ -165,6 +166,35 @@ def inference_leg(torch, model_cls, Modes, su, mel, iters=10):
                    'uses LWS for phase (third-party, not restated).')
 
 
+def joint_leg(torch, n=64, iters=3):
+  """BASELINE configs[4] on one GPU: z -> MelspecGAN generator -> mel [64 x 80] -> AdVoc (full model at
+  subseq_len 64, its (1,2)-stride layers) -> Griffin-Lim (60 iterations) -> 16 kHz waveform; random
+  weights (no checkpoints are reachable), synthetic z.  Samples per second, end to end on the GPU."""
+  from advoc_amd.infer import vocode_batch
+  from advoc_amd.melspecgan import MelspecGANGenerator
+  from advoc_amd.model import Advoc, Modes
+  G = MelspecGANGenerator(dim=64)
+  voc = Advoc(Modes.INFER)
+  voc.subseq_len = 64
+  voc.audio_fs = 16000
+  voc.build(batch_size=2 * n, seed=0)
+  z = torch.randn(n, 100, generator=torch.Generator().manual_seed(0))
+
+  def run():
+    mel = G(z, denorm=True)
+    return vocode_batch(voc, mel, phase_estimation='gl60', chunk_batch=2 * n)[1]
+  run()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(iters):
+    wav = run()
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / iters
+  return dict(value=n / dt, unit='generated 64-frame clips/s (z -> 16 kHz waveform, Griffin-Lim 60)', batch=n,
+              ms_per_batch=dt * 1e3, samples_per_clip=int(wav.shape[1]),
+              note='MelspecGAN G + AdVoc-full(subseq_len 64) + GL60, random weights; the reference uses LWS')
+
+
 def recorded_traffic(kernel, model, batch):
   """L2-miss bytes per launch from the committed counter passes (tools/pmc_summary.py), if they
   were taken on this workload."""
@@ -286,6 +316,7 @@ def main():
     extractor = extractor_leg(torch, spectral, pool[0])
     mel0 = su.mag_to_mel_linear_spec(spectral.stft_magnitude(pool[0], 1024, 256, pad_end=False))
     inference = inference_leg(torch, AdvocSmall if args.model == 'small' else Advoc, Modes, su, mel0)
+    inference['joint_sc09'] = joint_leg(torch)
   dp.barrier()
 
   cpu = None

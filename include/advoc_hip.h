@@ -113,6 +113,11 @@ int advoc_stft_c64(const float* wav, int64_t batch, int64_t nsamps, const float*
 int advoc_matmul_nt_f32(const float* x, const float* w, float* out, int64_t rows, int32_t k,
                         int32_t n, advoc_stream_t stream);
 
+/* y[i] = tanh(x[i]) * scale + shift (x == y allowed).  Replaces tf.nn.tanh + feats_denorm at the end of
+ * the MelspecGAN generator, models/melspecgan/conv2d.py:139 and util.py:11-12 (scale = shift = 0.5). */
+int advoc_tanh_affine_f32(const float* x, float* y, int64_t n, float scale, float shift,
+                          advoc_stream_t stream);
+
 /* In-place r9y9 dB normalisation of a linear mel spectrogram:
  *   v = clip((20*log10(max(min_level, v)) - ref_db - min_db) / -min_db, 0, 1)
  * Replaces advoc/spectral.py:210-225. */

@@ -48,7 +48,9 @@ if __name__ == '__main__':
     name = os.path.splitext(os.path.split(spec_fp)[1])[0]
     spec = np.load(spec_fp)
     if model is None:
-      wave = r9y9_melspec_to_waveform(spec, fs=args.fs, phase_estimation=args.phase_estimation)
+      # (float64 is what melspec_to_waveform insists on, spectral.py:359-360; generated MelspecGAN
+      #  spectrograms are stored as float32)
+      wave = r9y9_melspec_to_waveform(spec.astype(np.float64), fs=args.fs, phase_estimation=args.phase_estimation)
     else:
       gen_mag = vocode_melspec(model, spec)
       if args.save_mag:

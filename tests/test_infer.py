@@ -98,3 +98,34 @@ def test_vocoding_script_writes_wavs(hip, tmp_path):
   assert x.shape == (11 * 256 + 1024, 1, 1) and x.dtype == np.float32
   with pytest.raises(NotImplementedError):
     su.audio_from_mag_spec(mag, phase_estimation='lws')
+
+
+@gpu
+def test_vocode_batch_equals_per_sample_vocoding(hip):
+  """The batched z -> mel -> magnitude -> waveform path (BASELINE configs[4]: 64-frame SC09 clips through
+  the full model with its (1,2)-stride layers) gives, per sample, what the per-utterance path gives."""
+  from advoc_amd import spectral
+  from advoc_amd.infer import vocode_batch, vocode_melspec
+  from advoc_amd.model import Advoc, Modes
+  m = Advoc(Modes.INFER)
+  m.subseq_len = 64
+  m.audio_fs = 16000
+  m.build(batch_size=6, seed=1)
+  rng = np.random.default_rng(5)
+  specs = rng.uniform(0.1, 0.9, size=(3, 64, 80, 1)).astype(np.float32)
+  masks = {k: (torch.rand(buf.shape, generator=torch.Generator().manual_seed(i)) >= 0.5).to(torch.uint8)
+           for i, (k, buf) in enumerate((('decoder_%d' % idx, b[0]) for idx, b in m._built['masks'].items()))}
+  m.set_dropout_masks(masks)
+  gen, wav = vocode_batch(m, specs, phase_estimation='gl2', chunk_batch=6,
+                          unit_phase=torch.full((3, 64, 513), 0.25, device='cuda'))
+  assert tuple(gen.shape) == (3, 64, 513) and tuple(wav.shape) == (3, 63 * 256 + 1024)
+  assert torch.isfinite(wav).all()
+  for i in range(3):
+    m.build(batch_size=2)
+    m.set_dropout_masks({k: v[2 * i:2 * i + 2] for k, v in masks.items()})
+    one = vocode_melspec(m, specs[i].astype(np.float64), chunk_batch=2)
+    assert np.linalg.norm(one[:, :, 0] - gen[i].cpu().numpy()) / np.linalg.norm(one) < 1e-5
+  g0, none = vocode_batch(m, specs[:1], phase_estimation=None, chunk_batch=2)
+  assert none is None and tuple(g0.shape) == (1, 64, 513)
+  with pytest.raises(NotImplementedError):
+    vocode_batch(m, specs[:1], phase_estimation='lws', chunk_batch=2)
