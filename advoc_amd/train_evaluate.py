@@ -8,9 +8,10 @@ Multi-GPU: launch one process per GPU with torch.distributed.run; every rank tak
 shard of the file list and gradients are all-reduced over RCCL (advoc_amd/parallel.py).
 
 Differences from the reference, by necessity: checkpoints are torch files
-(WORK_DIR/model.ckpt-<step>.pt + a `checkpoint` index; variables keep their TF names), scalar
-summaries go to WORK_DIR/summaries.jsonl instead of TensorBoard event files, and audio summaries
-(host LWS phase reconstruction) are not produced yet.
+(WORK_DIR/model.ckpt-<step>.pt + a `checkpoint` index; variables keep their TF names; TensorFlow
+checkpoint prefixes can be restored too), scalar summaries go to WORK_DIR/summaries.jsonl AND to a
+TensorBoard event file written without TensorFlow (advoc_amd/tb_events.py); image / audio summaries
+are not produced.
 """
 import glob
 import json
@@ -148,6 +149,8 @@ def train(fps, args):
 
   last_ckpt = last_summary = time.time()
   log = open(os.path.join(args.train_dir, 'summaries.jsonl'), 'a') if dp.rank == 0 else None
+  from advoc_amd.tb_events import EventWriter
+  events = EventWriter(args.train_dir) if dp.rank == 0 else None
   _step = model.step
   while _step < args.max_steps:
     _step = model.train_loop()
@@ -156,6 +159,7 @@ def train(fps, args):
       rec = dict(step=_step, time=now, **model.losses())
       log.write(json.dumps(rec) + '\n')
       log.flush()
+      events.add_scalars(model.losses(), _step, wall_time=now)      # tags as advoc_model.py:263-266
       last_summary = now
     if dp.rank == 0 and now - last_ckpt >= args.train_ckpt_every_nsecs:
       save_checkpoint(args.train_dir, model)
@@ -202,6 +206,10 @@ def eval(fps, args, poll=True):   # noqa: A001  (name kept from the reference)
       l1, n = evaluate_checkpoint(fps, args, model, ckpt_fp)
       with open(os.path.join(eval_dir, 'summaries.jsonl'), 'a') as f:
         f.write(json.dumps(dict(step=model.step, gen_loss_L1=l1, batches=n)) + '\n')
+      from advoc_amd.tb_events import EventWriter
+      ew = EventWriter(eval_dir)
+      ew.add_scalars({'gen_loss_L1': l1}, model.step)               # train_evaluate.py:143-145
+      ew.close()
       if l1 < best:
         # the reference never updates its best value (train_evaluate.py:153,184-186), so it saves
         # every evaluated checkpoint; here "best" means best.

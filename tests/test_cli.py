@@ -85,6 +85,11 @@ def test_train_resume_eval_infer_end_to_end(hip, tmp_path, capsys):
   assert os.path.isfile(os.path.join(work, 'model.ckpt-3.pt'))
   recs = [json.loads(l) for l in open(os.path.join(work, 'summaries.jsonl'))]
   assert recs[-1]['step'] == 3 and all(np.isfinite(r['gen_loss_total']) for r in recs)
+  # the same scalars as a TensorBoard event file (tags of advoc_model.py:263-266)
+  import glob as _glob
+  from advoc_amd.tb_events import read_events
+  ev = read_events(_glob.glob(os.path.join(work, 'events.out.tfevents.*'))[0])
+  assert ev[-1][0] == 3 and abs(ev[-1][1]['gen_loss_total'] - recs[-1]['gen_loss_total']) < 1e-4 * abs(recs[-1]['gen_loss_total'])
   # resume: continues from step 3
   TE.main(['train', work] + common + ['--max_steps', '5'])
   assert 'Restoring from' in capsys.readouterr().out

@@ -108,3 +108,21 @@ def test_model_restores_from_a_tf_checkpoint(hip, tmp_path):
   x = torch.rand(1, 32, 513, 1)
   src.set_dropout_masks(None)
   assert tuple(g.build_generator(x).shape) == (1, 32, 513, 1)
+
+
+def test_tensorboard_event_file_round_trip(tmp_path):
+  from advoc_amd.tb_events import EventWriter, read_events
+  w = EventWriter(str(tmp_path))
+  w.add_scalars({'disc_loss': 1.25, 'gen_loss_L1': 0.5}, 10, wall_time=123.0)
+  w.add_scalars({'disc_loss': 1.0}, 2 ** 40)
+  w.close()
+  raw = open(w.path, 'rb').read()
+  assert os.path.basename(w.path).startswith('events.out.tfevents.')
+  assert b'brain.Event:2' in raw[:64]
+  ev = read_events(w.path)
+  assert ev == [(10, {'disc_loss': 1.25, 'gen_loss_L1': 0.5}), (2 ** 40, {'disc_loss': 1.0})]
+  bad = bytearray(raw)
+  bad[-6] ^= 1
+  open(w.path, 'wb').write(bytes(bad))
+  with pytest.raises(ValueError):
+    read_events(w.path)
