@@ -67,6 +67,10 @@ PROTOTYPES = {
     'advoc_conv_backward_bias': (ctypes.c_int, [_p, _p, _p, _i32, _p]),
     'advoc_bn_forward': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _f32, _p, _p, _p, _p, _p, _p]),
     'advoc_bn_backward': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p]),
+    'advoc_bn_forward_stats': (ctypes.c_int, [_p, _i64, _i32, _p, _p]),
+    'advoc_bn_forward_finalize': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _f32, _p, _p, _p, _p, _p]),
+    'advoc_bn_backward_stats': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p]),
+    'advoc_bn_backward_apply': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i64, _p]),
     'advoc_conv_kernel_name': (ctypes.c_int, [_p, _i32, ctypes.c_char_p, _i32]),
     'advoc_gan_d_loss': (ctypes.c_int, [_p, _p, _i64, _p, _p, _p, _p]),
     'advoc_gan_g_loss': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _f32, _f32, _p, _p, _i32, _p, _p]),

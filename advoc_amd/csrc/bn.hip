@@ -124,6 +124,33 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ s1, const double
   dbeta[i] = accumulate ? dbeta[i] + db : db;
 }
 
+// pivot-shifted sums -> rank-independent (sum z, sum z^2): what cross-replica batch norm adds up
+__global__ void bn_unpivot_kernel(const float* __restrict__ pivot, double* __restrict__ s1, double* __restrict__ s2,
+                                  double n, int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const double p = (double)pivot[i], a = s1[i], b = s2[i];
+  s1[i] = a + n * p;
+  s2[i] = b + 2.0 * p * a + n * p * p;
+}
+
+__global__ void bn_finalize_sums_kernel(const double* __restrict__ s1, const double* __restrict__ s2,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        double inv_n, float eps, int c, float* __restrict__ scale,
+                                        float* __restrict__ shift, float* __restrict__ mean,
+                                        float* __restrict__ invstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const double m = s1[i] * inv_n;
+  const float var = (float)fmax(s2[i] * inv_n - m * m, 0.0);
+  const float is = 1.0f / sqrtf(var + eps);
+  const float sc = gamma[i] * is;
+  mean[i] = (float)m;
+  invstd[i] = is;
+  scale[i] = sc;
+  shift[i] = beta[i] - (float)m * sc;
+}
+
 int launch_colsum2(const float* a, const float* b, const float* pa, const float* pb, int64_t npix, int c,
                    double* s1, double* s2, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(s1, 0, sizeof(double) * (size_t)c, stream);
@@ -188,6 +215,76 @@ extern "C" int advoc_bn_backward(const float* z, float* g, int64_t npix, int32_t
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(bn_backward_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z,
                      g, total4, c, gamma, mean, invstd, w1, w1 + c, 1.0f / (float)npix);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split forms for cross-replica (synchronised) batch norm: the caller sums `work` (2c doubles) over
+// the replicas between the two halves and passes the global pixel count to the second.
+// advoc_bn_forward == forward_stats + forward_finalize(count = npix); likewise backward.
+// ---------------------------------------------------------------------------------------------
+extern "C" int advoc_bn_forward_stats(const float* z, int64_t npix, int32_t c, float* work, advoc_stream_t stream) {
+  if (!z || !work) return ADVOC_ERR_NULL;
+  if (npix <= 0 || c <= 0) return ADVOC_ERR_BAD_SHAPE;
+  if (!bn_shape_ok(npix, c)) return ADVOC_ERR_UNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(work) & 7) return ADVOC_ERR_UNSUPPORTED;
+  double* w1 = reinterpret_cast<double*>(work);
+  int rc = launch_colsum2(z, z, z, z, npix, c, w1, w1 + c, as_stream(stream));
+  if (rc != ADVOC_OK) return rc;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(bn_unpivot_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), z, w1, w1 + c,
+                     (double)npix, c);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+extern "C" int advoc_bn_forward_finalize(const float* work, int64_t count_total, int32_t c, const float* gamma,
+                                         const float* beta, float epsilon, float* scale, float* shift,
+                                         float* mean, float* invstd, advoc_stream_t stream) {
+  if (!work || !gamma || !beta || !scale || !shift || !mean || !invstd) return ADVOC_ERR_NULL;
+  if (count_total <= 0 || c <= 0) return ADVOC_ERR_BAD_SHAPE;
+  if (reinterpret_cast<uintptr_t>(work) & 7) return ADVOC_ERR_UNSUPPORTED;
+  const double* w1 = reinterpret_cast<const double*>(work);
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), w1, w1 + c,
+                     gamma, beta, 1.0 / (double)count_total, epsilon, c, scale, shift, mean, invstd);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+extern "C" int advoc_bn_backward_stats(const float* z, const float* g, int64_t npix, int32_t c, const float* mean,
+                                       const float* invstd, float* dgamma, float* dbeta, int32_t accumulate,
+                                       float* work, advoc_stream_t stream) {
+  if (!z || !g || !mean || !invstd || !dgamma || !dbeta || !work) return ADVOC_ERR_NULL;
+  if (npix <= 0 || c <= 0) return ADVOC_ERR_BAD_SHAPE;
+  if (!bn_shape_ok(npix, c)) return ADVOC_ERR_UNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(work) & 7) return ADVOC_ERR_UNSUPPORTED;
+  double* w1 = reinterpret_cast<double*>(work);
+  int rc = launch_colsum2(g, z, nullptr, mean, npix, c, w1, w1 + c, as_stream(stream));
+  if (rc != ADVOC_OK) return rc;
+  // the parameter gradients are THIS replica's contribution (they are summed with the other gradients)
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), w1, w1 + c,
+                     invstd, c, accumulate, dgamma, dbeta);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+extern "C" int advoc_bn_backward_apply(const float* z, float* g, int64_t npix, int32_t c, const float* gamma,
+                                       const float* mean, const float* invstd, const float* work,
+                                       int64_t count_total, advoc_stream_t stream) {
+  if (!z || !g || !gamma || !mean || !invstd || !work) return ADVOC_ERR_NULL;
+  if (npix <= 0 || c <= 0 || count_total <= 0) return ADVOC_ERR_BAD_SHAPE;
+  if (!bn_shape_ok(npix, c)) return ADVOC_ERR_UNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(work) & 7) return ADVOC_ERR_UNSUPPORTED;
+  const double* w1 = reinterpret_cast<const double*>(work);
+  const int64_t total4 = npix * (c / 4);
+  int64_t blocks = advoc::ceil_div(total4, 256 * 4);
+  if (blocks > 4096) blocks = 4096;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(bn_backward_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, g,
+                     total4, c, gamma, mean, invstd, w1, w1 + c, 1.0f / (float)count_total);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }

@@ -132,6 +132,7 @@ class Advoc(Model):
     self._rank = 0
     self._allreduce = None
     self._reduce_async = None      # (start(flat, lo, hi), finish(), bucket_elems) from parallel.DataParallel
+    self._sync_bn = None           # in-place cross-replica sum of a small float64 tensor (batch-norm statistics)
 
   # ------------------------------------------------------------------------------------------
   # structure helpers
@@ -441,22 +442,44 @@ class Advoc(Model):
   # batch-norm plumbing
   # ------------------------------------------------------------------------------------------
   def _bn_forward(self, b):
-    _lib.check(_lib.load().advoc_bn_forward(
-        _lib.ptr(b['z']), b['npix'], b['c'], _lib.ptr(b['gamma']), _lib.ptr(b['beta']), 1e-5,
-        _lib.ptr(b['scale']), _lib.ptr(b['shift']), _lib.ptr(b['mean']), _lib.ptr(b['invstd']),
-        _lib.ptr(b['work']), _lib.stream()), 'advoc_bn_forward')
+    lib = _lib.load()
+    if self._sync_bn is None:
+      _lib.check(lib.advoc_bn_forward(
+          _lib.ptr(b['z']), b['npix'], b['c'], _lib.ptr(b['gamma']), _lib.ptr(b['beta']), 1e-5,
+          _lib.ptr(b['scale']), _lib.ptr(b['shift']), _lib.ptr(b['mean']), _lib.ptr(b['invstd']),
+          _lib.ptr(b['work']), _lib.stream()), 'advoc_bn_forward')
+    else:
+      # statistics over the GLOBAL batch: (sum z, sum z^2) in double, summed across the replicas
+      _lib.check(lib.advoc_bn_forward_stats(_lib.ptr(b['z']), b['npix'], b['c'], _lib.ptr(b['work']), _lib.stream()),
+                 'advoc_bn_forward_stats')
+      self._sync_bn(b['work'].view(torch.float64)[:2 * b['c']])
+      _lib.check(lib.advoc_bn_forward_finalize(
+          _lib.ptr(b['work']), b['npix'] * self._world_size, b['c'], _lib.ptr(b['gamma']), _lib.ptr(b['beta']), 1e-5,
+          _lib.ptr(b['scale']), _lib.ptr(b['shift']), _lib.ptr(b['mean']), _lib.ptr(b['invstd']), _lib.stream()),
+          'advoc_bn_forward_finalize')
     for sc, sh in b['copies']:
       sc.copy_(b['scale'])
       sh.copy_(b['shift'])
 
   def _bn_backward(self, b, g, accumulate=False, discard_param_grads=False):
     st = self._built
+    lib = _lib.load()
     dg, db = (st['d_bn_scratch'][0][:b['c']], st['d_bn_scratch'][1][:b['c']]) if discard_param_grads \
         else (b['dgamma'], b['dbeta'])
-    _lib.check(_lib.load().advoc_bn_backward(
+    if self._sync_bn is None:
+      _lib.check(lib.advoc_bn_backward(
+          _lib.ptr(b['z']), _lib.ptr(g), b['npix'], b['c'], _lib.ptr(b['gamma']), _lib.ptr(b['mean']),
+          _lib.ptr(b['invstd']), _lib.ptr(dg), _lib.ptr(db), int(accumulate), _lib.ptr(b['work']),
+          _lib.stream()), 'advoc_bn_backward')
+      return
+    _lib.check(lib.advoc_bn_backward_stats(
+        _lib.ptr(b['z']), _lib.ptr(g), b['npix'], b['c'], _lib.ptr(b['mean']), _lib.ptr(b['invstd']),
+        _lib.ptr(dg), _lib.ptr(db), int(accumulate), _lib.ptr(b['work']), _lib.stream()), 'advoc_bn_backward_stats')
+    self._sync_bn(b['work'].view(torch.float64)[:2 * b['c']])
+    _lib.check(lib.advoc_bn_backward_apply(
         _lib.ptr(b['z']), _lib.ptr(g), b['npix'], b['c'], _lib.ptr(b['gamma']), _lib.ptr(b['mean']),
-        _lib.ptr(b['invstd']), _lib.ptr(dg), _lib.ptr(db), int(accumulate), _lib.ptr(b['work']),
-        _lib.stream()), 'advoc_bn_backward')
+        _lib.ptr(b['invstd']), _lib.ptr(b['work']), b['npix'] * self._world_size, _lib.stream()),
+        'advoc_bn_backward_apply')
 
   # ------------------------------------------------------------------------------------------
   # parameters in / out (TF variable names)

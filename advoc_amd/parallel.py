@@ -8,7 +8,8 @@ point-to-point, ring all-reduce is per-link bound, so buckets are big (default 8
 fused Adam kernel applies 1/N.  The generator's arena is laid out in backward-completion order
 and its buckets are reduced asynchronously as soon as the backward pass has filled them, next to
 the remaining backward kernels; the (small) discriminator arena is reduced in one go.  Dropout masks are Philox streams keyed by the GLOBAL clip index,
-so sharding does not change them.
+so sharding does not change them, and with use_batchnorm=True the batch statistics are summed over the
+replicas (advoc_bn_*_stats / _finalize / _apply) -- synchronised batch norm.
 """
 import os
 
@@ -91,6 +92,12 @@ class DataParallel(object):
     else:
       fn(t, **kw)
 
+  def sum_small_(self, t):
+    """In-place cross-rank sum of a small tensor (batch-norm statistics: 2*c float64 values)."""
+    if self.enabled:
+      self._collective(dist.all_reduce, t, op=dist.ReduceOp.SUM)
+    return t
+
   def attach(self, model):
     """Makes `model` (advoc_amd.model.Advoc) average gradients across ranks before Adam."""
     model._world_size = self.world_size
@@ -98,6 +105,9 @@ class DataParallel(object):
     model._allreduce = self.allreduce_ if self.enabled else None
     # generator gradients: reduce arena ranges while the rest of the backward pass still runs
     model._reduce_async = (self.reduce_range_async, self.finish_reductions, self.bucket_elems) if self.enabled else None
+    # batch norm (use_batchnorm=True): statistics over the global batch, one small float64 all-reduce per
+    # normalised tensor and direction, so that N replicas still equal one device on the global batch
+    model._sync_bn = self.sum_small_ if self.enabled else None
     return model
 
   def broadcast_parameters(self, model):

@@ -231,6 +231,23 @@ int advoc_bn_backward(const float* z, float* g, int64_t npix, int32_t c, const f
                       const float* mean, const float* invstd, float* dgamma, float* dbeta,
                       int32_t accumulate, float* work, advoc_stream_t stream);
 
+/* Split forms of the two calls above, for batch norm whose statistics span several replicas
+ * (data parallelism): *_stats leaves 2*c doubles in `work` -- forward: (sum z, sum z^2); backward:
+ * (sum g, sum g (z - mean)) -- which the caller adds up across replicas (e.g. an all-reduce of `work`
+ * viewed as float64) before calling *_finalize / *_apply with the GLOBAL pixel count.  The parameter
+ * gradients written by advoc_bn_backward_stats are this replica's contribution.  With count_total ==
+ * npix and no exchange they reproduce advoc_bn_forward / advoc_bn_backward. */
+int advoc_bn_forward_stats(const float* z, int64_t npix, int32_t c, float* work, advoc_stream_t stream);
+int advoc_bn_forward_finalize(const float* work, int64_t count_total, int32_t c, const float* gamma,
+                              const float* beta, float epsilon, float* scale, float* shift, float* mean,
+                              float* invstd, advoc_stream_t stream);
+int advoc_bn_backward_stats(const float* z, const float* g, int64_t npix, int32_t c, const float* mean,
+                            const float* invstd, float* dgamma, float* dbeta, int32_t accumulate, float* work,
+                            advoc_stream_t stream);
+int advoc_bn_backward_apply(const float* z, float* g, int64_t npix, int32_t c, const float* gamma,
+                            const float* mean, const float* invstd, const float* work, int64_t count_total,
+                            advoc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Losses, optimiser, dropout masks
  * ---------------------------------------------------------------------------------------- */

@@ -272,3 +272,51 @@ def test_short_training_run_reduces_l1(hip):
     hist.append(ls['gen_loss_L1'])
   assert m.step == 81
   assert np.mean(hist[-5:]) < 0.6 * first['gen_loss_L1'], (first, hist[-5:])
+
+
+@gpu
+def test_batch_norm_split_entry_points_reproduce_global_statistics(hip):
+  """advoc_bn_*_stats on two shards + a sum of the 2c doubles + *_finalize / *_apply with the global
+  count == the one-call batch norm on the whole batch (what synchronised BN across replicas relies on)."""
+  from advoc_amd import _lib
+  lib = _lib.load()
+  dev = torch.device('cuda')
+  g_ = torch.Generator().manual_seed(2)
+  n, c = 6 * 5 * 7, 64
+  z = (torch.randn(n, c, generator=g_) * 2 + 3).to(dev)
+  grad = torch.randn(n, c, generator=g_).to(dev)
+  gamma = (1 + 0.1 * torch.randn(c, generator=g_)).to(dev)
+  beta = (0.1 * torch.randn(c, generator=g_)).to(dev)
+  new = lambda: [torch.zeros(c, device=dev) for _ in range(4)]            # noqa: E731  scale shift mean invstd
+  # reference: one call on everything
+  sc, sh, mu, isd = new()
+  work = torch.zeros(4 * c, device=dev)
+  _lib.check(lib.advoc_bn_forward(_lib.ptr(z), n, c, _lib.ptr(gamma), _lib.ptr(beta), 1e-5, _lib.ptr(sc), _lib.ptr(sh),
+                                  _lib.ptr(mu), _lib.ptr(isd), _lib.ptr(work), _lib.stream()), 'fwd')
+  g_all = grad.clone()
+  dga, dbe = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+  _lib.check(lib.advoc_bn_backward(_lib.ptr(z), _lib.ptr(g_all), n, c, _lib.ptr(gamma), _lib.ptr(mu), _lib.ptr(isd),
+                                   _lib.ptr(dga), _lib.ptr(dbe), 0, _lib.ptr(work), _lib.stream()), 'bwd')
+  # two shards of unequal size
+  cut = 80
+  shards = [(z[:cut].contiguous(), grad[:cut].clone()), (z[cut:].contiguous(), grad[cut:].clone())]
+  works = [torch.zeros(4 * c, device=dev) for _ in shards]
+  for (zs, _), w in zip(shards, works):
+    _lib.check(lib.advoc_bn_forward_stats(_lib.ptr(zs), zs.shape[0], c, _lib.ptr(w), _lib.stream()), 'stats')
+  tot = works[0].view(torch.float64) + works[1].view(torch.float64)
+  sc2, sh2, mu2, isd2 = new()
+  wsum = tot.view(torch.float32).contiguous()
+  _lib.check(lib.advoc_bn_forward_finalize(_lib.ptr(wsum), n, c, _lib.ptr(gamma), _lib.ptr(beta), 1e-5, _lib.ptr(sc2),
+                                           _lib.ptr(sh2), _lib.ptr(mu2), _lib.ptr(isd2), _lib.stream()), 'finalize')
+  for a, b in ((sc, sc2), (sh, sh2), (mu, mu2), (isd, isd2)):
+    assert rel(b, a) < 1e-6
+  dga2, dbe2 = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+  for i, ((zs, gs), w) in enumerate(zip(shards, works)):
+    _lib.check(lib.advoc_bn_backward_stats(_lib.ptr(zs), _lib.ptr(gs), zs.shape[0], c, _lib.ptr(mu2), _lib.ptr(isd2),
+                                           _lib.ptr(dga2), _lib.ptr(dbe2), int(i > 0), _lib.ptr(w), _lib.stream()), 'bstats')
+  tot = (works[0].view(torch.float64) + works[1].view(torch.float64)).view(torch.float32).contiguous()
+  for zs, gs in shards:
+    _lib.check(lib.advoc_bn_backward_apply(_lib.ptr(zs), _lib.ptr(gs), zs.shape[0], c, _lib.ptr(gamma), _lib.ptr(mu2),
+                                           _lib.ptr(isd2), _lib.ptr(tot), n, _lib.stream()), 'apply')
+  assert rel(torch.cat([shards[0][1], shards[1][1]]), g_all) < 1e-5
+  assert close(dga2, dga, 1e-5) and close(dbe2, dbe, 1e-5)

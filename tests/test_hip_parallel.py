@@ -51,16 +51,17 @@ def _train(model, batches, lo, hi):
   return {k: v.cpu() for k, v in model.state_dict().items()}
 
 
-def _make(batch):
+def _make(batch, bn=False):
   from advoc_amd.model import AdvocSmall, Modes
   m = AdvocSmall(Modes.TRAIN)
+  m.use_batchnorm = bn
   m.subseq_len = T
   m.train_batch_size = batch
   m.build(batch_size=batch, seed=13)
   return m
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, bn):
   sys.path.insert(0, ROOT)
   os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                     MASTER_PORT=str(port), ADVOC_DP_BACKEND='gloo', ADVOC_DP_DEVICE='0')
@@ -68,7 +69,7 @@ def _worker(rank, world, port, out_dir):
   dp = DataParallel(bucket_bytes=1 << 20).init_from_env()       # 1 MiB buckets: several async pieces
   assert dp.enabled and dp.world_size == world
   local = GLOBAL_B // world
-  m = _make(local)
+  m = _make(local, bn)
   dp.attach(m)
   dp.broadcast_parameters(m)
   state = _train(m, _global_batches(), rank * local, (rank + 1) * local)
@@ -77,12 +78,14 @@ def _worker(rank, world, port, out_dir):
 
 
 @gpu
-def test_two_ranks_equal_one_process_on_the_global_batch(hip, tmp_path):
-  mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize('bn', [False, True])
+def test_two_ranks_equal_one_process_on_the_global_batch(hip, tmp_path, bn):
+  """bn=True additionally needs the batch statistics summed over the ranks (synchronised batch norm)."""
+  mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), bn), nprocs=2, join=True)
   r0 = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
   r1 = torch.load(os.path.join(str(tmp_path), 'rank1.pt'))
-  single = _train(_make(GLOBAL_B), _global_batches(), 0, GLOBAL_B)
-  init = {k: v.cpu() for k, v in _make(GLOBAL_B).state_dict().items()}
+  single = _train(_make(GLOBAL_B, bn), _global_batches(), 0, GLOBAL_B)
+  init = {k: v.cpu() for k, v in _make(GLOBAL_B, bn).state_dict().items()}
   worst = 0.0
   for k, v in single.items():
     if k == 'global_step':
@@ -91,7 +94,15 @@ def test_two_ranks_equal_one_process_on_the_global_batch(hip, tmp_path):
     assert torch.equal(r0[k], r1[k]), k                        # the ranks stay in lock step
     upd, upd_dp = (v - init[k]).double(), (r0[k] - init[k]).double()
     # Adam's first steps move every weight by ~lr whatever the gradient's size: compare the UPDATES
+    if bn and k.endswith('/bias') and not any(t in k for t in ('decoder_1', 'encoder_1', 'layer_1', 'layer_5')):
+      continue           # a conv bias in front of a batch norm: zero gradient, Adam steps on pure round-off
     err = float((upd - upd_dp).norm() / upd.norm().clamp_min(1e-30))
     worst = max(worst, err)
-    assert err < 1e-4, (k, err)        # measured: 2-3e-6
+    # measured: 2-3e-6 without batch norm.  With it, Adam turns round-off-sized differences of near-zero
+    # gradient elements into +-lr differences (see test_hip_model.py): bound the fraction that moved differently
+    if bn:
+      off = int(((upd - upd_dp).abs() > 0.25 * upd.abs().max()).sum())
+      assert off <= max(2, 0.05 * upd.numel()), (k, off, err)
+    else:
+      assert err < 1e-4, (k, err)
   print('worst relative update difference, 2 ranks vs 1 process: %.3g' % worst)
