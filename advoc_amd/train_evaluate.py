@@ -224,9 +224,11 @@ def eval(fps, args, poll=True):   # noqa: A001  (name kept from the reference)
 
 def infer(fps, args):
   """Runs the generator over the dataset from --infer_ckpt_path (or the latest checkpoint) and
-  writes input / target / generated magnitude spectrograms as .npy under WORK_DIR/infer_*.
-  (The reference writes LWS-vocoded audio summaries and then raises NotImplementedError,
-  train_evaluate.py:190-329; waveform synthesis is the next row of the build)"""
+  writes, under WORK_DIR/infer_*, the input / target / generated magnitude spectrograms (.npy) and
+  the three audio clips the reference puts into its TensorBoard audio summaries
+  (train_evaluate.py:262-281: the real waveform, the vocoded pseudo-inverse "heuristic" and the vocoded
+  generator output) as PCM16 .wav files.  Phase comes from Griffin-Lim (60 iterations, on the GPU)
+  where the reference uses LWS."""
   from advoc_amd.model import Modes
   from advoc_amd.spectral_util import SpectralUtil
   infer_dir = os.path.join(args.train_dir, 'infer_{}'.format(args.infer_dataset_name)
@@ -241,13 +243,23 @@ def infer(fps, args):
   restore_checkpoint(ckpt_fp, model, with_optimizer=False)
   spectral = SpectralUtil(n_mels=model.n_mels, fs=model.audio_fs)
   pipe = _loader(fps, args, model, args.infer_batch_size, False)
-  for i, (x_magspec, _) in enumerate(pipe.batches()):
+  from advoc_amd import spectral as S
+  from advoc_amd.audioio import save_as_wav
+  for i, (x_magspec, x_wav) in enumerate(pipe.batches()):
     x_melspec = spectral.mag_to_mel_linear_spec(x_magspec)
     x_inv = spectral.mel_linear_to_mag_spec(x_melspec, transform='inverse')
     gen = model.build_generator(x_inv)
     np.save(os.path.join(infer_dir, 'batch%06d_gen_magspec.npy' % i), gen.cpu().numpy())
     np.save(os.path.join(infer_dir, 'batch%06d_target_magspec.npy' % i), x_magspec.cpu().numpy())
     np.save(os.path.join(infer_dir, 'batch%06d_input_magspec.npy' % i), x_inv.cpu().numpy())
+    both = torch.cat([x_inv[..., 0], gen[..., 0]], dim=0).abs().contiguous()       # [2b, T, 513]
+    wav = S.griffin_lim_batch(both, spectral.NFFT, spectral.NHOP, 60, torch.rand(both.shape, device=both.device))
+    b = x_inv.shape[0]
+    for j in range(b):
+      stem = os.path.join(infer_dir, 'batch%06d_clip%02d' % (i, j))
+      save_as_wav(stem + '_real.wav', int(model.audio_fs), x_wav[j].cpu().numpy().reshape(-1, 1, 1))
+      save_as_wav(stem + '_heuristic.wav', int(model.audio_fs), wav[j].cpu().numpy().reshape(-1, 1, 1))
+      save_as_wav(stem + '_generated.wav', int(model.audio_fs), wav[b + j].cpu().numpy().reshape(-1, 1, 1))
   pipe.close()
   print('Done!')
 

@@ -107,3 +107,9 @@ def test_train_resume_eval_infer_end_to_end(hip, tmp_path, capsys):
   assert any(f.endswith('gen_magspec.npy') for f in files)
   g = np.load(os.path.join(work, 'infer_valid', sorted(f for f in files if f.endswith('gen_magspec.npy'))[0]))
   assert g.shape == (2, 64, 513, 1) and np.isfinite(g).all()
+  # the reference's three audio summaries, as WAV files
+  from advoc_amd.audioio import decode_audio
+  for kind in ('real', 'heuristic', 'generated'):
+    fp = os.path.join(work, 'infer_valid', 'batch000000_clip00_%s.wav' % kind)
+    fs, wav = decode_audio(fp, fastwav=True)
+    assert fs == 22050 and wav.shape[0] in (64 * 256, 63 * 256 + 1024) and np.isfinite(wav).all()
