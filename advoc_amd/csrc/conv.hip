@@ -222,9 +222,17 @@ int run_two_stage(const GatherGemmParams& p, float* ws, hipStream_t stream, cons
   return launch_tap_sum(p, ws, cols, stream);
 }
 
+// every kernel indexes activations with 32-bit element offsets: refuse tensors beyond that range
+bool fits_int32(int64_t batch, int64_t rows, int64_t pitch, int64_t c) {
+  return batch * rows * pitch * c <= 0x7fffffffLL;
+}
+
 int run_gather(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only = nullptr,
                float* ws = nullptr, int64_t ws_bytes = 0) {
   const int K = p.c0 + p.c1, N = p.n_total;
+  if (!fits_int32(p.batch, p.a_h, p.a0_pitch, p.c0) || !fits_int32(p.batch, p.a_h, p.a1_pitch, p.c1) ||
+      !fits_int32(p.batch, p.out_h, p.d[0].pitch, p.d[0].c) || !fits_int32(p.batch, p.out_h, p.d[1].pitch, p.d[1].c))
+    return ADVOC_ERR_UNSUPPORTED;
   if (two_stage_ok(p) && ws && ws_bytes >= two_stage_bytes(p) && (b_kn ? N == 1 : true))
     return run_two_stage(p, ws, stream, name_only);
   if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0)
@@ -346,6 +354,10 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
   WgradParams p;
   rc = build_backward_weight(L, dy, dw, p);
   if (rc != ADVOC_OK) return rc;
+  if (!fits_int32(L->x0.n, L->x0.h, L->x0.w_pitch, L->x0.c) ||
+      !fits_int32(L->x0.n, L->x0.h, L->x1.p ? L->x1.w_pitch : 0, L->x1.p ? L->x1.c : 0) ||
+      !fits_int32(L->y.n, L->y.h, L->y.w_pitch, L->y.c))
+    return ADVOC_ERR_UNSUPPORTED;
   p.accumulate = accumulate;
   const int ca = p.P.c0 + p.P.c1;
   if (ca <= 2) {

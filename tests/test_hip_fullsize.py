@@ -128,3 +128,33 @@ def test_dropout_stream_is_shard_invariant_at_full_size(hip):
   assert torch.equal(whole[B // 2 * per_clip:], half)
   keep = float(whole.float().mean())
   assert abs(keep - 0.5) < 2e-3
+
+
+@gpu
+def test_offset_range_limits(hip):
+  """The kernels index tensors with 32-bit element offsets.  Just under 2^31 elements the last image
+  of a 2040-clip discriminator layer_1 batch (8.6 GB of output) must equal the same image run alone; past the limit the
+  call is refused with ADVOC_ERR_UNSUPPORTED, not executed with wrapped offsets."""
+  from advoc_amd import _lib, conv
+  dev = torch.device('cuda')
+  g = torch.Generator(device='cuda').manual_seed(1)
+  w = torch.randn(4, 4, 2, 32, device=dev, generator=g) * 0.05
+  b = torch.randn(32, device=dev, generator=g) * 0.1
+
+  def run(n, x0, x1):
+    y = torch.empty(n, 128, 256, 32, device=dev)
+    conv.Layer(conv.CONV, x0, y, w, b, x1=x1, stride=(2, 2), pad=(1, 1), in_act=conv.ACT_NONE).forward()
+    return y
+  n = 2040                                                   # 2040*128*256*32 = 2.139e9 output elements < 2^31
+  x0 = torch.randn(n, 256, 513, 1, device=dev, generator=g)
+  x1 = torch.randn(n, 256, 513, 1, device=dev, generator=g)
+  y = run(n, x0, x1)
+  for i in (0, n // 2, n - 1):
+    alone = run(1, x0[i:i + 1].contiguous(), x1[i:i + 1].contiguous())
+    assert torch.equal(y[i:i + 1], alone), i
+  del y
+  n = 2056                                                   # 2.156e9 output elements: past int32
+  y = torch.empty(n, 128, 256, 32, device=dev)
+  x0 = torch.zeros(n, 256, 513, 1, device=dev)
+  with pytest.raises(_lib.AdvocHipError, match='unsupported'):
+    conv.Layer(conv.CONV, x0, y, w, b, x1=x0, stride=(2, 2), pad=(1, 1), in_act=conv.ACT_NONE).forward()
