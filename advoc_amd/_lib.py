@@ -136,7 +136,14 @@ def require_device(t, name='tensor'):
 
 
 def ptr(t):
-  return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+  """Raw address of a tensor for the C ABI (NULL for None).  The kernels address dense row-major
+  buffers: a strided view would be read as if it were contiguous, so it is refused here."""
+  if t is None:
+    return ctypes.c_void_p(0)
+  if not t.is_contiguous():
+    raise AdvocHipError('non-contiguous tensor (shape {}, strides {}) passed to the HIP library'.format(
+        tuple(t.shape), tuple(t.stride())))
+  return ctypes.c_void_p(t.data_ptr())
 
 
 def stream():

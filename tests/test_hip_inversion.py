@@ -21,8 +21,9 @@ REF_GL60_L1 = 0.0310892466788    # :202
 
 
 def rel_l2(a, b):
-  a = np.asarray(a, dtype=np.float64)
-  b = np.asarray(b, dtype=np.float64)
+  cplx = np.iscomplexobj(a) or np.iscomplexobj(b)
+  a = np.asarray(a, dtype=np.complex128 if cplx else np.float64)
+  b = np.asarray(b, dtype=np.complex128 if cplx else np.float64)
   return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
