@@ -8,7 +8,10 @@ kernels.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 
 Pinning status ("Oracle"):
   * spectral_np  -- pinned against the reference's own known-answer constants
-                    (tests/test_spectral.py:33-46,74-76) and the r9y9 fixture.
+                    (tests/test_spectral.py:33-46,74-76) and the r9y9 fixture.  Its iSTFT /
+                    Griffin-Lim part reproduces the reference's Griffin-Lim constants
+                    (tests/test_spectral.py:200-203) to 0.1 % with scipy's resampler standing in
+                    for librosa's (8-decimal pin NOT reproducible); LWS is not restated.
   * audioio      -- pinned against outputs of the reference's advoc/audioio.py
                     imported in the build container (tests/golden/make_golden.py).
   * advoc_torch  -- PARITY UNPINNED: the reference holds no test or golden
@@ -17,4 +20,6 @@ Pinning status ("Oracle"):
                     against closed-form micro cases (tests/test_oracle_conv.py).
   * loader_np    -- PARITY UNPINNED (no reference test); restates
                     advoc/loader.py:133-186 and tf.contrib.signal.frame.
+  * melspecgan_torch -- PARITY UNPINNED (no reference test, golden tensor or reachable
+                    checkpoint); restates the MelspecGAN generator's inference graph.
 """
