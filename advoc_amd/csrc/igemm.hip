@@ -479,6 +479,8 @@ int dispatch_bk(const GatherGemmParams& p, hipStream_t stream, const char** name
     if (force == 2) return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, stream, name_only);
     if (force == 3 && bn == 128) return launch_cfg<2, 2, 2, 2, B_KN, BK>(p, stream, name_only);
     if (force == 3) return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, stream, name_only);
+    if (force == 4 && bn == 128) return launch_cfg<1, 2, 2, 2, B_KN, BK>(p, stream, name_only);   // 64 x 128
+    if (force == 4) return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, stream, name_only);
   }
   if (big_blocks < 900 || !deep) return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, stream, name_only);   // 64 x 64
   if (bn == 128) return launch_cfg<2, 2, 2, 2, B_KN, BK>(p, stream, name_only);          // 128 x 128
