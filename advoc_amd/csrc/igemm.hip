@@ -226,10 +226,14 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
     _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                                 \
       float4 v = ra[i];                                                                              \
       const float live_ = ((a_ok >> i) & 1u) ? 1.f : 0.f;   /* zero padding stays zero */            \
+      if (p.in_scale) {   /* uniform: only batch-norm models carry an affine */                      \
       v.x = fmaf(v.x, sc_.x, sh_.x * live_); v.y = fmaf(v.y, sc_.y, sh_.y * live_);                  \
       v.z = fmaf(v.z, sc_.z, sh_.z * live_); v.w = fmaf(v.w, sc_.w, sh_.w * live_);                  \
+      }                                                                                              \
+      if (slope != 1.f) {   /* uniform: backward-data gathers a gradient, no activation */          \
       v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);                                  \
       v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);                                  \
+      }                                                                                              \
       if (p.a_mask && a_first) {                                                                     \
         uchar4 mk_ = make_uchar4(0, 0, 0, 0);                                                        \
         if ((a_ok >> i) & 1u) mk_ = *reinterpret_cast<const uchar4*>(p.a_mask + a_moff[i]);          \

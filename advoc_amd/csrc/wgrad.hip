@@ -117,8 +117,10 @@ __device__ __forceinline__ float4 transform4(const Operand& op, float4 v, int ch
     const float k = live ? 1.f : 0.f;     // padding stays zero
     v.x = v.x * sc.x + sh.x * k; v.y = v.y * sc.y + sh.y * k; v.z = v.z * sc.z + sh.z * k; v.w = v.w * sc.w + sh.w * k;
   }
-  v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
-  v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
+  if (slope != 1.f) {     // uniform per operand: the dY operand has no activation
+    v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
+    v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
+  }
   if (op.mask && ch < op.c0 && live) {
     const uchar4 mk = *reinterpret_cast<const uchar4*>(op.mask + off);
     v.x *= mk.x * op.mask_scale; v.y *= mk.y * op.mask_scale;
