@@ -6,7 +6,7 @@ The reference feeds 256-frame chunks to the generator ONE AT A TIME through `ses
 batches.  Kept exactly: de-normalisation + pseudo-inverse without a >= 0 clamp (:15-22), padding to
 ``int(T / subseq_len) * subseq_len + subseq_len`` frames -- i.e. one extra all-zero chunk when T
 is already a multiple (:83-84) --, trimming back to T (:93-94), dropout active at inference.
-Phase estimation (LWS, :95) is the next row of the build and is not performed here.
+Phase estimation: the reference uses LWS (:95); `vocode_batch` / the script run Griffin-Lim on the GPU.
 """
 import numpy as np
 import torch

@@ -18,8 +18,8 @@ Two calling conventions, as in the reference:
 The mel filterbank and its pseudo-inverse are float64 host constants computed
 once (reference: librosa.filters.mel + np.linalg.pinv, spectral.py:86-94).
 
-Phase reconstruction (Griffin-Lim / LWS, spectral.py:294-326) is the step AFTER
-this path and is not implemented yet.
+Phase reconstruction (spectral.py:294-326): Griffin-Lim and the inverse STFT run on the GPU
+(advoc_istft_f32 & friends); LWS is the third-party lws library and raises NotImplementedError.
 """
 from functools import lru_cache
 
@@ -502,7 +502,7 @@ def melspec_to_waveform(
 
   Args:
     X_mel_dbnorm: nd-array float64 [?, mel_num_bins, 1].
-    phase_estimation: 'gl<N>' (Griffin-Lim, N iterations) or 'lws' (not built yet).
+    phase_estimation: 'gl<N>' (Griffin-Lim, N iterations, on the GPU) or 'lws' (third-party: raises).
     waveform_len: pad or clip the output to this length.
   Returns:
     nd-array float32 [waveform_len, 1, 1].
