@@ -279,3 +279,42 @@ def test_channel_counts_outside_the_mfma_kernels(hip, case):
   assert rel(dx0, dx0_o) < TOL
   with pytest.raises(_lib.AdvocHipError, match='unsupported'):
     L.backward_weight(dy, torch.zeros_like(w), torch.zeros_like(b))
+
+
+def _random_cases(n, seed):
+  """Seeded random layer shapes: channel counts any multiple of 32 (an `ngf=96` override is legal), odd
+  sizes, both kinds, strides (2,2) / (1,2) / (1,1), skip concat + trim, every activation, dropout."""
+  rng = np.random.default_rng(seed)
+  out = []
+  for i in range(n):
+    kind = int(rng.integers(0, 2))
+    chans = [32, 64, 96, 128, 160, 192, 224, 256]
+    c0 = int(rng.choice(chans))
+    c1 = int(rng.choice([0, 0] + chans)) if kind == 1 else int(rng.choice([0, 0, 0, 32, 96]))
+    cout = int(rng.choice(chans))
+    B = int(rng.integers(1, 4))
+    H, W = int(rng.integers(1, 12)), int(rng.integers(2, 20))
+    if kind == 0:
+      stride = [(2, 2), (1, 2), (1, 1)][int(rng.integers(0, 3))]
+      pad = None if stride != (1, 1) and rng.random() < 0.5 else (1, 1)
+      if pad == (1, 1) and (H + 2 < 4 or W + 2 < 4):
+        H, W = H + 3, W + 3
+      trim = 0
+    else:
+      stride = [(2, 2), (1, 2)][int(rng.integers(0, 2))]
+      pad = (1, 1)
+      trim = 1 if c1 else 0
+    act = int(rng.integers(0, 3))
+    drop = bool(rng.random() < 0.3)
+    out.append(('rand%02d_k%d_%dx%dx%d_c%d+%d_o%d_s%d%d' % (i, kind, B, H, W, c0, c1, cout, stride[0], stride[1]),
+                kind, (B, H, W), c0, c1, cout, trim, stride, pad, act, drop, 0))
+  return out
+
+
+RANDOM = _random_cases(28, seed=2024)
+
+
+@gpu
+@pytest.mark.parametrize('case', RANDOM, ids=[c[0] for c in RANDOM])
+def test_random_layer_shapes(hip, case):
+  test_layer_all_directions(hip, case)

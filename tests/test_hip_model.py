@@ -28,9 +28,14 @@ def close(a, b, bar):
   return float((a - b).norm()) < max(bar * float(b.norm()), 1e-6 * (1 + a.numel()) ** 0.5 * 1e-1)
 
 
-def make(small, subseq_len, B, seed=0, bn=False):
+def make(small, subseq_len, B, seed=0, bn=False, ngf=None, ndf=None):
   from advoc_amd.model import Advoc, AdvocSmall, Modes
-  cfg = A.Config(small=small, subseq_len=subseq_len, use_batchnorm=bn)
+  kw = {}
+  if ngf is not None:
+    kw['ngf'] = ngf
+  if ndf is not None:
+    kw['ndf'] = ndf
+  cfg = A.Config(small=small, subseq_len=subseq_len, use_batchnorm=bn, **kw)
   P = A.init_params(cfg, seed=seed)
   # non-zero biases (and non-trivial BN affine) so those paths are exercised
   g = torch.Generator().manual_seed(seed + 1)
@@ -41,6 +46,10 @@ def make(small, subseq_len, B, seed=0, bn=False):
       P[k] = 1.0 + torch.randn(P[k].shape, generator=g) * 0.1
   m = (AdvocSmall if small else Advoc)(Modes.TRAIN)
   m.use_batchnorm = bn
+  if ngf is not None:
+    m.ngf = ngf
+  if ndf is not None:
+    m.ndf = ndf
   m.subseq_len = subseq_len
   m.train_batch_size = B
   m.build(batch_size=B)
@@ -320,3 +329,24 @@ def test_batch_norm_split_entry_points_reproduce_global_statistics(hip):
                                            _lib.ptr(isd2), _lib.ptr(tot), n, _lib.stream()), 'apply')
   assert rel(torch.cat([shards[0][1], shards[1][1]]), g_all) < 1e-5
   assert close(dga2, dga, 1e-5) and close(dbe2, dbe, 1e-5)
+
+
+@gpu
+def test_width_override_ngf96_ndf64(hip):
+  """--model_overrides "ngf=96,ndf=64": channel counts that are multiples of 32 but not powers of two
+  (96, 192, 384, 768) through every kernel family, one full G step against the float64 oracle."""
+  cfg, P, m = make(True, 32, 2, seed=2, ngf=96, ndf=64)
+  x, target = batch(2, 32, 8)
+  masks = A.make_dropout_masks(cfg, 2, seed=4)
+  m.set_dropout_masks(dev_masks(masks))
+  dev = torch.device('cuda')
+  P64 = {k: v.double() for k, v in P.items()}
+  m64 = {k: v.double() for k, v in masks.items()}
+  gG, LG = A.grads(P64, x.double(), target.double(), cfg, m64, 'G')
+  gG32, _ = A.grads(P, x, target, cfg, masks, 'G')
+  m._lr = 0.0
+  m.g_step((x.to(dev), target.to(dev)))
+  assert abs(m.losses()['gen_loss_total'] - float(LG['g_loss'])) < 1e-4 * abs(float(LG['g_loss']))
+  st = m._built
+  for k, v in gG.items():
+    assert close(st['g_G'][k], v, max(GRAD_BAR, 3 * rel(gG32[k], v))), (k, rel(st['g_G'][k], v), rel(gG32[k], v))
