@@ -169,8 +169,10 @@ int launch_colsum2(const float* a, const float* b, const float* pa, const float*
 }
 
 bool bn_shape_ok(int64_t npix, int c) {
+  // a thread owns 4 channels; up to 256 quads per pass (threads beyond groups * quads idle, so any
+  // multiple of 4 channels works), more only in whole passes of 256
   const int quads = c / 4;
-  return npix > 0 && c > 0 && c % 4 == 0 && 256 % (quads < 256 ? quads : 256) == 0 && quads % (quads < 256 ? quads : 256) == 0;
+  return npix > 0 && c > 0 && c % 4 == 0 && (quads <= 256 || quads % 256 == 0);
 }
 
 }  // namespace

@@ -332,10 +332,11 @@ def test_batch_norm_split_entry_points_reproduce_global_statistics(hip):
 
 
 @gpu
-def test_width_override_ngf96_ndf64(hip):
+@pytest.mark.parametrize('bn', [False, True])
+def test_width_override_ngf96_ndf64(hip, bn):
   """--model_overrides "ngf=96,ndf=64": channel counts that are multiples of 32 but not powers of two
   (96, 192, 384, 768) through every kernel family, one full G step against the float64 oracle."""
-  cfg, P, m = make(True, 32, 2, seed=2, ngf=96, ndf=64)
+  cfg, P, m = make(True, 32, 2, seed=2, ngf=96, ndf=64, bn=bn)
   x, target = batch(2, 32, 8)
   masks = A.make_dropout_masks(cfg, 2, seed=4)
   m.set_dropout_masks(dev_masks(masks))
@@ -348,5 +349,8 @@ def test_width_override_ngf96_ndf64(hip):
   m.g_step((x.to(dev), target.to(dev)))
   assert abs(m.losses()['gen_loss_total'] - float(LG['g_loss'])) < 1e-4 * abs(float(LG['g_loss']))
   st = m._built
+  # with batch norm at this size one leaky-ReLU gate within round-off of 0 moves a gradient by ~1e-3
+  # (see test_train_loop_matches_oracle_trainer); the kernels themselves are exact at these widths
+  bar = 10 * GRAD_BAR if bn else GRAD_BAR
   for k, v in gG.items():
-    assert close(st['g_G'][k], v, max(GRAD_BAR, 3 * rel(gG32[k], v))), (k, rel(st['g_G'][k], v), rel(gG32[k], v))
+    assert close(st['g_G'][k], v, max(bar, 3 * rel(gG32[k], v))), (k, rel(st['g_G'][k], v), rel(gG32[k], v))
