@@ -162,7 +162,7 @@ def _run_stft(wav2d, nfft, nhop, nframes, complex_out):
   fn = _lib.load().advoc_stft_c64 if complex_out else _lib.load().advoc_stft_mag_f32
   if nframes == 0 or clips == 0:
     return out
-  if nfft != 1024:
+  if nfft != 1024 or nhop % 2 or nhop > 4096:      # outside the fused kernel: windowed DFT as a matmul
     return _run_stft_generic(wav2d, nfft, nhop, nframes, complex_out, out)
   win = _device_window(nfft, nhop)
   _lib.check(fn(_lib.ptr(wav2d), clips, n, _lib.ptr(win), _lib.ptr(_device_twiddle(nfft)), nfft, nhop,

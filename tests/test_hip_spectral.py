@@ -251,3 +251,31 @@ def test_tacotron2_preset(S):
   want = O.waveform_to_tacotron2_melspec(x)
   assert got.shape == want.shape == (80, 80, 1) and got.dtype == np.float64     # 24000 / 300 frames
   assert np.abs(got - want).max() < 1e-4
+
+
+def _random_stft_cases(n, seed):
+  rng = np.random.default_rng(seed)
+  out = []
+  for i in range(n):
+    hop = int(rng.choice([2, 64, 100, 128, 255, 256, 300, 333, 512, 1000, 1024, 2048]))
+    ns = int(rng.choice([1, 2, 255, 256, 257, 1023, 1024, 1025, int(rng.integers(1, 9000))]))
+    out.append((int(rng.integers(1, 4)), ns, hop, bool(rng.integers(0, 2))))
+  return out
+
+
+@gpu
+@pytest.mark.parametrize('case', _random_stft_cases(24, 7), ids=lambda c: 'b%d_n%d_h%d_pad%d' % c)
+def test_stft_random_lengths_and_hops(S, case):
+  """Ragged tails, clips shorter than a frame, odd sample counts (the scalar load path), hops from 2 to
+  2048: frame counts and values against the oracle."""
+  b, ns, hop, pad_end = case
+  rng = np.random.default_rng(ns + hop)
+  x = (0.4 * rng.standard_normal((b, ns, 1, 1))).astype(np.float32)
+  want = O.stft_mag_f64(x, 1024, hop, pad_end=pad_end)
+  got = S.stft_magnitude(x, 1024, hop, pad_end=pad_end).cpu().numpy()
+  assert got.shape == want.shape
+  if want.size:
+    assert rel_l2(got, want) < TIGHT * 5
+  gc = S.stft_tf(x, 1024, hop, pad_end=pad_end).cpu().numpy()
+  wc = O.stft_tf(x, 1024, hop, pad_end=pad_end)
+  assert gc.shape == wc.shape and (wc.size == 0 or rel_l2(gc, wc) < 1e-5)
