@@ -137,7 +137,8 @@ def require_device(t, name='tensor'):
 
 def ptr(t):
   """Raw address of a tensor for the C ABI (NULL for None).  The kernels address dense row-major
-  buffers: a strided view would be read as if it were contiguous, so it is refused here."""
+  buffers: a strided view would be read as if it were contiguous, so it is refused here.  The returned
+  address does NOT keep `t` alive: pass named tensors, never temporaries."""
   if t is None:
     return ctypes.c_void_p(0)
   if not t.is_contiguous():

@@ -176,7 +176,8 @@ def test_projection_and_polar_entry_points(S):
   assert rel_l2(torch.view_as_complex(spec).cpu().numpy(), want) < 1e-6
   u = rng.random((7, 513)).astype(np.float32)
   out = torch.empty(7, 513, 2, device='cuda')
-  _lib.check(lib.advoc_polar_c64(_lib.ptr(m), _lib.ptr(torch.from_numpy(u).cuda()), _lib.ptr(out), X.size,
+  u_d = torch.from_numpy(u).cuda()
+  _lib.check(lib.advoc_polar_c64(_lib.ptr(m), _lib.ptr(u_d), _lib.ptr(out), X.size,
                                  _lib.stream()), 'polar')
   assert rel_l2(torch.view_as_complex(out).cpu().numpy(), mag * np.exp(2j * np.pi * u.astype(np.float64))) < 1e-6
   # fused projection + inverse == projection, then inverse

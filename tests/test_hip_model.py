@@ -249,7 +249,8 @@ def test_adam_matches_tf_formula(hip):
   pr, mr, vr = p0.double().clone(), torch.zeros(n).double(), torch.zeros(n).double()
   for t, gr in enumerate(grads, 1):
     lr_t = 0.0002 * math.sqrt(1 - 0.999 ** t) / (1 - 0.5 ** t)
-    _lib.check(_lib.load().advoc_adam_tf_f32(_lib.ptr(p), _lib.ptr(gr.to(dev)), _lib.ptr(m_), _lib.ptr(v_),
+    gr_d = gr.to(dev)
+    _lib.check(_lib.load().advoc_adam_tf_f32(_lib.ptr(p), _lib.ptr(gr_d), _lib.ptr(m_), _lib.ptr(v_),
                                              n, lr_t, 0.5, 0.999, 1e-8, 0.5, _lib.stream()))
     gd = gr.double() * 0.5
     mr = 0.5 * mr + 0.5 * gd
@@ -354,3 +355,40 @@ def test_width_override_ngf96_ndf64(hip, bn):
   bar = 10 * GRAD_BAR if bn else GRAD_BAR
   for k, v in gG.items():
     assert close(st['g_G'][k], v, max(bar, 3 * rel(gG32[k], v))), (k, rel(st['g_G'][k], v), rel(gG32[k], v))
+
+
+@gpu
+def test_losses_saturate_like_the_tf_formulas(hip):
+  """Extreme logits: sigmoid saturates to exactly 0 / 1 in fp32 and the EPS = 1e-12 inside the logs is
+  what keeps the losses finite (advoc_model.py:8,238-241); values and gradients must follow those
+  literal formulas (autograd of the same fp32 expressions), not a numerically 'nicer' softplus."""
+  from advoc_amd import _lib
+  lib = _lib.load()
+  dev = torch.device('cuda')
+  zr = torch.tensor([-100.0, -20.0, -1.5, 0.0, 0.7, 20.0, 100.0, 3.0, -3.0], requires_grad=True)
+  zf = torch.tensor([100.0, 20.0, 1.5, 0.0, -0.7, -20.0, -100.0, -3.0, 3.0], requires_grad=True)
+  n = zr.numel()
+  p_r, p_f = torch.sigmoid(zr), torch.sigmoid(zf)
+  d_loss = torch.mean(-(torch.log(p_r + 1e-12) + torch.log(1 - p_f + 1e-12)))
+  gr, gf = torch.autograd.grad(d_loss, [zr, zf])
+  dzr, dzf, sums = torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(4, device=dev)
+  zr_d, zf_d = zr.detach().to(dev), zf.detach().to(dev)       # named: _lib.ptr() does not keep its tensor alive
+  _lib.check(lib.advoc_gan_d_loss(_lib.ptr(zr_d), _lib.ptr(zf_d), n, _lib.ptr(dzr),
+                                  _lib.ptr(dzf), _lib.ptr(sums[0:1]), _lib.stream()), 'd_loss')
+  assert np.isfinite(float(sums[0])) and abs(float(sums[0]) / n - float(d_loss.detach())) < 1e-5 * abs(float(d_loss.detach()))
+  assert torch.allclose(dzr.cpu(), gr, rtol=1e-5, atol=1e-12) and torch.allclose(dzf.cpu(), gf, rtol=1e-5, atol=1e-12)
+  # generator side
+  zf2 = zf.detach().clone().requires_grad_(True)
+  g_gan = torch.mean(-torch.log(torch.sigmoid(zf2) + 1e-12))
+  (gg,) = torch.autograd.grad(g_gan, [zf2])
+  gen, tgt = torch.rand(1, 4, 513, 1), torch.rand(1, 4, 513, 1)
+  dz, dgen, s2 = torch.zeros(n, device=dev), torch.zeros(gen.shape, device=dev), torch.zeros(4, device=dev)
+  gen_d, tgt_d = gen.to(dev), tgt.to(dev)
+  _lib.check(lib.advoc_gan_g_loss(_lib.ptr(zf_d), n, _lib.ptr(gen_d), _lib.ptr(tgt_d),
+                                  gen.numel(), 1.0, 10.0, _lib.ptr(dz), _lib.ptr(dgen), 0, _lib.ptr(s2[0:2]),
+                                  _lib.stream()), 'g_loss')
+  assert abs(float(s2[0]) / n - float(g_gan.detach())) < 1e-5 * abs(float(g_gan.detach()))
+  assert torch.allclose(dz.cpu(), gg, rtol=1e-5, atol=1e-12)
+  assert abs(float(s2[1]) / gen.numel() - float((tgt - gen).abs().mean())) < 1e-6
+  want_dgen = -10.0 / gen.numel() * torch.sign(tgt - gen)
+  assert torch.allclose(dgen.cpu(), want_dgen, rtol=1e-6, atol=0)
