@@ -168,6 +168,10 @@ class Advoc(Model):
         raise ValueError('subseq_len {}: decoder heights do not match the encoder skips'.format(self.subseq_len))
     if 2 * hs[0] != int(self.subseq_len):
       raise ValueError('subseq_len must be even')
+    # PatchGAN: three stride-2 convs, then two 4x4 stride-1 convs with pad 1 (each -1): needs T/8 - 2 >= 1
+    if self.mode == Modes.TRAIN and int(self.subseq_len) // 8 - 2 < 1:
+      raise ValueError('subseq_len {} leaves the discriminator no output rows (needs >= 24; TF fails on the '
+                       'same graph with a negative dimension)'.format(self.subseq_len))
 
   def _encoder_strides(self):
     """advoc_model.py:90-116: (2,2) while the reference's running `n_time` (halved as a float per

@@ -54,9 +54,10 @@ def test_unsupported_ablations_fail_loudly():
       m._check_supported()
   # a clip length whose halvings and doublings do not retrace each other cannot be built in the
   # reference either (tf.concat shape error at advoc_model.py:137)
-  m, _ = override_model_attrs(Advoc(Modes.TRAIN), 'subseq_len=100')
-  with pytest.raises(ValueError):
-    m._check_supported()
+  for bad in ('subseq_len=100', 'subseq_len=16'):          # 16: the PatchGAN would have no output rows
+    m, _ = override_model_attrs(Advoc(Modes.TRAIN), bad)
+    with pytest.raises(ValueError):
+      m._check_supported()
   # shorter power-of-two clips use the (1,2)-stride layers (advoc_model.py:109-116): supported
   for n, want in ((64, 2), (32, 3), (256, 0)):
     m, _ = override_model_attrs(Advoc(Modes.TRAIN), 'subseq_len=%d' % n)
