@@ -514,11 +514,13 @@ int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
       (int64_t)p.batch * p.out_h * p.d[0].pitch * p.d[0].c > lim ||
       (int64_t)p.batch * p.out_h * p.d[1].pitch * p.d[1].c > lim)
     return ADVOC_ERR_UNSUPPORTED;
-  // taps-inner K order by default: same speed as taps-outer on MI355X but ~9x less L2-miss traffic
-  // on the stride-1 backward-data of discriminator layer_4 (rocprofv3 FETCH_SIZE 1039 -> 117 MB);
-  // ADVOC_IGEMM_KORDER=0 restores the other order for A/B runs.
+  // K order (L2-miss traffic, rocprofv3 FETCH_SIZE; the run time does not depend on it): taps-inner is the
+  // better order almost everywhere (D layer_4 backward-data 1039 -> 117 MB raw, decoder_3 forward 442 -> 122,
+  // encoder_3 both directions), except the stride-2 gathers with 32 input channels (one 128-byte line per
+  // pixel: encoder_2 / layer_2 forward, 304 vs 175 MB), where walking both 64-byte halves of a line back to
+  // back wins.  ADVOC_IGEMM_KORDER=0|1 forces one order for A/B runs.
   const char* ko = getenv("ADVOC_IGEMM_KORDER");
-  const int k_order = ko ? atoi(ko) : 1;
+  const int k_order = ko ? atoi(ko) : ((p.sy == 2 && p.nphase == 1 && ktot <= 32) ? 0 : 1);
   GatherGemmParams q = p;
   q.k_order = k_order;
   return b_kn ? dispatch<true>(q, stream, name_only) : dispatch<false>(q, stream, name_only);

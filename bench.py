@@ -217,6 +217,9 @@ def main():
   ap.add_argument('--model', choices=['small', 'regular'], default='small')
   ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--train-only', action='store_true',
+                  help='skip the extractor / inference legs that run after the timed region (profiling runs: '
+                       'keeps the per-kernel statistics to the train step)')
   ap.add_argument('--no-launch-timing', action='store_true',
                   help='skip per-launch HIP events (roofline object becomes null)')
   args = ap.parse_args()
@@ -312,7 +315,7 @@ def main():
           tot, len(sampled), elapsed * 1e3, args.steps), file=sys.stderr)
 
   extractor = inference = None
-  if dp.rank == 0:
+  if dp.rank == 0 and not args.train_only:
     extractor = extractor_leg(torch, spectral, pool[0])
     mel0 = su.mag_to_mel_linear_spec(spectral.stft_magnitude(pool[0], 1024, 256, pad_end=False))
     inference = inference_leg(torch, AdvocSmall if args.model == 'small' else Advoc, Modes, su, mel0)

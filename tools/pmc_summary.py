@@ -8,8 +8,11 @@ WRITE_SIZE, each with --kernel-trace --output-format csv; never combined with ot
 Units / corrections (MI355X_MICROARCH.md, "HBM"): both counters are in KiB; on gfx950 FETCH_SIZE
 reports half of the bytes of 16-byte-per-lane streaming reads, so it is doubled; WRITE_SIZE is taken
 as is (checked here on l1_kernel: 2 x 16.8 MB read -> FETCH_SIZE 16.4 MB, 16.8 MB written ->
-WRITE_SIZE 16.5 MB).  Infinity-Cache hits are counted: this is L2-miss traffic, an upper bound
-on HBM bytes."""
+WRITE_SIZE 16.5 MB; weight-gradient kernel reading 195 MB of 128-byte rows once -> 97 MB raw).
+Calibration caveat for the gather GEMM: its A loads are 64-byte segments (4 lanes x 16 B per pixel row);
+a pointwise instance that reads 270 MB exactly once reports 168 MB raw (factor 1.6, not 2), so the
+doubled figure over-states that kernel's traffic by ~25 %.  Infinity-Cache hits are counted: this is
+L2-miss traffic, an upper bound on HBM bytes."""
 import collections
 import csv
 import json
@@ -38,7 +41,7 @@ def main():
     out[k] = dict(launches=len(fetch[k]), fetch_kib_raw=f, write_kib=w, traffic_bytes=traffic)
     print('| `%s` | %d | %.2f | %.2f | %.1f |' % (k, len(fetch[k]), f / 1024, w / 1024, traffic / 1e6))
   if '--json' in sys.argv:
-    out['_workload'] = dict(model='small', batch=32, command='python bench.py --steps 3 --warmup 1')
+    out['_workload'] = dict(model='small', batch=32, command='python bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-only')
     json.dump(out, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1, sort_keys=True)
 
 
