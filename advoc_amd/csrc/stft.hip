@@ -16,8 +16,9 @@
 //     barrier anywhere).
 //   * samples are read straight from global memory, 8 bytes per lane on 512-byte rows; the 75 %
 //     overlap between neighbouring frames is served by L1/L2.
-//   * twiddles and the window live in registers for the life of the wave (they depend only on
-//     the lane) and a wave grid-strides over many frame pairs, so that set-up is amortised.
+//   * the window and the pass twiddles (they depend only on the lane) sit in LDS, the split twiddles in
+//     registers; one transpose plane per wave serves the real and then the imaginary parts: 126 VGPRs and
+//     30 KB of LDS per workgroup, i.e. four waves per SIMD.  A wave grid-strides over many frame pairs.
 //   * the real-FFT split pairs Z[k] with Z[512-k] by one cross-lane permute per value, then
 //     each lane stores 8 magnitudes per frame: 256 B contiguous per store instruction.
 // Algorithmic traffic is 256 new samples in + 513 floats out per frame.
@@ -79,11 +80,12 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
     const float* __restrict__ wav, int64_t nsamps, const float* __restrict__ window,
     const float2* __restrict__ twiddle, int nhop, int64_t nframes, float* __restrict__ out,
     int pairs_per_clip, int64_t total_pairs) {
-  __shared__ f2 planes[kWaves][2 * kPlane];
+  // ONE transpose plane per wave, used for the real and then the imaginary parts: half the LDS, so that
+  // four workgroups (instead of three) fit a CU
+  __shared__ f2 planes[kWaves][kPlane];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  f2* xr_plane = &planes[wave][0];
-  f2* xi_plane = xr_plane + kPlane;
+  f2* plane = &planes[wave][0];
 
   // ---- per-lane constants ----
   // They depend on the lane only.  The split twiddles stay in registers; the window and the
@@ -140,12 +142,12 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
   }
   const int64_t pair0 = (int64_t)blockIdx.x * kWaves + wave;
   const int64_t pstride = (int64_t)gridDim.x * kWaves;
-  if (pair0 < total_pairs) ADVOC_STFT_FETCH(pair0);
   for (int64_t pair = pair0; pair < total_pairs; pair += pstride) {
     const int64_t clip = pair / pairs_per_clip;
     const int64_t f = (pair - clip * pairs_per_clip) * 2;     // frames f and f + 1
     const bool two = f + 1 < nframes;
 
+    ADVOC_STFT_FETCH(pair);
     f2 re[8], im[8];
     // z[n] = x[2n] w[2n] + i x[2n+1] w[2n+1]
 #pragma unroll
@@ -154,47 +156,52 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
       re[a] = f2{raw0[a].x, raw1[a].x} * w.x;
       im[a] = f2{raw0[a].y, raw1[a].y} * w.y;
     }
-    if (pair + pstride < total_pairs) ADVOC_STFT_FETCH(pair + pstride);
 
     // pass 1: DFT over a -> p, twiddle, transpose (b,c | p) -> (p,c | b)
     dft8(re, im);
+    {
+      f2 ti[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const float2 t = s_t1[p][lane];
-      const f2 r = re[p] * t.x - im[p] * t.y;
-      const f2 i = re[p] * t.y + im[p] * t.x;
-      const int addr = (8 * p + hi) * 9 + lo;
-      xr_plane[addr] = r;
-      xi_plane[addr] = i;
-    }
-    wave_lds_sync();
+      for (int p = 0; p < 8; ++p) {
+        const float2 t = s_t1[p][lane];
+        const f2 r = re[p] * t.x - im[p] * t.y;
+        ti[p] = re[p] * t.y + im[p] * t.x;
+        plane[(8 * p + hi) * 9 + lo] = r;
+      }
+      wave_lds_sync();
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const int addr = (8 * hi + b) * 9 + lo;
-      re[b] = xr_plane[addr];
-      im[b] = xi_plane[addr];
+      for (int b = 0; b < 8; ++b) re[b] = plane[(8 * hi + b) * 9 + lo];
+      wave_lds_sync();
+#pragma unroll
+      for (int p = 0; p < 8; ++p) plane[(8 * p + hi) * 9 + lo] = ti[p];
+      wave_lds_sync();
+#pragma unroll
+      for (int b = 0; b < 8; ++b) im[b] = plane[(8 * hi + b) * 9 + lo];
+      wave_lds_sync();
     }
-    wave_lds_sync();
 
     // pass 2: DFT over b -> q, twiddle, transpose (p,c | q) -> (q,p | c)
     dft8(re, im);
+    {
+      f2 ti[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float2 t = s_t2[q][lane];
-      const f2 r = re[q] * t.x - im[q] * t.y;
-      const f2 i = re[q] * t.y + im[q] * t.x;
-      const int addr = (8 * q + hi) * 9 + lo;
-      xr_plane[addr] = r;
-      xi_plane[addr] = i;
-    }
-    wave_lds_sync();
+      for (int q = 0; q < 8; ++q) {
+        const float2 t = s_t2[q][lane];
+        const f2 r = re[q] * t.x - im[q] * t.y;
+        ti[q] = re[q] * t.y + im[q] * t.x;
+        plane[(8 * q + hi) * 9 + lo] = r;
+      }
+      wave_lds_sync();
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int addr = lane * 9 + c;
-      re[c] = xr_plane[addr];
-      im[c] = xi_plane[addr];
+      for (int c = 0; c < 8; ++c) re[c] = plane[lane * 9 + c];
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) plane[(8 * q + hi) * 9 + lo] = ti[q];
+      wave_lds_sync();
+#pragma unroll
+      for (int c = 0; c < 8; ++c) im[c] = plane[lane * 9 + c];
+      wave_lds_sync();
     }
-    wave_lds_sync();
 
     // pass 3: DFT over c -> r.  Lane now holds Z[lane + 64 r].
     dft8(re, im);
