@@ -291,9 +291,13 @@ def build_parser():
 
 
 def parse_data_cfg(path, args):
-  """`key,value` lines -> args.data_<key>, int if it parses as int else float (:375-382)."""
+  """`key,value` lines -> args.data_<key>, int if it parses as int else float (:375-382).
+  Blank lines and lines starting with `#` are ignored (an extension: the reference's files have neither)."""
   with open(path, 'r') as f:
     for line in f.read().strip().splitlines():
+      line = line.strip()
+      if not line or line.startswith('#'):
+        continue
       k, v = line.split(',')
       try:
         v = int(v)

@@ -1,31 +1,44 @@
 #!/usr/bin/env python
-"""Directory of WAVs -> directory of r9y9 mel spectrograms (.npy [T, 80, 1] float64), features
-computed by the HIP extractor.  Same flags as the reference script
-(scripts/audio_to_spectrogram.py:15-29); only --data_fast_wav decoding is available."""
-import glob
+"""Feature dump: every audio file of a directory becomes one dB-normalised mel spectrogram
+(`<stem>.npy`, float64 [frames, 80, 1], r9y9 preset) computed by the HIP extractor on the GPU.
+
+Command line of the reference's scripts/audio_to_spectrogram.py (flags :15-29): --wave_dir, --out_dir,
+--fs (default 22050), --data_fast_wav.  Only the fast WAV decoder exists here (advoc_amd.audioio); a file
+that needs resampling or a non-WAV codec makes decode_audio raise, as documented there."""
+import argparse
 import os
 import sys
+from pathlib import Path
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
 
-if __name__ == '__main__':
-  from argparse import ArgumentParser
+
+def parse_args(argv=None):
+  ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+  ap.add_argument('--wave_dir', required=True, help='directory with the audio files')
+  ap.add_argument('--out_dir', required=True, help='directory the .npy spectrograms are written to')
+  ap.add_argument('--fs', type=int, default=22050, help='sample rate the features are defined at')
+  ap.add_argument('--data_fast_wav', action='store_true', help='decode standard WAV files with scipy (fast path)')
+  return ap.parse_args(argv)
+
+
+def dump_features(wave_dir, out_dir, fs, fast_wav):
   import numpy as np
   from advoc_amd.audioio import decode_audio
   from advoc_amd.spectral import waveform_to_r9y9_melspec
+  target = Path(out_dir)
+  target.mkdir(parents=True, exist_ok=True)
+  written = 0
+  for src in sorted(Path(wave_dir).iterdir()):
+    if not src.is_file():
+      continue
+    _, samples = decode_audio(str(src), fs=fs, mono=True, normalize=True, fastwav=fast_wav)
+    np.save(str(target / (src.stem + '.npy')), waveform_to_r9y9_melspec(samples, fs=fs))
+    written += 1
+  return written
 
-  parser = ArgumentParser()
-  parser.add_argument('--wave_dir', type=str, required=True, help='Directory of audio files')
-  parser.add_argument('--out_dir', type=str, required=True, help='Directory for spectrograms')
-  parser.add_argument('--fs', type=int, help='Sample rate')
-  parser.add_argument('--data_fast_wav', action='store_true', dest='data_fast_wav',
-                      help='If set, provides faster loading of standard WAV files via scipy')
-  parser.set_defaults(wave_dir=None, out_dir=None, fs=22050, data_fast_wav=False)
-  args = parser.parse_args()
 
-  if not os.path.isdir(args.out_dir):
-    os.makedirs(args.out_dir)
-  for wave_fp in sorted(glob.glob(os.path.join(args.wave_dir, '*'))):
-    name = os.path.splitext(os.path.split(wave_fp)[1])[0]
-    _, wave = decode_audio(wave_fp, fs=args.fs, fastwav=args.data_fast_wav, mono=True, normalize=True)
-    np.save(os.path.join(args.out_dir, name + '.npy'), waveform_to_r9y9_melspec(wave, fs=args.fs))
+if __name__ == '__main__':
+  a = parse_args()
+  dump_features(a.wave_dir, a.out_dir, a.fs, a.data_fast_wav)

@@ -129,3 +129,28 @@ def test_vocode_batch_equals_per_sample_vocoding(hip):
   assert none is None and tuple(g0.shape) == (1, 64, 513)
   with pytest.raises(NotImplementedError):
     vocode_batch(m, specs[:1], phase_estimation='lws', chunk_batch=2)
+
+
+@gpu
+def test_feature_dump_script(hip, tmp_path, golden_dir):
+  """scripts/audio_to_spectrogram.py: WAV directory in, one float64 [T, 80, 1] .npy per file out, equal
+  to waveform_to_r9y9_melspec of the normalised mono decode (reference scripts/audio_to_spectrogram.py:36-51)."""
+  import os
+  import shutil
+  import subprocess
+  import sys
+  from advoc_amd import spectral
+  from advoc_amd.audioio import decode_audio
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  wavs = tmp_path / 'wavs'
+  wavs.mkdir()
+  shutil.copy(os.path.join(golden_dir, 'sc09.wav'), wavs / 'a.wav')
+  out = tmp_path / 'mels'
+  r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'audio_to_spectrogram.py'), '--wave_dir', str(wavs),
+                      '--out_dir', str(out), '--fs', '16000', '--data_fast_wav'], capture_output=True, text=True)
+  assert r.returncode == 0, r.stderr[-2000:]
+  got = np.load(out / 'a.npy')
+  _, x = decode_audio(str(wavs / 'a.wav'), fs=16000, mono=True, normalize=True, fastwav=True)
+  want = spectral.waveform_to_r9y9_melspec(x, fs=16000)
+  assert got.dtype == np.float64 and got.shape == want.shape and got.shape[1:] == (80, 1)
+  assert np.abs(got - want).max() < 1e-6
