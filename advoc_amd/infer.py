@@ -11,7 +11,6 @@ Phase estimation: the reference uses LWS (:95); `vocode_batch` / the script run 
 import numpy as np
 import torch
 
-from advoc_amd import _lib
 from advoc_amd.spectral_util import SpectralUtil
 
 

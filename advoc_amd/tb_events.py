@@ -15,7 +15,7 @@ import socket
 import struct
 import time
 
-from advoc_amd.tf_checkpoint import _field, _get_varint, _parse_proto, _put_varint, crc32c, mask_crc, unmask_crc
+from advoc_amd.tf_checkpoint import _field, _parse_proto, _put_varint, crc32c, mask_crc, unmask_crc
 
 
 def _record(data):

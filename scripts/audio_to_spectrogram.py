@@ -6,7 +6,6 @@ Command line of the reference's scripts/audio_to_spectrogram.py (flags :15-29): 
 --fs (default 22050), --data_fast_wav.  Only the fast WAV decoder exists here (advoc_amd.audioio); a file
 that needs resampling or a non-WAV codec makes decode_audio raise, as documented there."""
 import argparse
-import os
 import sys
 from pathlib import Path
 
