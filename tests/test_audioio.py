@@ -70,3 +70,19 @@ def test_empty_wave_roundtrip():
     save_as_wav(tf.name, 16000, np.zeros((0, 1, 1), np.float32))
     fs, x = decode_audio(tf.name, fastwav=True, normalize=True)
     assert fs == 16000 and x.shape == (0, 1, 1)
+
+
+def test_general_decode_branch(golden_dir):
+  """reference tests/test_audioio.py:41-52, 68-74: the non-fastwav branch returns the
+  same samples for a WAV, and the reference's shape when resampling."""
+  wav = os.path.join(golden_dir, 'mono.wav')
+  fs_g, x_g = decode_audio(wav, fastwav=False)
+  fs_f, x_f = decode_audio(wav, fastwav=True)
+  assert fs_g == fs_f and type(fs_g) == type(fs_f)
+  assert np.array_equal(x_g, x_f)
+  fs, x = decode_audio(wav, fs=22050)
+  assert fs == 22050 and x.shape == (82432, 1, 1) and x.dtype == np.float32
+  # decimation by two of a band-limited clip keeps its envelope
+  assert abs(float(np.abs(x).max()) - float(np.abs(x_f).max())) < 0.05
+  with pytest.raises(ValueError):
+    decode_audio(os.path.join(golden_dir, 'mono.mp3'))
