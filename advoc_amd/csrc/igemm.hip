@@ -60,8 +60,8 @@ struct Cfg {
   static constexpr int A_LOADS = BM * QPR / 256;           // float4 per thread per K tile
   static constexpr int B_LOADS = (BN * QPR + 255) / 256;   // float4 per thread per K tile
   // Exactly the two double-buffered tiles: 40 KiB for 128x128 so FOUR workgroups fit a CU's
-  // 160 KiB.  The tap table lives in the (never written) pad words of the first A rows and the
-  // epilogue's pixel table / transpose patches reuse the tile buffers once the K loop is done.
+  // 160 KiB.  The epilogue's pixel table / transpose patches reuse the tile buffers once the K loop
+  // is done.
   static constexpr size_t LDS_BYTES = sizeof(float) * (2 * A_TILE + 2 * B_TILE);
 };
 
@@ -84,9 +84,6 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                               // [2][BM][LDA]
   float* Bs = smem + 2 * C::A_TILE;               // [2][B_TILE]
-  // tap t -> pad word (column BK) of A row t: tile stores only touch columns [0, BK)
-  int* s_tapw = reinterpret_cast<int*>(smem) + BK;
-#define ADVOC_TAP(T) s_tapw[(T) * LDA]
   // epilogue tables, carved from the tile buffers AFTER the last K-loop barrier:
   //   [0, 4*32*36) floats  per-wave transpose patches;  then [2][BM] ints pixel table
   int* s_pix = reinterpret_cast<int*>(smem + 4 * 32 * 36);
@@ -113,8 +110,6 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   const int kpt = ktot / BK;         // K tiles per tap
   const int nkt = kpt * p.ntaps;
   const float slope = act_slope(p.in_act);
-
-  if (tid < kMaxTaps) ADVOC_TAP(tid) = p.tap[phase][tid];
 
   // ---- per-thread A rows (fixed for the whole K loop); 32-bit element offsets ----
   const int kq = tid % QPR;  // which float4 of the BK-wide K slice
@@ -156,7 +151,6 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
       b_live[i] = n0 + n < n_valid;
     }
   }
-  __syncthreads();
 
   float4 ra[AL], rb[BL];
   unsigned a_ok = 0;
@@ -184,7 +178,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
       ld_k0 += BK;                                                                                   \
       if (ld_k0 == ktot) { ld_k0 = 0; if (++ld_tap == p.ntaps) ld_tap = 0; }                         \
     }                                                                                                \
-    const int tp_ = ADVOC_TAP(ti_);                                                                  \
+    /* tap word straight from the kernel arguments: a scalar load, so the tap / weight-slab offsets */ \
+    /* below are SALU work (through LDS they were 64-bit VALU multiplies on every K tile)          */ \
+    const int tp_ = __builtin_amdgcn_readfirstlane(p.tap[phase][ti_]);                               \
     const int dy_ = (int)(int8_t)(tp_ & 0xff), dx_ = (int)(int8_t)((tp_ >> 8) & 0xff);              \
     const int wtap_ = tp_ >> 16;                                                                     \
     const bool second_ = k0_ >= p.c0;                                                                \
@@ -308,7 +304,6 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   }
 #undef ADVOC_LOAD_TILE
 #undef ADVOC_STORE_TILE
-#undef ADVOC_TAP
 
   // ---- epilogue ----
   for (int r = tid; r < BM; r += 256) {
