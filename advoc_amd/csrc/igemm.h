@@ -65,12 +65,20 @@ struct GatherGemmParams {
   const uint8_t* y_mask;   // forward dropout mask, indexed like d[0]
   float y_mask_scale;
   int grad_act;            // != ADVOC_ACT_NONE: multiply result by act'(d[i].xpre)
+  // ---- tail split (filled in by the launcher, see launch_cfg) ----
+  int tail_main;           // > 0: 1-D launch; tiles [0, tail_main) whole, the rest in tail_split K slices each
+  int tail_split;
+  float* tail_ws;          // [tail tiles][tail_split][BM * BN] partial accumulators
+  int* tail_cnt;           // [tail tiles] arrival counters (zero before and after every launch)
 };
 
 // B_KN = true : weights stored [tap][K][N] (N contiguous)   conv fwd, deconv bwd-data
 // B_KN = false: weights stored [tap][N][K] (K contiguous)   deconv fwd, conv bwd-data
-// name_only != nullptr: do not launch, just report the kernel instance that would run
+// name_only != nullptr: do not launch, just report the kernel instance that would run.
+// scratch / scratch_bytes: optional caller workspace for the tail split (see launch_cfg); without it
+// the launch is a plain one.  scratch_query != nullptr: do not launch, report the bytes wanted.
 int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
-                       const char** name_only = nullptr);
+                       const char** name_only = nullptr, float* scratch = nullptr,
+                       int64_t scratch_bytes = 0, int64_t* scratch_query = nullptr);
 
 }  // namespace advoc

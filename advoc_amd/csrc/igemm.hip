@@ -21,6 +21,7 @@
 //     destinations (skip-connection gradients); 128 B contiguous per 32-lane store.
 #include <stdlib.h>
 
+#include <atomic>
 #include <string>
 
 #include "common.h"
@@ -92,17 +93,34 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int phase = blockIdx.z;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (each XCD has its own L2); remap so that
   // an XCD walks a CONTIGUOUS run of tiles: neighbouring M tiles share input halo rows and the
   // N tiles of one M tile share the whole A tile, so those re-reads hit the local L2.
   const int ntn = p.n_total / BN;                       // N tiles
-  int tile;
+  // Tail split (p.tail_main > 0, 1-D launch over all phases): the first tail_main tiles -- whole
+  // rounds of the chip -- run as usual; each of the remaining tiles is cut into tail_split K
+  // slices, one workgroup each, in launch order AFTER the whole tiles and NOT remapped, so the
+  // slices spread over every XCD / CU instead of giving a few CUs one more whole tile.
+  int tile, phase, ks_idx = blockIdx.y, ks_cnt = gridDim.y, tail_tile = -1;
   {
-    const int nb = gridDim.x, b = blockIdx.x;
+    const bool tail_mode = p.tail_main > 0;
+    const int nb = tail_mode ? p.tail_main : (int)gridDim.x, b = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = b & 7, slot = b >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;   // bijective for any nb
+    phase = blockIdx.z;
+    if (tail_mode) {
+      if (b >= nb) {
+        const int piece = b - nb;
+        tail_tile = piece / p.tail_split;
+        ks_idx = piece - tail_tile * p.tail_split;
+        ks_cnt = p.tail_split;
+        tile = nb + tail_tile;
+      }
+      const int tpp = (int)((M + BM - 1) / BM) * ntn;   // tiles per phase
+      phase = tile / tpp;
+      tile -= phase * tpp;
+    }
   }
   const int64_t m0 = (int64_t)(tile / ntn) * BM;
   const int n0 = (tile % ntn) * BN;
@@ -163,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   // pixels on consecutive K tiles (L2 hits) instead of once per pass over the channels.
   // split-K: blockIdx.y owns K tiles [kt_begin, kt_end); partial results are combined with
   // hardware fp32 atomics in the epilogue (launch_cfg zeroes the destination first)
-  const int kt_begin = (int)((int64_t)nkt * blockIdx.y / gridDim.y);
-  const int kt_end = (int)((int64_t)nkt * (blockIdx.y + 1) / gridDim.y);
+  const int kt_begin = (int)((int64_t)nkt * ks_idx / ks_cnt);
+  const int kt_end = (int)((int64_t)nkt * (ks_idx + 1) / ks_cnt);
   const bool taps_inner = p.k_order != 0;
   int ld_tap = taps_inner ? kt_begin % p.ntaps : kt_begin / kpt;
   int ld_k0 = (taps_inner ? kt_begin / p.ntaps : kt_begin % kpt) * BK;
@@ -305,6 +323,52 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
 #undef ADVOC_LOAD_TILE
 #undef ADVOC_STORE_TILE
 
+  // ---- tail slices: park the partial tile; the LAST slice to arrive sums all of them in slice
+  // order (run-to-run reproducible) and carries on into the ordinary epilogue.  The partials and
+  // the counter move with device-coherent (agent-scope atomic, sc1) accesses, which go past the
+  // per-XCD L2s: a __threadfence() pair would do too, but it writes back and invalidates a whole
+  // L2 per wave, which on ~1000 waves cost more than the balance gained (measured). ----
+  if (tail_tile >= 0) {
+    constexpr int TILE = BM * BN;
+    float* part = p.tail_ws + ((size_t)tail_tile * ks_cnt + ks_idx) * TILE;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          __hip_atomic_store(part + (((wave * MT + i) * NT + j) * 16 + r) * 64 + lane, acc[i][j][r],
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);        // this thread's partial has reached the coherent level ...
+    __syncthreads();
+    int* s_flag = reinterpret_cast<int*>(smem);
+    if (tid == 0)                         // ... before the workgroup is counted
+      *s_flag = __hip_atomic_fetch_add(p.tail_cnt + tail_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int arrived = *s_flag;
+    __syncthreads();                      // smem is reused below
+    if (arrived != ks_cnt - 1) return;
+    if (tid == 0)                         // ready for the next launch
+      __hip_atomic_store(p.tail_cnt + tail_tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float* all = p.tail_ws + (size_t)tail_tile * ks_cnt * TILE;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        floatx16 sum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum[r] = 0.f;
+        for (int sl = 0; sl < ks_cnt; ++sl) {
+          const float* src = all + (size_t)sl * TILE + (((wave * MT + i) * NT + j) * 16) * 64 + lane;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            sum[r] += __hip_atomic_load(src + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        acc[i][j] = sum;
+      }
+  }
+  const bool atomic_split = tail_tile < 0 && ks_cnt > 1;
+
   // ---- epilogue ----
   for (int r = tid; r < BM; r += 256) {
     const int64_t m = m0 + r;
@@ -340,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
     if (d.p == nullptr || nt0 >= n_valid) continue;
     const int ch = (di ? nt0 - p.n_split : nt0) + 4 * tq;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && blockIdx.y == 0) bias4 = *reinterpret_cast<const float4*>(p.bias + nt0 + 4 * tq);
+    if (p.bias && (ks_idx == 0 || !atomic_split)) bias4 = *reinterpret_cast<const float4*>(p.bias + nt0 + 4 * tq);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -374,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
           v.x *= mk.x * d.gmask_scale; v.y *= mk.y * d.gmask_scale;
           v.z *= mk.z * d.gmask_scale; v.w *= mk.w * d.gmask_scale;
         }
-        if (gridDim.y > 1) {   // every epilogue factor above is linear in the accumulator
+        if (atomic_split) {   // every epilogue factor above is linear in the accumulator
           unsafeAtomicAdd(d.p + off, v.x); unsafeAtomicAdd(d.p + off + 1, v.y);
           unsafeAtomicAdd(d.p + off + 2, v.z); unsafeAtomicAdd(d.p + off + 3, v.w);
           continue;
@@ -398,9 +462,73 @@ bool split_k_allowed() {
   return e ? atoi(e) != 0 : true;
 }
 
+struct LaunchCtx {
+  hipStream_t stream;
+  const char** name_only;    // report the kernel instance instead of launching
+  float* scratch;            // caller workspace for the tail split (may be null)
+  int64_t scratch_bytes;
+  int64_t* scratch_query;    // report the workspace bytes wanted instead of launching
+};
+
+// ADVOC_IGEMM_TAIL=0 disables the tail split (A/B measurements).
+bool tail_split_allowed() {
+  const char* e = getenv("ADVOC_IGEMM_TAIL");
+  return e ? atoi(e) != 0 : true;
+}
+
+int device_cu_count() {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    (void)hipGetLastError();
+    return n > 0 ? n : 256;
+  }();
+  return cus;
+}
+
+// Arrival counters of the tail split: a ring of slots so that launches in flight on different
+// streams do not share counters; every launch leaves its slot zeroed again (see the kernel).
+constexpr int kTailSlots = 64;
+constexpr int kTailMaxTiles = 256;
+__device__ int g_tail_cnt[kTailSlots * kTailMaxTiles];
+
+int* tail_counter_slot() {
+  static std::atomic<unsigned> next{0};
+  int* base = nullptr;
+  if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_tail_cnt)) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return base + (next.fetch_add(1) % kTailSlots) * kTailMaxTiles;
+}
+
+// A launch of T equal workgroups on C compute units costs ceil(T / C) rounds when they are all
+// resident (measured: 1024 tiles 193 us, 1056 tiles 230 us on 256 CUs).  Plan: the last T mod C
+// tiles are cut into `split` K slices each so that the extra round is 1/split of a tile long.
+struct TailPlan { int main = 0, rem = 0, split = 0; };
+TailPlan plan_tail(int64_t tiles, int nkt) {
+  TailPlan t;
+  const int cus = device_cu_count();
+  if (!tail_split_allowed() || tiles < cus || tiles > 0x3fffffffLL) return t;
+  const int rem = (int)(tiles % cus);
+  if (rem == 0 || rem > kTailMaxTiles) return t;
+  int split = cus / rem;
+  if (split > 8) split = 8;
+  while (split > 1 && nkt / split < 8) --split;
+  if (split < 2) return t;
+  t.main = (int)(tiles - rem); t.rem = rem; t.split = split;
+  return t;
+}
+
 template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK>
-int launch_cfg(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
+int launch_cfg(const GatherGemmParams& p, const LaunchCtx& ctx) {
   using C = Cfg<MT, NT, WGM, WGN, B_KN, BK>;
+  hipStream_t stream = ctx.stream;
+  const char** name_only = ctx.name_only;
+  float* scratch = ctx.scratch;
+  const int64_t scratch_bytes = ctx.scratch_bytes;
+  int64_t* scratch_query = ctx.scratch_query;
   if (name_only) {
     static const std::string name = std::string("gather_gemm_kernel<") + std::to_string(MT) + ", " +
                                     std::to_string(NT) + ", " + std::to_string(WGM) + ", " +
@@ -424,6 +552,23 @@ int launch_cfg(const GatherGemmParams& p, hipStream_t stream, const char** name_
     if (ksplit > nkt / 16) ksplit = nkt / 16;
     if (ksplit > 16) ksplit = 16;
     if (ksplit < 1) ksplit = 1;
+  }
+  TailPlan tail;
+  if (ksplit == 1) tail = plan_tail(tiles, nkt);
+  const int64_t tail_bytes = (int64_t)sizeof(float) * tail.rem * tail.split * C::BM * C::BN;
+  if (scratch_query) { *scratch_query = tail_bytes; return ADVOC_OK; }
+  if (tail.split > 1 && scratch && scratch_bytes >= tail_bytes) {
+    GatherGemmParams q = p;
+    q.tail_main = tail.main; q.tail_split = tail.split; q.tail_ws = scratch;
+    q.tail_cnt = tail_counter_slot();
+    if (q.tail_cnt) {
+      dim3 grid((unsigned)(tail.main + tail.rem * tail.split), 1, 1);
+      auto kern = gather_gemm_kernel<MT, NT, WGM, WGN, B_KN, BK>;
+      ADVOC_CLEAR_LAUNCH_ERROR();
+      hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, q);
+      ADVOC_RETURN_IF_LAUNCH_FAILED();
+      return ADVOC_OK;
+    }
   }
   if (ksplit > 1) {
     for (int i = 0; i < 2; ++i) {
@@ -458,12 +603,12 @@ int preferred_bk() {
 // under-filled (528 workgroups: ~70 TFLOP/s) and 64x64 tiles, which quarter the tile and double
 // the residency, win (~80-94 TFLOP/s on the same layers).  32 output channels: 128x32.
 template <bool B_KN, int BK>
-int dispatch_bk(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
+int dispatch_bk(const GatherGemmParams& p, const LaunchCtx& ctx) {
   const int N = p.n_total;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   // 32 output channels: 128 x 32 (measured 3-11 % faster than 256 x 32 on every such layer: 6 instead
   // of 3 workgroups per CU)
-  if (N % 64 != 0) return launch_cfg<1, 1, 4, 1, B_KN, BK>(p, stream, name_only);
+  if (N % 64 != 0) return launch_cfg<1, 1, 4, 1, B_KN, BK>(p, ctx);
   const int bn = N % 128 == 0 ? 128 : 64;
   const int64_t big_blocks = ceil_div(M, 128) * (N / bn) * p.nphase;
   // ... and the big tiles only pay off on deep contractions: with taps x channels < 2048 (< 1024
@@ -474,31 +619,33 @@ int dispatch_bk(const GatherGemmParams& p, hipStream_t stream, const char** name
   {
     const char* e = getenv("ADVOC_IGEMM_TILE");
     const int force = e ? atoi(e) : 0;
-    if (force == 1) return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, stream, name_only);
-    if (force == 2) return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, stream, name_only);
-    if (force == 3 && bn == 128) return launch_cfg<2, 2, 2, 2, B_KN, BK>(p, stream, name_only);
-    if (force == 3) return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, stream, name_only);
-    if (force == 4 && bn == 128) return launch_cfg<1, 2, 2, 2, B_KN, BK>(p, stream, name_only);   // 64 x 128
-    if (force == 4) return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, stream, name_only);
+    if (force == 1) return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, ctx);
+    if (force == 2) return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, ctx);
+    if (force == 3 && bn == 128) return launch_cfg<2, 2, 2, 2, B_KN, BK>(p, ctx);
+    if (force == 3) return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, ctx);
+    if (force == 4 && bn == 128) return launch_cfg<1, 2, 2, 2, B_KN, BK>(p, ctx);   // 64 x 128
+    if (force == 4) return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, ctx);
   }
-  if (big_blocks < 900 || !deep) return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, stream, name_only);   // 64 x 64
-  if (bn == 128) return launch_cfg<2, 2, 2, 2, B_KN, BK>(p, stream, name_only);          // 128 x 128
-  return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, stream, name_only);                          // 128 x 64
+  if (big_blocks < 900 || !deep) return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, ctx);   // 64 x 64
+  if (bn == 128) return launch_cfg<2, 2, 2, 2, B_KN, BK>(p, ctx);          // 128 x 128
+  return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, ctx);                          // 128 x 64
 }
 
 template <bool B_KN>
-int dispatch(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
+int dispatch(const GatherGemmParams& p, const LaunchCtx& ctx) {
   const int ktot = p.c0 + p.c1;
   const bool can32 = ktot % 32 == 0 && p.c0 % 32 == 0;
   int bk = preferred_bk();
   if (bk != 16 && bk != 32) bk = 16;
-  if (bk == 32 && can32) return dispatch_bk<B_KN, 32>(p, stream, name_only);
-  return dispatch_bk<B_KN, 16>(p, stream, name_only);
+  if (bk == 32 && can32) return dispatch_bk<B_KN, 32>(p, ctx);
+  return dispatch_bk<B_KN, 16>(p, ctx);
 }
 
 }  // namespace
 
-int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only) {
+int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only,
+                       float* scratch, int64_t scratch_bytes, int64_t* scratch_query) {
+  if (scratch_query) *scratch_query = 0;
   const int ktot = p.c0 + p.c1;
   if (p.batch <= 0 || p.gh <= 0 || p.gw <= 0 || ktot <= 0 || p.n_total <= 0) return ADVOC_ERR_BAD_SHAPE;
   if (ktot % 16 || p.c0 % 16 || p.n_total % 32 || p.n_split % 32) return ADVOC_ERR_UNSUPPORTED;
@@ -518,7 +665,9 @@ int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
   const int k_order = ko ? atoi(ko) : ((p.sy == 2 && p.nphase == 1 && ktot <= 32) ? 0 : 1);
   GatherGemmParams q = p;
   q.k_order = k_order;
-  return b_kn ? dispatch<true>(q, stream, name_only) : dispatch<false>(q, stream, name_only);
+  q.tail_main = 0; q.tail_split = 0; q.tail_ws = nullptr; q.tail_cnt = nullptr;
+  const LaunchCtx ctx = {stream, name_only, scratch, scratch_bytes, scratch_query};
+  return b_kn ? dispatch<true>(q, ctx) : dispatch<false>(q, ctx);
 }
 
 }  // namespace advoc

@@ -173,7 +173,10 @@ typedef struct advoc_conv_layer {
   /* optional scratch (caller-owned, 16-byte aligned).  Layers with <= 2 output channels (forward)
    * or <= 2 input channels (backward-data) run as a pointwise MFMA GEMM into this buffer followed
    * by a tap gather-sum when it holds at least advoc_conv_workspace_bytes(); without it they
-   * use the slower direct kernel. */
+   * use the slower direct kernel.  The gather-GEMM layers use it to balance a launch whose
+   * workgroup count is not a whole number of rounds of the chip (the last tiles are cut into K
+   * slices whose partial sums are parked here); without it they launch unbalanced.  Contents are
+   * scratch: nothing is kept between calls, one buffer can serve every layer on a stream. */
   float* workspace;
   int64_t workspace_bytes;
 } advoc_conv_layer;

@@ -141,6 +141,49 @@ def test_layer_single_k_pass(hip, case, monkeypatch):
   assert torch.equal(ys[0], ys[1])
 
 
+# Launches of >= 512 tiles whose count is not a multiple of the CU count: the last tiles are cut
+# into K slices, parked in the workspace and summed by the last slice to arrive (igemm.hip).
+# enc_tail: 537 forward tiles, 1076 backward-data tiles (4 phases); dec_tail_drop: 1092 / 546.
+TAIL = [
+    ('enc_tail',      0, (65, 32, 65), 32, 0, 64, 0, (2, 2), None, 1, False, 0),
+    ('dec_tail_drop', 1, (33, 16, 33), 64, 64, 64, 1, (2, 2), (1, 1), 2, True, 0),
+]
+
+
+@gpu
+@pytest.mark.parametrize('case', TAIL, ids=[c[0] for c in TAIL])
+def test_layer_tail_split(hip, case, monkeypatch):
+  import ctypes
+  from advoc_amd import _lib, conv
+  c = build_case(case)
+  dev = torch.device('cuda')
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w = c['w'].to(dev)
+  cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+
+  def forward():
+    y = torch.full((x0.shape[0], c['oh'], c['out_w'], cout), float('nan'), device=dev)
+    L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'],
+                   in_act=c['act'])
+    L.forward()
+    return L, y
+
+  L, y_a = forward()
+  # the path under test is really taken: both directions ask for scratch, and get it
+  for direction in (0, 1):
+    assert _lib.load().advoc_conv_workspace_bytes(ctypes.byref(L.struct), direction) > 0
+  assert L.struct.workspace_bytes > 0
+  _, y_b = forward()
+  assert torch.equal(y_a, y_b)                      # fixed summation order: run-to-run reproducible
+  monkeypatch.setenv('ADVOC_IGEMM_TAIL', '0')
+  _, y_plain = forward()
+  assert rel(y_a, y_plain.double()) < 1e-6          # same numbers up to the order of one sum
+  monkeypatch.delenv('ADVOC_IGEMM_TAIL')
+  test_layer_all_directions(hip, case)              # all three directions against the float64 oracle
+  test_layer_all_directions(hip, case, workspace=False)
+
+
 @gpu
 def test_two_stage_path_is_selected(hip):
   from advoc_amd import conv
