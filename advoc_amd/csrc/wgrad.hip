@@ -100,16 +100,8 @@ __device__ __forceinline__ float4 load_op4_at(const Operand& op, int pix0, int p
   return v;
 }
 
-// raw 16-byte load + the element offset it came from (transforms are applied later, at the
-// LDS-store stage, so that the load itself can stay in flight across the MFMA block)
-__device__ __forceinline__ float4 load_raw4_at(const Operand& op, int pix0, int pix1, int ch, int* off_out) {
-  const bool second = ch >= op.c0;
-  const float* src = second ? op.p1 : op.p0;
-  const int off = second ? pix1 * op.c1 + (ch - op.c0) : pix0 * op.c0 + ch;
-  *off_out = off;
-  return *reinterpret_cast<const float4*>(src + off);
-}
-
+// transforms are applied at the LDS-store stage, so that the raw load itself can stay in flight
+// across the MFMA block
 __device__ __forceinline__ float4 transform4(const Operand& op, float4 v, int ch, int off, float slope, bool live) {
   if (op.scale) {
     const float4 sc = *reinterpret_cast<const float4*>(op.scale + ch);
@@ -178,31 +170,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
 #define P_COL(i) (4 * ((tid + 256 * (i)) % (BM / 4)))
 #define Q_K(i) ((tid + 256 * (i)) / (BN / 4))
 #define Q_COL(i) (4 * ((tid + 256 * (i)) % (BN / 4)))
-  int p_ch[PL], p_gx[PL], p_gy[PL], p_img[PL], p_dydx[PL];
-  int q_gx[QL], q_gy[QL], q_img[QL];
-  bool p_on[PL], q_on[QL];
+  // Each slot keeps the ELEMENT OFFSET of its current pixel in its source tensor (a slot never
+  // changes source: its channel quad is fixed) and moves it with three per-slot deltas -- 16 grid
+  // points along x, x wrap to the next grid row, y wrap to the next image -- instead of rebuilding
+  // ((img * H + y) * pitch + x) * C every K step (four 32-bit multiply-adds per slot and step,
+  // quarter-rate VALU work that competed with the MFMAs).
+  int p_ch[PL], p_gx[PL], p_gy[PL], p_x[PL], p_y[PL], p_off[PL], p_ds[PL], p_dwx[PL], p_dwy[PL];
+  int q_gx[QL], q_gy[QL], q_off[QL], q_ds[QL], q_dwx[QL], q_dwy[QL];
+  bool p_on[PL], q_on[QL], p_second[PL], q_second[QL];
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
     const int row = a0 + P_COL(i);
     p_on[i] = P_K(i) < WK && row < rows_total;
     const int t_ = p_on[i] ? row / ca : 0;
     p_ch[i] = row - t_ * ca;
-    p_dydx[i] = p.tap[t_] & 0xffff;
+    const int tw = p.tap[t_];
     const int64_t g = g_begin + (P_K(i) < WK ? P_K(i) : 0);
     p_gx[i] = (int)(g % p.gw);
     const int64_t t = g / p.gw;
     p_gy[i] = (int)(t % p.gh);
-    p_img[i] = (int)(t / p.gh);
+    const int img = (int)(t / p.gh);
+    p_second[i] = p_ch[i] >= p.P.c0;
+    const int cs = p_second[i] ? p.P.c1 : p.P.c0, pitch = p_second[i] ? p.P.pitch1 : p.P.pitch0;
+    p_x[i] = p_gx[i] * p.sx + (int)(int8_t)((tw >> 8) & 0xff);
+    p_y[i] = p_gy[i] * p.sy + (int)(int8_t)(tw & 0xff);
+    p_off[i] = (int)((((int64_t)img * p.P.h + p_y[i]) * pitch + p_x[i]) * cs + (p_second[i] ? p_ch[i] - p.P.c0 : p_ch[i]));
+    p_ds[i] = WK * p.sx * cs;
+    p_dwx[i] = (p.sy * pitch - p.gw * p.sx) * cs;
+    p_dwy[i] = (p.P.h - p.gh * p.sy) * pitch * cs;
   }
 #pragma unroll
   for (int i = 0; i < QL; ++i) {
-    q_on[i] = Q_K(i) < WK && b0 + Q_COL(i) < cb;
+    const int ch = b0 + Q_COL(i);
+    q_on[i] = Q_K(i) < WK && ch < cb;
     const int64_t g = g_begin + (Q_K(i) < WK ? Q_K(i) : 0);
     q_gx[i] = (int)(g % p.gw);
     const int64_t t = g / p.gw;
     q_gy[i] = (int)(t % p.gh);
-    q_img[i] = (int)(t / p.gh);
+    const int img = (int)(t / p.gh);
+    q_second[i] = ch >= p.Q.c0;
+    const int cs = q_second[i] ? p.Q.c1 : p.Q.c0, pitch = q_second[i] ? p.Q.pitch1 : p.Q.pitch0;
+    q_off[i] = (int)((((int64_t)img * p.Q.h + q_gy[i]) * pitch + q_gx[i]) * cs + (q_second[i] ? ch - p.Q.c0 : ch));
+    q_ds[i] = WK * cs;
+    q_dwx[i] = (pitch - p.gw) * cs;
+    q_dwy[i] = (p.Q.h - p.gh) * pitch * cs;
   }
+  const int span = (int)(g_end - g_begin);   // grid points of this chunk (chunk fits 31 bits)
 
   float4 rp[PL], rq[QL];
   int rp_off[PL], rq_off[QL];
@@ -211,33 +224,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
   // loads the slots' current grid points, then advances them by WK
 #define ADVOC_W_LOAD(KT)                                                                             \
   {                                                                                                  \
-    const int64_t gb_ = g_begin + (int64_t)(KT) * WK;                                                \
+    const int kb_ = (KT) * WK;                                                                       \
     rp_live = 0; rq_live = 0;                                                                        \
     _Pragma("unroll") for (int i = 0; i < PL; ++i) {                                                 \
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
       rp_off[i] = 0;                                                                                 \
-      const int y = p_gy[i] * p.sy + (int)(int8_t)(p_dydx[i] & 0xff);                                \
-      const int x = p_gx[i] * p.sx + (int)(int8_t)(p_dydx[i] >> 8);                                  \
-      if (p_on[i] && gb_ + P_K(i) < g_end && (unsigned)y < (unsigned)p.P.h && (unsigned)x < (unsigned)p.P.w) { \
-        const int row = p_img[i] * p.P.h + y;                                                        \
-        v = load_raw4_at(p.P, row * p.P.pitch0 + x, row * p.P.pitch1 + x, p_ch[i], &rp_off[i]);     \
+      if (p_on[i] && kb_ + P_K(i) < span && (unsigned)p_y[i] < (unsigned)p.P.h &&                    \
+          (unsigned)p_x[i] < (unsigned)p.P.w) {                                                      \
+        v = *reinterpret_cast<const float4*>((p_second[i] ? p.P.p1 : p.P.p0) + p_off[i]);           \
+        rp_off[i] = p_off[i];                                                                        \
         rp_live |= 1u << i;                                                                          \
       }                                                                                              \
       rp[i] = v;                                                                                     \
-      p_gx[i] += WK;                                                                                 \
-      while (p_gx[i] >= p.gw) { p_gx[i] -= p.gw; if (++p_gy[i] >= p.gh) { p_gy[i] = 0; ++p_img[i]; } } \
+      p_gx[i] += WK; p_x[i] += WK * p.sx; p_off[i] += p_ds[i];                                       \
+      while (p_gx[i] >= p.gw) {                                                                      \
+        p_gx[i] -= p.gw; p_x[i] -= p.gw * p.sx; p_y[i] += p.sy; p_off[i] += p_dwx[i];                \
+        if (++p_gy[i] >= p.gh) { p_gy[i] = 0; p_y[i] -= p.gh * p.sy; p_off[i] += p_dwy[i]; }         \
+      }                                                                                              \
     }                                                                                                \
     _Pragma("unroll") for (int i = 0; i < QL; ++i) {                                                 \
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
       rq_off[i] = 0;                                                                                 \
-      if (q_on[i] && gb_ + Q_K(i) < g_end) {                                                         \
-        const int row = q_img[i] * p.Q.h + q_gy[i];                                                  \
-        v = load_raw4_at(p.Q, row * p.Q.pitch0 + q_gx[i], row * p.Q.pitch1 + q_gx[i], b0 + Q_COL(i), &rq_off[i]); \
+      if (q_on[i] && kb_ + Q_K(i) < span) {                                                          \
+        v = *reinterpret_cast<const float4*>((q_second[i] ? p.Q.p1 : p.Q.p0) + q_off[i]);           \
+        rq_off[i] = q_off[i];                                                                        \
         rq_live |= 1u << i;                                                                          \
       }                                                                                              \
       rq[i] = v;                                                                                     \
-      q_gx[i] += WK;                                                                                 \
-      while (q_gx[i] >= p.gw) { q_gx[i] -= p.gw; if (++q_gy[i] >= p.gh) { q_gy[i] = 0; ++q_img[i]; } } \
+      q_gx[i] += WK; q_off[i] += q_ds[i];                                                            \
+      while (q_gx[i] >= p.gw) {                                                                      \
+        q_gx[i] -= p.gw; q_off[i] += q_dwx[i];                                                       \
+        if (++q_gy[i] >= p.gh) { q_gy[i] = 0; q_off[i] += q_dwy[i]; }                                \
+      }                                                                                              \
     }                                                                                                \
   }
 

@@ -1,3 +1,5 @@
+"""Stress test of the tail split hand-over (igemm.hip): the workspace is poisoned with NaN before every
+launch, so a slice summed before it was visible shows up as NaN / a wrong value."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
