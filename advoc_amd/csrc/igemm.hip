@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  // grid points: < 2^31 (checked by the launcher), so the (row -> image, y, x) splits below are
+  // 32-bit divisions; as int64 they were ~a third of this kernel's VALU work on shallow layers
+  const unsigned M = (unsigned)p.batch * (unsigned)p.gh * (unsigned)p.gw;
   // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (each XCD has its own L2); remap so that
   // an XCD walks a CONTIGUOUS run of tiles: neighbouring M tiles share input halo rows and the
   // N tiles of one M tile share the whole A tile, so those re-reads hit the local L2.
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
       tile -= phase * tpp;
     }
   }
-  const int64_t m0 = (int64_t)(tile / ntn) * BM;
+  const unsigned m0 = (unsigned)(tile / ntn) * BM;
   const int n0 = (tile % ntn) * BN;
   const int ktot = p.c0 + p.c1;
   const int kpt = ktot / BK;         // K tiles per tap
@@ -135,12 +137,13 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   bool row_ok[AL];
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
-    const int64_t m = m0 + tid / QPR + RPP * i;
+    const unsigned m = m0 + tid / QPR + RPP * i;
     row_ok[i] = m < M;
-    const int64_t mm = row_ok[i] ? m : 0;
-    const int gx = (int)(mm % p.gw);
-    const int64_t t = mm / p.gw;
-    const int gy = (int)(t % p.gh), img = (int)(t / p.gh);
+    const unsigned mm = row_ok[i] ? m : 0u;
+    const unsigned t = mm / (unsigned)p.gw;
+    const int gx = (int)(mm - t * (unsigned)p.gw);
+    const int img = (int)(t / (unsigned)p.gh);
+    const int gy = (int)(t - (unsigned)img * (unsigned)p.gh);
     row_x[i] = gx * p.sx;
     row_y[i] = gy * p.sy;
     base0[i] = ((img * p.a_h + row_y[i]) * p.a0_pitch + row_x[i]) * p.c0 + 4 * kq;
@@ -371,13 +374,13 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
 
   // ---- epilogue ----
   for (int r = tid; r < BM; r += 256) {
-    const int64_t m = m0 + r;
+    const unsigned m = m0 + r;
     int pix0 = -1, pix1 = -1;
     if (m < M) {
-      const int gx = (int)(m % p.gw);
-      const int64_t t = m / p.gw;
-      const int gy = (int)(t % p.gh);
-      const int img = (int)(t / p.gh);
+      const unsigned t = m / (unsigned)p.gw;
+      const int gx = (int)(m - t * (unsigned)p.gw);
+      const int img = (int)(t / (unsigned)p.gh);
+      const int gy = (int)(t - (unsigned)img * (unsigned)p.gh);
       const int oy = gy * p.osy + p.ooy[phase], ox = gx * p.osx + p.oox[phase];
       if (oy < p.out_h && ox < p.out_w) {
         pix0 = (img * p.out_h + oy) * p.d[0].pitch + ox;
@@ -538,8 +541,8 @@ int launch_cfg(const GatherGemmParams& p, const LaunchCtx& ctx) {
     return ADVOC_OK;
   }
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  if (M > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;       // the kernel splits rows with 32-bit divisions
   const int64_t gx = ceil_div(M, C::BM);
-  if (gx > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
   if (gx * (p.n_total / C::BN) > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
   // Small pixel grids with deep contractions (encoder_5.., decoder_5.. and their gradients) would
   // put < 2 workgroups on a CU, each walking hundreds of K tiles alone: split K until the launch
