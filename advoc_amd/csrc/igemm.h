@@ -65,6 +65,10 @@ struct GatherGemmParams {
   const uint8_t* y_mask;   // forward dropout mask, indexed like d[0]
   float y_mask_scale;
   int grad_act;            // != ADVOC_ACT_NONE: multiply result by act'(d[i].xpre)
+  // ---- split-bf16 path (filled in by the launcher): the weights pre-split into three bf16 planes,
+  // wq[plane][tap][n_total][c0 + c1] (contraction axis contiguous, zeros for n >= n_valid) ----
+  const uint16_t* wq;
+  int wq_taps;
   // ---- tail split (filled in by the launcher, see launch_cfg) ----
   int tail_main;           // > 0: 1-D launch; tiles [0, tail_main) whole, the rest in tail_split K slices each
   int tail_split;

@@ -49,7 +49,7 @@ __device__ __forceinline__ float act_grad(float x, int act) {
   return 1.f;
 }
 
-template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK>
+template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK, bool X6 = false>
 struct Cfg {
   static constexpr int BM = 32 * MT * WGM;
   static constexpr int BN = 32 * NT * WGN;
@@ -63,8 +63,26 @@ struct Cfg {
   // Exactly the two double-buffered tiles: 40 KiB for 128x128 so FOUR workgroups fit a CU's
   // 160 KiB.  The epilogue's pixel table / transpose patches reuse the tile buffers once the K loop
   // is done.
-  static constexpr size_t LDS_BYTES = sizeof(float) * (2 * A_TILE + 2 * B_TILE);
+  // split-bf16 path: three bf16 planes per operand, rows of 16 contraction slots = 8 dwords
+  static constexpr int XA = 3 * BM * 8;                    // dwords per A stage
+  static constexpr int XB = 3 * BN * 8;
+  static constexpr size_t LDS_BYTES = X6 ? sizeof(float) * 2 * (XA + XB) : sizeof(float) * (2 * A_TILE + 2 * B_TILE);
 };
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = x0 + x1 + x2 exactly, each term a bf16 (8 significant bits, truncation): the high halves of
+// the three words.  x1 / x2 take the next 8 / the last <= 8 bits of the remainder.
+__device__ __forceinline__ void split3(float x, unsigned& h0, unsigned& h1, unsigned& h2) {
+  h0 = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h0);
+  h1 = __float_as_uint(r1) & 0xffff0000u;
+  h2 = __float_as_uint(r1 - __uint_as_float(h1));
+}
+// two bf16 (high halves of lo / hi) in one dword, lo in the low half
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) {
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
 
 // act(v) = max(v, slope * v): slope 1 -> identity, 0.2 -> leaky ReLU, 0 -> ReLU (branch-free)
 __device__ __forceinline__ float act_slope(int act) {
@@ -74,9 +92,10 @@ __device__ __forceinline__ float act_slope(int act) {
 // launch_bounds(256, 2): budget registers for 2 waves per SIMD (<= 256 VGPR+AGPR).  With the
 // default bound hipcc chases a higher occupancy and spills the prefetch registers to scratch,
 // which serialises the global loads behind s_waitcnt vmcnt(0).
-template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK>
+template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK, bool X6 = false>
 __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmParams p) {
-  using C = Cfg<MT, NT, WGM, WGN, B_KN, BK>;
+  using C = Cfg<MT, NT, WGM, WGN, B_KN, BK, X6>;
+  static_assert(!X6 || (BK == 16 && !B_KN), "split-bf16 path: K tile of 16, pre-split weights");
   constexpr int BM = C::BM, BN = C::BN, LDA = C::LDA, QPR = C::QPR;
   constexpr int AL = C::A_LOADS, BL = C::B_LOADS;
   constexpr int RPP = 256 / QPR;   // tile rows covered by one pass of the 256 loader threads
@@ -174,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   }
 
   float4 ra[AL], rb[BL];
+  uint4 rbx0 = make_uint4(0, 0, 0, 0), rbx1 = rbx0, rbx2 = rbx0;   // split-bf16 path: 16 bytes per weight plane
   unsigned a_ok = 0;
   int a_chan = 0;
   bool a_first = true;     // the staged A slice comes from source 0 (the only one a_mask covers)
@@ -223,11 +243,22 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
         a_ok |= 1u << i;                                                                             \
       }                                                                                              \
     }                                                                                                \
+    if constexpr (X6) {                                                                              \
+      /* pre-split weights: 16 bytes = 8 contraction slots of one output channel, per plane */      \
+      const uint16_t* wq_ = p.wq + ((int64_t)wtap_ * p.n_total + n0 + (tid >> 1)) * ktot + k0_ + 8 * (tid & 1); \
+      const int64_t plane_ = (int64_t)p.wq_taps * p.n_total * ktot;                                  \
+      if (tid < 2 * BN) {                                                                            \
+        rbx0 = *reinterpret_cast<const uint4*>(wq_);                                                 \
+        rbx1 = *reinterpret_cast<const uint4*>(wq_ + plane_);                                        \
+        rbx2 = *reinterpret_cast<const uint4*>(wq_ + 2 * plane_);                                    \
+      }                                                                                              \
+    } else {                                                                                         \
     const float* wb_ = B_KN ? p.w + ((int64_t)wtap_ * ktot + k0_) * p.n_total                        \
                             : p.w + (int64_t)wtap_ * n_valid * ktot + k0_;                           \
     _Pragma("unroll") for (int i = 0; i < BL; ++i) {                                                 \
       rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
       if (b_live[i]) rb[i] = *reinterpret_cast<const float4*>(wb_ + b_goff[i]);                      \
+    }                                                                                                \
     }                                                                                                \
   }
 
@@ -257,10 +288,33 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
         v.x *= mk_.x * p.a_mask_scale; v.y *= mk_.y * p.a_mask_scale;                                \
         v.z *= mk_.z * p.a_mask_scale; v.w *= mk_.w * p.a_mask_scale;                                \
       }                                                                                              \
+      if constexpr (X6) {                                                                            \
+        unsigned* Ax_ = reinterpret_cast<unsigned*>(smem) + (BUF) * (C::XA + C::XB);                 \
+        unsigned h0_[4], h1_[4], h2_[4];                                                             \
+        split3(v.x, h0_[0], h1_[0], h2_[0]); split3(v.y, h0_[1], h1_[1], h2_[1]);                    \
+        split3(v.z, h0_[2], h1_[2], h2_[2]); split3(v.w, h0_[3], h1_[3], h2_[3]);                    \
+        const int row_ = tid / QPR + RPP * i;                                                        \
+        *reinterpret_cast<uint2*>(Ax_ + (0 * BM + row_) * 8 + 2 * kq) =                              \
+            make_uint2(pack_hi16(h0_[0], h0_[1]), pack_hi16(h0_[2], h0_[3]));                        \
+        *reinterpret_cast<uint2*>(Ax_ + (1 * BM + row_) * 8 + 2 * kq) =                              \
+            make_uint2(pack_hi16(h1_[0], h1_[1]), pack_hi16(h1_[2], h1_[3]));                        \
+        *reinterpret_cast<uint2*>(Ax_ + (2 * BM + row_) * 8 + 2 * kq) =                              \
+            make_uint2(pack_hi16(h2_[0], h2_[1]), pack_hi16(h2_[2], h2_[3]));                        \
+      } else {                                                                                       \
       *reinterpret_cast<float4*>(Ab_ + (tid / QPR + RPP * i) * LDA + 4 * kq) = v;                    \
+      }                                                                                              \
     }                                                                                                \
+    if constexpr (X6) {                                                                              \
+      unsigned* Bx_ = reinterpret_cast<unsigned*>(smem) + (BUF) * (C::XA + C::XB) + C::XA;           \
+      if (tid < 2 * BN) {                                                                            \
+        *reinterpret_cast<uint4*>(Bx_ + 4 * tid) = rbx0;                                             \
+        *reinterpret_cast<uint4*>(Bx_ + BN * 8 + 4 * tid) = rbx1;                                    \
+        *reinterpret_cast<uint4*>(Bx_ + 2 * BN * 8 + 4 * tid) = rbx2;                                \
+      }                                                                                              \
+    } else {                                                                                         \
     _Pragma("unroll") for (int i = 0; i < BL; ++i)                                                   \
         if (b_store[i]) *reinterpret_cast<float4*>(Bb_ + b_loff[i]) = rb[i];                         \
+    }                                                                                                \
   }
 
   floatx16 acc[MT][NT];
@@ -284,6 +338,35 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
     // prefetch registers out of a conditional region
     ADVOC_LOAD_TILE(kt + 1);
 
+    if constexpr (X6) {
+      // six bf16 products per 32x32x16 block, smallest terms first: a1 b1, a0 b2, a2 b0, a0 b1, a1 b0, a0 b0
+      // (the dropped a1 b2, a2 b1, a2 b2 are <= 2^-22 of the product).  Lane (l32, half) holds
+      // contraction slots [8 half, 8 half + 8) of row / column l32.
+      const unsigned* Ax = reinterpret_cast<const unsigned*>(smem) + buf * (C::XA + C::XB);
+      const unsigned* Bx = Ax + C::XA;
+      bf16x8 af[MT][3], bq[NT][3];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          af[i][pl] = *reinterpret_cast<const bf16x8*>(Ax + (pl * BM + (wm * MT + i) * 32 + l32) * 8 + 4 * half);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          bq[j][pl] = *reinterpret_cast<const bf16x8*>(Bx + (pl * BN + (wn * NT + j) * 32 + l32) * 8 + 4 * half);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bq[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][0], acc[i][j], 0, 0, 0);
+        }
+    } else {
     const float* Ab = As + buf * C::A_TILE;
     const float* Bb = Bs + buf * C::B_TILE;
     constexpr int KH = BK / 2;   // K slots per wave half: lanes 0-31 take [0, KH), lanes 32-63 [KH, BK)
@@ -319,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
 
     if (more) ADVOC_STORE_TILE(buf ^ 1);
     __syncthreads();
@@ -524,19 +608,77 @@ TailPlan plan_tail(int64_t tiles, int nkt) {
   return t;
 }
 
-template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK>
-int launch_cfg(const GatherGemmParams& p, const LaunchCtx& ctx) {
-  using C = Cfg<MT, NT, WGM, WGN, B_KN, BK>;
+// Split-bf16 path: weights to three bf16 planes [plane][tap][n_total][K], contraction axis contiguous.
+// One workgroup = one 32 (k) x 32 (n) tile of one tap, through LDS so that both the fp32 reads (along n
+// for the [tap][k][n] layout, along k for [tap][n][k]) and the bf16 writes (along k) are contiguous.
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ wq,
+                                                            int taps, int n_total, int n_valid, int ktot, int b_kn) {
+  __shared__ float tile[32][33];
+  const int tk = (ktot + 31) / 32, tn = (n_total + 31) / 32;
+  const int64_t plane = (int64_t)taps * n_total * ktot;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  for (int b = blockIdx.x; b < taps * tk * tn; b += gridDim.x) {
+    const int t = b / (tk * tn), r = b - t * (tk * tn);
+    const int k0 = (r / tn) * 32, n0 = (r % tn) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = ty + 8 * i;
+      float x = 0.f;
+      if (b_kn) {            // tile[k][n]: lanes along n
+        const int k = k0 + row, n = n0 + tx;
+        if (k < ktot && n < n_valid) x = w[((int64_t)t * ktot + k) * n_total + n];
+        tile[row][tx] = x;
+      } else {               // tile[k][n] filled from rows of n: lanes along k
+        const int n = n0 + row, k = k0 + tx;
+        if (k < ktot && n < n_valid) x = w[((int64_t)t * n_valid + n) * ktot + k];
+        tile[tx][row] = x;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + ty + 8 * i, k = k0 + tx;
+      if (n < n_total && k < ktot) {
+        unsigned h0, h1, h2;
+        split3(tile[tx][ty + 8 * i], h0, h1, h2);
+        const int64_t o = ((int64_t)t * n_total + n) * ktot + k;
+        wq[o] = (uint16_t)(h0 >> 16);
+        wq[plane + o] = (uint16_t)(h1 >> 16);
+        wq[2 * plane + o] = (uint16_t)(h2 >> 16);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int weight_taps(const GatherGemmParams& p) {
+  int t = 0;
+  for (int ph = 0; ph < p.nphase; ++ph)
+    for (int i = 0; i < p.ntaps; ++i) t = (p.tap[ph][i] >> 16) + 1 > t ? (p.tap[ph][i] >> 16) + 1 : t;
+  return t;
+}
+
+// Large launches run on the bf16 matrix path with every operand split into three bf16 terms (fp32-level
+// error, see split3); needs caller workspace for the split weights.  ADVOC_IGEMM_X6=0 keeps everything
+// on the fp32 MFMA kernels (A/B measurements).
+bool x6_allowed() {
+  const char* e = getenv("ADVOC_IGEMM_X6");
+  return e ? atoi(e) != 0 : true;
+}
+
+template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK, bool X6 = false>
+int launch_cfg(const GatherGemmParams& p, const LaunchCtx& ctx, bool b_kn_src = B_KN) {
+  using C = Cfg<MT, NT, WGM, WGN, B_KN, BK, X6>;
   hipStream_t stream = ctx.stream;
   const char** name_only = ctx.name_only;
   float* scratch = ctx.scratch;
-  const int64_t scratch_bytes = ctx.scratch_bytes;
+  int64_t scratch_bytes = ctx.scratch_bytes;
   int64_t* scratch_query = ctx.scratch_query;
   if (name_only) {
     static const std::string name = std::string("gather_gemm_kernel<") + std::to_string(MT) + ", " +
                                     std::to_string(NT) + ", " + std::to_string(WGM) + ", " +
                                     std::to_string(WGN) + ", " + (B_KN ? "true" : "false") + ", " +
-                                    std::to_string(BK) + ">";
+                                    std::to_string(BK) + (X6 ? ", true>" : ">");
     *name_only = name.c_str();
     return ADVOC_OK;
   }
@@ -559,14 +701,32 @@ int launch_cfg(const GatherGemmParams& p, const LaunchCtx& ctx) {
   TailPlan tail;
   if (ksplit == 1) tail = plan_tail(tiles, nkt);
   const int64_t tail_bytes = (int64_t)sizeof(float) * tail.rem * tail.split * C::BM * C::BN;
+  GatherGemmParams px = p;
+  if (X6) {
+    const int taps = weight_taps(p), ktot = p.c0 + p.c1;
+    const int64_t wq_bytes = ((int64_t)3 * taps * p.n_total * ktot * 2 + 255) / 256 * 256;
+    if (scratch_query) { *scratch_query = wq_bytes + tail_bytes; return ADVOC_OK; }
+    if (!scratch || scratch_bytes < wq_bytes) return ADVOC_ERR_UNSUPPORTED;   // caller falls back to fp32 MFMA
+    px.wq = reinterpret_cast<const uint16_t*>(scratch);
+    px.wq_taps = taps;
+    int64_t blocks = (int64_t)taps * ((ktot + 31) / 32) * ((p.n_total + 31) / 32);
+    if (blocks > 4096) blocks = 4096;
+    ADVOC_CLEAR_LAUNCH_ERROR();
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p.w,
+                       reinterpret_cast<uint16_t*>(scratch), taps, p.n_total, p.n_valid ? p.n_valid : p.n_total,
+                       ktot, b_kn_src ? 1 : 0);
+    ADVOC_RETURN_IF_LAUNCH_FAILED();
+    scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + wq_bytes);
+    scratch_bytes -= wq_bytes;
+  }
   if (scratch_query) { *scratch_query = tail_bytes; return ADVOC_OK; }
   if (tail.split > 1 && scratch && scratch_bytes >= tail_bytes) {
-    GatherGemmParams q = p;
+    GatherGemmParams q = px;
     q.tail_main = tail.main; q.tail_split = tail.split; q.tail_ws = scratch;
     q.tail_cnt = tail_counter_slot();
     if (q.tail_cnt) {
       dim3 grid((unsigned)(tail.main + tail.rem * tail.split), 1, 1);
-      auto kern = gather_gemm_kernel<MT, NT, WGM, WGN, B_KN, BK>;
+      auto kern = gather_gemm_kernel<MT, NT, WGM, WGN, B_KN, BK, X6>;
       ADVOC_CLEAR_LAUNCH_ERROR();
       hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, q);
       ADVOC_RETURN_IF_LAUNCH_FAILED();
@@ -584,9 +744,9 @@ int launch_cfg(const GatherGemmParams& p, const LaunchCtx& ctx) {
     }
   }
   dim3 grid((unsigned)(gx * (p.n_total / C::BN)), (unsigned)ksplit, (unsigned)p.nphase);
-  auto kern = gather_gemm_kernel<MT, NT, WGM, WGN, B_KN, BK>;
+  auto kern = gather_gemm_kernel<MT, NT, WGM, WGN, B_KN, BK, X6>;
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, px);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }
@@ -613,6 +773,23 @@ int dispatch_bk(const GatherGemmParams& p, const LaunchCtx& ctx) {
   // of 3 workgroups per CU)
   if (N % 64 != 0) return launch_cfg<1, 1, 4, 1, B_KN, BK>(p, ctx);
   const int bn = N % 128 == 0 ? 128 : 64;
+  if (BK == 16 && x6_allowed()) {
+    // split-bf16 path (weights pre-split, so one kernel serves both weight layouts)
+    // Measured per layer (tools/layer_times.py, both models): the split path wins from ~500 tiles up
+    // (2 per CU: its workgroups are 1.3-1.5x faster than the fp32 ones); 128x128 when that many exist,
+    // else 128x64; below, the fp32 kernels with their smaller tiles / split-K stay ahead.
+    const char* te = getenv("ADVOC_IGEMM_X6_TILE");
+    const int xt = te ? atoi(te) : 0;
+    const int64_t rows128 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * p.nphase;
+    const int64_t t128 = bn == 128 ? rows128 * (N / 128) : 0, t64 = rows128 * (N / 64);
+    int rc = ADVOC_ERR_UNSUPPORTED;
+    if (xt == 1) rc = launch_cfg<1, 1, 2, 2, false, 16, true>(p, ctx, B_KN);
+    else if (xt == 2) rc = launch_cfg<2, 1, 2, 2, false, 16, true>(p, ctx, B_KN);
+    else if (xt == 3 && bn == 128) rc = launch_cfg<2, 2, 2, 2, false, 16, true>(p, ctx, B_KN);
+    else if (t128 >= 448) rc = launch_cfg<2, 2, 2, 2, false, 16, true>(p, ctx, B_KN);
+    else if (t64 >= 448) rc = launch_cfg<2, 1, 2, 2, false, 16, true>(p, ctx, B_KN);
+    if (rc != ADVOC_ERR_UNSUPPORTED) return rc;     // small grid, or no / too little workspace: fp32 MFMA below
+  }
   const int64_t big_blocks = ceil_div(M, 128) * (N / bn) * p.nphase;
   // ... and the big tiles only pay off on deep contractions: with taps x channels < 2048 (< 1024
   // for a plain forward epilogue) the 64x64 kernel measured 5-15 % faster on every such layer.
