@@ -12,6 +12,8 @@
 //   * wgrad_thin_kernel: the gathered operand has <= 2 channels (encoder_1, layer_1, decoder_1,
 //     layer_5): HBM-bound outer products, threads own channels of the wide operand.
 //   * bias_grad_kernel: per-channel column sums.
+#include <stdlib.h>
+
 #include <string>
 
 #include "conv_internal.h"
@@ -68,7 +70,7 @@ __device__ __forceinline__ float load_op1(const Operand& op, int img, int y, int
 // ---------------------------------------------------------------------------------------------
 constexpr int WK = 16;  // grid points per K step
 
-template <int MT, int NT, int WGM, int WGN>
+template <int MT, int NT, int WGM, int WGN, bool X6 = false>
 struct WCfg {
   static constexpr int BM = 32 * MT * WGM;   // channels of P per block
   static constexpr int BN = 32 * NT * WGN;   // channels of Q per block
@@ -76,8 +78,31 @@ struct WCfg {
   static constexpr int LDQ = BN + 4;
   static constexpr int P_LOADS = (WK * BM / 4 + 255) / 256;
   static constexpr int Q_LOADS = (WK * BN / 4 + 255) / 256;
-  static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (WK * LDP + WK * LDQ);
+  // split-bf16 path (see igemm.hip): per operand three planes of [8 pixel pairs][channels] dwords, one dword =
+  // the bf16 terms of two consecutive grid points of one channel
+  static constexpr int XP = 3 * (WK / 2) * LDP, XQ = 3 * (WK / 2) * LDQ;   // dwords per stage
+  static constexpr size_t LDS_BYTES = X6 ? sizeof(float) * 2 * (XP + XQ) : sizeof(float) * 2 * (WK * LDP + WK * LDQ);
 };
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = x0 + x1 + x2 exactly, each a bf16 by truncation (the high halves of h0, h1, h2); see igemm.hip
+__device__ __forceinline__ void split3(float x, unsigned& h0, unsigned& h1, unsigned& h2) {
+  h0 = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h0);
+  h1 = __float_as_uint(r1) & 0xffff0000u;
+  h2 = __float_as_uint(r1 - __uint_as_float(h1));
+}
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) {
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+// the three planes' dwords for one channel at two consecutive grid points (a = even, b = odd)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& d0, unsigned& d1, unsigned& d2) {
+  unsigned a0, a1, a2, b0, b1, b2;
+  split3(a, a0, a1, a2);
+  split3(b, b0, b1, b2);
+  d0 = pack_hi16(a0, b0); d1 = pack_hi16(a1, b1); d2 = pack_hi16(a2, b2);
+}
 
 // float4 of `op` at a precomputed pixel index (img*h + y)*pitch + x per source, channels ch..ch+3
 __device__ __forceinline__ float4 load_op4_at(const Operand& op, int pix0, int pix1, int ch, float slope) {
@@ -126,10 +151,11 @@ __device__ __forceinline__ float slope_of(int act) {
 }
 
 // launch_bounds(256, 2): see igemm.hip -- keeps the prefetch registers out of scratch.
-template <int MT, int NT, int WGM, int WGN>
+template <int MT, int NT, int WGM, int WGN, bool X6 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p, int tiles_n, int tiles,
                                                             int chunk) {
-  using C = WCfg<MT, NT, WGM, WGN>;
+  using C = WCfg<MT, NT, WGM, WGN, X6>;
+  static_assert(!X6 || (C::P_LOADS == 2 && C::Q_LOADS == 2), "split-bf16 path: 128 x 128 channel tiles");
   constexpr int BM = C::BM, BN = C::BN;
   constexpr int PL = C::P_LOADS, QL = C::Q_LOADS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -166,10 +192,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
   // slot's grid point advances by WK per K step and is tracked incrementally (no divisions).
   // (slot -> tile position is recomputed from tid where needed: registers are what keeps this
   //  kernel at 3 workgroups per CU instead of 4)
-#define P_K(i) ((tid + 256 * (i)) / (BM / 4))
-#define P_COL(i) (4 * ((tid + 256 * (i)) % (BM / 4)))
-#define Q_K(i) ((tid + 256 * (i)) / (BN / 4))
-#define Q_COL(i) (4 * ((tid + 256 * (i)) % (BN / 4)))
+  // split-bf16 path: a thread's two slots are the SAME channel quad at two consecutive grid points
+  // (2 kp, 2 kp + 1), so that their bf16 terms pack into one dword per channel and plane
+#define P_K(i) (X6 ? 2 * (tid / (BM / 4)) + (i) : (tid + 256 * (i)) / (BM / 4))
+#define P_COL(i) (X6 ? 4 * (tid % (BM / 4)) : 4 * ((tid + 256 * (i)) % (BM / 4)))
+#define Q_K(i) (X6 ? 2 * (tid / (BN / 4)) + (i) : (tid + 256 * (i)) / (BN / 4))
+#define Q_COL(i) (X6 ? 4 * (tid % (BN / 4)) : 4 * ((tid + 256 * (i)) % (BN / 4)))
   // Each slot keeps the ELEMENT OFFSET of its current pixel in its source tensor (a slot never
   // changes source: its channel quad is fixed) and moves it with three per-slot deltas -- 16 grid
   // points along x, x wrap to the next grid row, y wrap to the next image -- instead of rebuilding
@@ -261,6 +289,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
 
 #define ADVOC_W_STORE(BUF)                                                                           \
   {                                                                                                  \
+    if constexpr (X6) {                                                                              \
+      unsigned* Px_ = reinterpret_cast<unsigned*>(smem) + (BUF) * (C::XP + C::XQ);                   \
+      unsigned* Qx_ = Px_ + C::XP;                                                                   \
+      const int kp_ = tid / (BM / 4);                                                                \
+      {                                                                                              \
+        const float4 e_ = transform4(p.P, rp[0], p_ch[0], rp_off[0], pslope, rp_live & 1u);          \
+        const float4 o_ = transform4(p.P, rp[1], p_ch[1], rp_off[1], pslope, (rp_live >> 1) & 1u);   \
+        uint4 d0_, d1_, d2_;                                                                         \
+        split_pair(e_.x, o_.x, d0_.x, d1_.x, d2_.x); split_pair(e_.y, o_.y, d0_.y, d1_.y, d2_.y);    \
+        split_pair(e_.z, o_.z, d0_.z, d1_.z, d2_.z); split_pair(e_.w, o_.w, d0_.w, d1_.w, d2_.w);    \
+        unsigned* w_ = Px_ + kp_ * C::LDP + P_COL(0);                                                \
+        *reinterpret_cast<uint4*>(w_) = d0_;                                                         \
+        *reinterpret_cast<uint4*>(w_ + (WK / 2) * C::LDP) = d1_;                                     \
+        *reinterpret_cast<uint4*>(w_ + 2 * (WK / 2) * C::LDP) = d2_;                                 \
+      }                                                                                              \
+      {                                                                                              \
+        const int kq_ = tid / (BN / 4);                                                              \
+        const float4 e_ = transform4(p.Q, rq[0], b0 + Q_COL(0), rq_off[0], qslope, rq_live & 1u);    \
+        const float4 o_ = transform4(p.Q, rq[1], b0 + Q_COL(1), rq_off[1], qslope, (rq_live >> 1) & 1u); \
+        uint4 d0_, d1_, d2_;                                                                         \
+        split_pair(e_.x, o_.x, d0_.x, d1_.x, d2_.x); split_pair(e_.y, o_.y, d0_.y, d1_.y, d2_.y);    \
+        split_pair(e_.z, o_.z, d0_.z, d1_.z, d2_.z); split_pair(e_.w, o_.w, d0_.w, d1_.w, d2_.w);    \
+        unsigned* w_ = Qx_ + kq_ * C::LDQ + Q_COL(0);                                                \
+        *reinterpret_cast<uint4*>(w_) = d0_;                                                         \
+        *reinterpret_cast<uint4*>(w_ + (WK / 2) * C::LDQ) = d1_;                                     \
+        *reinterpret_cast<uint4*>(w_ + 2 * (WK / 2) * C::LDQ) = d2_;                                 \
+      }                                                                                              \
+      (void)kp_;                                                                                     \
+    } else {                                                                                         \
     float* Pb_ = Ps + (BUF) * WK * C::LDP;                                                           \
     float* Qb_ = Qs + (BUF) * WK * C::LDQ;                                                           \
     _Pragma("unroll") for (int i = 0; i < PL; ++i)                                                   \
@@ -269,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
     _Pragma("unroll") for (int i = 0; i < QL; ++i)                                                   \
         if (Q_K(i) < WK) *reinterpret_cast<float4*>(Qb_ + Q_K(i) * C::LDQ + Q_COL(i)) =              \
             transform4(p.Q, rq[i], b0 + Q_COL(i), rq_off[i], qslope, (rq_live >> i) & 1u);           \
+    }                                                                                                \
   }
 
   floatx16 acc[MT][NT];
@@ -288,6 +346,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
     const int buf = kt & 1;
     // unconditional prefetch; past the end every slot fails the g_end test and loads nothing
     ADVOC_W_LOAD(kt + 1);
+    if constexpr (X6) {
+      // lane (l32, half): grid points [8 half, 8 half + 8) = pixel pairs 4 half .. 4 half + 3 of its channel;
+      // six bf16 products per 32x32x16 block, smallest terms first (igemm.hip)
+      const unsigned* Px = reinterpret_cast<const unsigned*>(smem) + buf * (C::XP + C::XQ);
+      const unsigned* Qx = Px + C::XP;
+      bf16x8 af[MT][3], bq[NT][3];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const unsigned* q = Px + (pl * (WK / 2) + 4 * half) * C::LDP + (wm * MT + i) * 32 + l32;
+          const uint4 d = make_uint4(q[0], q[C::LDP], q[2 * C::LDP], q[3 * C::LDP]);
+          af[i][pl] = __builtin_bit_cast(bf16x8, d);
+        }
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const unsigned* q = Qx + (pl * (WK / 2) + 4 * half) * C::LDQ + (wn * NT + j) * 32 + l32;
+          const uint4 d = make_uint4(q[0], q[C::LDQ], q[2 * C::LDQ], q[3 * C::LDQ]);
+          bq[j][pl] = __builtin_bit_cast(bf16x8, d);
+        }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bq[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][0], acc[i][j], 0, 0, 0);
+        }
+    } else {
     const float* Pb = Ps + buf * WK * C::LDP;
     const float* Qb = Qs + buf * WK * C::LDQ;
 #pragma unroll
@@ -303,6 +395,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
     }
     if (kt + 1 < nkt) ADVOC_W_STORE(buf ^ 1);
     __syncthreads();
@@ -333,13 +426,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
   }
 }
 
-template <int MT, int NT, int WGM, int WGN>
+template <int MT, int NT, int WGM, int WGN, bool X6 = false>
 int launch_wcfg(const WgradParams& p, hipStream_t stream, const char** name_only) {
-  using C = WCfg<MT, NT, WGM, WGN>;
+  using C = WCfg<MT, NT, WGM, WGN, X6>;
   if (name_only) {
     static const std::string name = std::string("wgrad_mfma_kernel<") + std::to_string(MT) + ", " +
                                     std::to_string(NT) + ", " + std::to_string(WGM) + ", " +
-                                    std::to_string(WGN) + ">";
+                                    std::to_string(WGN) + (X6 ? ", true>" : ">");
     *name_only = name.c_str();
     return ADVOC_OK;
   }
@@ -356,7 +449,7 @@ int launch_wcfg(const WgradParams& p, hipStream_t stream, const char** name_only
   // 1/3-full second round.  Two rounds when the work allows it (shorter tail, same traffic).
   static const int64_t resident = [] {
     int per_cu = 0, dev = 0, cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_mfma_kernel<MT, NT, WGM, WGN>, 256,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_mfma_kernel<MT, NT, WGM, WGN, X6>, 256,
                                                      C::LDS_BYTES) != hipSuccess || per_cu < 1)
       per_cu = 3;
     hipDeviceProp_t prop;
@@ -376,7 +469,7 @@ int launch_wcfg(const WgradParams& p, hipStream_t stream, const char** name_only
   if (chunk > 0x7fffffffLL || tiles * ksplit > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
   dim3 grid((unsigned)(tiles * ksplit), 1, 1);
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL((wgrad_mfma_kernel<MT, NT, WGM, WGN>), grid, dim3(256), C::LDS_BYTES, stream, p,
+  hipLaunchKernelGGL((wgrad_mfma_kernel<MT, NT, WGM, WGN, X6>), grid, dim3(256), C::LDS_BYTES, stream, p,
                      tiles_n, (int)tiles, (int)chunk);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
@@ -558,7 +651,13 @@ int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream, const char** nam
   if (p.P.c1 && p.P.c0 % 32) return ADVOC_ERR_UNSUPPORTED;  // a 32-row MFMA tile stays in one source
   if (p.Q.c1 && p.Q.c0 % 32) return ADVOC_ERR_UNSUPPORTED;
   // rows = taps x ca (>= 512): 128-row tiles; the column tile follows cb
-  if (cb % 128 == 0) return launch_wcfg<2, 2, 2, 2>(p, stream, name_only);   // 128 x 128
+  if (cb % 128 == 0) {                                                       // 128 x 128
+    // split-bf16 path (igemm.hip): both operands split into three bf16 terms while they are parked in LDS;
+    // ADVOC_WGRAD_X6=0 keeps the fp32 MFMA kernel (A/B measurements)
+    const char* e = getenv("ADVOC_WGRAD_X6");
+    if (e ? atoi(e) != 0 : true) return launch_wcfg<2, 2, 2, 2, true>(p, stream, name_only);
+    return launch_wcfg<2, 2, 2, 2>(p, stream, name_only);
+  }
   if (cb % 64 == 0) return launch_wcfg<2, 1, 2, 2>(p, stream, name_only);    // 128 x 64
   return launch_wcfg<1, 1, 4, 1>(p, stream, name_only);                      // 128 x 32
 }
