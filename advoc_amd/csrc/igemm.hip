@@ -674,6 +674,10 @@ int launch_cfg(const GatherGemmParams& p, const LaunchCtx& ctx, bool b_kn_src = 
   float* scratch = ctx.scratch;
   int64_t scratch_bytes = ctx.scratch_bytes;
   int64_t* scratch_query = ctx.scratch_query;
+  if (X6 && !scratch_query) {   // the split path needs room for the split weights; else the caller falls back
+    const int64_t need = ((int64_t)3 * weight_taps(p) * p.n_total * (p.c0 + p.c1) * 2 + 255) / 256 * 256;
+    if (!scratch || scratch_bytes < need) return ADVOC_ERR_UNSUPPORTED;
+  }
   if (name_only) {
     static const std::string name = std::string("gather_gemm_kernel<") + std::to_string(MT) + ", " +
                                     std::to_string(NT) + ", " + std::to_string(WGM) + ", " +
@@ -771,7 +775,17 @@ int dispatch_bk(const GatherGemmParams& p, const LaunchCtx& ctx) {
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   // 32 output channels: 128 x 32 (measured 3-11 % faster than 256 x 32 on every such layer: 6 instead
   // of 3 workgroups per CU)
-  if (N % 64 != 0) return launch_cfg<1, 1, 4, 1, B_KN, BK>(p, ctx);
+  if (N % 64 != 0) {
+    if (BK == 16 && x6_allowed()) {
+      const char* te = getenv("ADVOC_IGEMM_X6_N32");
+      const int64_t t32 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * p.nphase * (N / 32);
+      if ((te ? atoi(te) != 0 : true) && t32 >= 1024) {
+        const int rc = launch_cfg<1, 1, 4, 1, false, 16, true>(p, ctx, B_KN);
+        if (rc != ADVOC_ERR_UNSUPPORTED) return rc;
+      }
+    }
+    return launch_cfg<1, 1, 4, 1, B_KN, BK>(p, ctx);
+  }
   const int bn = N % 128 == 0 ? 128 : 64;
   if (BK == 16 && x6_allowed()) {
     // split-bf16 path (weights pre-split, so one kernel serves both weight layouts)

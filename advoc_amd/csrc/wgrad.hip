@@ -76,8 +76,10 @@ struct WCfg {
   static constexpr int BN = 32 * NT * WGN;   // channels of Q per block
   static constexpr int LDP = BM + 4;
   static constexpr int LDQ = BN + 4;
-  static constexpr int P_LOADS = (WK * BM / 4 + 255) / 256;
-  static constexpr int Q_LOADS = (WK * BN / 4 + 255) / 256;
+  // split-bf16 path: always two slots per thread (one channel quad at two consecutive grid points);
+  // with a 64-channel Q tile only half of the threads carry Q slots
+  static constexpr int P_LOADS = X6 ? 2 : (WK * BM / 4 + 255) / 256;
+  static constexpr int Q_LOADS = X6 ? 2 : (WK * BN / 4 + 255) / 256;
   // split-bf16 path (see igemm.hip): per operand three planes of [8 pixel pairs][channels] dwords, one dword =
   // the bf16 terms of two consecutive grid points of one channel
   static constexpr int XP = 3 * (WK / 2) * LDP, XQ = 3 * (WK / 2) * LDQ;   // dwords per stage
@@ -155,7 +157,7 @@ template <int MT, int NT, int WGM, int WGN, bool X6 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p, int tiles_n, int tiles,
                                                             int chunk) {
   using C = WCfg<MT, NT, WGM, WGN, X6>;
-  static_assert(!X6 || (C::P_LOADS == 2 && C::Q_LOADS == 2), "split-bf16 path: 128 x 128 channel tiles");
+  static_assert(!X6 || (C::BM == 128 && (C::BN == 128 || C::BN == 64)), "split-bf16 path: 128 x 128 / 128 x 64 channel tiles");
   constexpr int BM = C::BM, BN = C::BN;
   constexpr int PL = C::P_LOADS, QL = C::Q_LOADS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -312,9 +314,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p,
         split_pair(e_.x, o_.x, d0_.x, d1_.x, d2_.x); split_pair(e_.y, o_.y, d0_.y, d1_.y, d2_.y);    \
         split_pair(e_.z, o_.z, d0_.z, d1_.z, d2_.z); split_pair(e_.w, o_.w, d0_.w, d1_.w, d2_.w);    \
         unsigned* w_ = Qx_ + kq_ * C::LDQ + Q_COL(0);                                                \
-        *reinterpret_cast<uint4*>(w_) = d0_;                                                         \
-        *reinterpret_cast<uint4*>(w_ + (WK / 2) * C::LDQ) = d1_;                                     \
-        *reinterpret_cast<uint4*>(w_ + 2 * (WK / 2) * C::LDQ) = d2_;                                 \
+        if (kq_ < WK / 2) {                                                                          \
+          *reinterpret_cast<uint4*>(w_) = d0_;                                                       \
+          *reinterpret_cast<uint4*>(w_ + (WK / 2) * C::LDQ) = d1_;                                   \
+          *reinterpret_cast<uint4*>(w_ + 2 * (WK / 2) * C::LDQ) = d2_;                               \
+        }                                                                                            \
       }                                                                                              \
       (void)kp_;                                                                                     \
     } else {                                                                                         \
@@ -658,7 +662,13 @@ int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream, const char** nam
     if (e ? atoi(e) != 0 : true) return launch_wcfg<2, 2, 2, 2, true>(p, stream, name_only);
     return launch_wcfg<2, 2, 2, 2>(p, stream, name_only);
   }
-  if (cb % 64 == 0) return launch_wcfg<2, 1, 2, 2>(p, stream, name_only);    // 128 x 64
+  if (cb % 64 == 0) {                                                        // 128 x 64
+    // the split variant of this tile measured 3-6 % SLOWER than fp32 (half of the threads carry no Q slot):
+    // only on request (ADVOC_WGRAD_X6=2)
+    const char* e = getenv("ADVOC_WGRAD_X6");
+    if (e && atoi(e) == 2) return launch_wcfg<2, 1, 2, 2, true>(p, stream, name_only);
+    return launch_wcfg<2, 1, 2, 2>(p, stream, name_only);
+  }
   return launch_wcfg<1, 1, 4, 1>(p, stream, name_only);                      // 128 x 32
 }
 
