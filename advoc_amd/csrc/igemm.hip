@@ -682,7 +682,7 @@ int launch_cfg(const GatherGemmParams& p, const LaunchCtx& ctx, bool b_kn_src = 
     static const std::string name = std::string("gather_gemm_kernel<") + std::to_string(MT) + ", " +
                                     std::to_string(NT) + ", " + std::to_string(WGM) + ", " +
                                     std::to_string(WGN) + ", " + (B_KN ? "true" : "false") + ", " +
-                                    std::to_string(BK) + (X6 ? ", true>" : ">");
+                                    std::to_string(BK) + (X6 ? ", true>" : ", false>");
     *name_only = name.c_str();
     return ADVOC_OK;
   }

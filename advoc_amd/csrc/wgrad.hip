@@ -436,7 +436,7 @@ int launch_wcfg(const WgradParams& p, hipStream_t stream, const char** name_only
   if (name_only) {
     static const std::string name = std::string("wgrad_mfma_kernel<") + std::to_string(MT) + ", " +
                                     std::to_string(NT) + ", " + std::to_string(WGM) + ", " +
-                                    std::to_string(WGN) + (X6 ? ", true>" : ">");
+                                    std::to_string(WGN) + (X6 ? ", true>" : ", false>");
     *name_only = name.c_str();
     return ADVOC_OK;
   }

@@ -295,7 +295,7 @@ def main():
     mfma = 'mfma' in name or 'gather_gemm' in name
     if mfma:
       achieved = r['flops'] / (r['ms'] * 1e-3) / 1e12
-      x6 = name.endswith(', true>') and 'gather_gemm' in name and name.count(',') == 6
+      x6 = name.endswith(', true>') and (name.startswith('gather_gemm_kernel<') or name.startswith('wgrad_mfma_kernel<'))
       peak = X6_PEAK_TFLOPS if x6 else FP32_MFMA_PEAK_TFLOPS
       roofline = dict(bound='mfma', kernel=name, achieved=achieved, peak=round(peak, 1),
                       unit='TFLOP/s', frac=achieved / peak,

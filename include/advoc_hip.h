@@ -175,8 +175,11 @@ typedef struct advoc_conv_layer {
    * by a tap gather-sum when it holds at least advoc_conv_workspace_bytes(); without it they
    * use the slower direct kernel.  The gather-GEMM layers use it to balance a launch whose
    * workgroup count is not a whole number of rounds of the chip (the last tiles are cut into K
-   * slices whose partial sums are parked here); without it they launch unbalanced.  Contents are
-   * scratch: nothing is kept between calls, one buffer can serve every layer on a stream. */
+   * slices whose partial sums are parked here) and, for launches of >= ~450 row tiles, to hold
+   * the weights split into three bf16 planes for the split-bf16 matrix path (every fp32 product
+   * as six bf16 MFMA products with fp32 accumulation: fp32-level error, ~1.4x faster); without it
+   * they launch unbalanced on the fp32 MFMA kernels.  Contents are scratch: nothing is kept
+   * between calls, one buffer can serve every layer on a stream. */
   float* workspace;
   int64_t workspace_bytes;
 } advoc_conv_layer;

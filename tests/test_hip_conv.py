@@ -184,6 +184,51 @@ def test_layer_tail_split(hip, case, monkeypatch):
   test_layer_all_directions(hip, case, workspace=False)
 
 
+# Launches of >= 448 tiles of 128 rows run on the bf16 matrix cores with every fp32 operand split exactly
+# into three bf16 terms (igemm.hip, wgrad.hip): same tolerance as the fp32 MFMA kernels, and the two paths
+# agree with each other far below it.
+SPLIT = [
+    ('enc_split',      0, (32, 64, 129), 64, 0, 128, 0, (2, 2), None, 1, False, 0),
+    ('dec_split_drop', 1, (16, 32, 65), 64, 64, 128, 1, (2, 2), (1, 1), 2, True, 0),
+]
+
+
+@gpu
+@pytest.mark.parametrize('case', SPLIT, ids=[c[0] for c in SPLIT])
+def test_layer_split_bf16_path(hip, case, monkeypatch):
+  from advoc_amd import conv
+  c = build_case(case)
+  dev = torch.device('cuda')
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w, dy = c['w'].to(dev), c['dy'].to(dev)
+  cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+
+  def run():
+    y = torch.full((x0.shape[0], c['oh'], c['out_w'], cout), float('nan'), device=dev)
+    L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'],
+                   in_act=c['act'])
+    L.forward()
+    dx0 = torch.full_like(x0, 7.0)
+    dx1 = torch.full_like(x1, 7.0) if x1 is not None else None
+    L.backward_data(dy, dx0, dx1)
+    dw = torch.full_like(w, float('nan'))
+    L.backward_weight(dy, dw)
+    return [L.kernel_name(d) for d in range(3)], y, dx0[:, :, :c['in_w']].clone(), dw
+
+  names, y, dx, dw = run()
+  assert all(n.endswith(', true>') for n in names), names          # the split kernels are the ones that ran
+  monkeypatch.setenv('ADVOC_IGEMM_X6', '0')
+  monkeypatch.setenv('ADVOC_WGRAD_X6', '0')
+  names32, y32, dx32, dw32 = run()
+  assert not any(n.endswith(', true>') for n in names32), names32
+  for a, b in ((y, y32), (dx, dx32), (dw, dw32)):
+    assert rel(a, b) < 3e-6, rel(a, b)
+  monkeypatch.delenv('ADVOC_IGEMM_X6')
+  monkeypatch.delenv('ADVOC_WGRAD_X6')
+  test_layer_all_directions(hip, case)              # all three directions against the float64 oracle
+
+
 @gpu
 def test_two_stage_path_is_selected(hip):
   from advoc_amd import conv
