@@ -192,6 +192,8 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
     }
   }
 
+  // split-bf16 path: this thread's 16 bytes of the pre-split weight tile (row n0 + tid / 2, half tid & 1)
+  const int wq_row = (n0 + (tid >> 1)) * ktot + 8 * (tid & 1);
   float4 ra[AL], rb[BL];
   uint4 rbx0 = make_uint4(0, 0, 0, 0), rbx1 = rbx0, rbx2 = rbx0;   // split-bf16 path: 16 bytes per weight plane
   unsigned a_ok = 0;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
     }                                                                                                \
     if constexpr (X6) {                                                                              \
       /* pre-split weights: 16 bytes = 8 contraction slots of one output channel, per plane */      \
-      const uint16_t* wq_ = p.wq + ((int64_t)wtap_ * p.n_total + n0 + (tid >> 1)) * ktot + k0_ + 8 * (tid & 1); \
+      const uint16_t* wq_ = p.wq + ((int64_t)wtap_ * p.n_total * ktot + k0_) + wq_row;               \
       const int64_t plane_ = (int64_t)p.wq_taps * p.n_total * ktot;                                  \
       if (tid < 2 * BN) {                                                                            \
         rbx0 = *reinterpret_cast<const uint4*>(wq_);                                                 \
