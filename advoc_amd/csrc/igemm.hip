@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
   const int wq_row = (n0 + (tid >> 1)) * ktot + 8 * (tid & 1);
   float4 ra[AL], rb[BL];
   uint4 rbx0 = make_uint4(0, 0, 0, 0), rbx1 = rbx0, rbx2 = rbx0;   // split-bf16 path: 16 bytes per weight plane
+  uint4 rby0 = rbx0, rby1 = rbx0, rby2 = rbx0;                     // ... and of rows 128.. of a 256-column tile
   unsigned a_ok = 0;
   int a_chan = 0;
   bool a_first = true;     // the staged A slice comes from source 0 (the only one a_mask covers)
@@ -253,6 +254,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
         rbx0 = *reinterpret_cast<const uint4*>(wq_);                                                 \
         rbx1 = *reinterpret_cast<const uint4*>(wq_ + plane_);                                        \
         rbx2 = *reinterpret_cast<const uint4*>(wq_ + 2 * plane_);                                    \
+      }                                                                                              \
+      if constexpr (BN > 128) {   /* second half of a 256-column tile: rows n0 + 128 + tid / 2 */    \
+        rby0 = *reinterpret_cast<const uint4*>(wq_ + 128 * ktot);                                    \
+        rby1 = *reinterpret_cast<const uint4*>(wq_ + 128 * ktot + plane_);                           \
+        rby2 = *reinterpret_cast<const uint4*>(wq_ + 128 * ktot + 2 * plane_);                       \
       }                                                                                              \
     } else {                                                                                         \
     const float* wb_ = B_KN ? p.w + ((int64_t)wtap_ * ktot + k0_) * p.n_total                        \
@@ -312,6 +318,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
         *reinterpret_cast<uint4*>(Bx_ + 4 * tid) = rbx0;                                             \
         *reinterpret_cast<uint4*>(Bx_ + BN * 8 + 4 * tid) = rbx1;                                    \
         *reinterpret_cast<uint4*>(Bx_ + 2 * BN * 8 + 4 * tid) = rbx2;                                \
+      }                                                                                              \
+      if constexpr (BN > 128) {                                                                      \
+        *reinterpret_cast<uint4*>(Bx_ + 1024 + 4 * tid) = rby0;                                      \
+        *reinterpret_cast<uint4*>(Bx_ + BN * 8 + 1024 + 4 * tid) = rby1;                             \
+        *reinterpret_cast<uint4*>(Bx_ + 2 * BN * 8 + 1024 + 4 * tid) = rby2;                         \
       }                                                                                              \
     } else {                                                                                         \
     _Pragma("unroll") for (int i = 0; i < BL; ++i)                                                   \
@@ -668,6 +679,16 @@ bool x6_allowed() {
   return e ? atoi(e) != 0 : true;
 }
 
+// 128 x 256 split tile (A is split once per 256 output columns; 256 registers, two workgroups per CU):
+// measured 6-20 % faster than 128 x 128 on deep contractions with >= ~500 such tiles (D layer_4, the
+// 512-channel generator layers of the full model), 10-150 % slower on shallow ones or small grids.
+// ADVOC_IGEMM_X6_WIDE=<tiles> overrides the tile threshold and drops the depth condition (experiments).
+bool x6_wide(int64_t tiles256, int k_total) {
+  const char* e = getenv("ADVOC_IGEMM_X6_WIDE");
+  if (e) return tiles256 >= atoll(e);
+  return tiles256 >= 500 && k_total >= 4096;
+}
+
 template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK, bool X6 = false>
 int launch_cfg(const GatherGemmParams& p, const LaunchCtx& ctx, bool b_kn_src = B_KN) {
   using C = Cfg<MT, NT, WGM, WGN, B_KN, BK, X6>;
@@ -802,6 +823,8 @@ int dispatch_bk(const GatherGemmParams& p, const LaunchCtx& ctx) {
     if (xt == 1) rc = launch_cfg<1, 1, 2, 2, false, 16, true>(p, ctx, B_KN);
     else if (xt == 2) rc = launch_cfg<2, 1, 2, 2, false, 16, true>(p, ctx, B_KN);
     else if (xt == 3 && bn == 128) rc = launch_cfg<2, 2, 2, 2, false, 16, true>(p, ctx, B_KN);
+    else if (N % 256 == 0 && x6_wide(rows128 * (N / 256), p.ntaps * (p.c0 + p.c1)))
+      rc = launch_cfg<2, 4, 2, 2, false, 16, true>(p, ctx, B_KN);
     else if (t128 >= 448) rc = launch_cfg<2, 2, 2, 2, false, 16, true>(p, ctx, B_KN);
     else if (t64 >= 448) rc = launch_cfg<2, 1, 2, 2, false, 16, true>(p, ctx, B_KN);
     if (rc != ADVOC_ERR_UNSUPPORTED) return rc;     // small grid, or no / too little workspace: fp32 MFMA below
