@@ -683,10 +683,11 @@ bool x6_allowed() {
 // measured 6-20 % faster than 128 x 128 on deep contractions with >= ~500 such tiles (D layer_4, the
 // 512-channel generator layers of the full model), 10-150 % slower on shallow ones or small grids.
 // ADVOC_IGEMM_X6_WIDE=<tiles> overrides the tile threshold and drops the depth condition (experiments).
-bool x6_wide(int64_t tiles256, int k_total) {
+bool x6_wide(int64_t tiles256, int k_total, int nphase) {
   const char* e = getenv("ADVOC_IGEMM_X6_WIDE");
   if (e) return tiles256 >= atoll(e);
-  return tiles256 >= 500 && k_total >= 4096;
+  // ... and on single-phase launches (forward / stride-1 layers) already from 2 048 deep with >= 900 tiles
+  return (tiles256 >= 500 && k_total >= 4096) || (nphase == 1 && tiles256 >= 900 && k_total >= 2048);
 }
 
 template <int MT, int NT, int WGM, int WGN, bool B_KN, int BK, bool X6 = false>
@@ -823,7 +824,7 @@ int dispatch_bk(const GatherGemmParams& p, const LaunchCtx& ctx) {
     if (xt == 1) rc = launch_cfg<1, 1, 2, 2, false, 16, true>(p, ctx, B_KN);
     else if (xt == 2) rc = launch_cfg<2, 1, 2, 2, false, 16, true>(p, ctx, B_KN);
     else if (xt == 3 && bn == 128) rc = launch_cfg<2, 2, 2, 2, false, 16, true>(p, ctx, B_KN);
-    else if (N % 256 == 0 && x6_wide(rows128 * (N / 256), p.ntaps * (p.c0 + p.c1)))
+    else if (N % 256 == 0 && x6_wide(rows128 * (N / 256), p.ntaps * (p.c0 + p.c1), p.nphase))
       rc = launch_cfg<2, 4, 2, 2, false, 16, true>(p, ctx, B_KN);
     else if (t128 >= 448) rc = launch_cfg<2, 2, 2, 2, false, 16, true>(p, ctx, B_KN);
     else if (t64 >= 448) rc = launch_cfg<2, 1, 2, 2, false, 16, true>(p, ctx, B_KN);
