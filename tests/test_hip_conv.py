@@ -189,6 +189,8 @@ def test_layer_tail_split(hip, case, monkeypatch):
 # agree with each other far below it.
 SPLIT = [
     ('enc_split',      0, (32, 64, 129), 64, 0, 128, 0, (2, 2), None, 1, False, 0),
+    # 455 tiles: the split kernels together with split-K (atomics) in the forward pass
+    ('enc_split_k',    0, (28, 64, 129), 64, 0, 128, 0, (2, 2), None, 1, False, 0),
     ('dec_split_drop', 1, (16, 32, 65), 64, 64, 128, 1, (2, 2), (1, 1), 2, True, 0),
 ]
 
