@@ -285,6 +285,58 @@ def test_short_training_run_reduces_l1(hip):
 
 
 @gpu
+def test_training_on_split_bf16_path_tracks_fp32_path(hip, monkeypatch):
+  """At the benchmark geometry (32 clips x 256 frames) most contractions run on the split-bf16 matrix path
+  (igemm.hip / wgrad.hip); with ADVOC_IGEMM_X6=0 ADVOC_WGRAD_X6=0 the same model runs on the fp32 MFMA
+  kernels.  The first step's gradients agree to round-off, and 12 train_loops on one batch end at the same
+  losses (Adam amplifies round-off, so the trajectories are compared, not the weights)."""
+  from advoc_amd.model import AdvocSmall, Modes
+  dev = torch.device('cuda')
+  x, target = batch(32, 256, 5)
+  x, target = x.to(dev), target.to(dev)
+
+  def run(split):
+    for k in ('ADVOC_IGEMM_X6', 'ADVOC_WGRAD_X6'):
+      if split:
+        monkeypatch.delenv(k, raising=False)
+      else:
+        monkeypatch.setenv(k, '0')
+    m = AdvocSmall(Modes.TRAIN)
+    m.train_batch_size = 32
+    m.build(batch_size=32, seed=11)
+    m((x, target))
+    m.train_loop()
+    torch.cuda.synchronize()
+    st = m._built
+    grads = {k: v.detach().clone() for name in ('d_G', 'g_G') for k, v in st[name].items()}
+    names = set(l.kernel_name(0) for l in st['g_layers'].values())
+    hist = [m.losses()]
+    for _ in range(11):
+      m.train_loop()
+      hist.append(m.losses())
+    return grads, hist, names
+
+  g_s, h_s, n_s = run(True)
+  g_f, h_f, n_f = run(False)
+  split = lambda n: n.startswith('gather_gemm_kernel<') and n.endswith(', true>')       # noqa: E731
+  assert any(split(n) for n in n_s) and not any(split(n) for n in n_f), (n_s, n_f)
+  worst = 0.0
+  for k in g_f:
+    if not k.startswith('discriminator'):      # D gradients are taken at identical weights
+      continue
+    e = rel(g_s[k], g_f[k])
+    worst = max(worst, e)
+    assert e < 1e-4, (k, e)          # measured 1.5e-5 (the deepest D layers; single convs agree to 3e-6)
+  for a, b in zip(h_s, h_f):
+    assert all(np.isfinite(v) for v in a.values()), a
+  for key in ('gen_loss_L1', 'disc_loss'):
+    a, b = h_s[-1][key], h_f[-1][key]
+    assert abs(a - b) <= 0.02 * abs(b) + 1e-3, (key, a, b)
+  print('split vs fp32: first-step D gradients %.2e; final L1 %.5f vs %.5f, D loss %.5f vs %.5f' % (
+      worst, h_s[-1]['gen_loss_L1'], h_f[-1]['gen_loss_L1'], h_s[-1]['disc_loss'], h_f[-1]['disc_loss']))
+
+
+@gpu
 def test_batch_norm_split_entry_points_reproduce_global_statistics(hip):
   """advoc_bn_*_stats on two shards + a sum of the 2c doubles + *_finalize / *_apply with the global
   count == the one-call batch norm on the whole batch (what synchronised BN across replicas relies on)."""
