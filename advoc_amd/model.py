@@ -266,7 +266,7 @@ class Advoc(Model):
     st['B'] = B
     if 'side_stream' not in st:
       st['side_stream'] = torch.cuda.Stream(device=dev)
-      st['side_on'] = os.environ.get('ADVOC_WGRAD_STREAM', '0') == '1'
+      st['side_on'] = os.environ.get('ADVOC_WGRAD_STREAM', '1') == '1'
     self._bind(st, B, dev)
     self._built = st
     if not hasattr(self, 'step'):
@@ -665,12 +665,14 @@ class Advoc(Model):
 
   def _wgrad_ctx(self):
     """Weight / bias gradients are off the critical path of the backward pass (nothing downstream
-    reads them before Adam): with ADVOC_WGRAD_STREAM=1 they run on a side stream so that their
-    launches fill the tail of the backward-data kernels and vice versa (measured -1.7 % step time).
-    Off by default: concurrent kernels share the CUs, which makes per-kernel durations -- and every
-    roofline figure derived from them -- uninterpretable.  Returns a context manager."""
+    reads them before Adam): they run on a side stream so that their launches fill the issue slots
+    and tails the backward-data kernels leave idle, and vice versa (measured -3.3 % step time;
+    ADVOC_WGRAD_STREAM=0 keeps everything on one stream).  Concurrent kernels share the CUs, which
+    makes per-kernel durations uninterpretable: while a launch profiler is attached
+    (conv.Layer.profiler, bench.py's instrumented steps) the step runs serially.  Returns a context
+    manager."""
     st = self._built
-    if not st.get('side_on', False):
+    if not st.get('side_on', False) or C.Layer.profiler is not None:
       return contextlib.nullcontext()
     side = st['side_stream']
     side.wait_stream(torch.cuda.current_stream())       # everything enqueued so far (dy is ready)

@@ -12,6 +12,10 @@ on the GPU first (advoc/loader.py:116-128 + models/advoc/train_evaluate.py:55-56
 synthetic waveforms (uniform noise + 3 sinusoids, seeded) already resident in HBM; weights are
 N(0, 0.02) random init; dropout masks come from the on-device Philox stream.
 
+Every 4th timed step carries the per-launch HIP-event instrumentation behind `roofline` and therefore runs
+on one stream; the other steps run the weight-gradient kernels on a side stream as the trainer does by
+default (advoc_amd.model._wgrad_ctx), about 3 % faster.  --no-launch-timing times uninstrumented steps only.
+
 value = (global batch x 256 frames x steps) / wall time: the conservative accounting (the step
 consumes TWO batches; only one is counted).  N > 1: batch sharded 32 per GPU (weak scaling), RCCL
 all-reduce of the D and G gradient arenas.

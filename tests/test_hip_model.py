@@ -285,6 +285,42 @@ def test_short_training_run_reduces_l1(hip):
 
 
 @gpu
+def test_side_stream_weight_gradients_equal_serial_execution(hip, monkeypatch):
+  """Weight / bias gradients run on a side stream by default (model._wgrad_ctx); ADVOC_WGRAD_STREAM=0 keeps
+  the step on one stream.  Same gradients (up to the order of the weight-gradient atomics), same losses
+  after a few steps -- a missing stream dependency would show as stale or torn gradients."""
+  from advoc_amd.model import AdvocSmall, Modes
+  dev = torch.device('cuda')
+  x, target = batch(16, 128, 9)
+  x, target = x.to(dev), target.to(dev)
+
+  def run(side):
+    monkeypatch.setenv('ADVOC_WGRAD_STREAM', '1' if side else '0')
+    m = AdvocSmall(Modes.TRAIN)
+    m.subseq_len = 128
+    m.train_batch_size = 16
+    m.build(batch_size=16, seed=4)
+    assert m._built['side_on'] == side
+    m((x, target))
+    m.train_loop()
+    torch.cuda.synchronize()
+    st = m._built
+    grads = {k: v.detach().clone() for name in ('d_G', 'g_G') for k, v in st[name].items()}
+    for _ in range(5):
+      m.train_loop()
+    return grads, m.losses()
+
+  for trial in range(2):
+    g1, l1 = run(True)
+    g0, l0 = run(False)
+    for k in g0:
+      if k.startswith('discriminator'):          # taken at identical weights
+        assert rel(g1[k], g0[k]) < 1e-5, (trial, k, rel(g1[k], g0[k]))
+    for key in ('gen_loss_L1', 'disc_loss', 'gen_loss_GAN'):
+      assert abs(l1[key] - l0[key]) <= 0.02 * abs(l0[key]) + 1e-3, (trial, key, l1[key], l0[key])
+
+
+@gpu
 def test_training_on_split_bf16_path_tracks_fp32_path(hip, monkeypatch):
   """At the benchmark geometry (32 clips x 256 frames) most contractions run on the split-bf16 matrix path
   (igemm.hip / wgrad.hip); with ADVOC_IGEMM_X6=0 ADVOC_WGRAD_X6=0 the same model runs on the fp32 MFMA
