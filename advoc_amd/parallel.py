@@ -38,7 +38,9 @@ class DataParallel(object):
     backend = backend or os.environ.get('ADVOC_DP_BACKEND')
     if 'ADVOC_DP_DEVICE' in os.environ:
       self.local_rank = int(os.environ['ADVOC_DP_DEVICE'])
-    if self.world_size > 1:
+    # ADVOC_DP_FORCE=1: take the N-rank code path even with ONE rank (RCCL all-reduce over a single rank is
+    # the identity): exercises the real RCCL calls, streams and bucket logic on a 1-GPU box
+    if self.world_size > 1 or os.environ.get('ADVOC_DP_FORCE') == '1':
       os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
       if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
