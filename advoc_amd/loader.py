@@ -6,8 +6,8 @@ What is different by construction
   * the reference builds a tf.data graph and returns two lazy tensors bound to a one-shot
     iterator; this returns a ``BatchPipeline`` whose ``next()`` yields the same
     ``(features, audio)`` pair (also iterable, and unpackable into two per-field views so
-    ``x_feats, x_audio = decode_extract_and_batch(...)`` keeps working: each view's ``next()`` pulls
-    a fresh batch like a ``sess.run`` on the reference tensor);
+    ``x_feats, x_audio = decode_extract_and_batch(...)`` keeps working: the k-th ``next()`` of either
+    view returns its field of the SAME k-th batch, as one ``sess.run`` on both reference tensors does);
   * host threads only decode WAVs and plan slices (integer arithmetic); the STFT / mel features
     of each file are computed on the GPU by the HIP kernels (advoc_amd.spectral) and sliced,
     shuffled and batched as device tensors -- features never cross PCIe.
@@ -82,13 +82,19 @@ def _frames(x, start, count, length, hop):
 
 
 class _FieldView(object):
-  """One field of the pipeline's output; `next()` pulls a fresh batch (like sess.run)."""
+  """One field of the pipeline's output.  The reference returns both tensors from ONE iterator
+  `get_next` (loader.py:209-216), so a `sess.run([x_feats, x_audio])` fetches a PAIRED batch: the two
+  views therefore share batches -- the k-th `next()` of either view returns its field of the k-th batch
+  (a view that runs ahead pulls the new batch, the other one then reads the same batch)."""
 
   def __init__(self, pipe, index):
     self._pipe, self._index = pipe, index
+    self._served = 0
 
   def next(self):
-    return self._pipe.next()[self._index]
+    batch = self._pipe._view_batch(self._served)
+    self._served += 1
+    return batch[self._index]
 
   __next__ = next
 
@@ -121,7 +127,12 @@ class BatchPipeline(object):
     self.nsamps_per_tstep = float(audio_fs) / float(feature_fs)
     self.slice_hop, self.audio_slice_len, self.audio_slice_hop = slice_geometry(
         self.slice_len, audio_fs, feature_fs, slice_overlap_ratio)
+    # two independent streams: the producer thread draws the per-epoch file order, the consumer thread the
+    # slice offsets and shuffle-buffer slots -- one shared generator would interleave non-deterministically
     self.rng = np.random.RandomState(seed)
+    self._order_rng = np.random.RandomState(None if seed is None else (int(seed) * 2654435761 + 97) % (2 ** 32))
+    self._view_cache = collections.deque()     # (index, batch) pairs not yet read by both field views
+    self._view_next = 0
     self._examples = self._example_stream()
     self._buffer = []
     self._exhausted = False
@@ -140,7 +151,7 @@ class BatchPipeline(object):
     while True:
       order = list(range(len(self.fps)))
       if self.shuffle:
-        self.rng.shuffle(order)
+        self._order_rng.shuffle(order)
       for i in order:
         yield self.fps[i]
       if not self.repeat:
@@ -164,7 +175,14 @@ class BatchPipeline(object):
         while pending:
           self._put(pending.popleft())
     finally:
-      self._decoded.put(None)
+      # end-of-stream marker; after close() nobody reads the queue any more: never block on it
+      while True:
+        try:
+          self._decoded.put(None, timeout=0.1)
+          break
+        except queue.Full:
+          if self._stop.is_set():
+            break
 
   def _put(self, fut):
     try:
@@ -237,6 +255,24 @@ class BatchPipeline(object):
     return torch.stack(feats), torch.stack(audio)
 
   __next__ = next
+
+  def _view_batch(self, k):
+    """k-th batch as seen by the field views (pulled on first request, dropped once both have read it)."""
+    while self._view_next <= k:
+      self._view_cache.append([self._view_next, self.next(), 0])
+      self._view_next += 1
+    for entry in self._view_cache:
+      if entry[0] == k:
+        entry[2] += 1
+        batch = entry[1]
+        break
+    else:
+      raise RuntimeError('batch %d was already read by both field views' % k)
+    while self._view_cache and self._view_cache[0][2] >= 2:
+      self._view_cache.popleft()
+    while len(self._view_cache) > 4:           # a caller that only ever reads one field: keep memory bounded
+      self._view_cache.popleft()
+    return batch
 
   def __iter__(self):
     # unpacking `feats, audio = pipeline` yields the two field views

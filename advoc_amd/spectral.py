@@ -362,7 +362,15 @@ def waveform_to_melspec(
                              norm_ref_level_db=norm_ref_level_db)
   y = y[0].cpu().numpy().astype(np.float64)
   if not norm_allow_clipping:
-    assert y.max() < 1 and y.min() > 0
+    # the reference asserts on the dB values BEFORE the clip, bounds inclusive (spectral.py:150-151): recompute
+    # them from the linear mel spectrogram (device STFT + projection, dB on the host)
+    xd = _to_device_f32(x[np.newaxis])
+    T = _frames_pad_end(nsamps, nhop)
+    mag = _run_stft(_clips_first(xd), nfft, nhop, T, complex_out=False)
+    mel = matmul_last(mag, _device_melbank(fs, nfft, mel_min, mel_max, mel_num_bins)).cpu().numpy().astype(np.float64)
+    min_level = np.exp(norm_min_level_db / 20 * np.log(10))
+    db = 20 * np.log10(np.maximum(min_level, mel)) - norm_ref_level_db
+    assert db.max() <= 0 and db.min() - norm_min_level_db >= 0
   return y
 
 

@@ -56,7 +56,25 @@ def latest_checkpoint(train_dir):
   return None
 
 
-def save_checkpoint(train_dir, model, generator_only=False, name=None):
+def _prune(train_dir, pattern, keep):
+  """Keeps the newest `keep` files matching `pattern` (step number = the integer before the extension), like
+  tf.train.Saver(max_to_keep=...) does for the reference (default 5; its eval saver keeps 1,
+  train_evaluate.py:150)."""
+  import glob
+  import re
+
+  def step_of(fp):
+    m = re.search(r'-(\d+)\.pt$', fp)
+    return int(m.group(1)) if m else -1
+  fps = sorted(glob.glob(os.path.join(train_dir, pattern)), key=step_of)
+  for fp in fps[:-keep] if keep > 0 else []:
+    try:
+      os.remove(fp)
+    except OSError:
+      pass
+
+
+def save_checkpoint(train_dir, model, generator_only=False, name=None, max_to_keep=5):
   state = {'model': {k: v.cpu() for k, v in model.state_dict().items()}, 'step': model.step}
   if generator_only:
     state['model'] = {k: v for k, v in state['model'].items()
@@ -72,6 +90,9 @@ def save_checkpoint(train_dir, model, generator_only=False, name=None):
   with open(os.path.join(train_dir, 'checkpoint.tmp'), 'w') as f:
     f.write(name)
   os.replace(os.path.join(train_dir, 'checkpoint.tmp'), os.path.join(train_dir, 'checkpoint'))
+  stem = name[:name.rfind('-') + 1] if '-' in name else None
+  if stem and max_to_keep:
+    _prune(train_dir, stem + '*.pt', max_to_keep)
   return os.path.join(train_dir, name)
 
 
@@ -98,7 +119,9 @@ def restore_checkpoint(fp, model, with_optimizer=True):
   return model.step
 
 
-def _loader(fps, args, model, batch_size, training):
+def _loader(fps, args, model, batch_size, training, first_only=None):
+  """train: train_evaluate.py:35-54; eval: :95-114 (slice_first_only from the datacfg); infer: :212-230
+  (no slice_first_only argument there: the loader default False applies)."""
   from advoc_amd.loader import decode_extract_and_batch
   return decode_extract_and_batch(
       fps,
@@ -114,7 +137,7 @@ def _loader(fps, args, model, batch_size, training):
       repeat=training,
       shuffle=training,
       shuffle_buffer_size=512 if training else None,
-      slice_first_only=args.data_slice_first_only,
+      slice_first_only=args.data_slice_first_only if first_only is None else first_only,
       slice_randomize_offset=args.data_slice_randomize_offset if training else False,
       slice_overlap_ratio=args.data_slice_overlap_ratio if training else 0.,
       slice_pad_end=args.data_slice_pad_end if training else True,
@@ -214,7 +237,8 @@ def eval(fps, args, poll=True):   # noqa: A001  (name kept from the reference)
         # the reference never updates its best value (train_evaluate.py:153,184-186), so it saves
         # every evaluated checkpoint; here "best" means best.
         best = l1
-        save_checkpoint(eval_dir, model, generator_only=True, name='best_gen_loss_l1-%d.pt' % model.step)
+        save_checkpoint(eval_dir, model, generator_only=True, name='best_gen_loss_l1-%d.pt' % model.step,
+                        max_to_keep=1)
         print('Saved best gen loss l1!')
       print('Done!')
     if not poll:
@@ -242,7 +266,7 @@ def infer(fps, args):
   print('Infereing From {}'.format(ckpt_fp))
   restore_checkpoint(ckpt_fp, model, with_optimizer=False)
   spectral = SpectralUtil(n_mels=model.n_mels, fs=model.audio_fs)
-  pipe = _loader(fps, args, model, args.infer_batch_size, False)
+  pipe = _loader(fps, args, model, args.infer_batch_size, False, first_only=False)
   from advoc_amd import spectral as S
   from advoc_amd.audioio import save_as_wav
   for i, (x_magspec, x_wav) in enumerate(pipe.batches()):

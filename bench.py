@@ -4,43 +4,46 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config.workload): BASELINE.json configs[1] -- AdVoc-small, LJSpeech geometry
-(22.05 kHz, nfft 1024 / hop 256, 256-frame clips), batch 32 per GPU.  One "step" = one reference
-train_loop (models/advoc/advoc_model.py:285-289): a discriminator update on one batch and a
-generator update on the NEXT batch, each batch going waveform -> |STFT| -> mel -> pseudo-inverse
-on the GPU first (advoc/loader.py:116-128 + models/advoc/train_evaluate.py:55-56).  Inputs are
-synthetic waveforms (uniform noise + 3 sinusoids, seeded) already resident in HBM; weights are
-N(0, 0.02) random init; dropout masks come from the on-device Philox stream.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under
+torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1).
 
-Every 4th timed step carries the per-launch HIP-event instrumentation behind `roofline` and therefore runs
-on one stream; the other steps run the weight-gradient kernels on a side stream as the trainer does by
-default (advoc_amd.model._wgrad_ctx), about 3 % faster.  --no-launch-timing times uninstrumented steps only.
+Workload (config.workload): BASELINE.json configs[2] -- AdVoc (full: ngf = ndf = 64, 8 encoders), LJSpeech
+geometry (22.05 kHz, nfft 1024 / hop 256, 256-frame clips), batch 64 per GPU, the HIP STFT / mel / pinv
+extractor in the loop; N > 1 is configs[3] (64 clips per GPU, RCCL all-reduce of the D and G gradient arenas,
+weak scaling).  One "step" = one reference train_loop (models/advoc/advoc_model.py:285-289): a discriminator
+update on one batch and a generator update on the NEXT batch, each batch going waveform -> |STFT| -> mel ->
+pseudo-inverse on the GPU first (advoc/loader.py:116-128 + models/advoc/train_evaluate.py:55-56).  Inputs are
+synthetic waveforms (uniform noise + 3 sinusoids, seeded) already resident in HBM; weights are N(0, 0.02)
+random init; dropout masks come from the on-device Philox stream.
 
-value = (global batch x 256 frames x steps) / wall time: the conservative accounting (the step
-consumes TWO batches; only one is counted).  N > 1: batch sharded 32 per GPU (weak scaling), RCCL
-all-reduce of the D and G gradient arenas.
+value = (global batch x 256 frames x steps) / wall time of K uniform, uninstrumented steps: the conservative
+accounting (the step consumes TWO batches; only one is counted).
 
 Extra objects on the JSON line:
-  roofline      the kernel instance with the largest total time in the timed region, timed per
-                launch with HIP events on the launch stream (every 4th step of the timed region
-                is instrumented): algorithmic flops / measured time against the roof of the
-                pipe the kernel runs on: dense fp32 MFMA (157.3 TFLOP/s), or, for the split-bf16
-                kernels, dense bf16 MFMA / 6 partial products (416.7 TFLOP/s algorithmic).
-                `traffic` = L2-miss bytes per launch of that kernel from the committed rocprofv3
-                counter passes of this same command (profiles/r01_traffic.json; FETCH_SIZE
-                doubled per the gfx950 correction + WRITE_SIZE), null when not recorded.
-  extractor     the HBM-bound leg: waveform -> |STFT| (stft1024_kernel) timed per launch with HIP
-                events; algorithmic bytes = 790 528 per clip against 8 TB/s.
+  roofline      the conv-stack kernel instance with the largest total time, timed per launch with HIP events on
+                the launch stream over --prof-steps extra steps that follow the timed region in the same process
+                (per-launch events serialise the weight-gradient side stream, so they are kept out of `value`):
+                algorithmic flops / measured time against the roof of the pipe the kernel runs on: dense fp32
+                MFMA (157.3 TFLOP/s), or, for the split-bf16 kernels, dense bf16 MFMA / 6 partial products
+                (416.7 TFLOP/s algorithmic).  `traffic` = L2-miss bytes per launch of that kernel from the
+                committed rocprofv3 counter passes of this same command (profiles/r02_traffic.json; FETCH_SIZE
+                doubled per the gfx950 correction + WRITE_SIZE), null when not recorded for this workload.
+                `kernels` lists every instance with its share, so the HBM-bound ones can be read too.
+  extractor     the HBM-bound leg: waveform -> |STFT| -> mel -> pseudo-inverse, timed per launch with HIP
+                events; algorithmic bytes per clip from SURVEY.md §8d against 8 TB/s.
   inference     vocoded clips/s: mel -> pseudo-inverse -> generator forward on 256-frame chunks
-                (scripts/spectrogram_advoc.py:80-94 semantics, batched; phase estimation not
-                included), plus `joint_sc09`: z -> MelspecGAN -> AdVoc -> Griffin-Lim waveform
-                (BASELINE configs[4] on one GPU).  Measured after the timed region; not part of `value`.
-  cpu_baseline  the torch-CPU restatement of the reference graph (oracle/, "port") timed on this
-                box's host cores on a bounded sample (rank 0, N = 1 only).
+                (scripts/spectrogram_advoc.py:80-94 semantics, batched), plus phase reconstruction legs and
+                `joint_sc09`: z -> MelspecGAN -> AdVoc -> waveform (BASELINE configs[4] on one GPU).
+  small         BASELINE configs[1] (AdVoc-small, 32 clips) train step, a short secondary run.
+  loader        WAV directory -> decode_extract_and_batch -> batches: mel-frames/s of the real input pipeline.
+  cpu_baseline  the torch-CPU restatement of the reference graph (oracle/, "port") timed on this box's host
+                cores on a bounded sample (rank 0, N = 1 only): all cores, and 8 threads.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -49,14 +52,15 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-# Kernels of the split-bf16 path (template flag `true>` at the end of the instance name) run every fp32
-# product as SIX bf16 MFMA products (x = x0 + x1 + x2 exactly; the three smallest of the nine partial
-# products are dropped): their roof in ALGORITHMIC fp32 flops is the dense bf16 peak / 6.
+# Kernels of the split-bf16 path run every fp32 product as SIX bf16 MFMA products (x = x0 + x1 + x2 exactly; the
+# three smallest of the nine partial products are dropped): their roof in ALGORITHMIC fp32 flops is the dense
+# bf16 peak / 6.
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # ibid., "BF16/F16 ~2.5 PF dense"
 X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 HBM_PEAK_GBS = 8000.0           # ibid., HBM3E peak BW
 CLIP_FRAMES = 256
 CLIP_SAMPLES = (CLIP_FRAMES - 1) * 256 + 1024   # 66304
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
 
 
 def synth_waveforms(batch, seed, device):
@@ -72,14 +76,22 @@ def synth_waveforms(batch, seed, device):
   return x.reshape(batch, CLIP_SAMPLES, 1, 1).to(device)
 
 
-def cpu_baseline(model_small=True, budget_s=20.0):
+def is_split_bf16(name):
+  """Kernel instances of the split-bf16 matrix path (priced against 2500 / 6 TFLOP/s)."""
+  return ('x6' in name.split('<')[0]) or (
+      name.endswith(', true>') and (name.startswith('gather_gemm_kernel<') or name.startswith('wgrad_mfma_kernel<')))
+
+
+def cpu_baseline(model_small, threads, batch, budget_s, warm=True):
   """Reference-equivalent CPU restatement (oracle/advoc_torch.py + oracle/spectral_np.py),
-  one train_loop = D update + G update, batch 8 (reference default, advoc_model.py:18)."""
+  one train_loop = D update + G update at the reference default batch 8 (advoc_model.py:18) or smaller."""
   import numpy as np
   import torch
   from oracle import advoc_torch as A
   from oracle import spectral_np as S
-  B = 8
+  if threads:
+    torch.set_num_threads(threads)
+  B = batch
   cfg = A.Config(small=model_small)
   tr = A.Trainer(cfg, seed=0)
   W = S.create_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80).astype(np.float32)
@@ -93,7 +105,8 @@ def cpu_baseline(model_small=True, budget_s=20.0):
     inv = S.mel_linear_to_mag_spec(mel, Wi)
     return torch.from_numpy(inv), torch.from_numpy(mag)
   masks = A.make_dropout_masks(cfg, B, seed=1)
-  tr.train_loop(make_batch(), make_batch(), masks, masks)      # warm-up (thread pools, allocator)
+  if warm:
+    tr.train_loop(make_batch(), make_batch(), masks, masks)      # warm-up (thread pools, allocator)
   n, t_total = 0, 0.0
   while n == 0 or t_total < budget_s:
     t0 = time.perf_counter()
@@ -101,82 +114,122 @@ def cpu_baseline(model_small=True, budget_s=20.0):
     t_total += time.perf_counter() - t0
     n += 1
   return dict(value=B * CLIP_FRAMES * n / t_total, unit='mel-frames/s', cores=torch.get_num_threads(),
-              kind='port',
-              sample='%d train_loop iterations (1 D + 1 G update each) of AdVoc-small at batch %d, '
-                     'STFT/mel in numpy, convs in torch-CPU fp32' % (n, B))
+              kind='port', seconds=t_total,
+              sample='%d train_loop iterations (1 D + 1 G update each) of AdVoc-%s at batch %d, '
+                     'STFT/mel in numpy, convs in torch-CPU fp32' % (n, 'small' if model_small else 'full', B))
 
 
-def extractor_leg(torch, spectral, wav, launches=30):
-  """waveform -> |STFT| alone through the C ABI with a preallocated output: GB/s of algorithmic
-  traffic (waveform read once + |X| written once).  Measured at the training batch
-  (one launch = 32 x 256 frames: too small to fill 256 CUs) and at 512 clips per launch (what the
-  loader's whole-file extraction looks like)."""
+def event_timed(torch, call, launches, warm=3):
+  for _ in range(warm):
+    call()
+  evs = []
+  for _ in range(launches):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call()
+    e1.record()
+    evs.append((e0, e1))
+  torch.cuda.synchronize()
+  return sum(a.elapsed_time(b) for a, b in evs) / launches
+
+
+def extractor_leg(torch, spectral, su, wav, launches=30):
+  """The feature extractor through the C ABI with preallocated outputs, GB/s of algorithmic traffic
+  (SURVEY.md §8d).  `stft`: waveform -> |STFT| alone (790 528 B per clip); `triple`: waveform -> (|X|, mel,
+  pseudo-inverse) = what a training batch needs (1 397 760 B per clip), fused when the library has the fused
+  entry point.  Measured at 512 clips per launch (whole-file extraction in the loader) and at the training
+  step's feed (one launch for the two batches of a train_loop)."""
   from advoc_amd import _lib
   lib = _lib.load()
   win = spectral._device_window(1024, 256)
   tw = spectral._device_twiddle(1024)
 
-  def run(clips):
-    x = wav[:, :, 0, 0].repeat((clips + wav.shape[0] - 1) // wav.shape[0], 1)[:clips].contiguous()
+  def clips_of(n):
+    return wav[:, :, 0, 0].repeat((n + wav.shape[0] - 1) // wav.shape[0], 1)[:n].contiguous()
+
+  def run_stft(clips):
+    x = clips_of(clips)
     out = torch.empty(clips, CLIP_FRAMES, 513, dtype=torch.float32, device=x.device)
     call = lambda: _lib.check(lib.advoc_stft_mag_f32(_lib.ptr(x), clips, x.shape[1], _lib.ptr(win), _lib.ptr(tw),   # noqa: E731
                                                      1024, 256, CLIP_FRAMES, _lib.ptr(out), _lib.stream()), 'stft')
-    for _ in range(3):
-      call()
-    evs = []
-    for _ in range(launches):
-      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-      e0.record()
-      call()
-      e1.record()
-      evs.append((e0, e1))
-    torch.cuda.synchronize()
-    ms = sum(a.elapsed_time(b) for a, b in evs) / launches
-    nbytes = clips * (CLIP_SAMPLES * 4 + CLIP_FRAMES * 513 * 4)
-    return ms, nbytes
-  ms_b, bytes_b = run(wav.shape[0])
-  ms_l, bytes_l = run(512)
+    return event_timed(torch, call, launches), clips * (CLIP_SAMPLES * 4 + CLIP_FRAMES * 513 * 4)
+
+  def run_triple(clips):
+    x = clips_of(clips).reshape(clips, CLIP_SAMPLES, 1, 1)
+    call = lambda: su.extract_training_triple(x)   # noqa: E731
+    return event_timed(torch, call, launches), clips * (CLIP_SAMPLES * 4 + CLIP_FRAMES * (80 + 2 * 513) * 4)
+
+  nb = 2 * wav.shape[0]
+  ms_l, bytes_l = run_stft(512)
+  ms_b, bytes_b = run_stft(nb)
   gbs = bytes_l / (ms_l * 1e-3) / 1e9
-  return dict(kernel='stft1024_kernel<false>', bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
-              frac=gbs / HBM_PEAK_GBS, clips_per_launch=512, bytes_per_launch=bytes_l, avg_launch_ms=ms_l,
-              frames_per_s=512 * CLIP_FRAMES / (ms_l * 1e-3),
-              at_train_batch=dict(clips_per_launch=int(wav.shape[0]), avg_launch_ms=ms_b,
-                                  achieved=bytes_b / (ms_b * 1e-3) / 1e9,
-                                  frames_per_s=wav.shape[0] * CLIP_FRAMES / (ms_b * 1e-3)))
+  out = dict(kernel='stft1024_kernel', bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
+             frac=gbs / HBM_PEAK_GBS, clips_per_launch=512, bytes_per_launch=bytes_l, avg_launch_ms=ms_l,
+             frames_per_s=512 * CLIP_FRAMES / (ms_l * 1e-3),
+             at_train_feed=dict(clips_per_launch=nb, avg_launch_ms=ms_b, achieved=bytes_b / (ms_b * 1e-3) / 1e9,
+                                frac=bytes_b / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                frames_per_s=nb * CLIP_FRAMES / (ms_b * 1e-3)))
+  if hasattr(su, 'extract_training_triple'):
+    ms_t, bytes_t = run_triple(512)
+    ms_tb, bytes_tb = run_triple(nb)
+    out['triple'] = dict(what='waveform -> |X|, mel, pinv(mel) (1 397 760 B per clip)', clips_per_launch=512,
+                         avg_ms=ms_t, achieved=bytes_t / (ms_t * 1e-3) / 1e9,
+                         frac=bytes_t / (ms_t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         at_train_feed=dict(clips_per_launch=nb, avg_ms=ms_tb,
+                                            achieved=bytes_tb / (ms_tb * 1e-3) / 1e9,
+                                            frac=bytes_tb / (ms_tb * 1e-3) / 1e9 / HBM_PEAK_GBS))
+  return out
 
 
-def inference_leg(torch, model_cls, Modes, su, mel, iters=10):
+def inference_leg(torch, model_cls, Modes, su, mel, iters=50, warm=5):
   """clips/s of mel -> magnitude through the generator (INFER mode, dropout active as in the
-  reference), batch = the training batch."""
+  reference), batch = the training batch.  Wall clock over `iters` batches after `warm` warm-ups, with
+  the HIP-event time of the same region beside it."""
+  from advoc_amd import spectral
   m = model_cls(Modes.INFER)
   B = mel.shape[0]
   m.build(batch_size=B, seed=0)
-  for _ in range(2):
+  for _ in range(warm):
     m.build_generator(su.mel_linear_to_mag_spec(mel))
   torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   t0 = time.perf_counter()
+  e0.record()
   for _ in range(iters):
     m.build_generator(su.mel_linear_to_mag_spec(mel))
+  e1.record()
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
-  # waveform synthesis on top: Griffin-Lim, 60 iterations (advoc/spectral.py:294-311), all clips at once
-  from advoc_amd import spectral
+  dt_ev = e0.elapsed_time(e1) * 1e-3
+  out = dict(value=B * iters / dt, unit='vocoded 256-frame clips/s', batch=B, iters=iters, warmup=warm,
+             ms_per_batch=dt / iters * 1e3, ms_per_batch_hip_events=dt_ev / iters * 1e3,
+             note='value: mel -> pinv projection -> generator forward (magnitudes), wall clock')
+  # waveform synthesis on top, all clips of the batch at once
   mag = m.build_generator(su.mel_linear_to_mag_spec(mel))[..., 0].abs().contiguous()
   u = torch.rand(mag.shape, device=mag.device)
   spectral.griffin_lim_batch(mag, 1024, 256, 2, u)
   torch.cuda.synchronize()
   t0 = time.perf_counter()
-  spectral.griffin_lim_batch(mag, 1024, 256, 60, u)
+  for _ in range(3):
+    spectral.griffin_lim_batch(mag, 1024, 256, 60, u)
   torch.cuda.synchronize()
-  dt_gl = time.perf_counter() - t0
-  return dict(value=B * iters / dt, unit='vocoded 256-frame clips/s', batch=B, ms_per_batch=dt / iters * 1e3,
-              with_gl60_clips_per_s=B / (dt / iters + dt_gl), gl60_ms_per_batch=dt_gl * 1e3,
-              note='value: mel -> pinv projection -> generator forward (magnitudes); with_gl60: plus 60 '
-                   'Griffin-Lim iterations (iSTFT/STFT/projection kernels) to a waveform.  The reference '
-                   'uses LWS for phase (third-party, not restated).')
+  dt_gl = (time.perf_counter() - t0) / 3
+  out.update(with_gl60_clips_per_s=B / (dt / iters + dt_gl), gl60_ms_per_batch=dt_gl * 1e3)
+  if hasattr(spectral, 'lws_batch'):
+    spectral.lws_batch(mag, 1024, 256)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+      spectral.lws_batch(mag, 1024, 256)
+    torch.cuda.synchronize()
+    dt_lws = (time.perf_counter() - t0) / 3
+    out.update(with_lws_clips_per_s=B / (dt / iters + dt_lws), lws_ms_per_batch=dt_lws * 1e3,
+               lws_note='LWS (the reference default phase_estimation): restated from the published algorithm, '
+                        'parity unpinned (lws 1.2 is third-party and absent)')
+  return out
 
 
-def joint_leg(torch, n=64, iters=3):
+def joint_leg(torch, n=64, iters=5):
   """BASELINE configs[4] on one GPU: z -> MelspecGAN generator -> mel [64 x 80] -> AdVoc (full model at
   subseq_len 64, its (1,2)-stride layers) -> Griffin-Lim (60 iterations) -> 16 kHz waveform; random
   weights (no checkpoints are reachable), synthetic z.  Samples per second, end to end on the GPU."""
@@ -193,7 +246,8 @@ def joint_leg(torch, n=64, iters=3):
   def run():
     mel = G(z, denorm=True)
     return vocode_batch(voc, mel, phase_estimation='gl60', chunk_batch=2 * n)[1]
-  run()
+  for _ in range(2):
+    run()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for _ in range(iters):
@@ -202,16 +256,62 @@ def joint_leg(torch, n=64, iters=3):
   dt = (time.perf_counter() - t0) / iters
   return dict(value=n / dt, unit='generated 64-frame clips/s (z -> 16 kHz waveform, Griffin-Lim 60)', batch=n,
               ms_per_batch=dt * 1e3, samples_per_clip=int(wav.shape[1]),
-              note='MelspecGAN G + AdVoc-full(subseq_len 64) + GL60, random weights; the reference uses LWS')
+              note='MelspecGAN G + AdVoc-full(subseq_len 64) + GL60, random weights')
+
+
+def loader_leg(torch, seconds=6.0, n_files=48, batch=64):
+  """The real input pipeline: a directory of synthetic PCM16 WAVs with LJSpeech-like lengths (1.1-10.1 s at
+  22.05 kHz) -> advoc_amd.loader.decode_extract_and_batch (decode threads, device STFT, slicing, shuffle buffer,
+  batching) -> [B,256,513,1] batches; mel-frames/s delivered, beside what one GPU's train step consumes."""
+  import shutil
+  import tempfile
+  import numpy as np
+  from advoc_amd import audioio, loader
+  d = tempfile.mkdtemp(prefix='advoc_bench_wav_')
+  try:
+    rng = np.random.default_rng(0)
+    fps = []
+    for i in range(n_files):
+      n = int(22050 * rng.uniform(1.1, 10.1))
+      x = (rng.uniform(-0.5, 0.5, size=(n, 1, 1)) * 0.5).astype(np.float32)
+      fp = os.path.join(d, '%04d.wav' % i)
+      audioio.save_as_wav(fp, 22050, x)
+      fps.append(fp)
+    out = {}
+    for workers in (4, 16):
+      pipe = loader.BatchPipeline(
+          fps, batch, 256, audio_fs=22050, audio_mono=True, audio_normalize=True, decode_fastwav=True,
+          decode_parallel_calls=workers, extract_type='magspec', extract_nfft=1024, extract_nhop=256,
+          repeat=True, shuffle=True, shuffle_buffer_size=512,
+          slice_first_only=False, slice_randomize_offset=True, slice_overlap_ratio=0.25, slice_pad_end=False,
+          prefetch_size=8, seed=0)
+      for _ in range(3):
+        pipe.next()
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      nb = 0
+      while time.perf_counter() - t0 < seconds / 2:
+        pipe.next()
+        nb += 1
+      torch.cuda.synchronize()
+      dt = time.perf_counter() - t0
+      pipe.close()
+      out['workers_%d' % workers] = dict(frames_per_s=nb * batch * CLIP_FRAMES / dt, batches=nb, seconds=dt)
+    best = max(v['frames_per_s'] for v in out.values())
+    return dict(value=best, unit='mel-frames/s delivered (WAV files -> [B,256,513,1] batches)', batch=batch,
+                files=n_files, detail=out,
+                note='synthetic PCM16 WAVs, LJSpeech-like lengths; decode on host threads, STFT / slicing / '
+                     'shuffle / batching on the device (advoc/loader.py:66-214 semantics)')
+  finally:
+    shutil.rmtree(d, ignore_errors=True)
 
 
 def recorded_traffic(kernel, model, batch):
   """L2-miss bytes per launch from the committed counter passes (tools/pmc_summary.py), if they
   were taken on this workload."""
-  fp = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-  if not os.path.exists(fp):
+  if not os.path.exists(TRAFFIC_JSON):
     return None
-  rec = json.load(open(fp))
+  rec = json.load(open(TRAFFIC_JSON))
   meta = rec.get('_workload', {})
   if meta.get('model') != model or meta.get('batch') != batch:
     return None
@@ -219,130 +319,186 @@ def recorded_traffic(kernel, model, batch):
   return row['traffic_bytes'] if row else None
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=20)
-  ap.add_argument('--warmup', type=int, default=3)
-  ap.add_argument('--model', choices=['small', 'regular'], default='small')
-  ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
-  ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--train-only', action='store_true',
-                  help='skip the extractor / inference legs that run after the timed region (profiling runs: '
-                       'keeps the per-kernel statistics to the train step)')
-  ap.add_argument('--no-launch-timing', action='store_true',
-                  help='skip per-launch HIP events (roofline object becomes null)')
-  args = ap.parse_args()
+def roofline_from(prof, model, batch, ms_per_step, prof_steps, verbose):
+  rows = prof.rows()
+  tot = sum(v['ms'] for v in rows.values())
+  kernels = []
+  for k, v in sorted(rows.items(), key=lambda kv: -kv[1]['ms']):
+    mfma = 'mfma' in k or 'gather_gemm' in k or 'x6' in k
+    entry = dict(kernel=k, launches_per_step=v['launches'] / prof_steps, share_of_conv_stack=v['ms'] / tot,
+                 avg_launch_ms=v['ms'] / v['launches'])
+    if mfma and v['flops'] > 0:
+      peak = X6_PEAK_TFLOPS if is_split_bf16(k) else FP32_MFMA_PEAK_TFLOPS
+      entry.update(bound='mfma', achieved=v['flops'] / (v['ms'] * 1e-3) / 1e12, peak=round(peak, 1), unit='TFLOP/s')
+    else:
+      entry.update(bound='hbm', achieved=v['bytes'] / (v['ms'] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s')
+    entry['frac'] = entry['achieved'] / entry['peak']
+    kernels.append(entry)
+  name, r = max(rows.items(), key=lambda kv: kv[1]['ms'])
+  top = kernels[0]
+  roofline = dict(bound=top['bound'], kernel=name, achieved=top['achieved'], peak=top['peak'], unit=top['unit'],
+                  frac=top['frac'], traffic=recorded_traffic(name, model, batch),
+                  algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
+                  launches=r['launches'], avg_launch_ms=r['ms'] / r['launches'],
+                  share_of_step=r['ms'] / prof_steps / ms_per_step, instrumented_steps=prof_steps,
+                  measured='HIP events per launch on %d serial steps right after the timed region' % prof_steps,
+                  kernels=kernels[:24])
+  if top['bound'] == 'mfma':
+    x6 = is_split_bf16(name)
+    roofline.update(pipe=('bf16 MFMA, 6 partial products per fp32 product (2500 / 6 TFLOP/s algorithmic)' if x6
+                          else 'fp32 MFMA'),
+                    vs_fp32_mfma_peak=top['achieved'] / FP32_MFMA_PEAK_TFLOPS,
+                    flops_per_launch=r['flops'] / r['launches'])
+  if verbose:
+    for k, v in sorted(rows.items(), key=lambda kv: -kv[1]['ms']):
+      tf = v['flops'] / max(v['ms'], 1e-9) / 1e9
+      print('  %-52s launches %5d  %9.2f ms (%5.1f%%)  %7.2f TFLOP/s  %7.1f GB/s alg' % (
+          k, v['launches'], v['ms'], 100 * v['ms'] / tot, tf, v['bytes'] / max(v['ms'], 1e-9) / 1e6),
+          file=sys.stderr)
+    print('  conv-stack launches total %.2f ms in %d instrumented steps; %.2f ms per timed step' % (
+        tot, prof_steps, ms_per_step), file=sys.stderr)
+  return roofline
 
-  import torch
+
+def train_leg(torch, model_name, B, steps, warmup, dp, dev, prof_steps):
+  """Returns (elapsed seconds of `steps` uninstrumented train_loops [max over ranks], model, su, pool, profiler)."""
   from advoc_amd import conv, spectral
   from advoc_amd.model import Advoc, AdvocSmall, Modes
-  from advoc_amd.parallel import DataParallel
   from advoc_amd.spectral_util import SpectralUtil
-
-  dp = DataParallel().init_from_env()
-  if dp.world_size != args.gpus:
-    raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, dp.world_size))
-  dev = torch.device('cuda', dp.local_rank)
-  torch.cuda.set_device(dev)
-
-  B = args.batch
-  model = (AdvocSmall if args.model == 'small' else Advoc)(Modes.TRAIN)
+  model = (AdvocSmall if model_name == 'small' else Advoc)(Modes.TRAIN)
   model.train_batch_size = B
   model.build(batch_size=B, seed=0)
   dp.attach(model)
   dp.broadcast_parameters(model)
   su = SpectralUtil(n_mels=model.n_mels, fs=model.audio_fs)
-
   pool = [synth_waveforms(B, 1234 + 17 * dp.rank + i, dev) for i in range(4)]
   state = {'i': 0}
 
   def feed():
     wav = pool[state['i'] % len(pool)]
     state['i'] += 1
-    mag = spectral.stft_magnitude(wav, 1024, 256, pad_end=False)          # [B,256,513,1]
-    mel = su.mag_to_mel_linear_spec(mag)
-    inv = su.mel_linear_to_mag_spec(mel)
+    if hasattr(su, 'extract_training_triple'):
+      mag, mel, inv = su.extract_training_triple(wav)
+    else:
+      mag = spectral.stft_magnitude(wav, 1024, 256, pad_end=False)          # [B,256,513,1]
+      mel = su.mag_to_mel_linear_spec(mag)
+      inv = su.mel_linear_to_mag_spec(mel)
     return inv, mag, wav, mel
   model(feed)
 
-  for _ in range(args.warmup):
+  for _ in range(warmup):
     model.train_loop()
   torch.cuda.synchronize()
   dp.barrier()
   torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    model.train_loop()
+  torch.cuda.synchronize()
+  dp.barrier()
+  torch.cuda.synchronize()
+  elapsed = dp.max_over_ranks(time.perf_counter() - t0)
 
   prof = None
-  if not args.no_launch_timing:
+  if prof_steps > 0:
     prof = conv.LaunchProfiler()
-  # per-launch HIP events cost ~0.6 ms of host time per fully instrumented step (3 %): instrument
-  # every 4th step of the timed region; average launch durations do not depend on which steps
-  sampled = [i for i in range(args.steps) if i % 4 == 0] if prof is not None else []
-  t0 = time.perf_counter()
-  for i in range(args.steps):
-    conv.Layer.profiler = prof if (prof is not None and i % 4 == 0) else None
-    model.train_loop()
-  torch.cuda.synchronize()
-  dp.barrier()
-  torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t0
-  conv.Layer.profiler = None
-  elapsed = dp.max_over_ranks(elapsed)
+    conv.Layer.profiler = prof
+    for _ in range(prof_steps):
+      model.train_loop()
+    torch.cuda.synchronize()
+    conv.Layer.profiler = None
+  return elapsed, model, su, pool, prof
 
+
+def free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=40)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--model', choices=['small', 'regular'], default='regular')
+  ap.add_argument('--batch', type=int, default=0, help='clips per GPU (default 64 regular / 32 small)')
+  ap.add_argument('--prof-steps', type=int, default=4,
+                  help='instrumented (per-launch HIP events, serial) steps after the timed region; 0: no roofline')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--train-only', action='store_true',
+                  help='skip the extractor / inference / small / loader legs that run after the timed region '
+                       '(profiling runs: keeps the per-kernel statistics to the train step)')
+  ap.add_argument('--no-launch-timing', action='store_true', help='same as --prof-steps 0')
+  args = ap.parse_args()
+
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    # plain `python bench.py --gpus N`: become the launcher (one rank per GPU, RCCL over xGMI)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+  import torch
+  from advoc_amd import spectral
+  from advoc_amd.model import Advoc, AdvocSmall, Modes
+  from advoc_amd.parallel import DataParallel
+
+  dp = DataParallel().init_from_env()
+  if dp.world_size != args.gpus:
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, dp.world_size))
+  dev = torch.device('cuda', dp.local_rank)
+  torch.cuda.set_device(dev)
+
+  B = args.batch or (32 if args.model == 'small' else 64)
+  prof_steps = 0 if args.no_launch_timing else args.prof_steps
+  elapsed, model, su, pool, prof = train_leg(torch, args.model, B, args.steps, args.warmup, dp, dev, prof_steps)
   frames = B * dp.world_size * CLIP_FRAMES * args.steps
   value = frames / elapsed
+  ms_per_step = elapsed * 1e3 / args.steps
 
   roofline = None
-  if prof is not None:
-    rows = prof.rows()
-    name, r = max(rows.items(), key=lambda kv: kv[1]['ms'])
-    mfma = 'mfma' in name or 'gather_gemm' in name
-    if mfma:
-      achieved = r['flops'] / (r['ms'] * 1e-3) / 1e12
-      x6 = name.endswith(', true>') and (name.startswith('gather_gemm_kernel<') or name.startswith('wgrad_mfma_kernel<'))
-      peak = X6_PEAK_TFLOPS if x6 else FP32_MFMA_PEAK_TFLOPS
-      roofline = dict(bound='mfma', kernel=name, achieved=achieved, peak=round(peak, 1),
-                      unit='TFLOP/s', frac=achieved / peak,
-                      pipe=('bf16 MFMA, 6 partial products per fp32 product (2500 / 6 TFLOP/s algorithmic)' if x6
-                            else 'fp32 MFMA'),
-                      vs_fp32_mfma_peak=achieved / FP32_MFMA_PEAK_TFLOPS,
-                      traffic=recorded_traffic(name, args.model, B),
-                      algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
-                      launches=r['launches'], avg_launch_ms=r['ms'] / r['launches'],
-                      flops_per_launch=r['flops'] / r['launches'],
-                      share_of_step=r['ms'] / (elapsed * 1e3 * len(sampled) / args.steps),
-                      instrumented_steps=len(sampled))
-    else:
-      achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
-      roofline = dict(bound='hbm', kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                      frac=achieved / HBM_PEAK_GBS, traffic=recorded_traffic(name, args.model, B),
-                      launches=r['launches'],
-                      avg_launch_ms=r['ms'] / r['launches'],
-                      share_of_step=r['ms'] / (elapsed * 1e3 * len(sampled) / args.steps), instrumented_steps=len(sampled))
-    if dp.rank == 0 and os.environ.get('ADVOC_BENCH_VERBOSE'):
-      tot = sum(v['ms'] for v in rows.values())
-      for k, v in sorted(rows.items(), key=lambda kv: -kv[1]['ms']):
-        tf = v['flops'] / max(v['ms'], 1e-9) / 1e9
-        print('  %-44s launches %5d  %9.2f ms (%5.1f%%)  %7.2f TFLOP/s  %7.1f GB/s alg' % (
-            k, v['launches'], v['ms'], 100 * v['ms'] / tot, tf, v['bytes'] / max(v['ms'], 1e-9) / 1e6),
-            file=sys.stderr)
-      print('  conv-stack launches total %.2f ms in %d instrumented steps; %.2f ms wall for %d steps' % (
-          tot, len(sampled), elapsed * 1e3, args.steps), file=sys.stderr)
+  if prof is not None and dp.rank == 0:
+    roofline = roofline_from(prof, args.model, B, ms_per_step, prof_steps, bool(os.environ.get('ADVOC_BENCH_VERBOSE')))
+  losses = model.losses() if dp.rank == 0 else None
 
-  extractor = inference = None
+  extractor = inference = small = loader_res = None
   if dp.rank == 0 and not args.train_only:
-    extractor = extractor_leg(torch, spectral, pool[0])
+    extractor = extractor_leg(torch, spectral, su, pool[0])
     mel0 = su.mag_to_mel_linear_spec(spectral.stft_magnitude(pool[0], 1024, 256, pad_end=False))
     inference = inference_leg(torch, AdvocSmall if args.model == 'small' else Advoc, Modes, su, mel0)
     inference['joint_sc09'] = joint_leg(torch)
+    try:
+      loader_res = loader_leg(torch)
+    except Exception as e:   # the loader leg must never take the headline line down
+      loader_res = dict(error=repr(e))
   dp.barrier()
+  if not args.train_only and args.model == 'regular' and dp.world_size == 1:
+    # secondary: BASELINE configs[1] (AdVoc-small, 32 clips), short
+    del model
+    torch.cuda.empty_cache()
+    from advoc_amd.parallel import DataParallel as _DP
+    el_s, m_s, _, _, _ = train_leg(torch, 'small', 32, 20, 3, _DP(), dev, 0)
+    small = dict(workload='AdVoc-small train_loop, 32 clips x 256 frames (BASELINE configs[1])', steps=20,
+                 ms_per_step=el_s * 1e3 / 20, value=32 * CLIP_FRAMES * 20 / el_s, unit='mel-frames/s')
+    del m_s
 
   cpu = None
   if dp.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-    cpu = cpu_baseline(model_small=(args.model == 'small'))
+    is_small = args.model == 'small'
+    # all host cores, reference default batch 8; then 8 threads (the reference's extract_parallel_calls=8,
+    # train_evaluate.py:41) on a smaller sample so that the default run stays within minutes
+    cpu = cpu_baseline(is_small, 0, 8, 10.0 if is_small else 8.0)
+    ncores = os.cpu_count() or 8
+    if ncores > 8:
+      c8 = cpu_baseline(is_small, 8, 8 if is_small else 2, 4.0, warm=False)
+      cpu['threads_8'] = dict(value=c8['value'], unit=c8['unit'], cores=8, sample=c8['sample'], seconds=c8['seconds'])
+    cpu['host_cpus'] = ncores
 
   if dp.rank == 0:
-    losses = model.losses()
     out = {
         'metric': 'mel-frames/sec (AdVoc G+D train step)',
         'value': value,
@@ -350,7 +506,7 @@ def main():
         'n_gpus': args.gpus,
         'steps': args.steps,
         'warmup': args.warmup,
-        'ms_per_step': elapsed * 1e3 / args.steps,
+        'ms_per_step': ms_per_step,
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
@@ -362,17 +518,22 @@ def main():
         'config': {
             'workload': 'AdVoc-%s train_loop (1 D update + 1 G update on fresh batches), LJSpeech '
                         'geometry 22.05 kHz nfft 1024 hop 256, %d clips x 256 frames per GPU, HIP '
-                        'STFT/mel/pinv extractor in the loop' % (args.model, B),
+                        'STFT/mel/pinv extractor in the loop (BASELINE configs[%d])' % (
+                            'full' if args.model == 'regular' else 'small', B,
+                            (3 if dp.world_size > 1 else 2) if args.model == 'regular' else 1),
             'global_batch': B * dp.world_size,
             'frames_per_clip': CLIP_FRAMES,
             'parallelism': 'dp%d' % dp.world_size,
             'frames_counted_per_step': 'global_batch*256 (the step consumes 2 batches; 1 is counted)',
         },
         'per_gpu_value': value / dp.world_size,
+        'target_frames_per_s_per_gpu': 50000,
         'losses': losses,
         'roofline': roofline,
         'extractor': extractor,
         'inference': inference,
+        'small': small,
+        'loader': loader_res,
         'cpu_baseline': cpu,
     }
     print(json.dumps(out))

@@ -1,0 +1,10 @@
+"""Same module path as the reference (models/advoc/util.py, imported flat -- `from util import ...` -- by the
+scripts next to it); the implementation lives in advoc_amd/model.py."""
+import os
+import sys
+
+_ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+if _ROOT not in sys.path:
+  sys.path.insert(0, _ROOT)
+
+from advoc_amd.model import override_model_attrs  # noqa: E402,F401
