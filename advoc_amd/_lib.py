@@ -49,6 +49,7 @@ PROTOTYPES = {
     'advoc_error_string': (ctypes.c_char_p, [ctypes.c_int]),
     'advoc_target_arch': (ctypes.c_char_p, []),
     'advoc_last_hip_error': (ctypes.c_char_p, []),
+    'advoc_tuning_reload': (None, []),
     'advoc_stft_mag_f32': (ctypes.c_int, [_p, _i64, _i64, _p, _p, _i32, _i32, _i64, _p, _p]),
     'advoc_stft_c64': (ctypes.c_int, [_p, _i64, _i64, _p, _p, _i32, _i32, _i64, _p, _p]),
     'advoc_stft_twiddle_host': (ctypes.c_int, [_p, _i32]),
@@ -115,6 +116,11 @@ def load():
       raise AdvocHipError('ABI version mismatch: library reports {}'.format(lib.advoc_abi_version()))
     _lib = lib
   return _lib
+
+
+def reload_env():
+  """Makes the library re-read its ADVOC_* diagnostic switches from os.environ (it caches them on first use)."""
+  load().advoc_tuning_reload()
 
 
 def check(rc, what=''):

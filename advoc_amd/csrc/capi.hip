@@ -24,3 +24,66 @@ extern "C" const char* advoc_error_string(int code) {
     default: return "unknown advoc error code";
   }
 }
+
+// ---- diagnostic switches: environment read once, re-read on request (tuning.h) ----
+#include <stdlib.h>
+
+#include <atomic>
+#include <mutex>
+
+#include "tuning.h"
+
+namespace advoc {
+namespace {
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+Tuning read_env() {
+  Tuning t;
+  t.igemm_splitk = env_int("ADVOC_IGEMM_SPLITK", 1);
+  t.igemm_tail = env_int("ADVOC_IGEMM_TAIL", 1);
+  t.igemm_x6 = env_int("ADVOC_IGEMM_X6", 1);
+  const char* w = getenv("ADVOC_IGEMM_X6_WIDE");
+  t.igemm_x6_wide = w && *w ? atoll(w) : -1;
+  t.igemm_bk = env_int("ADVOC_IGEMM_BK", 0);
+  t.igemm_x6_n32 = env_int("ADVOC_IGEMM_X6_N32", 1);
+  t.igemm_x6_tile = env_int("ADVOC_IGEMM_X6_TILE", 0);
+  t.igemm_tile = env_int("ADVOC_IGEMM_TILE", 0);
+  t.igemm_korder = env_int("ADVOC_IGEMM_KORDER", -1);
+  t.wgrad_x6 = env_int("ADVOC_WGRAD_X6", 1);
+  t.x6d = env_int("ADVOC_X6D", 1);
+  t.x6d_tile = env_int("ADVOC_X6D_TILE", 0);
+  t.x6d_stages = env_int("ADVOC_X6D_STAGES", 0);
+  t.x6d_skip_prep = env_int("ADVOC_X6D_SKIP_PREP", 0);
+  t.x6d_min_tiles = env_int("ADVOC_X6D_MIN_TILES", 448);
+  return t;
+}
+// two slots + an index: a reload publishes a complete new table; readers never see a half-written one
+Tuning g_tuning[2];
+std::atomic<int> g_tuning_idx{-1};
+std::mutex g_tuning_mu;
+}  // namespace
+
+const Tuning& tuning() {
+  int i = g_tuning_idx.load(std::memory_order_acquire);
+  if (i < 0) {
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    i = g_tuning_idx.load(std::memory_order_acquire);
+    if (i < 0) {
+      g_tuning[0] = read_env();
+      g_tuning_idx.store(0, std::memory_order_release);
+      i = 0;
+    }
+  }
+  return g_tuning[i];
+}
+}  // namespace advoc
+
+extern "C" void advoc_tuning_reload(void) {
+  std::lock_guard<std::mutex> lk(advoc::g_tuning_mu);
+  const int cur = advoc::g_tuning_idx.load(std::memory_order_acquire);
+  const int nxt = cur == 0 ? 1 : 0;
+  advoc::g_tuning[nxt] = advoc::read_env();
+  advoc::g_tuning_idx.store(nxt, std::memory_order_release);
+}

@@ -235,8 +235,12 @@ int run_gather(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const c
     return ADVOC_ERR_UNSUPPORTED;
   if (two_stage_ok(p) && ws && ws_bytes >= two_stage_bytes(p) && (b_kn ? N == 1 : true))
     return run_two_stage(p, ws, stream, name_only);
-  if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0)
+  if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0) {
+    // big launches: operand images + LDS-DMA kernel when the caller's workspace holds the images
+    const int rc = launch_gather_gemm_x6d(p, b_kn, stream, name_only, ws, ws_bytes, nullptr);
+    if (rc != ADVOC_ERR_UNSUPPORTED) return rc;
     return launch_gather_gemm(p, b_kn, stream, name_only, ws, ws_bytes);
+  }
   if (N <= 2 && K % 4 == 0 && p.c0 % 4 == 0) return launch_gather_dot(p, b_kn, stream, name_only);
   if (K <= 2 && N % 32 == 0 && p.ntaps * K <= 32) {
     const int rc = launch_thin_k_gemm(p, b_kn, stream, name_only);
@@ -332,11 +336,12 @@ extern "C" int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* L, int32_t
   if (two_stage_ok(p) && !(b_kn && p.n_total != 1)) return two_stage_bytes(p);
   // gather-GEMM path: partial tiles of the tail split (igemm.hip, launch_cfg)
   const int K = p.c0 + p.c1, N = p.n_total;
-  int64_t want = 0;
-  if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0 &&
-      launch_gather_gemm(p, b_kn, nullptr, nullptr, nullptr, 0, &want) == ADVOC_OK)
-    return want;
-  return 0;
+  int64_t want = 0, want_img = 0;
+  if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0) {
+    if (launch_gather_gemm_x6d(p, b_kn, nullptr, nullptr, nullptr, 0, &want_img) != ADVOC_OK) want_img = 0;
+    if (launch_gather_gemm(p, b_kn, nullptr, nullptr, nullptr, 0, &want) != ADVOC_OK) want = 0;
+  }
+  return want_img > want ? want_img : want;
 }
 
 extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* dy, float* dx0,

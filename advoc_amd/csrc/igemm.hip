@@ -26,6 +26,8 @@
 
 #include "common.h"
 #include "igemm.h"
+#include "tuning.h"
+#include "x6.h"
 
 namespace advoc {
 namespace {
@@ -70,19 +72,6 @@ struct Cfg {
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// x = x0 + x1 + x2 exactly, each term a bf16 (8 significant bits, truncation): the high halves of
-// the three words.  x1 / x2 take the next 8 / the last <= 8 bits of the remainder.
-__device__ __forceinline__ void split3(float x, unsigned& h0, unsigned& h1, unsigned& h2) {
-  h0 = __float_as_uint(x) & 0xffff0000u;
-  const float r1 = x - __uint_as_float(h0);
-  h1 = __float_as_uint(r1) & 0xffff0000u;
-  h2 = __float_as_uint(r1 - __uint_as_float(h1));
-}
-// two bf16 (high halves of lo / hi) in one dword, lo in the low half
-__device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) {
-  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
-}
 
 // act(v) = max(v, slope * v): slope 1 -> identity, 0.2 -> leaky ReLU, 0 -> ReLU (branch-free)
 __device__ __forceinline__ float act_slope(int act) {
@@ -557,10 +546,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
 // ADVOC_IGEMM_SPLITK=0 keeps every launch on one K pass (bitwise run-to-run reproducible results;
 // split-K combines partial sums with atomics, whose order varies).  Read per launch so a test
 // can toggle it.
-bool split_k_allowed() {
-  const char* e = getenv("ADVOC_IGEMM_SPLITK");
-  return e ? atoi(e) != 0 : true;
-}
+bool split_k_allowed() { return tuning().igemm_splitk != 0; }
 
 struct LaunchCtx {
   hipStream_t stream;
@@ -571,10 +557,9 @@ struct LaunchCtx {
 };
 
 // ADVOC_IGEMM_TAIL=0 disables the tail split (A/B measurements).
-bool tail_split_allowed() {
-  const char* e = getenv("ADVOC_IGEMM_TAIL");
-  return e ? atoi(e) != 0 : true;
-}
+bool tail_split_allowed() { return tuning().igemm_tail != 0; }
+
+}  // namespace
 
 int device_cu_count() {
   static const int cus = [] {
@@ -606,7 +591,6 @@ int* tail_counter_slot() {
 // A launch of T equal workgroups on C compute units costs ceil(T / C) rounds when they are all
 // resident (measured: 1024 tiles 193 us, 1056 tiles 230 us on 256 CUs).  Plan: the last T mod C
 // tiles are cut into `split` K slices each so that the extra round is 1/split of a tile long.
-struct TailPlan { int main = 0, rem = 0, split = 0; };
 TailPlan plan_tail(int64_t tiles, int nkt) {
   TailPlan t;
   const int cus = device_cu_count();
@@ -621,48 +605,7 @@ TailPlan plan_tail(int64_t tiles, int nkt) {
   return t;
 }
 
-// Split-bf16 path: weights to three bf16 planes [plane][tap][n_total][K], contraction axis contiguous.
-// One workgroup = one 32 (k) x 32 (n) tile of one tap, through LDS so that both the fp32 reads (along n
-// for the [tap][k][n] layout, along k for [tap][n][k]) and the bf16 writes (along k) are contiguous.
-__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ wq,
-                                                            int taps, int n_total, int n_valid, int ktot, int b_kn) {
-  __shared__ float tile[32][33];
-  const int tk = (ktot + 31) / 32, tn = (n_total + 31) / 32;
-  const int64_t plane = (int64_t)taps * n_total * ktot;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
-  for (int b = blockIdx.x; b < taps * tk * tn; b += gridDim.x) {
-    const int t = b / (tk * tn), r = b - t * (tk * tn);
-    const int k0 = (r / tn) * 32, n0 = (r % tn) * 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = ty + 8 * i;
-      float x = 0.f;
-      if (b_kn) {            // tile[k][n]: lanes along n
-        const int k = k0 + row, n = n0 + tx;
-        if (k < ktot && n < n_valid) x = w[((int64_t)t * ktot + k) * n_total + n];
-        tile[row][tx] = x;
-      } else {               // tile[k][n] filled from rows of n: lanes along k
-        const int n = n0 + row, k = k0 + tx;
-        if (k < ktot && n < n_valid) x = w[((int64_t)t * n_valid + n) * ktot + k];
-        tile[tx][row] = x;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = n0 + ty + 8 * i, k = k0 + tx;
-      if (n < n_total && k < ktot) {
-        unsigned h0, h1, h2;
-        split3(tile[tx][ty + 8 * i], h0, h1, h2);
-        const int64_t o = ((int64_t)t * n_total + n) * ktot + k;
-        wq[o] = (uint16_t)(h0 >> 16);
-        wq[plane + o] = (uint16_t)(h1 >> 16);
-        wq[2 * plane + o] = (uint16_t)(h2 >> 16);
-      }
-    }
-    __syncthreads();
-  }
-}
+namespace {
 
 int weight_taps(const GatherGemmParams& p) {
   int t = 0;
@@ -674,18 +617,14 @@ int weight_taps(const GatherGemmParams& p) {
 // Large launches run on the bf16 matrix path with every operand split into three bf16 terms (fp32-level
 // error, see split3); needs caller workspace for the split weights.  ADVOC_IGEMM_X6=0 keeps everything
 // on the fp32 MFMA kernels (A/B measurements).
-bool x6_allowed() {
-  const char* e = getenv("ADVOC_IGEMM_X6");
-  return e ? atoi(e) != 0 : true;
-}
+bool x6_allowed() { return tuning().igemm_x6 != 0; }
 
 // 128 x 256 split tile (A is split once per 256 output columns; 256 registers, two workgroups per CU):
 // measured 6-20 % faster than 128 x 128 on deep contractions with >= ~500 such tiles (D layer_4, the
 // 512-channel generator layers of the full model), 10-150 % slower on shallow ones or small grids.
 // ADVOC_IGEMM_X6_WIDE=<tiles> overrides the tile threshold and drops the depth condition (experiments).
 bool x6_wide(int64_t tiles256, int k_total, int nphase) {
-  const char* e = getenv("ADVOC_IGEMM_X6_WIDE");
-  if (e) return tiles256 >= atoll(e);
+  if (tuning().igemm_x6_wide >= 0) return tiles256 >= tuning().igemm_x6_wide;
   // ... and on single-phase launches (forward / stride-1 layers) already from 2 048 deep with >= 900 tiles
   return (tiles256 >= 500 && k_total >= 4096) || (nphase == 1 && tiles256 >= 900 && k_total >= 2048);
 }
@@ -737,13 +676,9 @@ int launch_cfg(const GatherGemmParams& p, const LaunchCtx& ctx, bool b_kn_src = 
     if (!scratch || scratch_bytes < wq_bytes) return ADVOC_ERR_UNSUPPORTED;   // caller falls back to fp32 MFMA
     px.wq = reinterpret_cast<const uint16_t*>(scratch);
     px.wq_taps = taps;
-    int64_t blocks = (int64_t)taps * ((ktot + 31) / 32) * ((p.n_total + 31) / 32);
-    if (blocks > 4096) blocks = 4096;
-    ADVOC_CLEAR_LAUNCH_ERROR();
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p.w,
-                       reinterpret_cast<uint16_t*>(scratch), taps, p.n_total, p.n_valid ? p.n_valid : p.n_total,
-                       ktot, b_kn_src ? 1 : 0);
-    ADVOC_RETURN_IF_LAUNCH_FAILED();
+    const int rcw = launch_split_weights(p.w, reinterpret_cast<uint16_t*>(scratch), taps, p.n_total,
+                                         p.n_valid ? p.n_valid : p.n_total, ktot, b_kn_src, false, stream);
+    if (rcw != ADVOC_OK) return rcw;
     scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + wq_bytes);
     scratch_bytes -= wq_bytes;
   }
@@ -781,13 +716,7 @@ int launch_cfg(const GatherGemmParams& p, const LaunchCtx& ctx, bool b_kn_src = 
 
 // K tile depth: 32 when every channel slice allows it (fewer barriers, full 128-B rows per
 // gather), overridable with ADVOC_IGEMM_BK=16|32 for A/B measurements.
-int preferred_bk() {
-  static const int v = [] {
-    const char* e = getenv("ADVOC_IGEMM_BK");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
+int preferred_bk() { return tuning().igemm_bk; }
 
 // Tile choice (measured on MI355X, AdVoc layer shapes): 128x128 / 128x64 tiles reach ~108 / ~97
 // TFLOP/s once >= ~900 workgroups are in the launch (4 resident per CU); below that the chip is
@@ -801,9 +730,8 @@ int dispatch_bk(const GatherGemmParams& p, const LaunchCtx& ctx) {
   // of 3 workgroups per CU)
   if (N % 64 != 0) {
     if (BK == 16 && x6_allowed()) {
-      const char* te = getenv("ADVOC_IGEMM_X6_N32");
       const int64_t t32 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * p.nphase * (N / 32);
-      if ((te ? atoi(te) != 0 : true) && t32 >= 1024) {
+      if (tuning().igemm_x6_n32 != 0 && t32 >= 1024) {
         const int rc = launch_cfg<1, 1, 4, 1, false, 16, true>(p, ctx, B_KN);
         if (rc != ADVOC_ERR_UNSUPPORTED) return rc;
       }
@@ -816,8 +744,7 @@ int dispatch_bk(const GatherGemmParams& p, const LaunchCtx& ctx) {
     // Measured per layer (tools/layer_times.py, both models): the split path wins from ~500 tiles up
     // (2 per CU: its workgroups are 1.3-1.5x faster than the fp32 ones); 128x128 when that many exist,
     // else 128x64; below, the fp32 kernels with their smaller tiles / split-K stay ahead.
-    const char* te = getenv("ADVOC_IGEMM_X6_TILE");
-    const int xt = te ? atoi(te) : 0;
+    const int xt = tuning().igemm_x6_tile;
     const int64_t rows128 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * p.nphase;
     const int64_t t128 = bn == 128 ? rows128 * (N / 128) : 0, t64 = rows128 * (N / 64);
     int rc = ADVOC_ERR_UNSUPPORTED;
@@ -837,8 +764,7 @@ int dispatch_bk(const GatherGemmParams& p, const LaunchCtx& ctx) {
   const bool heavy_epilogue = p.grad_act != ADVOC_ACT_NONE || p.d[1].p != nullptr;
   const bool deep = k_total >= (heavy_epilogue ? 2048 : 1024);
   {
-    const char* e = getenv("ADVOC_IGEMM_TILE");
-    const int force = e ? atoi(e) : 0;
+    const int force = tuning().igemm_tile;
     if (force == 1) return launch_cfg<1, 1, 2, 2, B_KN, BK>(p, ctx);
     if (force == 2) return launch_cfg<2, 1, 2, 2, B_KN, BK>(p, ctx);
     if (force == 3 && bn == 128) return launch_cfg<2, 2, 2, 2, B_KN, BK>(p, ctx);
@@ -881,8 +807,8 @@ int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
   // encoder_3 both directions), except the stride-2 gathers with 32 input channels (one 128-byte line per
   // pixel: encoder_2 / layer_2 forward, 304 vs 175 MB), where walking both 64-byte halves of a line back to
   // back wins.  ADVOC_IGEMM_KORDER=0|1 forces one order for A/B runs.
-  const char* ko = getenv("ADVOC_IGEMM_KORDER");
-  const int k_order = ko ? atoi(ko) : ((p.sy == 2 && p.nphase == 1 && ktot <= 32) ? 0 : 1);
+  const int k_order = tuning().igemm_korder >= 0 ? tuning().igemm_korder
+                                                 : ((p.sy == 2 && p.nphase == 1 && ktot <= 32) ? 0 : 1);
   GatherGemmParams q = p;
   q.k_order = k_order;
   q.tail_main = 0; q.tail_split = 0; q.tail_ws = nullptr; q.tail_cnt = nullptr;

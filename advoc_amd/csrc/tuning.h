@@ -1,0 +1,27 @@
+// Diagnostic switches of the library, read from the environment ONCE (first use) instead of on every launch;
+// advoc_tuning_reload() (C ABI) re-reads them -- tests and A/B measurements flip a variable and call it.
+#pragma once
+
+namespace advoc {
+
+struct Tuning {
+  int igemm_splitk;     // ADVOC_IGEMM_SPLITK   0: every launch one K pass (bitwise run-to-run reproducible)
+  int igemm_tail;       // ADVOC_IGEMM_TAIL     0: no tail split
+  int igemm_x6;         // ADVOC_IGEMM_X6       0: every contraction on the fp32 MFMA kernels
+  long long igemm_x6_wide;   // ADVOC_IGEMM_X6_WIDE  >= 0: tile threshold of the 128x256 register-split tile
+  int igemm_bk;         // ADVOC_IGEMM_BK       16 | 32 (fp32 kernels)
+  int igemm_x6_n32;     // ADVOC_IGEMM_X6_N32   0: 32-channel outputs stay on fp32 MFMA
+  int igemm_x6_tile;    // ADVOC_IGEMM_X6_TILE  1..3: force a register-split tile
+  int igemm_tile;       // ADVOC_IGEMM_TILE     1..4: force an fp32 tile
+  int igemm_korder;     // ADVOC_IGEMM_KORDER   0 | 1, -1: per-layer rule
+  int wgrad_x6;         // ADVOC_WGRAD_X6       0: fp32 weight-gradient kernels; 2: also the 128x64 split tile
+  int x6d;              // ADVOC_X6D            0: no operand-image kernels (register-split path instead)
+  int x6d_tile;         // ADVOC_X6D_TILE       1: 128x128, 2: 128x256, 3: 256x128 forced
+  int x6d_stages;       // ADVOC_X6D_STAGES     2 | 3 LDS stages forced
+  int x6d_skip_prep;    // ADVOC_X6D_SKIP_PREP  1: (micro-benchmarks only) reuse the images already in the workspace
+  int x6d_min_tiles;    // ADVOC_X6D_MIN_TILES  smallest launch (128-row tiles) that takes the image path
+};
+
+const Tuning& tuning();
+
+}  // namespace advoc

@@ -17,6 +17,7 @@
 #include <string>
 
 #include "conv_internal.h"
+#include "tuning.h"
 
 namespace advoc {
 namespace {
@@ -658,15 +659,13 @@ int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream, const char** nam
   if (cb % 128 == 0) {                                                       // 128 x 128
     // split-bf16 path (igemm.hip): both operands split into three bf16 terms while they are parked in LDS;
     // ADVOC_WGRAD_X6=0 keeps the fp32 MFMA kernel (A/B measurements)
-    const char* e = getenv("ADVOC_WGRAD_X6");
-    if (e ? atoi(e) != 0 : true) return launch_wcfg<2, 2, 2, 2, true>(p, stream, name_only);
+    if (tuning().wgrad_x6 != 0) return launch_wcfg<2, 2, 2, 2, true>(p, stream, name_only);
     return launch_wcfg<2, 2, 2, 2>(p, stream, name_only);
   }
   if (cb % 64 == 0) {                                                        // 128 x 64
     // the split variant of this tile measured 3-6 % SLOWER than fp32 (half of the threads carry no Q slot):
     // only on request (ADVOC_WGRAD_X6=2)
-    const char* e = getenv("ADVOC_WGRAD_X6");
-    if (e && atoi(e) == 2) return launch_wcfg<2, 1, 2, 2, true>(p, stream, name_only);
+    if (tuning().wgrad_x6 == 2) return launch_wcfg<2, 1, 2, 2, true>(p, stream, name_only);
     return launch_wcfg<2, 1, 2, 2>(p, stream, name_only);
   }
   return launch_wcfg<1, 1, 4, 1>(p, stream, name_only);                      // 128 x 32

@@ -1,0 +1,36 @@
+// Split-bf16 arithmetic shared by image.hip, igemm.hip, igemm_x6d.hip and wgrad.hip.
+//
+// Every fp32 operand is written as x = x0 + x1 + x2 EXACTLY, each term a bf16 (8 significand bits, by
+// truncation), and an fp32 product a * b is accumulated as six bf16 MFMA products with fp32 accumulation,
+// smallest first: a1 b1, a0 b2, a2 b0, a0 b1, a1 b0, a0 b0.  bf16 x bf16 products are exact in fp32; the dropped
+// a1 b2, a2 b1, a2 b2 are <= 2^-22 of the product: fp32-level error (2.5e-7 rel-L2 vs float64 on whole layers,
+// tools/micro/x6_check.py) at 6 / 16 of the fp32 MFMA cost.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace advoc {
+
+// the high halves of the three words are the bf16 terms; x1 / x2 take the next 8 / the last <= 8 bits
+__device__ __forceinline__ void split3(float x, unsigned& h0, unsigned& h1, unsigned& h2) {
+  h0 = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h0);
+  h1 = __float_as_uint(r1) & 0xffff0000u;
+  h2 = __float_as_uint(r1 - __uint_as_float(h1));
+}
+// two bf16 (high halves of lo / hi) in one dword, lo in the low half
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) {
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+
+// image.hip
+// act(scale * x + shift) * mask * mask_scale of `elems` fp32 values (channels innermost, c % 16 == 0) as 96-byte
+// K slices: img[elems / 16][plane][16] bf16.
+int launch_split_image(const float* x, uint16_t* img, int64_t elems, int c, const float* scale, const float* shift,
+                       int act, const uint8_t* mask, float mask_scale, hipStream_t stream);
+// weights [tap][k][n] (b_kn) or [tap][n][k] -> wq[plane][tap][n_total][ktot] or, sliced, wq[tap][n_total][ktot / 16]
+// [plane][16]; zeros for n >= n_valid
+int launch_split_weights(const float* w, uint16_t* wq, int taps, int n_total, int n_valid, int ktot, bool b_kn,
+                         bool sliced, hipStream_t stream);
+
+}  // namespace advoc

@@ -46,6 +46,9 @@ const char* advoc_error_string(int code);
 const char* advoc_last_hip_error(void);
 /* name of the GPU arch the kernels in this library were compiled for ("gfx950") */
 const char* advoc_target_arch(void);
+/* The library reads its diagnostic environment switches (ADVOC_IGEMM_*, ADVOC_WGRAD_X6, ADVOC_X6D*: kernel
+ * selection overrides for A/B measurements and tests) once, on first use; this re-reads them. */
+void advoc_tuning_reload(void);
 
 /* ------------------------------------------------------------------------------------------
  * Feature extractor

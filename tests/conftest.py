@@ -26,3 +26,28 @@ def hip():
   from advoc_amd import _lib
   assert torch.cuda.is_available(), 'gpu-marked test running without a HIP device'
   return _lib.load()
+
+
+@pytest.fixture
+def hipenv(hip):
+  """Sets ADVOC_* diagnostic switches for one test: the library caches its environment on first use, so every
+  change is followed by advoc_tuning_reload(); the previous values come back (and are re-read) afterwards."""
+  from advoc_amd import _lib
+  saved = {}
+
+  def set_env(**kw):
+    for k, v in kw.items():
+      if k not in saved:
+        saved[k] = os.environ.get(k)
+      if v is None:
+        os.environ.pop(k, None)
+      else:
+        os.environ[k] = str(v)
+    _lib.reload_env()
+  yield set_env
+  for k, v in saved.items():
+    if v is None:
+      os.environ.pop(k, None)
+    else:
+      os.environ[k] = v
+  _lib.reload_env()

@@ -117,14 +117,12 @@ SPLITK = [c for c in CASES if c[0] in ('enc_same_wide', 'enc_n256', 'dec_first_d
 
 @gpu
 @pytest.mark.parametrize('case', SPLITK, ids=[c[0] for c in SPLITK])
-def test_layer_single_k_pass(hip, case, monkeypatch):
+def test_layer_single_k_pass(hip, case, hipenv):
   """Small pixel grids split the contraction over workgroups (atomics) by default; with
   ADVOC_IGEMM_SPLITK=0 the same layers run one K pass.  Both must meet the bar, and the single-pass
   result must be bitwise reproducible."""
-  import os
   from advoc_amd import conv
-  monkeypatch.setenv('ADVOC_IGEMM_SPLITK', '0')
-  os.environ['ADVOC_IGEMM_SPLITK'] = '0'
+  hipenv(ADVOC_IGEMM_SPLITK=0)
   test_layer_all_directions(hip, case)
   c = build_case(case)
   dev = torch.device('cuda')
@@ -152,7 +150,7 @@ TAIL = [
 
 @gpu
 @pytest.mark.parametrize('case', TAIL, ids=[c[0] for c in TAIL])
-def test_layer_tail_split(hip, case, monkeypatch):
+def test_layer_tail_split(hip, case, hipenv):
   import ctypes
   from advoc_amd import _lib, conv
   c = build_case(case)
@@ -176,10 +174,10 @@ def test_layer_tail_split(hip, case, monkeypatch):
   assert L.struct.workspace_bytes > 0
   _, y_b = forward()
   assert torch.equal(y_a, y_b)                      # fixed summation order: run-to-run reproducible
-  monkeypatch.setenv('ADVOC_IGEMM_TAIL', '0')
+  hipenv(ADVOC_IGEMM_TAIL=0)
   _, y_plain = forward()
   assert rel(y_a, y_plain.double()) < 1e-6          # same numbers up to the order of one sum
-  monkeypatch.delenv('ADVOC_IGEMM_TAIL')
+  hipenv(ADVOC_IGEMM_TAIL=None)
   test_layer_all_directions(hip, case)              # all three directions against the float64 oracle
   test_layer_all_directions(hip, case, workspace=False)
 
@@ -197,7 +195,7 @@ SPLIT = [
 
 @gpu
 @pytest.mark.parametrize('case', SPLIT, ids=[c[0] for c in SPLIT])
-def test_layer_split_bf16_path(hip, case, monkeypatch):
+def test_layer_split_bf16_path(hip, case, hipenv):
   from advoc_amd import conv
   c = build_case(case)
   dev = torch.device('cuda')
@@ -218,17 +216,102 @@ def test_layer_split_bf16_path(hip, case, monkeypatch):
     L.backward_weight(dy, dw)
     return [L.kernel_name(d) for d in range(3)], y, dx0[:, :, :c['in_w']].clone(), dw
 
+  def split(n):
+    return n.endswith(', true>') or 'x6d' in n
+  hipenv(ADVOC_X6D=0)                                               # register-split kernels (igemm.hip, wgrad.hip)
   names, y, dx, dw = run()
-  assert all(n.endswith(', true>') for n in names), names          # the split kernels are the ones that ran
-  monkeypatch.setenv('ADVOC_IGEMM_X6', '0')
-  monkeypatch.setenv('ADVOC_WGRAD_X6', '0')
+  assert all(split(n) and 'x6d' not in n for n in names), names    # the split kernels are the ones that ran
+  hipenv(ADVOC_IGEMM_X6=0, ADVOC_WGRAD_X6=0)
   names32, y32, dx32, dw32 = run()
-  assert not any(n.endswith(', true>') for n in names32), names32
+  assert not any(split(n) for n in names32), names32
   for a, b in ((y, y32), (dx, dx32), (dw, dw32)):
     assert rel(a, b) < 3e-6, rel(a, b)
-  monkeypatch.delenv('ADVOC_IGEMM_X6')
-  monkeypatch.delenv('ADVOC_WGRAD_X6')
+  hipenv(ADVOC_IGEMM_X6=None, ADVOC_WGRAD_X6=None)
   test_layer_all_directions(hip, case)              # all three directions against the float64 oracle
+  # operand-image kernels (igemm_x6d.hip): the same six-product arithmetic in the same K order -> the very same bits
+  hipenv(ADVOC_X6D=1, ADVOC_X6D_MIN_TILES=1, ADVOC_IGEMM_KORDER=1)
+  names_d, y_d, dx_d, _ = run()
+  hipenv(ADVOC_X6D=0)
+  _, y_r, dx_r, _ = run()
+  assert 'x6d' in names_d[0], names_d      # (backward-data has 64 columns here: register-split kernel)
+  assert torch.equal(y_d, y_r) and torch.equal(dx_d, dx_r)
+  hipenv(ADVOC_X6D=None, ADVOC_X6D_MIN_TILES=None, ADVOC_IGEMM_KORDER=None)
+  test_layer_all_directions(hip, case)
+
+
+# Operand-image kernels (igemm_x6d.hip): every tile / stage instance against the float64 oracle, in all
+# directions that take them (forward, backward-data), on shapes with the features the loader has to get right:
+# rows that are not a multiple of the tile, two sources with a trimmed column, SAME padding on odd widths,
+# sub-pixel phases, stride-1 taps, dropout on either side.  ADVOC_X6D_MIN_TILES=1 lets these small launches in.
+X6D = [
+    ('x6d_enc',       0, (3, 16, 33), 128, 0, 256, 0, (2, 2), None, 1, False, 0),
+    ('x6d_enc_s1',    0, (2, 9, 12), 128, 0, 128, 0, (1, 1), (1, 1), 1, False, 0),
+    ('x6d_dec_skip',  1, (2, 8, 17), 128, 128, 256, 1, (2, 2), (1, 1), 2, True, 0),
+    ('x6d_dec_first', 1, (3, 4, 9), 256, 0, 128, 0, (2, 2), (1, 1), 2, True, 0),
+    ('x6d_enc_s12',   0, (3, 2, 17), 128, 0, 128, 0, (1, 2), None, 1, False, 0),
+    ('x6d_dec_mixed', 1, (2, 8, 9), 256, 128, 128, 1, (2, 2), (1, 1), 2, False, 0),
+]
+X6D_VARIANTS = [(1, 2), (1, 3), (2, 2), (2, 3), (3, 2), (3, 3)]
+
+
+@gpu
+@pytest.mark.parametrize('variant', X6D_VARIANTS, ids=['t%d_s%d' % v for v in X6D_VARIANTS])
+@pytest.mark.parametrize('case', X6D, ids=[c[0] for c in X6D])
+def test_layer_operand_image_kernels(hip, case, variant, hipenv):
+  from advoc_amd import conv
+  tile, stages = variant
+  hipenv(ADVOC_X6D_MIN_TILES=1, ADVOC_X6D_TILE=tile, ADVOC_X6D_STAGES=stages)
+  c = build_case(case)
+  dev = torch.device('cuda')
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w = c['w'].to(dev)
+  cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+  y = torch.empty(x0.shape[0], c['oh'], c['out_w'], cout, device=dev)
+  L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
+  want_tile = {1: '2, 2', 2: '2, 4', 3: '4, 2'}[tile]
+  cin = x0.shape[3] + (x1.shape[3] if x1 is not None else 0)
+  for direction, n_cols in ((0, cout), (1, cin)):
+    name = L.kernel_name(direction)
+    if tile == 2 and n_cols % 256:
+      want = 'gather_gemm_x6d_kernel<2, 2, %d>' % stages        # 256-column tile impossible: falls to 128 x 128
+    else:
+      want = 'gather_gemm_x6d_kernel<%s, %d>' % (want_tile, stages)
+    assert name == want, (direction, name, want)
+  test_layer_all_directions(hip, case)
+
+
+@gpu
+def test_operand_image_kernel_with_batchnorm_prologue(hip, hipenv):
+  """The image pass applies the producer's batch-norm affine and the dropout that follows it (in_scale / in_shift /
+  in_mask of advoc_conv_layer) before the split: compare with the fp32 MFMA path on the same layer."""
+  from advoc_amd import conv
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(11)
+  x0 = torch.randn(2, 8, 18, 128, generator=g).to(dev)
+  x1 = torch.randn(2, 8, 17, 128, generator=g).to(dev)
+  w = (torch.randn(4, 4, 128, 256, generator=g) * 0.05).to(dev)
+  sc = (torch.rand(256, generator=g) + 0.5).to(dev)
+  sh = (torch.randn(256, generator=g) * 0.3).to(dev)
+  mk = (torch.rand(2, 8, 18, 128, generator=g) >= 0.5).to(torch.uint8).to(dev)
+  dy = torch.randn(2, 16, 34, 128, generator=g).to(dev)
+
+  def run():
+    y = torch.empty(2, 16, 34, 128, device=dev)
+    L = conv.Layer(conv.DECONV, x0, y, w, None, x1=x1, in_w=17, stride=(2, 2), pad=(1, 1), in_act=conv.ACT_RELU,
+                   in_scale=sc, in_shift=sh, in_mask=mk, in_mask_scale=2.0)
+    L.forward()
+    dx0, dx1 = torch.zeros_like(x0), torch.zeros_like(x1)
+    L.backward_data(dy, dx0, dx1)
+    return L.kernel_name(0), L.kernel_name(1), y, dx0, dx1
+  hipenv(ADVOC_X6D_MIN_TILES=1)
+  n0, n1, y, dx0, dx1 = run()
+  assert 'x6d' in n0 and 'x6d' in n1, (n0, n1)
+  hipenv(ADVOC_IGEMM_X6=0)
+  m0, m1, y32, dx0_32, dx1_32 = run()
+  assert 'x6d' not in m0 and not m0.endswith(', true>')
+  for a, b in ((y, y32), (dx0, dx0_32), (dx1, dx1_32)):
+    assert rel(a, b) < 3e-6, rel(a, b)
 
 
 @gpu

@@ -321,7 +321,7 @@ def test_side_stream_weight_gradients_equal_serial_execution(hip, monkeypatch):
 
 
 @gpu
-def test_training_on_split_bf16_path_tracks_fp32_path(hip, monkeypatch):
+def test_training_on_split_bf16_path_tracks_fp32_path(hip, hipenv):
   """At the benchmark geometry (32 clips x 256 frames) most contractions run on the split-bf16 matrix path
   (igemm.hip / wgrad.hip); with ADVOC_IGEMM_X6=0 ADVOC_WGRAD_X6=0 the same model runs on the fp32 MFMA
   kernels.  The first step's gradients agree to round-off, and 12 train_loops on one batch end at the same
@@ -332,11 +332,7 @@ def test_training_on_split_bf16_path_tracks_fp32_path(hip, monkeypatch):
   x, target = x.to(dev), target.to(dev)
 
   def run(split):
-    for k in ('ADVOC_IGEMM_X6', 'ADVOC_WGRAD_X6'):
-      if split:
-        monkeypatch.delenv(k, raising=False)
-      else:
-        monkeypatch.setenv(k, '0')
+    hipenv(ADVOC_IGEMM_X6=None if split else 0, ADVOC_WGRAD_X6=None if split else 0)
     m = AdvocSmall(Modes.TRAIN)
     m.train_batch_size = 32
     m.build(batch_size=32, seed=11)
@@ -354,7 +350,7 @@ def test_training_on_split_bf16_path_tracks_fp32_path(hip, monkeypatch):
 
   g_s, h_s, n_s = run(True)
   g_f, h_f, n_f = run(False)
-  split = lambda n: n.startswith('gather_gemm_kernel<') and n.endswith(', true>')       # noqa: E731
+  split = lambda n: (n.startswith('gather_gemm_kernel<') and n.endswith(', true>')) or 'x6d' in n       # noqa: E731
   assert any(split(n) for n in n_s) and not any(split(n) for n in n_f), (n_s, n_f)
   worst = 0.0
   for k in g_f:

@@ -1,0 +1,38 @@
+"""Full-model layer shapes shared by the x6d micro-benchmarks."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from advoc_amd import conv
+dev = torch.device('cuda')
+SHAPES = {
+    # name: (kind, B, H, W, c0, c1, cout, stride, trim, act)
+    'enc4':  (0, 64, 32, 65, 256, 0, 512, (2, 2), 0, 1),
+    'enc3':  (0, 64, 64, 129, 128, 0, 256, (2, 2), 0, 1),
+    'enc2':  (0, 64, 128, 257, 64, 0, 128, (2, 2), 0, 1),
+    'd4':    (0, 128, 32, 64, 256, 0, 512, (1, 1), 0, 1),
+    'dec4':  (1, 64, 16, 33, 512, 512, 256, (2, 2), 1, 2),
+    'dec3':  (1, 64, 32, 65, 256, 256, 128, (2, 2), 1, 2),
+}
+
+
+def build(name):
+  kind, B, H, W, c0, c1, cout, stride, trim, act = SHAPES[name]
+  x0 = torch.randn(B, H, W + trim, c0, device=dev)
+  x1 = torch.randn(B, H, W, c1, device=dev) if c1 else None
+  if kind == 0:
+    if stride == (1, 1):
+      oh, ow = H - 1, W - 1
+    else:
+      oh, ow = -(-H // 2), -(-W // 2)
+    w = torch.randn(4, 4, c0 + c1, cout, device=dev) * 0.05
+  else:
+    oh, ow = 2 * H, 2 * W
+    w = torch.randn(4, 4, cout, c0 + c1, device=dev) * 0.05
+  y = torch.empty(B, oh, ow, cout, device=dev)
+  L = conv.Layer(kind, x0, y, w, None, x1=x1, in_w=W, stride=stride, pad=(1, 1), in_act=act)
+  dy = torch.randn_like(y)
+  dx0 = torch.empty_like(x0)
+  dx1 = torch.empty_like(x1) if x1 is not None else None
+  return L, dy, dx0, dx1
+
+
