@@ -52,11 +52,11 @@ Tuning read_env() {
   t.igemm_tile = env_int("ADVOC_IGEMM_TILE", 0);
   t.igemm_korder = env_int("ADVOC_IGEMM_KORDER", -1);
   t.wgrad_x6 = env_int("ADVOC_WGRAD_X6", 1);
-  t.x6d = env_int("ADVOC_X6D", 1);
-  t.x6d_tile = env_int("ADVOC_X6D_TILE", 0);
-  t.x6d_stages = env_int("ADVOC_X6D_STAGES", 0);
-  t.x6d_skip_prep = env_int("ADVOC_X6D_SKIP_PREP", 0);
-  t.x6d_min_tiles = env_int("ADVOC_X6D_MIN_TILES", 448);
+  t.h3 = env_int("ADVOC_H3", 1);
+  t.h3_tile = env_int("ADVOC_H3_TILE", 0);
+  t.h3_stages = env_int("ADVOC_H3_STAGES", 0);
+  t.h3_skip_prep = env_int("ADVOC_H3_SKIP_PREP", 0);
+  t.h3_min_tiles = env_int("ADVOC_H3_MIN_TILES", 128);
   return t;
 }
 // two slots + an index: a reload publishes a complete new table; readers never see a half-written one

@@ -237,7 +237,7 @@ int run_gather(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const c
     return run_two_stage(p, ws, stream, name_only);
   if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0) {
     // big launches: operand images + LDS-DMA kernel when the caller's workspace holds the images
-    const int rc = launch_gather_gemm_x6d(p, b_kn, stream, name_only, ws, ws_bytes, nullptr);
+    const int rc = launch_gather_gemm_h3(p, b_kn, stream, name_only, ws, ws_bytes, nullptr);
     if (rc != ADVOC_ERR_UNSUPPORTED) return rc;
     return launch_gather_gemm(p, b_kn, stream, name_only, ws, ws_bytes);
   }
@@ -338,7 +338,7 @@ extern "C" int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* L, int32_t
   const int K = p.c0 + p.c1, N = p.n_total;
   int64_t want = 0, want_img = 0;
   if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0) {
-    if (launch_gather_gemm_x6d(p, b_kn, nullptr, nullptr, nullptr, 0, &want_img) != ADVOC_OK) want_img = 0;
+    if (launch_gather_gemm_h3(p, b_kn, nullptr, nullptr, nullptr, 0, &want_img) != ADVOC_OK) want_img = 0;
     if (launch_gather_gemm(p, b_kn, nullptr, nullptr, nullptr, 0, &want) != ADVOC_OK) want = 0;
   }
   return want_img > want ? want_img : want;

@@ -69,12 +69,14 @@ struct GatherGemmParams {
   // wq[plane][tap][n_total][c0 + c1] (contraction axis contiguous, zeros for n >= n_valid) ----
   const uint16_t* wq;
   int wq_taps;
-  // ---- operand-image path (igemm_x6d.hip, filled in by its launcher): the A sources as arrays of 96-byte K slices,
-  // [pixel][channel / 16][plane][16] bf16 with the tensor's own geometry (image.hip); wq is then the sliced weight
-  // image [tap][n][k / 16][plane][16] ----
+  // ---- operand-image path (igemm_h3.hip, filled in by its launcher): the A sources as arrays of 128-byte K slices,
+  // [pixel][channel / 32][plane][32] fp16 with the tensor's own geometry (image.hip); wq is then the fp16 pair
+  // weight image [tap][n][k / 32][plane][32]; a_hdr / b_hdr: {largest magnitude bits, 2^-s} per operand ----
   const uint16_t* a0_img;
   const uint16_t* a1_img;
   int a0_img_bytes, a1_img_bytes;
+  const unsigned* a_hdr;
+  const unsigned* b_hdr;
   // ---- tail split (filled in by the launcher, see launch_cfg) ----
   int tail_main;           // > 0: 1-D launch; tiles [0, tail_main) whole, the rest in tail_split K slices each
   int tail_split;
@@ -99,10 +101,10 @@ struct TailPlan { int main = 0, rem = 0, split = 0; };
 TailPlan plan_tail(int64_t tiles, int nkt);
 int* tail_counter_slot();
 
-// Operand-image variant (igemm_x6d.hip): same problem description; the launcher writes the weight image and the
+// Operand-image variant (igemm_h3.hip): same problem description; the launcher writes the weight image and the
 // activation image(s) into the caller workspace first.  ADVOC_ERR_UNSUPPORTED when the problem is outside what
 // it takes (too small, channel counts, no / too little workspace): the caller falls back to launch_gather_gemm.
-int launch_gather_gemm_x6d(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only,
+int launch_gather_gemm_h3(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only,
                            float* scratch, int64_t scratch_bytes, int64_t* scratch_query);
 
 }  // namespace advoc

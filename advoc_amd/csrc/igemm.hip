@@ -677,7 +677,7 @@ int launch_cfg(const GatherGemmParams& p, const LaunchCtx& ctx, bool b_kn_src = 
     px.wq = reinterpret_cast<const uint16_t*>(scratch);
     px.wq_taps = taps;
     const int rcw = launch_split_weights(p.w, reinterpret_cast<uint16_t*>(scratch), taps, p.n_total,
-                                         p.n_valid ? p.n_valid : p.n_total, ktot, b_kn_src, false, stream);
+                                         p.n_valid ? p.n_valid : p.n_total, ktot, b_kn_src, stream);
     if (rcw != ADVOC_OK) return rcw;
     scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + wq_bytes);
     scratch_bytes -= wq_bytes;

@@ -1,28 +1,30 @@
-// Gather-GEMM on operand images: the split-bf16 convolution kernel whose operands arrive PRE-SPLIT.
+// Gather-GEMM on operand images: the convolution kernel whose operands arrive as fp16 PAIRS, one cache line
+// per tile row.
 //
 // Same GEMM view as igemm.hip (rows = output grid points, cols = output channels, depth = (tap, input
 // channel); replaces the cuDNN / Eigen Conv2D and Conv2DBackpropInput kernels TF1 runs for
-// models/advoc/advoc_model.py:25-69 in both directions) and the same arithmetic as its register-split
-// variant (x6.h: six bf16 MFMA products per fp32 product, fp32 accumulation, smallest terms first -- results
-// are bit-identical to that kernel for the same K order), but the instruction stream around the matrix
-// cores is gone:
-//   * A is read from an activation image (image.hip: act / BN affine / dropout already applied, ONCE per
-//     element instead of once per tap and column tile), B from the weight image.  Both images are arrays of
-//     96-byte K SLICES: the three bf16 planes of 16 consecutive contraction slots side by side -- one row of a
-//     K tile is ONE contiguous 96-byte piece;
-//   * both go global -> LDS by `buffer_load_dwordx4 ... lds` (LDS-DMA): no VGPR staging, no ds_write, no
-//     split arithmetic.  The hardware range check of the buffer descriptor supplies the zero padding: a tap
-//     that falls outside the input gets an offset beyond num_records and the DMA writes zeros;
-//   * one DMA instruction = 8 tile rows x 6 sixteen-byte chunks on lanes 0..47 (768 dense bytes of LDS); a wave
-//     issues BM / 32 of them per K tile for A and BN / 32 for B, each lane keeping ONE (row, chunk) per
-//     instruction slot for the whole K loop: per K tile the address work is two compares and a select per slot,
-//     everything else is scalar;
-//   * LDS rows are 96 bytes ([plane][16 slots]); the two 16-byte halves of every plane are stored swapped in
-//     odd 8-row blocks (applied to the SOURCE address, the DMA destination is lane-linear), which makes the MFMA
-//     fragment reads (ds_read_b128, one row per lane) conflict-free;
+// models/advoc/advoc_model.py:25-69 in both directions).  Arithmetic (image.hip): every fp32 operand, scaled by
+// one power of two per tensor, is the sum of two fp16 numbers to 2^-22; a product is three fp16 MFMA products
+// a0 b1 + a1 b0 + a0 b0 with fp32 accumulation, unscaled exactly in the epilogue -- fp32-level error at 3 / 16
+// of the fp32 MFMA cost (roof in algorithmic fp32 flops: dense f16 MFMA / 3).
+//
+// Why it looks the way it does (measured on MI355X): the register-split kernel of igemm.hip and a
+// first image kernel (bf16 triples, six products) both stopped at ~170-190 algorithmic TFLOP/s with the matrix
+// pipe busy 45 % of the time; removing every MFMA from the loop bought 16 %, removing the loads 49 %.  The loaders
+// were bound by the L2's request rate: 32-96 useful bytes of every 128-byte line they asked for.  Here
+//   * one row of a K tile (32 contraction slots x 2 planes) is exactly ONE 128-byte line of the image, fetched once;
+//   * both operands go global -> LDS by `buffer_load_dwordx4 ... lds` (LDS-DMA): no VGPR staging, no ds_write, no
+//     conversion.  The hardware range check of the buffer descriptor supplies the zero padding: a tap that falls
+//     outside the input gets an offset beyond num_records and the DMA writes zeros;
+//   * one DMA instruction = 8 tile rows x 8 sixteen-byte chunks (1 KiB of LDS, all 64 lanes); a wave issues BM / 32
+//     of them per K tile for A and BN / 32 for B, each lane keeping ONE (row, chunk) per instruction slot for the
+//     whole K loop: per K tile the address work is two compares and a select per slot, everything else is scalar;
+//   * LDS rows are 128 bytes; chunk c of row r sits at position c ^ ((r >> 1) & 7) (applied to the SOURCE address,
+//     the DMA destination is lane-linear), which makes the MFMA fragment reads (ds_read_b128, one row per lane,
+//     16 rows per LDS pass) conflict-free;
 //   * NS LDS stages (2 or 3), ONE s_barrier per K tile: wait for the own DMAs of tile t (counted vmcnt, the
 //     younger tiles stay in flight) -> barrier -> issue tile t + NS - 1 into the stage tile t - 1 just
-//     vacated -> 12 ds_read_b128 + 24 MFMAs (128 x 128 tile) of tile t.
+//     vacated -> 16 ds_read_b128 + 24 MFMAs (128 x 128 tile) of tile t.
 // Tile mapping (XCD-aware order), split-K, the tail split and the epilogue are those of igemm.hip.
 #include <stdlib.h>
 
@@ -37,7 +39,7 @@ namespace advoc {
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_void_p;
 
 __device__ __forceinline__ float act_slope(int act) {
@@ -45,18 +47,17 @@ __device__ __forceinline__ float act_slope(int act) {
 }
 
 template <int MT, int NT, int NS>
-struct DCfg {
+struct HCfg {
   static constexpr int WGM = 2, WGN = 2;
   static constexpr int BM = 32 * MT * WGM, BN = 32 * NT * WGN;
-  static constexpr int BK = 16;
-  static constexpr int ROWB = 6 * BK;                       // bytes of one tile row: 3 planes x 16 bf16
+  static constexpr int BK = 32;
+  static constexpr int ROWB = 4 * BK;                       // bytes of one tile row: 2 planes x 32 fp16 = one line
   static constexpr int A_TILE = BM * ROWB, B_TILE = BN * ROWB;
   static constexpr int STAGE = A_TILE + B_TILE;             // bytes
   static constexpr int RGA = BM / 32, CGB = BN / 32;        // 8-row DMA blocks per wave and K tile
   static constexpr int DMA_PER_TILE = RGA + CGB;
   static constexpr int EPI_BYTES = 4 * 32 * 36 * 4 + 2 * BM * 4;
   static constexpr size_t LDS_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
-  static_assert(MT % 2 == 0 && NT % 2 == 0, "whole 32-row DMA groups per wave");
 };
 
 template <int N>
@@ -65,13 +66,11 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// launch_bounds: 8 accumulators (128 x 256 / 256 x 128) need ~200 registers -> 2 waves per SIMD; the 128 x 128
-// tile fits 3 (<= 168 registers) when its LDS does (2 stages).
 // (the body is a __device__ function behind a one-line kernel: with the body inside the __global__ template itself
 // hipcc's HOST pass silently dropped the kernel handle -- no diagnostic, an undefined symbol at load time)
 template <int MT, int NT, int NS, int ABL = 0>
-__device__ __forceinline__ void gather_gemm_x6d_body(const GatherGemmParams& p) {
-  using C = DCfg<MT, NT, NS>;
+__device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
+  using C = HCfg<MT, NT, NS>;
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK, WGN = C::WGN;
   constexpr int RGA = C::RGA, CGB = C::CGB;
 
@@ -111,18 +110,16 @@ __device__ __forceinline__ void gather_gemm_x6d_body(const GatherGemmParams& p) 
   const int kpt = ktot / BK;
   const int nkt = kpt * p.ntaps;
 
-  // ---- DMA lanes 0..47: lane -> (row lane / 6 of an 8-row block, 16-byte chunk lane % 6 of the 96-byte row); odd
-  // blocks hold every plane's two halves swapped (chunk ^ 1) ----
-  const int lrow = lane / 6, lchunk = lane - 6 * lrow;
-  const bool dma_lane = lane < 48;
+  // ---- DMA lanes: lane -> (row lane / 8 of an 8-row block, LDS position lane % 8 of the 128-byte row); position q of
+  // row r holds chunk q ^ ((r >> 1) & 7) of the line ----
+  const int lrow = lane >> 3, lpos = lane & 7;
   int a_y[RGA], a_x[RGA], a_b0[RGA], a_b1[RGA];
   bool a_ok[RGA];
 #pragma unroll
   for (int g = 0; g < RGA; ++g) {
-    const int blk = wave * RGA + g;
-    const int r = blk * 8 + lrow;
+    const int r = (wave * RGA + g) * 8 + lrow;
     const unsigned m = m0 + r;
-    a_ok[g] = dma_lane && m < M;
+    a_ok[g] = m < M;
     const unsigned mm = a_ok[g] ? m : 0u;
     const unsigned t = mm / (unsigned)p.gw;
     const int gx = (int)(mm - t * (unsigned)p.gw);
@@ -130,17 +127,16 @@ __device__ __forceinline__ void gather_gemm_x6d_body(const GatherGemmParams& p) 
     const int gy = (int)(t - (unsigned)img * (unsigned)p.gh);
     a_x[g] = gx * p.sx;
     a_y[g] = gy * p.sy;
-    const int gc = lchunk ^ (blk & 1);
-    a_b0[g] = (((img * p.a_h + a_y[g]) * p.a0_pitch + a_x[g]) * p.c0) * 6 + gc * 16;     // bytes into the image
-    a_b1[g] = (((img * p.a_h + a_y[g]) * p.a1_pitch + a_x[g]) * p.c1) * 6 + gc * 16;
+    const int gc = lpos ^ ((r >> 1) & 7);
+    a_b0[g] = (((img * p.a_h + a_y[g]) * p.a0_pitch + a_x[g]) * p.c0) * 4 + gc * 16;     // bytes into the image
+    a_b1[g] = (((img * p.a_h + a_y[g]) * p.a1_pitch + a_x[g]) * p.c1) * 4 + gc * 16;
   }
   int b_off[CGB];
 #pragma unroll
   for (int g = 0; g < CGB; ++g) {
-    const int blk = wave * CGB + g;
-    const int n = blk * 8 + lrow;
-    const int gc = lchunk ^ (blk & 1);
-    b_off[g] = ((n0 + n) * ktot) * 6 + gc * 16;
+    const int n = (wave * CGB + g) * 8 + lrow;
+    const int gc = lpos ^ ((n >> 1) & 7);
+    b_off[g] = ((n0 + n) * ktot) * 4 + gc * 16;
   }
   // buffer descriptors over the whole images; the weight-slab / K-slice offsets go into soffset
   const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -148,7 +144,7 @@ __device__ __forceinline__ void gather_gemm_x6d_body(const GatherGemmParams& p) 
   const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(p.a1_img ? p.a1_img : p.a0_img), 0, p.a1_img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t*>(p.wq), 0, p.wq_taps * p.n_total * ktot * 6, 0x00020000);
+      const_cast<uint16_t*>(p.wq), 0, p.wq_taps * p.n_total * ktot * 4, 0x00020000);
 
   const int kt_begin = (int)((int64_t)nkt * ks_idx / ks_cnt);
   const int kt_end = (int)((int64_t)nkt * (ks_idx + 1) / ks_cnt);
@@ -156,9 +152,9 @@ __device__ __forceinline__ void gather_gemm_x6d_body(const GatherGemmParams& p) 
   int ld_tap = taps_inner ? kt_begin % p.ntaps : kt_begin / kpt;
   int ld_k0 = (taps_inner ? kt_begin / p.ntaps : kt_begin % kpt) * BK;
 
-  // Issues the DMAs of the next K tile of the walk into stage `st` (a compile-time constant in the unrolled
+  // Issues the DMAs of the next K tile of the walk into stage ST (a compile-time constant in the unrolled
   // loop below).  Tiles past kt_end wrap round to valid ones; their data is never read.
-#define ADVOC_X6D_ISSUE(ST)                                                                              \
+#define ADVOC_H3_ISSUE(ST)                                                                               \
   {                                                                                                      \
     const int ti_ = ld_tap;                                                                              \
     const int k0_ = ld_k0;                                                                               \
@@ -172,23 +168,23 @@ __device__ __forceinline__ void gather_gemm_x6d_body(const GatherGemmParams& p) 
     const int dy_ = (int)(int8_t)(tp_ & 0xff), dx_ = (int)(int8_t)((tp_ >> 8) & 0xff);                   \
     const int wtap_ = tp_ >> 16;                                                                         \
     const bool second_ = k0_ >= p.c0;                                                                    \
-    const int delta_ = second_ ? ((dy_ * p.a1_pitch + dx_) * p.c1 + (k0_ - p.c0)) * 6                    \
-                               : ((dy_ * p.a0_pitch + dx_) * p.c0 + k0_) * 6;                            \
+    const int delta_ = second_ ? ((dy_ * p.a1_pitch + dx_) * p.c1 + (k0_ - p.c0)) * 4                    \
+                               : ((dy_ * p.a0_pitch + dx_) * p.c0 + k0_) * 4;                            \
     unsigned char* st_ = smem_b + (ST) * C::STAGE;                                                       \
     _Pragma("unroll") for (int g = 0; g < RGA; ++g) {                                                    \
       const int iy_ = a_y[g] + dy_, ix_ = a_x[g] + dx_;                                                  \
       const bool ok_ = a_ok[g] && (unsigned)iy_ < (unsigned)p.in_h && (unsigned)ix_ < (unsigned)p.in_w;  \
       const int voff_ = ok_ ? (second_ ? a_b1[g] : a_b0[g]) + delta_ : (int)0x80000000;                  \
-      unsigned char* d_ = st_ + (wave * RGA + g) * 768;                                                  \
-      if (dma_lane && ABL != 3) {                                                                        \
+      unsigned char* d_ = st_ + (wave * RGA + g) * 1024;                                                 \
+      if (ABL != 3) {                                                                                    \
         if (second_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_void_p)(d_), 16, voff_, 0, 0, 0);    \
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (lds_void_p)(d_), 16, voff_, 0, 0, 0);      \
       }                                                                                                  \
     }                                                                                                    \
-    const int wslab_ = (wtap_ * p.n_total * ktot + k0_) * 6;                                             \
+    const int wslab_ = (wtap_ * p.n_total * ktot + k0_) * 4;                                             \
     _Pragma("unroll") for (int g = 0; g < CGB; ++g) {                                                    \
-      unsigned char* d_ = st_ + C::A_TILE + (wave * CGB + g) * 768;                                      \
-      if (dma_lane && ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_p)(d_), 16, b_off[g], wslab_, 0, 0); \
+      unsigned char* d_ = st_ + C::A_TILE + (wave * CGB + g) * 1024;                                     \
+      if (ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_p)(d_), 16, b_off[g], wslab_, 0, 0); \
     }                                                                                                    \
   }
 
@@ -201,42 +197,45 @@ __device__ __forceinline__ void gather_gemm_x6d_body(const GatherGemmParams& p) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int half = lane >> 5, l32 = lane & 31;
-  // fragment read offset: row l32 of a 32-row block, half `half` of a plane (stored swapped on rows 8-15, 24-31)
-  const int frag_off = l32 * C::ROWB + ((half ^ ((l32 >> 3) & 1)) * 16);
+  // fragment read offsets: row l32 of a 32-row block; chunk (plane, k step, half) = 4 plane + 2 ks + half sits at
+  // position chunk ^ ((row >> 1) & 7)
+  int frag_off[2][2];
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      frag_off[pl][ks] = l32 * C::ROWB + (((4 * pl + 2 * ks + half) ^ ((l32 >> 1) & 7)) * 16);
 
-  // six bf16 products per 32x32x16 block, smallest terms first: a1 b1, a0 b2, a2 b0, a0 b1, a1 b0, a0 b0
-#define ADVOC_X6D_COMPUTE(ST)                                                                            \
+  // three fp16 products per 32x32x16 block, small terms first: a0 b1, a1 b0, a0 b0
+#define ADVOC_H3_COMPUTE(ST)                                                                             \
   {                                                                                                      \
-    const unsigned char* Ax = smem_b + (ST) * C::STAGE + frag_off;                                       \
+    const unsigned char* Ax = smem_b + (ST) * C::STAGE;                                                  \
     const unsigned char* Bx = Ax + C::A_TILE;                                                            \
-    bf16x8 af[MT][3], bq[NT][3];                                                                         \
-    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                       \
-      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                   \
-        af[i][pl] = *reinterpret_cast<const bf16x8*>(Ax + pl * 32 + (wm * MT + i) * 32 * C::ROWB);       \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
-      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                   \
-        bq[j][pl] = *reinterpret_cast<const bf16x8*>(Bx + pl * 32 + (wn * NT + j) * 32 * C::ROWB);       \
-    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                       \
-      _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                   \
-        if constexpr (ABL == 0 || ABL == 3) {                                                            \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][1], acc[i][j], 0, 0, 0);     \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][2], acc[i][j], 0, 0, 0);     \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bq[j][0], acc[i][j], 0, 0, 0);     \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                   \
+      f16x8 af[MT][2], bq[NT][2];                                                                        \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                     \
+        _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                 \
+          af[i][pl] = *reinterpret_cast<const f16x8*>(Ax + frag_off[pl][ks] + (wm * MT + i) * 32 * C::ROWB); \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                     \
+        _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                 \
+          bq[j][pl] = *reinterpret_cast<const f16x8*>(Bx + frag_off[pl][ks] + (wn * NT + j) * 32 * C::ROWB); \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                 \
+          if constexpr (ABL != 2) {                                                                      \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bq[j][1], acc[i][j], 0, 0, 0);    \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bq[j][0], acc[i][j], 0, 0, 0);    \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bq[j][0], acc[i][j], 0, 0, 0);    \
+          } else {                                                                                       \
+            asm volatile("" ::"v"(af[i][0]), "v"(af[i][1]), "v"(bq[j][0]), "v"(bq[j][1]));               \
+          }                                                                                              \
         }                                                                                                \
-        if constexpr (ABL != 2) {                                                                        \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][1], acc[i][j], 0, 0, 0);     \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][0], acc[i][j], 0, 0, 0);     \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][0], acc[i][j], 0, 0, 0);     \
-        } else {                                                                                         \
-          asm volatile("" ::"v"(af[i][0]), "v"(af[i][1]), "v"(af[i][2]), "v"(bq[j][0]), "v"(bq[j][1]), "v"(bq[j][2])); \
-        }                                                                                                \
-      }                                                                                                  \
+    }                                                                                                    \
   }
 
   // ---- K loop: NS stages, one barrier per K tile ----
   // prologue: tiles kt_begin .. kt_begin + NS - 2 into stages 0 .. NS - 2
-  ADVOC_X6D_ISSUE(0);
-  if constexpr (NS == 3) ADVOC_X6D_ISSUE(1);
+  ADVOC_H3_ISSUE(0);
+  if constexpr (NS == 3) ADVOC_H3_ISSUE(1);
 
   int kt = kt_begin;
   // NS iterations per trip so that stage indices are compile-time constants; a trip may overshoot kt_end by
@@ -247,13 +246,13 @@ __device__ __forceinline__ void gather_gemm_x6d_body(const GatherGemmParams& p) 
       // tile kt + u sits in stage u; the next tile to issue goes into stage (u + NS - 1) % NS, vacated by tile kt + u - 1
       wait_vmcnt<C::DMA_PER_TILE*(NS - 2)>();
       __builtin_amdgcn_s_barrier();
-      ADVOC_X6D_ISSUE((u + NS - 1) % NS);
-      if (ABL != 4 && kt + u < kt_end) ADVOC_X6D_COMPUTE(u);
+      ADVOC_H3_ISSUE((u + NS - 1) % NS);
+      if (ABL != 4 && kt + u < kt_end) ADVOC_H3_COMPUTE(u);
     }
     kt += NS;
   }
-#undef ADVOC_X6D_ISSUE
-#undef ADVOC_X6D_COMPUTE
+#undef ADVOC_H3_ISSUE
+#undef ADVOC_H3_COMPUTE
   // the overshoot DMAs still target LDS: drain them before the epilogue reuses it
   wait_vmcnt<0>();
   __syncthreads();
@@ -323,6 +322,8 @@ __device__ __forceinline__ void gather_gemm_x6d_body(const GatherGemmParams& p) 
   __syncthreads();
 
   const float gslope = act_slope(p.grad_act);
+  // undo the operands' power-of-two scaling (exact)
+  const float unscale = __uint_as_float(p.a_hdr[1]) * __uint_as_float(p.b_hdr[1]);
   constexpr int LDT = 36;
   float* T = smem + wave * (32 * LDT);
   const int trow = lane >> 3, tq = lane & 7;
@@ -347,7 +348,8 @@ __device__ __forceinline__ void gather_gemm_x6d_body(const GatherGemmParams& p) 
         if (pix < 0) continue;
         const int off = pix * d.c + ch;
         float4 v = *reinterpret_cast<const float4*>(T + row * LDT + 4 * tq);
-        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        v.x = fmaf(v.x, unscale, bias4.x); v.y = fmaf(v.y, unscale, bias4.y);
+        v.z = fmaf(v.z, unscale, bias4.z); v.w = fmaf(v.w, unscale, bias4.w);
         if (p.y_mask) {
           const uchar4 mk = *reinterpret_cast<const uchar4*>(p.y_mask + off);
           v.x *= mk.x * p.y_mask_scale; v.y *= mk.y * p.y_mask_scale;
@@ -385,42 +387,50 @@ __device__ __forceinline__ void gather_gemm_x6d_body(const GatherGemmParams& p) 
 }
 
 template <int MT, int NT, int NS>
-__global__ __launch_bounds__(256, 2) void gather_gemm_x6d_kernel(const GatherGemmParams p) {
-  gather_gemm_x6d_body<MT, NT, NS>(p);
+__global__ __launch_bounds__(256, 2) void gather_gemm_h3_kernel(const GatherGemmParams p) {
+  gather_gemm_h3_body<MT, NT, NS>(p);
 }
-// timing experiments only (ADVOC_X6D_ABLATE=1..4): 1 three of the six products, 2 no MFMAs (fragment reads kept),
-// 3 no DMA, 4 DMA only
+// timing experiments only (ADVOC_H3_ABLATE=2..4): 2 no MFMAs (fragment reads kept), 3 no DMA, 4 DMA only
 template <int MT, int NT, int NS, int ABL>
-__global__ __launch_bounds__(256, 2) void gather_gemm_x6d_abl_kernel(const GatherGemmParams p) {
-  gather_gemm_x6d_body<MT, NT, NS, ABL>(p);
+__global__ __launch_bounds__(256, 2) void gather_gemm_h3_abl_kernel(const GatherGemmParams p) {
+  gather_gemm_h3_body<MT, NT, NS, ABL>(p);
 }
 
 template <int MT, int NT, int NS>
-int launch_d(const GatherGemmParams& p, hipStream_t stream, const char** name_only, const TailPlan& tail,
-             float* tail_ws, int* tail_cnt) {
-  using C = DCfg<MT, NT, NS>;
+int launch_h(const GatherGemmParams& p, hipStream_t stream, const char** name_only, const TailPlan& tail,
+             float* tail_ws, int* tail_cnt, int ksplit) {
+  using C = HCfg<MT, NT, NS>;
   if (name_only) {
-    static const std::string name = std::string("gather_gemm_x6d_kernel<") + std::to_string(MT) + ", " +
+    static const std::string name = std::string("gather_gemm_h3_kernel<") + std::to_string(MT) + ", " +
                                     std::to_string(NT) + ", " + std::to_string(NS) + ">";
     *name_only = name.c_str();
     return ADVOC_OK;
   }
-  static const int abl = getenv("ADVOC_X6D_ABLATE") ? atoi(getenv("ADVOC_X6D_ABLATE")) : 0;
-  auto kern = gather_gemm_x6d_kernel<MT, NT, NS>;
-  if (NS == 2 && NT == 4) {   // experiments: one instance is enough
-    if (abl == 1) kern = gather_gemm_x6d_abl_kernel<MT, NT, NS, 1>;
-    if (abl == 2) kern = gather_gemm_x6d_abl_kernel<MT, NT, NS, 2>;
-    if (abl == 3) kern = gather_gemm_x6d_abl_kernel<MT, NT, NS, 3>;
-    if (abl == 4) kern = gather_gemm_x6d_abl_kernel<MT, NT, NS, 4>;
+  static const int abl = getenv("ADVOC_H3_ABLATE") ? atoi(getenv("ADVOC_H3_ABLATE")) : 0;
+  auto kern = gather_gemm_h3_kernel<MT, NT, NS>;
+  if (NS == 2 && MT == 2 && NT >= 2) {   // experiments: two instances are enough
+    if (abl == 2) kern = gather_gemm_h3_abl_kernel<MT, NT, NS, 2>;
+    if (abl == 3) kern = gather_gemm_h3_abl_kernel<MT, NT, NS, 3>;
+    if (abl == 4) kern = gather_gemm_h3_abl_kernel<MT, NT, NS, 4>;
   }
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
   if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   const int64_t gx = ceil_div(M, C::BM) * (p.n_total / C::BN);
   GatherGemmParams q = p;
-  dim3 grid((unsigned)gx, 1, (unsigned)p.nphase);
-  if (tail.split > 1 && tail_ws && tail_cnt) {
+  dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)p.nphase);
+  if (ksplit > 1) {
+    // partial sums meet in the destination with fp32 atomics: start from zero (logical region only: columns
+    // beyond out_w -- pitch padding -- stay untouched)
+    for (int i = 0; i < 2; ++i) {
+      const GemmDest& d = p.d[i];
+      if (d.p == nullptr || d.accum) continue;
+      hipError_t e = hipMemset2DAsync(d.p, sizeof(float) * (size_t)d.pitch * d.c, 0,
+                                      sizeof(float) * (size_t)p.out_w * d.c, (size_t)p.batch * p.out_h, stream);
+      if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    }
+  } else if (tail.split > 1 && tail_ws && tail_cnt) {
     q.tail_main = tail.main; q.tail_split = tail.split; q.tail_ws = tail_ws; q.tail_cnt = tail_cnt;
     grid = dim3((unsigned)(tail.main + tail.rem * tail.split), 1, 1);
   }
@@ -432,98 +442,125 @@ int launch_d(const GatherGemmParams& p, hipStream_t stream, const char** name_on
 
 struct Pick { int mt, nt, ns; };
 
-// Tile choice.  128 x 256 / 256 x 128 halve the L2 -> LDS traffic of one operand per flop; they need >= ~2 tiles
-// per CU to fill the chip.  Measured on MI355X (tools/layer_times.py), see DESIGN.md §4.
+// Tile choice (tools/micro/h3_sweep.py).  ADVOC_H3_TILE=1|2|3 forces 128x128 | 128x256 | 256x128,
+// ADVOC_H3_STAGES=2|3 the LDS stages.
 Pick pick_tile(const GatherGemmParams& p) {
   const Tuning& t = tuning();
   const int N = p.n_total;
-  const int64_t rows128 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * p.nphase;
-  Pick k = {2, 2, 3};
-  if (t.x6d_tile == 2 && N % 256 == 0) k = {2, 4, 2};
-  else if (t.x6d_tile == 3) k = {4, 2, 2};
-  else if (t.x6d_tile == 0) {
-    if (N % 256 == 0 && rows128 * (N / 256) >= 512) k = {2, 4, 2};
-  }
-  if (t.x6d_stages == 2 || t.x6d_stages == 3) k.ns = t.x6d_stages;
+  Pick k = {2, 2, 2};
+  if (N % 128 != 0 || t.h3_tile == 4) k = {2, 1, 2};      // 64-column tiles (48 KiB: three workgroups per CU)
+  else if (t.h3_tile == 2 && N % 256 == 0) k = {2, 4, 2};
+  else if (t.h3_tile == 3) k = {4, 2, 2};
+  if (t.h3_stages == 2 || t.h3_stages == 3) k.ns = t.h3_stages;
+  if (k.ns == 3 && k.mt * k.nt > 4) k.ns = 2;       // 3 x 48 KiB + would not leave room: 128x256 runs two stages
   return k;
 }
 
-}  // namespace
-
-// Workspace layout of one launch: [weight image][image of source 0][image of source 1][tail partials]
-int64_t x6d_round(int64_t b) { return (b + 255) / 256 * 256; }
-
-bool x6d_eligible(const GatherGemmParams& p) {
-  const Tuning& t = tuning();
-  if (!t.x6d || !t.igemm_x6) return false;
-  const int ktot = p.c0 + p.c1, N = p.n_total;
-  if (ktot % 16 || p.c0 % 16 || p.c1 % 16 || N % 128 || p.n_split % 32) return false;
-  if (p.n_valid && p.n_valid != p.n_total) return false;
-  const int64_t rows128 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * p.nphase;
-  if (rows128 * (N / 128) < t.x6d_min_tiles) return false;
-  // 32-bit byte offsets inside the kernel: three planes of either source, and of the weights, below 2 GiB
-  const int64_t lim = 0x7fffffffLL;
-  const int64_t e0 = (int64_t)p.batch * p.a_h * p.a0_pitch * p.c0, e1 = (int64_t)p.batch * p.a_h * p.a1_pitch * p.c1;
-  if (6 * e0 > lim || 6 * e1 > lim) return false;
+int weight_taps_of(const GatherGemmParams& p) {
   int taps = 0;
   for (int ph = 0; ph < p.nphase; ++ph)
     for (int i = 0; i < p.ntaps; ++i) taps = (p.tap[ph][i] >> 16) + 1 > taps ? (p.tap[ph][i] >> 16) + 1 : taps;
-  if ((int64_t)6 * taps * N * ktot > lim) return false;
+  return taps;
+}
+
+int64_t round256(int64_t b) { return (b + 255) / 256 * 256; }
+
+}  // namespace
+
+bool h3_eligible(const GatherGemmParams& p) {
+  const Tuning& t = tuning();
+  if (!t.h3 || !t.igemm_x6) return false;
+  const int ktot = p.c0 + p.c1, N = p.n_total;
+  if (ktot % 32 || p.c0 % 32 || p.c1 % 32 || N % 64 || p.n_split % 32) return false;
+  if (p.n_valid && p.n_valid != p.n_total) return false;
+  const int64_t rows128 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * p.nphase;
+  if (rows128 * ((N + 127) / 128) < t.h3_min_tiles) return false;
+  // 32-bit byte offsets inside the kernel: either source image, and the weight image, below 2 GiB
+  const int64_t lim = 0x7fffffffLL;
+  const int64_t e0 = (int64_t)p.batch * p.a_h * p.a0_pitch * p.c0, e1 = (int64_t)p.batch * p.a_h * p.a1_pitch * p.c1;
+  if (4 * e0 > lim || 4 * e1 > lim) return false;
+  if ((int64_t)4 * weight_taps_of(p) * N * ktot > lim) return false;
   return true;
 }
 
-int launch_gather_gemm_x6d(const GatherGemmParams& p_in, bool b_kn, hipStream_t stream, const char** name_only,
-                           float* scratch, int64_t scratch_bytes, int64_t* scratch_query) {
-  if (!x6d_eligible(p_in)) return ADVOC_ERR_UNSUPPORTED;
+// Workspace layout of one launch: [operand headers 256 B][weight image][image of source 0][image of source 1]
+// [tail partials]
+int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t stream, const char** name_only,
+                          float* scratch, int64_t scratch_bytes, int64_t* scratch_query) {
+  if (!h3_eligible(p_in)) return ADVOC_ERR_UNSUPPORTED;
   GatherGemmParams p = p_in;
   const int ktot = p.c0 + p.c1, N = p.n_total;
-  int taps = 0;
-  for (int ph = 0; ph < p.nphase; ++ph)
-    for (int i = 0; i < p.ntaps; ++i) taps = (p.tap[ph][i] >> 16) + 1 > taps ? (p.tap[ph][i] >> 16) + 1 : taps;
+  const int taps = weight_taps_of(p);
   const int64_t e0 = (int64_t)p.batch * p.a_h * p.a0_pitch * p.c0, e1 = (int64_t)p.batch * p.a_h * p.a1_pitch * p.c1;
-  const int64_t wq_bytes = x6d_round((int64_t)6 * taps * N * ktot);
-  const int64_t i0_bytes = x6d_round(6 * e0), i1_bytes = x6d_round(6 * e1);
+  const int64_t hdr_bytes = 256;
+  const int64_t wq_bytes = round256((int64_t)4 * taps * N * ktot);
+  const int64_t i0_bytes = round256(4 * e0), i1_bytes = round256(4 * e1);
   const Pick k = pick_tile(p);
   const int BM = 64 * k.mt, BN = 64 * k.nt;
   const int64_t tiles = ceil_div((int64_t)p.batch * p.gh * p.gw, BM) * (N / BN) * p.nphase;
-  const int nkt = ktot / 16 * p.ntaps;
-  const TailPlan tail = plan_tail(tiles, nkt);
+  const int nkt = ktot / 32 * p.ntaps;
+  // Small pixel grids with deep contractions (encoder_5.., decoder_5.. and their gradients) would leave CUs idle:
+  // split K until the launch holds ~4 workgroups per CU, keeping >= 8 K tiles per slice (igemm.hip does the same)
+  int ksplit = 1;
+  if (tiles < 512 && tuning().igemm_splitk) {
+    ksplit = (int)ceil_div((int64_t)1024, tiles);
+    if (ksplit > nkt / 8) ksplit = nkt / 8;
+    if (ksplit > 16) ksplit = 16;
+    if (ksplit < 1) ksplit = 1;
+  }
+  TailPlan tail;
+  if (ksplit == 1) tail = plan_tail(tiles, nkt);
   const int64_t tail_bytes = (int64_t)sizeof(float) * tail.rem * tail.split * BM * BN;
-  const int64_t need = wq_bytes + i0_bytes + i1_bytes;
+  const int64_t need = hdr_bytes + wq_bytes + i0_bytes + i1_bytes;
   if (scratch_query) { *scratch_query = need + tail_bytes; return ADVOC_OK; }
   if (!scratch || scratch_bytes < need) return ADVOC_ERR_UNSUPPORTED;
   p.k_order = tuning().igemm_korder >= 0 ? tuning().igemm_korder : 1;
   char* ws = reinterpret_cast<char*>(scratch);
-  p.wq = reinterpret_cast<const uint16_t*>(ws);
+  unsigned* hdr_a = reinterpret_cast<unsigned*>(ws);
+  unsigned* hdr_b = hdr_a + 2;
+  uint16_t* wq = reinterpret_cast<uint16_t*>(ws + hdr_bytes);
+  uint16_t* img0 = reinterpret_cast<uint16_t*>(ws + hdr_bytes + wq_bytes);
+  uint16_t* img1 = reinterpret_cast<uint16_t*>(ws + hdr_bytes + wq_bytes + i0_bytes);
+  p.a_hdr = hdr_a; p.b_hdr = hdr_b;
+  p.wq = wq;
   p.wq_taps = taps;
-  p.a0_img = reinterpret_cast<const uint16_t*>(ws + wq_bytes);
-  p.a1_img = e1 ? reinterpret_cast<const uint16_t*>(ws + wq_bytes + i0_bytes) : nullptr;
-  p.a0_img_bytes = (int)(6 * e0);
-  p.a1_img_bytes = (int)(6 * e1);
+  p.a0_img = img0;
+  p.a1_img = e1 ? img1 : nullptr;
+  p.a0_img_bytes = (int)(4 * e0);
+  p.a1_img_bytes = (int)(4 * e1);
   float* tail_ws = scratch_bytes >= need + tail_bytes ? reinterpret_cast<float*>(ws + need) : nullptr;
   int* tail_cnt = nullptr;
-  if (!name_only && tuning().x6d_skip_prep) {
+  if (!name_only && tuning().h3_skip_prep) {
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
   } else if (!name_only) {
-    int rc = launch_split_weights(p.w, reinterpret_cast<uint16_t*>(ws), taps, N, N, ktot, b_kn, true, stream);
+    hipError_t e = hipMemsetAsync(hdr_a, 0, 16, stream);
+    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    int rc = launch_pair_weights(p.w, wq, taps, N, ktot, b_kn, hdr_b, stream);
     if (rc != ADVOC_OK) return rc;
-    rc = launch_split_image(p.a0, reinterpret_cast<uint16_t*>(ws + wq_bytes), e0, p.c0, p.in_scale, p.in_shift,
-                            p.in_act, p.a_mask, p.a_mask_scale, stream);
+    // one scale for the whole A operand: the largest magnitude over both sources of a channel concat
+    rc = launch_amax(p.a0, e0, p.c0, p.in_scale, p.in_shift, p.in_act, p.a_mask, p.a_mask_scale, hdr_a, stream);
+    if (rc != ADVOC_OK) return rc;
+    const float* sc1 = p.in_scale ? p.in_scale + p.c0 : nullptr;
+    const float* sh1 = p.in_shift ? p.in_shift + p.c0 : nullptr;
+    if (e1) {
+      rc = launch_amax(p.a1, e1, p.c1, sc1, sh1, p.in_act, nullptr, 0.f, hdr_a, stream);
+      if (rc != ADVOC_OK) return rc;
+    }
+    rc = launch_pair_image(p.a0, img0, e0, p.c0, p.in_scale, p.in_shift, p.in_act, p.a_mask, p.a_mask_scale, hdr_a,
+                           stream);
     if (rc != ADVOC_OK) return rc;
     if (e1) {
-      rc = launch_split_image(p.a1, reinterpret_cast<uint16_t*>(ws + wq_bytes + i0_bytes), e1, p.c1,
-                              p.in_scale ? p.in_scale + p.c0 : nullptr, p.in_shift ? p.in_shift + p.c0 : nullptr,
-                              p.in_act, nullptr, 0.f, stream);
+      rc = launch_pair_image(p.a1, img1, e1, p.c1, sc1, sh1, p.in_act, nullptr, 0.f, hdr_a, stream);
       if (rc != ADVOC_OK) return rc;
     }
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
   }
-  if (k.mt == 2 && k.nt == 2 && k.ns == 3) return launch_d<2, 2, 3>(p, stream, name_only, tail, tail_ws, tail_cnt);
-  if (k.mt == 2 && k.nt == 2) return launch_d<2, 2, 2>(p, stream, name_only, tail, tail_ws, tail_cnt);
-  if (k.mt == 2 && k.nt == 4 && k.ns == 3) return launch_d<2, 4, 3>(p, stream, name_only, tail, tail_ws, tail_cnt);
-  if (k.mt == 2 && k.nt == 4) return launch_d<2, 4, 2>(p, stream, name_only, tail, tail_ws, tail_cnt);
-  if (k.mt == 4 && k.nt == 2 && k.ns == 3) return launch_d<4, 2, 3>(p, stream, name_only, tail, tail_ws, tail_cnt);
-  return launch_d<4, 2, 2>(p, stream, name_only, tail, tail_ws, tail_cnt);
+  if (k.mt == 2 && k.nt == 1 && k.ns == 3) return launch_h<2, 1, 3>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
+  if (k.mt == 2 && k.nt == 1) return launch_h<2, 1, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
+  if (k.mt == 2 && k.nt == 2 && k.ns == 3) return launch_h<2, 2, 3>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
+  if (k.mt == 2 && k.nt == 2) return launch_h<2, 2, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
+  if (k.mt == 2 && k.nt == 4) return launch_h<2, 4, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
+  return launch_h<4, 2, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
 }
 
 }  // namespace advoc

@@ -1,79 +1,161 @@
-// Operand images of the split-bf16 matrix path: an fp32 tensor written ONCE as three bf16 planes
-// (x = x0 + x1 + x2 exactly, split3 in x6.h), so that the GEMM kernels (igemm_x6d.hip) stream bf16 operands
-// straight into LDS (buffer_load ... lds) instead of splitting every element again for every tap and every
-// column tile that reads it.
+// Operand images of the split matrix paths: an fp32 tensor rewritten ONCE in the form the matrix cores consume,
+// so that the GEMM kernels stream operands straight into LDS instead of transforming every element again for
+// every tap and every column tile that reads it.
 //
-//   activation image  [pixel (n, h, w_pitch)][c / 16][plane][16]   of  act(scale * x + shift) * mask * mask_scale
-//                     -- exactly the value the fp32 loaders of igemm.hip feed the matrix cores, i.e. the fused
-//                     input transform of a layer of models/advoc/advoc_model.py (lrelu :86-87,109; relu :138,155;
-//                     the batch-norm affine :77-84; dropout behind it :144-149)
-//   weight image      [tap][n][k / 16][plane][16]                  contraction axis innermost, from either kernel layout
-//                     ([kh,kw,ci,co] of tf.layers.conv2d, [kh,kw,co,ci] of conv2d_transpose)
-// The unit of both is the 96-byte K SLICE: the three planes of 16 consecutive contraction slots side by side, which is
-// what one row of a GEMM K tile consumes.  (A plane-major layout was built first: one K tile then touched three
-// 32-byte pieces in three distant cache lines per row, 3x the L1 / TA line traffic and a 4x longer L2 reuse distance
-// -- 25-28 % L2 misses against 2 % for the fp32 loader, and slower than it.)
+// (1) fp16 pair images (igemm_h3.hip).  x * 2^s = h0 + h1 + e with h0, h1 fp16 (round to nearest) and
+//     |e| <= 2^-22 |x 2^s|; s is ONE power of two per GEMM operand, chosen from the operand's largest magnitude so
+//     that it lands in [2^13, 2^14) (fp16 overflows at 65504; elements more than 2^17 below the largest lose
+//     relative precision only: their absolute error stays <= 2^-39 of the largest).  An fp32 product a b is then
+//     accumulated as THREE fp16 MFMA products a0 b1 + a1 b0 + a0 b0 with fp32 accumulation (fp16 x fp16 products
+//     are exact in fp32; the dropped a1 b1 is <= 2^-22 of the product) and the accumulator is multiplied by the
+//     exact 2^-(sa + sb) at the end: fp32-level error (measured at or below the fp32 MFMA chain against float64,
+//     tools/micro/h3_numerics.py, tests/test_hip_conv.py) at 3 / 16 of the fp32 MFMA cost.
+//       activation image  [pixel (n, h, w_pitch)][c / 32][plane][32]  of  act(scale * x + shift) * mask * mask_scale
+//                         -- exactly the value the fp32 loaders of igemm.hip feed the matrix cores, i.e. the
+//                         fused input transform of a layer of models/advoc/advoc_model.py (lrelu :86-87,109; relu
+//                         :138,155; the batch-norm affine :77-84; dropout behind it :144-149)
+//       weight image      [tap][n][k / 32][plane][32]                 contraction axis innermost, from either
+//                         kernel layout ([kh,kw,ci,co] of tf.layers.conv2d, [kh,kw,co,ci] of conv2d_transpose)
+//     The unit of both is the 128-byte K SLICE: the two planes of 32 consecutive contraction slots side by side
+//     = ONE cache line = what one row of a GEMM K tile consumes.  That is the point of the layout: the L2 serves
+//     a fixed number of line requests per clock, and a loader that uses 32-96 bytes of every 128-byte line it asks
+//     for (fp32 rows of 16 channels, separate bf16 planes, 96-byte slices -- all three were built and measured)
+//     saturates the L2 request rate at a third to a half of the useful bandwidth.
+// (2) bf16 triple weights for the register-split kernels of igemm.hip (x6.h), plane-major.
 //
-// Both kernels are HBM-bound elementwise passes: 4 B read + 6 B written per element.
+// All kernels here are HBM-bound elementwise passes.
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 #include "x6.h"
 
 namespace advoc {
 namespace {
 
-// one thread = 8 consecutive channels of one pixel (c % 8 == 0): two float4 loads, three 16-byte stores
-__global__ __launch_bounds__(256) void split_image_kernel(const float* __restrict__ x, uint16_t* __restrict__ img,
-                                                          int64_t n8, int c, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, float slope,
-                                                          const uint8_t* __restrict__ mask, float mask_scale) {
+__host__ __device__ __forceinline__ float slope_of(int act) {
+  return act == ADVOC_ACT_LRELU02 ? 0.2f : (act == ADVOC_ACT_RELU ? 0.f : 1.f);
+}
+
+// the 8 transformed values starting at element e (channels innermost, c % 8 == 0)
+__device__ __forceinline__ void load8(const float* __restrict__ x, int64_t e, int c, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, float slope, const uint8_t* __restrict__ mask,
+                                      float mask_scale, float v[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(x + e);
+  const float4 b = *reinterpret_cast<const float4*>(x + e + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  if (scale) {
+    const int ch = (int)(e % c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], scale[ch + j], shift[ch + j]);
+  }
+  if (slope != 1.f) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], slope * v[j]);
+  }
+  if (mask) {
+    const uint2 mk = *reinterpret_cast<const uint2*>(mask + e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] *= (float)((mk.x >> (8 * j)) & 0xffu) * mask_scale;
+      v[4 + j] *= (float)((mk.y >> (8 * j)) & 0xffu) * mask_scale;
+    }
+  }
+}
+
+// amax[0] = max(amax[0], max |transformed x|) as the bit pattern of a non-negative float (orders like an unsigned)
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n8, int c,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   float slope, const uint8_t* __restrict__ mask, float mask_scale,
+                                                   unsigned* __restrict__ amax) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    float v[8];
+    load8(x, i * 8, c, scale, shift, slope, mask, mask_scale, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f) atomicMax(amax, __float_as_uint(m));
+  }
+}
+
+// weights: plain max |w| (any layout)
+__global__ __launch_bounds__(256) void amax_flat_kernel(const float* __restrict__ w, int64_t n, unsigned* __restrict__ amax) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f) atomicMax(amax, __float_as_uint(m));
+  }
+}
+
+// power of two that takes the largest magnitude into [2^13, 2^14); 1 for an all-zero (or non-finite) operand
+__device__ __forceinline__ float up_scale(unsigned amax_bits) {
+  const int e = (int)((amax_bits >> 23) & 0xffu);           // biased exponent of the largest magnitude
+  if (e == 0 || e == 255) return 1.f;
+  int s = 13 - (e - 127);
+  s = s > 120 ? 120 : (s < -120 ? -120 : s);
+  return __uint_as_float((unsigned)(s + 127) << 23);
+}
+
+// one thread = 8 consecutive channels of one pixel: two float4 loads, two 16-byte stores.
+// hdr[0] = amax bits (input), hdr[1] = 2^-s as float bits (output, written by the first thread).
+__global__ __launch_bounds__(256) void pair_image_kernel(const float* __restrict__ x, __half* __restrict__ img,
+                                                         int64_t n8, int c, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float slope,
+                                                         const uint8_t* __restrict__ mask, float mask_scale,
+                                                         unsigned* __restrict__ hdr) {
+  const float up = up_scale(hdr[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = __float_as_uint(1.f / up);     // exact: a power of two
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
     const int64_t e = i * 8;
     float v[8];
-    const float4 a = *reinterpret_cast<const float4*>(x + e);
-    const float4 b = *reinterpret_cast<const float4*>(x + e + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    if (scale) {
-      const int ch = (int)(e % c);
+    load8(x, e, c, scale, shift, slope, mask, mask_scale, v);
+    __half2 h0[4], h1[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], scale[ch + j], shift[ch + j]);
+    for (int j = 0; j < 4; ++j) {
+      const float a = v[2 * j] * up, b = v[2 * j + 1] * up;
+      const __half a0 = __float2half_rn(a), b0 = __float2half_rn(b);
+      h0[j] = __halves2half2(a0, b0);
+      h1[j] = __halves2half2(__float2half_rn(a - __half2float(a0)), __float2half_rn(b - __half2float(b0)));
     }
-    if (slope != 1.f) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], slope * v[j]);
-    }
-    if (mask) {
-      const uint2 mk = *reinterpret_cast<const uint2*>(mask + e);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] *= (float)((mk.x >> (8 * j)) & 0xffu) * mask_scale;
-        v[4 + j] *= (float)((mk.y >> (8 * j)) & 0xffu) * mask_scale;
-      }
-    }
-    unsigned h0[8], h1[8], h2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) split3(v[j], h0[j], h1[j], h2[j]);
-    // element e = 16 s + 8 half + j  ->  slice s (48 uint16), plane pl at 16 pl, half at 8 half
-    uint16_t* o = img + (e >> 4) * 48 + ((e >> 3) & 1) * 8;
-    *reinterpret_cast<uint4*>(o) = make_uint4(pack_hi16(h0[0], h0[1]), pack_hi16(h0[2], h0[3]),
-                                              pack_hi16(h0[4], h0[5]), pack_hi16(h0[6], h0[7]));
-    *reinterpret_cast<uint4*>(o + 16) = make_uint4(pack_hi16(h1[0], h1[1]), pack_hi16(h1[2], h1[3]),
-                                                   pack_hi16(h1[4], h1[5]), pack_hi16(h1[6], h1[7]));
-    *reinterpret_cast<uint4*>(o + 32) = make_uint4(pack_hi16(h2[0], h2[1]), pack_hi16(h2[2], h2[3]),
-                                                   pack_hi16(h2[4], h2[5]), pack_hi16(h2[6], h2[7]));
+    // element e = 32 s + 8 q + j  ->  slice s (64 halves), plane pl at 32 pl, octet q at 8 q
+    __half* o = img + (e >> 5) * 64 + ((e >> 3) & 3) * 8;
+    *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(h0);
+    *reinterpret_cast<uint4*>(o + 32) = *reinterpret_cast<const uint4*>(h1);
   }
 }
 
-// One workgroup = one 32 (k) x 32 (n) tile of one tap, through LDS so that both the fp32 reads (along n
-// for the [tap][k][n] layout, along k for [tap][n][k]) and the bf16 writes (along k) are contiguous.
-// sliced != 0: [tap][n][k / 16][plane][16] (igemm_x6d.hip); else [plane][tap][n][k] (register-split path of igemm.hip)
+// One workgroup = one 32 (k) x 32 (n) tile of one tap, through LDS so that both the fp32 reads (along n for the
+// [tap][k][n] layout, along k for [tap][n][k]) and the 16-bit writes (along k) are contiguous.
+//   pairs == 0: bf16 triple, wq[plane][tap][n_total][ktot]                 (register-split path of igemm.hip)
+//   pairs != 0: fp16 pair,   wq[tap][n_total][ktot / 32][plane][32], scaled by the power of two from hdr[0]
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ wq,
                                                             int taps, int n_total, int n_valid, int ktot, int b_kn,
-                                                            int sliced) {
+                                                            int pairs, unsigned* __restrict__ hdr) {
   __shared__ float tile[32][33];
   const int tk = (ktot + 31) / 32, tn = (n_total + 31) / 32;
   const int64_t plane = (int64_t)taps * n_total * ktot;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  float up = 1.f;
+  if (pairs) {
+    up = up_scale(hdr[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = __float_as_uint(1.f / up);
+  }
   for (int b = blockIdx.x; b < taps * tk * tn; b += gridDim.x) {
     const int t = b / (tk * tn), r = b - t * (tk * tn);
     const int k0 = (r / tn) * 32, n0 = (r % tn) * 32;
@@ -96,15 +178,18 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     for (int i = 0; i < 4; ++i) {
       const int n = n0 + ty + 8 * i, k = k0 + tx;
       if (n < n_total && k < ktot) {
-        unsigned h0, h1, h2;
-        split3(tile[tx][ty + 8 * i], h0, h1, h2);
+        const float x = tile[tx][ty + 8 * i];
         const int64_t o = ((int64_t)t * n_total + n) * ktot + k;
-        if (sliced) {
-          uint16_t* q = wq + (o >> 4) * 48 + (o & 15);     // ktot % 16 == 0: slices never straddle rows
-          q[0] = (uint16_t)(h0 >> 16);
-          q[16] = (uint16_t)(h1 >> 16);
-          q[32] = (uint16_t)(h2 >> 16);
+        if (pairs) {
+          const float a = x * up;
+          const __half a0 = __float2half_rn(a);
+          const __half a1 = __float2half_rn(a - __half2float(a0));
+          uint16_t* q = wq + (o >> 5) * 64 + (o & 31);     // ktot % 32 == 0: slices never straddle rows
+          q[0] = __half_as_ushort(a0);
+          q[32] = __half_as_ushort(a1);
         } else {
+          unsigned h0, h1, h2;
+          split3(x, h0, h1, h2);
           wq[o] = (uint16_t)(h0 >> 16);
           wq[plane + o] = (uint16_t)(h1 >> 16);
           wq[2 * plane + o] = (uint16_t)(h2 >> 16);
@@ -115,32 +200,62 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
+int grid_for(int64_t items, int per_block) {
+  int64_t blocks = ceil_div(items, per_block);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  return (int)(blocks < 1 ? 1 : blocks);
+}
+
 }  // namespace
 
-int launch_split_image(const float* x, uint16_t* img, int64_t elems, int c, const float* scale, const float* shift,
-                       int act, const uint8_t* mask, float mask_scale, hipStream_t stream) {
-  if (!x || !img) return ADVOC_ERR_NULL;
+int launch_amax(const float* x, int64_t elems, int c, const float* scale, const float* shift, int act,
+                const uint8_t* mask, float mask_scale, unsigned* amax, hipStream_t stream) {
+  if (!x || !amax) return ADVOC_ERR_NULL;
   if (elems <= 0) return ADVOC_OK;
-  if (c % 16 || elems % 16) return ADVOC_ERR_UNSUPPORTED;
-  const int64_t n8 = elems / 8;
-  int64_t blocks = ceil_div(n8, 256);
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  const float slope = act == ADVOC_ACT_LRELU02 ? 0.2f : (act == ADVOC_ACT_RELU ? 0.f : 1.f);
+  if (c % 8 || elems % 8) return ADVOC_ERR_UNSUPPORTED;
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(split_image_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, img, n8, c, scale, shift,
-                     slope, mask, mask_scale);
+  hipLaunchKernelGGL(amax_kernel, dim3(grid_for(elems / 8, 256 * 4)), dim3(256), 0, stream, x, elems / 8, c, scale,
+                     shift, slope_of(act), mask, mask_scale, amax);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+int launch_pair_image(const float* x, uint16_t* img, int64_t elems, int c, const float* scale, const float* shift,
+                      int act, const uint8_t* mask, float mask_scale, unsigned* hdr, hipStream_t stream) {
+  if (!x || !img || !hdr) return ADVOC_ERR_NULL;
+  if (elems <= 0) return ADVOC_OK;
+  if (c % 32 || elems % 32) return ADVOC_ERR_UNSUPPORTED;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(pair_image_kernel, dim3(grid_for(elems / 8, 256)), dim3(256), 0, stream, x,
+                     reinterpret_cast<__half*>(img), elems / 8, c, scale, shift, slope_of(act), mask, mask_scale, hdr);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }
 
 int launch_split_weights(const float* w, uint16_t* wq, int taps, int n_total, int n_valid, int ktot, bool b_kn,
-                         bool sliced, hipStream_t stream) {
-  if (sliced && ktot % 16) return ADVOC_ERR_UNSUPPORTED;
+                         hipStream_t stream) {
   int64_t blocks = (int64_t)taps * ((ktot + 31) / 32) * ((n_total + 31) / 32);
   if (blocks > 4096) blocks = 4096;
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, wq, taps, n_total,
-                     n_valid, ktot, b_kn ? 1 : 0, sliced ? 1 : 0);
+                     n_valid, ktot, b_kn ? 1 : 0, 0, (unsigned*)nullptr);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+int launch_pair_weights(const float* w, uint16_t* wq, int taps, int n_total, int ktot, bool b_kn, unsigned* hdr,
+                        hipStream_t stream) {
+  if (!w || !wq || !hdr) return ADVOC_ERR_NULL;
+  if (ktot % 32) return ADVOC_ERR_UNSUPPORTED;
+  const int64_t n = (int64_t)taps * n_total * ktot;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(amax_flat_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, stream, w, n, hdr);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  int64_t blocks = (int64_t)taps * (ktot / 32) * ((n_total + 31) / 32);
+  if (blocks > 4096) blocks = 4096;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, wq, taps, n_total,
+                     n_total, ktot, b_kn ? 1 : 0, 1, hdr);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }

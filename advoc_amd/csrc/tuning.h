@@ -15,11 +15,11 @@ struct Tuning {
   int igemm_tile;       // ADVOC_IGEMM_TILE     1..4: force an fp32 tile
   int igemm_korder;     // ADVOC_IGEMM_KORDER   0 | 1, -1: per-layer rule
   int wgrad_x6;         // ADVOC_WGRAD_X6       0: fp32 weight-gradient kernels; 2: also the 128x64 split tile
-  int x6d;              // ADVOC_X6D            0: no operand-image kernels (register-split path instead)
-  int x6d_tile;         // ADVOC_X6D_TILE       1: 128x128, 2: 128x256, 3: 256x128 forced
-  int x6d_stages;       // ADVOC_X6D_STAGES     2 | 3 LDS stages forced
-  int x6d_skip_prep;    // ADVOC_X6D_SKIP_PREP  1: (micro-benchmarks only) reuse the images already in the workspace
-  int x6d_min_tiles;    // ADVOC_X6D_MIN_TILES  smallest launch (128-row tiles) that takes the image path
+  int h3;               // ADVOC_H3             0: no operand-image kernels (register-split path instead)
+  int h3_tile;          // ADVOC_H3_TILE        1: 128x128, 2: 128x256, 3: 256x128, 4: 128x64 forced
+  int h3_stages;        // ADVOC_H3_STAGES      2 | 3 LDS stages forced
+  int h3_skip_prep;     // ADVOC_H3_SKIP_PREP   1: (micro-benchmarks only) reuse the images already in the workspace
+  int h3_min_tiles;     // ADVOC_H3_MIN_TILES   smallest launch (128-row x 128-column tiles) that takes the image path
 };
 
 const Tuning& tuning();

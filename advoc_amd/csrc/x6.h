@@ -24,13 +24,22 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) {
 }
 
 // image.hip
-// act(scale * x + shift) * mask * mask_scale of `elems` fp32 values (channels innermost, c % 16 == 0) as 96-byte
-// K slices: img[elems / 16][plane][16] bf16.
-int launch_split_image(const float* x, uint16_t* img, int64_t elems, int c, const float* scale, const float* shift,
-                       int act, const uint8_t* mask, float mask_scale, hipStream_t stream);
-// weights [tap][k][n] (b_kn) or [tap][n][k] -> wq[plane][tap][n_total][ktot] or, sliced, wq[tap][n_total][ktot / 16]
-// [plane][16]; zeros for n >= n_valid
+// ---- fp16 pair images (igemm_h3.hip): see image.hip for the arithmetic ----
+// hdr: two words per GEMM operand in device memory: [0] bit pattern of the largest |value| (zero it, then run
+// launch_amax over every source of the operand), [1] the factor 2^-s that undoes the operand's scaling (written by
+// the image kernels, read by the GEMM epilogue).
+int launch_amax(const float* x, int64_t elems, int c, const float* scale, const float* shift, int act,
+                const uint8_t* mask, float mask_scale, unsigned* amax, hipStream_t stream);
+// act(scale * x + shift) * mask * mask_scale of `elems` fp32 values (channels innermost, c % 32 == 0) as 128-byte
+// K slices img[elems / 32][plane][32] fp16, scaled by the power of two derived from hdr[0]
+int launch_pair_image(const float* x, uint16_t* img, int64_t elems, int c, const float* scale, const float* shift,
+                      int act, const uint8_t* mask, float mask_scale, unsigned* hdr, hipStream_t stream);
+// weights [tap][k][n] (b_kn) or [tap][n][k] -> wq[tap][n_total][ktot / 32][plane][32] fp16 (amax pass included;
+// hdr[0] must be zero on entry)
+int launch_pair_weights(const float* w, uint16_t* wq, int taps, int n_total, int ktot, bool b_kn, unsigned* hdr,
+                        hipStream_t stream);
+// ---- bf16 triple weights (register-split kernels of igemm.hip): wq[plane][tap][n_total][ktot], zeros for n >= n_valid
 int launch_split_weights(const float* w, uint16_t* wq, int taps, int n_total, int n_valid, int ktot, bool b_kn,
-                         bool sliced, hipStream_t stream);
+                         hipStream_t stream);
 
 }  // namespace advoc

@@ -82,18 +82,19 @@ def _frames(x, start, count, length, hop):
 
 
 class _FieldView(object):
-  """One field of the pipeline's output.  The reference returns both tensors from ONE iterator
-  `get_next` (loader.py:209-216), so a `sess.run([x_feats, x_audio])` fetches a PAIRED batch: the two
-  views therefore share batches -- the k-th `next()` of either view returns its field of the k-th batch
-  (a view that runs ahead pulls the new batch, the other one then reads the same batch)."""
+  """One field of the pipeline's output.  The reference returns both tensors from ONE iterator `get_next`
+  (loader.py:209-216), so a `sess.run([x_feats, x_audio])` fetches a PAIRED batch: the two views therefore share
+  the current batch -- a view's `next()` returns its field of the current batch if it has not read that batch yet,
+  otherwise it pulls a new one (which the other view then reads too).  `f = feats.next(); a = audio.next()` is a
+  pair; a loop over one view alone gets a fresh batch per call, like repeated `sess.run` of one tensor."""
 
   def __init__(self, pipe, index):
     self._pipe, self._index = pipe, index
-    self._served = 0
+    self._seen = -1          # serial number of the last batch this view returned
 
   def next(self):
-    batch = self._pipe._view_batch(self._served)
-    self._served += 1
+    serial, batch = self._pipe._view_batch(self._seen)
+    self._seen = serial
     return batch[self._index]
 
   __next__ = next
@@ -131,7 +132,7 @@ class BatchPipeline(object):
     # slice offsets and shuffle-buffer slots -- one shared generator would interleave non-deterministically
     self.rng = np.random.RandomState(seed)
     self._order_rng = np.random.RandomState(None if seed is None else (int(seed) * 2654435761 + 97) % (2 ** 32))
-    self._view_cache = collections.deque()     # (index, batch) pairs not yet read by both field views
+    self._view_cur = None       # (serial, batch) the field views share
     self._view_next = 0
     self._examples = self._example_stream()
     self._buffer = []
@@ -256,23 +257,13 @@ class BatchPipeline(object):
 
   __next__ = next
 
-  def _view_batch(self, k):
-    """k-th batch as seen by the field views (pulled on first request, dropped once both have read it)."""
-    while self._view_next <= k:
-      self._view_cache.append([self._view_next, self.next(), 0])
+  def _view_batch(self, seen):
+    """(serial, batch) for a field view that last returned batch `seen`: the current batch if it is newer, else a
+    freshly pulled one."""
+    if self._view_cur is None or self._view_cur[0] <= seen:
+      self._view_cur = (self._view_next, self.next())
       self._view_next += 1
-    for entry in self._view_cache:
-      if entry[0] == k:
-        entry[2] += 1
-        batch = entry[1]
-        break
-    else:
-      raise RuntimeError('batch %d was already read by both field views' % k)
-    while self._view_cache and self._view_cache[0][2] >= 2:
-      self._view_cache.popleft()
-    while len(self._view_cache) > 4:           # a caller that only ever reads one field: keep memory bounded
-      self._view_cache.popleft()
-    return batch
+    return self._view_cur
 
   def __iter__(self):
     # unpacking `feats, audio = pipeline` yields the two field views

@@ -217,10 +217,10 @@ def test_layer_split_bf16_path(hip, case, hipenv):
     return [L.kernel_name(d) for d in range(3)], y, dx0[:, :, :c['in_w']].clone(), dw
 
   def split(n):
-    return n.endswith(', true>') or 'x6d' in n
-  hipenv(ADVOC_X6D=0)                                               # register-split kernels (igemm.hip, wgrad.hip)
+    return n.endswith(', true>') or 'h3' in n
+  hipenv(ADVOC_H3=0)                                                # register-split kernels (igemm.hip, wgrad.hip)
   names, y, dx, dw = run()
-  assert all(split(n) and 'x6d' not in n for n in names), names    # the split kernels are the ones that ran
+  assert all(split(n) and 'h3' not in n for n in names), names     # the split kernels are the ones that ran
   hipenv(ADVOC_IGEMM_X6=0, ADVOC_WGRAD_X6=0)
   names32, y32, dx32, dw32 = run()
   assert not any(split(n) for n in names32), names32
@@ -228,39 +228,43 @@ def test_layer_split_bf16_path(hip, case, hipenv):
     assert rel(a, b) < 3e-6, rel(a, b)
   hipenv(ADVOC_IGEMM_X6=None, ADVOC_WGRAD_X6=None)
   test_layer_all_directions(hip, case)              # all three directions against the float64 oracle
-  # operand-image kernels (igemm_x6d.hip): the same six-product arithmetic in the same K order -> the very same bits
-  hipenv(ADVOC_X6D=1, ADVOC_X6D_MIN_TILES=1, ADVOC_IGEMM_KORDER=1)
+  # operand-image kernels (igemm_h3.hip: fp16 pairs, three products): agree with the register-split result far
+  # below the oracle tolerance, and meet the oracle themselves
+  hipenv(ADVOC_H3=1, ADVOC_H3_MIN_TILES=1)
   names_d, y_d, dx_d, _ = run()
-  hipenv(ADVOC_X6D=0)
-  _, y_r, dx_r, _ = run()
-  assert 'x6d' in names_d[0], names_d      # (backward-data has 64 columns here: register-split kernel)
-  assert torch.equal(y_d, y_r) and torch.equal(dx_d, dx_r)
-  hipenv(ADVOC_X6D=None, ADVOC_X6D_MIN_TILES=None, ADVOC_IGEMM_KORDER=None)
+  assert 'h3' in names_d[0], names_d      # (backward-data has 64 columns here: register-split kernel)
+  assert rel(y_d, y) < 3e-6 and rel(dx_d, dx) < 3e-6, (rel(y_d, y), rel(dx_d, dx))
+  hipenv(ADVOC_H3=None, ADVOC_H3_MIN_TILES=None)
   test_layer_all_directions(hip, case)
 
 
-# Operand-image kernels (igemm_x6d.hip): every tile / stage instance against the float64 oracle, in all
+# Operand-image kernels (igemm_h3.hip): every tile / stage instance against the float64 oracle, in all
 # directions that take them (forward, backward-data), on shapes with the features the loader has to get right:
 # rows that are not a multiple of the tile, two sources with a trimmed column, SAME padding on odd widths,
-# sub-pixel phases, stride-1 taps, dropout on either side.  ADVOC_X6D_MIN_TILES=1 lets these small launches in.
-X6D = [
-    ('x6d_enc',       0, (3, 16, 33), 128, 0, 256, 0, (2, 2), None, 1, False, 0),
-    ('x6d_enc_s1',    0, (2, 9, 12), 128, 0, 128, 0, (1, 1), (1, 1), 1, False, 0),
-    ('x6d_dec_skip',  1, (2, 8, 17), 128, 128, 256, 1, (2, 2), (1, 1), 2, True, 0),
-    ('x6d_dec_first', 1, (3, 4, 9), 256, 0, 128, 0, (2, 2), (1, 1), 2, True, 0),
-    ('x6d_enc_s12',   0, (3, 2, 17), 128, 0, 128, 0, (1, 2), None, 1, False, 0),
-    ('x6d_dec_mixed', 1, (2, 8, 9), 256, 128, 128, 1, (2, 2), (1, 1), 2, False, 0),
+# sub-pixel phases, stride-1 taps, dropout on either side.  ADVOC_H3_MIN_TILES=1 lets these small launches in.
+H3 = [
+    ('h3_enc',       0, (3, 16, 33), 128, 0, 256, 0, (2, 2), None, 1, False, 0),
+    ('h3_enc_s1',    0, (2, 9, 12), 128, 0, 128, 0, (1, 1), (1, 1), 1, False, 0),
+    ('h3_dec_skip',  1, (2, 8, 17), 128, 128, 256, 1, (2, 2), (1, 1), 2, True, 0),
+    ('h3_dec_first', 1, (3, 4, 9), 256, 0, 128, 0, (2, 2), (1, 1), 2, True, 0),
+    ('h3_enc_s12',   0, (3, 2, 17), 128, 0, 128, 0, (1, 2), None, 1, False, 0),
+    ('h3_dec_mixed', 1, (2, 8, 9), 256, 128, 128, 1, (2, 2), (1, 1), 2, False, 0),
+    # 64 / 192 columns: the 128 x 64 tile whatever is asked for; 32-channel sources
+    ('h3_enc_n64',    0, (3, 16, 33), 32, 0, 64, 0, (2, 2), None, 1, False, 0),
+    ('h3_dec_n192',   1, (2, 8, 17), 64, 32, 192, 1, (2, 2), (1, 1), 2, True, 0),
+    # deep contraction on a small grid: split-K slices meeting with atomics
+    ('h3_deep_small', 0, (2, 8, 9), 512, 0, 128, 0, (2, 2), None, 1, False, 0),
 ]
-X6D_VARIANTS = [(1, 2), (1, 3), (2, 2), (2, 3), (3, 2), (3, 3)]
+H3_VARIANTS = [(1, 2), (1, 3), (2, 2), (3, 2), (4, 2), (4, 3)]
 
 
 @gpu
-@pytest.mark.parametrize('variant', X6D_VARIANTS, ids=['t%d_s%d' % v for v in X6D_VARIANTS])
-@pytest.mark.parametrize('case', X6D, ids=[c[0] for c in X6D])
+@pytest.mark.parametrize('variant', H3_VARIANTS, ids=['t%d_s%d' % v for v in H3_VARIANTS])
+@pytest.mark.parametrize('case', H3, ids=[c[0] for c in H3])
 def test_layer_operand_image_kernels(hip, case, variant, hipenv):
   from advoc_amd import conv
   tile, stages = variant
-  hipenv(ADVOC_X6D_MIN_TILES=1, ADVOC_X6D_TILE=tile, ADVOC_X6D_STAGES=stages)
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_TILE=tile, ADVOC_H3_STAGES=stages)
   c = build_case(case)
   dev = torch.device('cuda')
   x0 = c['x0'].to(dev)
@@ -269,14 +273,18 @@ def test_layer_operand_image_kernels(hip, case, variant, hipenv):
   cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
   y = torch.empty(x0.shape[0], c['oh'], c['out_w'], cout, device=dev)
   L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
-  want_tile = {1: '2, 2', 2: '2, 4', 3: '4, 2'}[tile]
+  want_tile = {1: '2, 2', 2: '2, 4', 3: '4, 2', 4: '2, 1'}[tile]
   cin = x0.shape[3] + (x1.shape[3] if x1 is not None else 0)
-  for direction, n_cols in ((0, cout), (1, cin)):
+  for direction, n_cols, k_ch in ((0, cout, cin), (1, cin, cout)):
     name = L.kernel_name(direction)
-    if tile == 2 and n_cols % 256:
-      want = 'gather_gemm_x6d_kernel<2, 2, %d>' % stages        # 256-column tile impossible: falls to 128 x 128
+    if k_ch % 32 or n_cols % 64 or x0.shape[3] % 32:
+      continue                                                   # outside the image path: other kernels, same oracle
+    if n_cols % 128:
+      want = 'gather_gemm_h3_kernel<2, 1, %d>' % stages          # 64 / 192 columns: 128 x 64 tiles
+    elif tile == 2 and n_cols % 256:
+      want = 'gather_gemm_h3_kernel<2, 2, %d>' % stages          # 256-column tile impossible: falls to 128 x 128
     else:
-      want = 'gather_gemm_x6d_kernel<%s, %d>' % (want_tile, stages)
+      want = 'gather_gemm_h3_kernel<%s, %d>' % (want_tile, 2 if tile in (2, 3) else stages)
     assert name == want, (direction, name, want)
   test_layer_all_directions(hip, case)
 
@@ -304,12 +312,12 @@ def test_operand_image_kernel_with_batchnorm_prologue(hip, hipenv):
     dx0, dx1 = torch.zeros_like(x0), torch.zeros_like(x1)
     L.backward_data(dy, dx0, dx1)
     return L.kernel_name(0), L.kernel_name(1), y, dx0, dx1
-  hipenv(ADVOC_X6D_MIN_TILES=1)
+  hipenv(ADVOC_H3_MIN_TILES=1)
   n0, n1, y, dx0, dx1 = run()
-  assert 'x6d' in n0 and 'x6d' in n1, (n0, n1)
+  assert 'h3' in n0 and 'h3' in n1, (n0, n1)
   hipenv(ADVOC_IGEMM_X6=0)
   m0, m1, y32, dx0_32, dx1_32 = run()
-  assert 'x6d' not in m0 and not m0.endswith(', true>')
+  assert 'h3' not in m0 and not m0.endswith(', true>')
   for a, b in ((y, y32), (dx0, dx0_32), (dx1, dx1_32)):
     assert rel(a, b) < 3e-6, rel(a, b)
 

@@ -1,5 +1,6 @@
-"""Size-independent properties at BASELINE.json's full sizes (AdVoc-small, 32 clips of 256 x 513 per
-GPU; the discriminator's 2B = 64 batch), where the CPU oracle would take minutes per layer:
+"""Size-independent properties at BASELINE.json's full sizes (configs[1]: AdVoc-small, 32 clips of 256 x 513 per
+GPU, the discriminator's 2B = 64 batch; configs[2]: AdVoc-full, 64 clips, 2B = 128), where the CPU oracle would take
+minutes per layer:
 
   * adjointness  <dy, conv(x)> == <conv_backward_data(dy), x> == <conv_backward_weight(dy), w>
     for every distinct layer shape of the two networks (bias 0, identity activation: the three
@@ -35,6 +36,34 @@ LAYERS = [
 ]
 
 
+# BASELINE configs[2]: AdVoc (full, ngf = ndf = 64, 8 encoders) at 64 clips per GPU -- the shapes of
+# profiles/r01_n_layer_times.md §full; the kernel-selection rules pick different instances here than at B = 1
+BF = 64
+LAYERS_FULL = [
+    ('encoder_1', 0, (BF, 256, 513), 1, 0, 64, 0, (2, 2), (1, 1)),
+    ('encoder_2', 0, (BF, 128, 257), 64, 0, 128, 0, (2, 2), (1, 1)),
+    ('encoder_3', 0, (BF, 64, 129), 128, 0, 256, 0, (2, 2), (1, 1)),
+    ('encoder_4', 0, (BF, 32, 65), 256, 0, 512, 0, (2, 2), (1, 1)),
+    ('encoder_5', 0, (BF, 16, 33), 512, 0, 512, 0, (2, 2), (1, 1)),
+    ('encoder_6', 0, (BF, 8, 17), 512, 0, 512, 0, (2, 2), (1, 1)),
+    ('encoder_7', 0, (BF, 4, 9), 512, 0, 512, 0, (2, 2), (1, 1)),
+    ('encoder_8', 0, (BF, 2, 5), 512, 0, 512, 0, (2, 2), (1, 1)),
+    ('decoder_8', 1, (BF, 1, 3), 512, 0, 512, 0, (2, 2), (1, 1)),
+    ('decoder_7', 1, (BF, 2, 5), 512, 512, 512, 1, (2, 2), (1, 1)),
+    ('decoder_6', 1, (BF, 4, 9), 512, 512, 512, 1, (2, 2), (1, 1)),
+    ('decoder_5', 1, (BF, 8, 17), 512, 512, 512, 1, (2, 2), (1, 1)),
+    ('decoder_4', 1, (BF, 16, 33), 512, 512, 256, 1, (2, 2), (1, 1)),
+    ('decoder_3', 1, (BF, 32, 65), 256, 256, 128, 1, (2, 2), (1, 1)),
+    ('decoder_2', 1, (BF, 64, 129), 128, 128, 64, 1, (2, 2), (1, 1)),
+    ('decoder_1', 1, (BF, 128, 257), 64, 64, 1, 1, (2, 2), (1, 1)),
+    ('layer_1', 0, (2 * BF, 256, 513), 1, 1, 64, 0, (2, 2), (1, 1)),
+    ('layer_2', 0, (2 * BF, 128, 256), 64, 0, 128, 0, (2, 2), (1, 1)),
+    ('layer_3', 0, (2 * BF, 64, 128), 128, 0, 256, 0, (2, 2), (1, 1)),
+    ('layer_4', 0, (2 * BF, 32, 64), 256, 0, 512, 0, (1, 1), (1, 1)),
+    ('layer_5', 0, (2 * BF, 31, 63), 512, 0, 1, 0, (1, 1), (1, 1)),
+]
+
+
 def dot(a, b):
   return float((a.double() * b.double()).sum())
 
@@ -62,10 +91,18 @@ def build(case, act):
   return L, x0, x1, w, b, y, dy, W
 
 
+ALL_LAYERS = [('small32', c) for c in LAYERS] + [('full64', c) for c in LAYERS_FULL]
+
+
 @gpu
-@pytest.mark.parametrize('case', LAYERS, ids=[c[0] for c in LAYERS])
-def test_three_directions_are_one_trilinear_form(hip, case):
+@pytest.mark.parametrize('model,case', ALL_LAYERS, ids=['%s-%s' % (m, c[0]) for m, c in ALL_LAYERS])
+def test_three_directions_are_one_trilinear_form(hip, model, case):
   L, x0, x1, w, b, y, dy, W = build(case, act=0)
+  if model == 'full64' and case[0] in ('encoder_2', 'encoder_3', 'encoder_4', 'decoder_5', 'decoder_4', 'decoder_3',
+                                       'layer_2', 'layer_3', 'layer_4'):
+    # the launches that dominate the configs[2] step run on the operand-image kernels (igemm_h3.hip)
+    assert 'gather_gemm_h3_kernel' in L.kernel_name(0), L.kernel_name(0)
+    assert 'gather_gemm_h3_kernel' in L.kernel_name(1), L.kernel_name(1)
   L.forward()
   lhs = dot(dy, y)
   dx0 = torch.zeros_like(x0)
@@ -84,8 +121,12 @@ def test_three_directions_are_one_trilinear_form(hip, case):
   assert float((db.double() - want_db).norm()) < 1e-5 * float(want_db.norm() + dy.double().norm())
 
 
+HOMOG = [LAYERS[1], LAYERS[7], LAYERS[13], LAYERS_FULL[2], LAYERS_FULL[12], LAYERS_FULL[19]]
+
+
 @gpu
-@pytest.mark.parametrize('case', [LAYERS[1], LAYERS[7], LAYERS[13]], ids=['encoder_2', 'decoder_3', 'layer_4'])
+@pytest.mark.parametrize('case', HOMOG, ids=['encoder_2', 'decoder_3', 'layer_4', 'full64-encoder_3', 'full64-decoder_4',
+                                             'full64-layer_4'])
 def test_leaky_relu_prologue_is_positively_homogeneous(hip, case):
   L, x0, x1, w, b, y, dy, W = build(case, act=1)
   b.copy_(torch.randn_like(b))

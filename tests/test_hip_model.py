@@ -315,7 +315,11 @@ def test_side_stream_weight_gradients_equal_serial_execution(hip, monkeypatch):
     g0, l0 = run(False)
     for k in g0:
       if k.startswith('discriminator'):          # taken at identical weights
-        assert rel(g1[k], g0[k]) < 1e-5, (trial, k, rel(g1[k], g0[k]))
+        # The real and the fake half of the 2B batch pull these gradients in opposite directions and nearly cancel at
+        # initialisation, which amplifies the order of the fp32 atomics (the only thing that differs between the two
+        # schedules) ~100x: measured 2e-7 .. 9e-6 between two runs of the SAME schedule (tools/micro/side_race.py);
+        # a missing dependency shows as >= 1e-2.
+        assert rel(g1[k], g0[k]) < 5e-5, (trial, k, rel(g1[k], g0[k]))
     for key in ('gen_loss_L1', 'disc_loss', 'gen_loss_GAN'):
       assert abs(l1[key] - l0[key]) <= 0.02 * abs(l0[key]) + 1e-3, (trial, key, l1[key], l0[key])
 
@@ -350,7 +354,7 @@ def test_training_on_split_bf16_path_tracks_fp32_path(hip, hipenv):
 
   g_s, h_s, n_s = run(True)
   g_f, h_f, n_f = run(False)
-  split = lambda n: (n.startswith('gather_gemm_kernel<') and n.endswith(', true>')) or 'x6d' in n       # noqa: E731
+  split = lambda n: (n.startswith('gather_gemm_kernel<') and n.endswith(', true>')) or 'h3' in n       # noqa: E731
   assert any(split(n) for n in n_s) and not any(split(n) for n in n_f), (n_s, n_f)
   worst = 0.0
   for k in g_f:

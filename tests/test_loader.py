@@ -130,3 +130,21 @@ def test_decode_errors_surface(hip, tmp_path):
   pipe = L.decode_extract_and_batch([bad], 1, 256, decode_fastwav=True, extract_type='magspec')
   with pytest.raises(ValueError):
     pipe.next()
+
+
+def test_field_views_share_the_current_batch():
+  """`x_feats, x_audio = decode_extract_and_batch(...)`: reading both views in turn yields PAIRED fields (one
+  iterator get_next feeds both reference tensors, loader.py:209-216); a view read twice in a row pulls a new batch."""
+  class Stub(object):
+    _view_batch = L.BatchPipeline._view_batch
+
+    def __init__(self):
+      self._view_cur, self._view_next, self.n = None, 0, 0
+
+    def next(self):
+      self.n += 1
+      return ('f%d' % self.n, 'a%d' % self.n)
+  p = Stub()
+  f, a = L._FieldView(p, 0), L._FieldView(p, 1)
+  got = [f.next(), a.next(), f.next(), f.next(), a.next(), a.next(), f.next()]
+  assert got == ['f1', 'a1', 'f2', 'f3', 'a3', 'a4', 'f4']

@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """One layer shape, forward (and optionally backward-data) a few times under the current ADVOC_* environment:
-the target of rocprofv3 counter passes.   python tools/micro/x6d_one.py SHAPE [reps] [dirs]"""
+the target of rocprofv3 counter passes.   python tools/micro/h3_one.py SHAPE [reps] [dirs]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
-from x6d_sweep_shapes import build
+from h3_sweep_shapes import build
 name = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dirs = sys.argv[3] if len(sys.argv) > 3 else 'f'

@@ -1,14 +1,14 @@
 #!/usr/bin/env python
 """Times the gather-GEMM variants on full-model layer shapes (forward / backward-data), GEMM kernel alone
-(ADVOC_X6D_SKIP_PREP=1 after the first call: the operand images stay in the workspace).
-    python tools/micro/x6d_sweep.py [shape ...]"""
+(ADVOC_H3_SKIP_PREP=1 after the first call: the operand images stay in the workspace).
+    python tools/micro/h3_sweep.py [shape ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from advoc_amd import _lib, conv
 dev = torch.device('cuda')
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from x6d_sweep_shapes import SHAPES, build
+from h3_sweep_shapes import SHAPES, build
 
 
 def setenv(**kw):
@@ -32,20 +32,20 @@ def t(fn, reps=10):
   return e0.elapsed_time(e1) / reps * 1e3
 
 
-VARIANTS = [('old', dict(ADVOC_X6D=0))] + [
-    ('t%d_s%d' % (tl, st), dict(ADVOC_X6D=1, ADVOC_X6D_TILE=tl, ADVOC_X6D_STAGES=st)) for tl in (1, 2, 3) for st in (2, 3)]
+VARIANTS = [('old', dict(ADVOC_H3=0))] + [('t3_s2', dict(ADVOC_H3=1, ADVOC_H3_TILE=3, ADVOC_H3_STAGES=2))] + [
+    ('t%d_s%d' % (tl, st), dict(ADVOC_H3=1, ADVOC_H3_TILE=tl, ADVOC_H3_STAGES=st)) for tl, st in ((1, 2), (1, 3), (2, 2))]
 
 for name in (sys.argv[1:] or list(SHAPES)):
   L, dy, dx0, dx1 = build(name)
   for tag, env in VARIANTS:
-    setenv(**dict(dict(ADVOC_X6D_SKIP_PREP=None, ADVOC_X6D_TILE=None, ADVOC_X6D_STAGES=None), **env))
+    setenv(**dict(dict(ADVOC_H3_SKIP_PREP=None, ADVOC_H3_TILE=None, ADVOC_H3_STAGES=None), **env))
     row = []
     for d, fn in ((0, L.forward), (1, lambda: L.backward_data(dy, dx0, dx1))):
       L._names = {}
       fn()                                    # images + weights into the workspace
-      setenv(ADVOC_X6D_SKIP_PREP=1)
+      setenv(ADVOC_H3_SKIP_PREP=1)
       us = t(fn)
-      setenv(ADVOC_X6D_SKIP_PREP=None)
+      setenv(ADVOC_H3_SKIP_PREP=None)
       us_all = t(fn, 5)
       row.append('%s %-34s %8.1f us %6.1f TF (with prep %8.1f us)' % (['fwd ', 'bwdD'][d], L.kernel_name(d), us, L.flops / us / 1e6, us_all))
     print('%-5s %-6s %s | %s' % (name, tag, row[0], row[1]), flush=True)

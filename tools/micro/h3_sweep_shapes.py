@@ -1,4 +1,4 @@
-"""Full-model layer shapes shared by the x6d micro-benchmarks."""
+"""Full-model layer shapes shared by the h3 micro-benchmarks."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
