@@ -58,6 +58,9 @@ PROTOTYPES = {
     'advoc_phase_project_c64': (ctypes.c_int, [_p, _p, _i64, _p]),
     'advoc_cabs_f32': (ctypes.c_int, [_p, _p, _i64, _p]),
     'advoc_polar_c64': (ctypes.c_int, [_p, _p, _p, _i64, _p]),
+    'advoc_lws_mean_mag_f32': (ctypes.c_int, [_p, _i64, _i64, _p, _p]),
+    'advoc_lws_causal_c64': (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p, _i32, _i32, _f32, _f32, _i32, _p]),
+    'advoc_lws_batch_c64': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _f32, _p]),
     'advoc_matmul_nt_f32': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
     'advoc_tanh_affine_f32': (ctypes.c_int, [_p, _p, _i64, _f32, _f32, _p]),
     'advoc_mel_dbnorm_f32': (ctypes.c_int, [_p, _i64, _f32, _f32, _f32, _p]),

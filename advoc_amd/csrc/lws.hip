@@ -1,0 +1,285 @@
+// Local Weighted Sums (LWS) phase reconstruction on the GPU: the reference's default vocoder back end,
+// lws.lws(nfft, nhop, mode='speech', perfectrec=False).run_lws(X_mag) at advoc/spectral.py:314-326 and
+// models/advoc/spectral_util.py:45-50 (third-party lws 1.2, C++, not part of /root/reference: the PUBLISHED algorithm
+// is restated -- Le Roux et al., DAFx 2010 / ASJ 2010 -- and the result is parity-UNPINNED; oracle/lws_np.py is the
+// CPU restatement these kernels are tested against).
+//
+// A complex spectrogram X is consistent (the STFT of a signal) iff X = P X with P = STFT o iSTFT, and P is a small
+// 2-D convolution: (P X)[t, f] = sum_{q, p} K_q(p) R_q(f + p) X[t + q, f + p], |q| < Q = nfft / nhop, kernel decaying
+// fast in |p| (truncated to |p| < L), R_q(m) = exp(-2 pi i m q nhop / nfft) for lws's frame-local phase convention
+// (periodic in m with period P = nfft / gcd(nfft, nhop): the caller hands over the products K_q(p) R_q(m mod P)).
+// LWS iterates  X[t, f] <- |A[t, f]| phase( sum_{(q, p) != (0, 0)} ... )  in three stages:
+//   lws_causal_kernel   one workgroup per clip walks the frames in time order with a 2Q-frame ring in LDS: a new frame
+//                       (look-ahead frames ahead) is initialised from the frames before it only ("no future"), the
+//                       current frame is refined `online_iterations` times with the look-ahead (Jacobi over its bins);
+//   lws_batch_kernel    one sweep over the whole spectrogram (all bins from the previous iterate), touching only bins
+//                       above the sweep's magnitude threshold; the host launches `batch_iterations` of them, ping-pong.
+// Both are cache / LDS bound: 63 complex taps per bin.
+#include "common.h"
+
+namespace {
+
+// W[q + Q - 1][p + L - 1][m mod P] = alpha_q(p) * exp(-2 pi i m q nhop / nfft), m = f + p: the rotation only depends on
+// m modulo P = nfft / gcd(nfft, nhop) (4 for the reference's nfft 1024 / hop 256), so the whole kernel is a table of
+// (2Q - 1)(2L - 1) P complex weights, staged in LDS
+struct LwsTables {
+  const float2* W;
+  int Q, L, P, nfft, bins;
+};
+constexpr int kMaxWeights = 1024;     // complex entries of the LDS copy
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// one-sided row -> bin m in (-bins, nfft): conjugate symmetry of a real signal's spectrum
+__device__ __forceinline__ float2 mirrored(const float2* row, int m, int bins, int nfft) {
+  if (m < 0) { const float2 v = row[-m]; return make_float2(v.x, -v.y); }
+  if (m >= bins) { const float2 v = row[nfft - m]; return make_float2(v.x, -v.y); }
+  return row[m];
+}
+
+// mag * z / |z|, or `fallback` when z == 0
+__device__ __forceinline__ float2 with_phase_of(float mag, float2 z, float2 fallback) {
+  const float a = sqrtf(z.x * z.x + z.y * z.y);
+  if (!(a > 0.f)) return fallback;
+  const float s = mag / a;
+  return make_float2(z.x * s, z.y * s);
+}
+
+constexpr int kRing = 8;       // frames in the LDS ring (>= 2Q - 1 = 7 for Q = 4)
+constexpr int kMaxNf = 8;      // no-future threshold steps
+
+struct CausalParams {
+  float2* spec;          // [clips][T][bins], written (read first when use_init)
+  const float* mag;      // [clips][T][bins]
+  const float* mean_mag; // [clips]
+  int T;
+  int look_ahead;
+  int nf_steps;
+  float nf_thr[kMaxNf];  // multiples of the clip's mean magnitude, last one 0 (every bin set)
+  int online_iterations;
+  float on_alpha, on_beta;
+  int use_init;          // != 0: spec holds initial phases (complex input of run_lws): frames are not re-initialised
+};
+
+// LDS: ring[kRing][bins] complex + the weight table.  QC / LC / PC > 0: compile-time Q, L, P (the reference's geometry
+// 4, 5, 4: fully unrolled tap loops, mask instead of modulo); 0: run-time values.  P is a power of two (checked by the
+// launcher), so m & (P - 1) is m mod P for negative m too.
+template <int QC, int LC, int PC>
+__global__ __launch_bounds__(576) void lws_causal_kernel(const CausalParams c, const LwsTables tb) {
+  extern __shared__ __attribute__((aligned(16))) float2 lws_smem[];
+  const int bins = tb.bins, nfft = tb.nfft, Q = QC ? QC : tb.Q, L = LC ? LC : tb.L;
+  float2* ring = lws_smem;                    // [kRing][bins]
+  float2* Ws = lws_smem + kRing * bins;       // [2Q - 1][2L - 1][P]
+  const int P = PC ? PC : tb.P, nW = (2 * Q - 1) * (2 * L - 1) * P;
+  for (int i = threadIdx.x; i < nW; i += blockDim.x) Ws[i] = tb.W[i];
+  const int clip = blockIdx.x;
+  const int f = threadIdx.x;
+  const bool live = f < bins;
+  float2* spec = c.spec + (int64_t)clip * c.T * bins;
+  const float* mag = c.mag + (int64_t)clip * c.T * bins;
+  const float ref = c.mean_mag[clip];
+  const int KW = 2 * L - 1;
+
+  for (int i = threadIdx.x; i < kRing * bins; i += blockDim.x) ring[i] = make_float2(0.f, 0.f);
+  __syncthreads();
+  int last_init = -1;          // newest frame whose ring slot holds valid data
+
+  // sum over frames t + q, q in [q_lo, q_hi], of the truncated projection at bin f of frame t
+  auto local_sum = [&](int t, int q_lo, int q_hi) -> float2 {
+    float2 z = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int q = -(Q - 1); q <= Q - 1; ++q) {
+      const int tq = t + q;
+      if (q < q_lo || q > q_hi || tq < 0 || tq >= c.T || tq > last_init) continue;
+      const float2* row = ring + (tq & (kRing - 1)) * bins;
+      const float2* Wq = Ws + (q + Q - 1) * KW * P;
+#pragma unroll
+      for (int p = -(L - 1); p < L; ++p) {
+        if (q == 0 && p == 0) continue;
+        const int m = f + p;
+        const float2 x = mirrored(row, m, bins, nfft);
+        const float2 wx = cmul(Wq[(p + L - 1) * P + (m & (P - 1))], x);
+        z.x += wx.x; z.y += wx.y;
+      }
+    }
+    return z;
+  };
+
+  // "no future": frame t from the frames before it (and its own bins set by earlier, higher thresholds)
+  auto init_frame = [&](int t) {
+    float2* slot = ring + (t & (kRing - 1)) * bins;
+    if (c.use_init) {
+      if (live) slot[f] = spec[(int64_t)t * bins + f];
+      last_init = t;
+      __syncthreads();
+      return;
+    }
+    if (live) slot[f] = make_float2(0.f, 0.f);
+    last_init = t;
+    __syncthreads();
+    for (int s = 0; s < c.nf_steps; ++s) {
+      float2 nv = make_float2(0.f, 0.f);
+      bool set = false;
+      if (live) {
+        const float a = mag[(int64_t)t * bins + f];
+        if (a > c.nf_thr[s] * ref || c.nf_thr[s] <= 0.f) {
+          nv = with_phase_of(a, local_sum(t, -(Q - 1), 0), make_float2(a, 0.f));     // zero phase when nothing is known yet
+          set = true;
+        }
+      }
+      __syncthreads();
+      if (set) slot[f] = nv;
+      __syncthreads();
+    }
+  };
+
+  const int la = c.look_ahead;
+  for (int t0 = 0; t0 <= la && t0 < c.T; ++t0) init_frame(t0);
+  for (int t = 0; t < c.T; ++t) {
+    const int ta = t + la;
+    if (ta < c.T && ta > la) init_frame(ta);
+    float2* slot = ring + (t & (kRing - 1)) * bins;
+    for (int i = 0; i < c.online_iterations; ++i) {
+      const float thr = c.online_iterations > 1 ? c.on_alpha * __expf(-c.on_beta * (float)i) * ref : 0.f;
+      float2 nv = make_float2(0.f, 0.f);
+      bool set = false;
+      if (live) {
+        const float a = mag[(int64_t)t * bins + f];
+        if (a > thr) {
+          nv = with_phase_of(a, local_sum(t, -(Q - 1), Q - 1), slot[f]);
+          set = true;
+        }
+      }
+      __syncthreads();
+      if (set) slot[f] = nv;
+      __syncthreads();
+    }
+    if (live) spec[(int64_t)t * bins + f] = slot[f];
+  }
+}
+
+template <int QC, int LC, int PC>
+__global__ __launch_bounds__(256) void lws_batch_kernel(const float2* __restrict__ in, float2* __restrict__ out,
+                                                        const float* __restrict__ mag, const float* __restrict__ mean_mag,
+                                                        int T, float thr_mult, LwsTables tb, int64_t total) {
+  __shared__ float2 Ws[kMaxWeights];
+  const int bins = tb.bins, nfft = tb.nfft, Q = QC ? QC : tb.Q, L = LC ? LC : tb.L, KW = 2 * L - 1, P = PC ? PC : tb.P;
+  for (int k = threadIdx.x; k < (2 * Q - 1) * KW * P; k += blockDim.x) Ws[k] = tb.W[k];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int f = (int)(i % bins);
+  const int64_t row = i / bins;
+  const int t = (int)(row % T);
+  const int64_t clip = row / T;
+  const float a = mag[i];
+  const float2 cur = in[i];
+  if (!(a > thr_mult * mean_mag[clip])) { out[i] = cur; return; }
+  float2 z = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int q = -(Q - 1); q < Q; ++q) {
+    const int tq = t + q;
+    if (tq < 0 || tq >= T) continue;
+    const float2* src = in + (clip * T + tq) * bins;
+    const float2* Wq = Ws + (q + Q - 1) * KW * P;
+#pragma unroll
+    for (int p = -(L - 1); p < L; ++p) {
+      if (q == 0 && p == 0) continue;
+      const int m = f + p;
+      const float2 x = mirrored(src, m, bins, nfft);
+      const float2 wx = cmul(Wq[(p + L - 1) * P + (m & (P - 1))], x);
+      z.x += wx.x; z.y += wx.y;
+    }
+  }
+  out[i] = with_phase_of(a, z, cur);
+}
+
+// mean_mag[clip] = mean of mag[clip][:][:]
+__global__ __launch_bounds__(256) void lws_mean_kernel(const float* __restrict__ mag, int64_t per_clip, float* __restrict__ mean_mag) {
+  const float* src = mag + (int64_t)blockIdx.x * per_clip;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < per_clip; i += blockDim.x) s += (double)src[i];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) mean_mag[blockIdx.x] = (float)(red[0] / (double)per_clip);
+}
+
+}  // namespace
+
+extern "C" int advoc_lws_mean_mag_f32(const float* mag, int64_t clips, int64_t per_clip, float* mean_mag,
+                                      advoc_stream_t stream) {
+  if (clips < 0 || per_clip <= 0) return ADVOC_ERR_BAD_SHAPE;
+  if (clips == 0) return ADVOC_OK;
+  if (!mag || !mean_mag) return ADVOC_ERR_NULL;
+  if (clips > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(lws_mean_kernel, dim3((unsigned)clips), dim3(256), 0, advoc::as_stream(stream), mag, per_clip, mean_mag);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+extern "C" int advoc_lws_causal_c64(float* spec, const float* mag, const float* mean_mag, int64_t clips, int64_t nframes,
+                                    int32_t nfft, int32_t nhop, const float* weights, int32_t period, int32_t L,
+                                    int32_t look_ahead, const float* nofuture_thresholds_host, int32_t nofuture_steps,
+                                    int32_t online_iterations, float online_alpha, float online_beta, int32_t use_init,
+                                    advoc_stream_t stream) {
+  if (clips < 0 || nframes < 0 || nfft < 4 || nhop < 1 || nhop > nfft) return ADVOC_ERR_BAD_SHAPE;
+  if (clips == 0 || nframes == 0) return ADVOC_OK;
+  if (!spec || !mag || !mean_mag || !weights || (nofuture_steps > 0 && !nofuture_thresholds_host)) return ADVOC_ERR_NULL;
+  const int bins = nfft / 2 + 1;
+  const int Q = (nfft + nhop - 1) / nhop;
+  if (period < 1 || (period & (period - 1)) || (int64_t)nhop * period % nfft || (2 * Q - 1) * (2 * L - 1) * period > kMaxWeights) return ADVOC_ERR_UNSUPPORTED;
+  if (nfft % 2 || bins > 576 || 2 * Q - 1 > kRing || L < 1 || L > 16 || look_ahead < 0 || look_ahead > Q - 1 ||
+      nofuture_steps < 1 || nofuture_steps > kMaxNf || online_iterations < 0 || clips > 0x7fffffffLL ||
+      nframes > 0x7fffffffLL)
+    return ADVOC_ERR_UNSUPPORTED;
+  CausalParams c = {};
+  c.spec = reinterpret_cast<float2*>(spec); c.mag = mag; c.mean_mag = mean_mag;
+  c.T = (int)nframes; c.look_ahead = look_ahead; c.nf_steps = nofuture_steps;
+  for (int i = 0; i < nofuture_steps; ++i) c.nf_thr[i] = nofuture_thresholds_host[i];
+  c.online_iterations = online_iterations; c.on_alpha = online_alpha; c.on_beta = online_beta; c.use_init = use_init;
+  LwsTables tb = {reinterpret_cast<const float2*>(weights), Q, L, period, nfft, bins};
+  const size_t lds = sizeof(float2) * ((size_t)kRing * bins + (size_t)(2 * Q - 1) * (2 * L - 1) * period);
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  if (Q == 4 && L == 5 && period == 4)
+    hipLaunchKernelGGL((lws_causal_kernel<4, 5, 4>), dim3((unsigned)clips), dim3(576), lds, advoc::as_stream(stream), c, tb);
+  else
+    hipLaunchKernelGGL((lws_causal_kernel<0, 0, 0>), dim3((unsigned)clips), dim3(576), lds, advoc::as_stream(stream), c, tb);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+extern "C" int advoc_lws_batch_c64(const float* spec_in, float* spec_out, const float* mag, const float* mean_mag,
+                                   int64_t clips, int64_t nframes, int32_t nfft, int32_t nhop, const float* weights,
+                                   int32_t period, int32_t L, float threshold, advoc_stream_t stream) {
+  if (clips < 0 || nframes < 0 || nfft < 4 || nhop < 1 || nhop > nfft) return ADVOC_ERR_BAD_SHAPE;
+  if (clips == 0 || nframes == 0) return ADVOC_OK;
+  if (!spec_in || !spec_out || !mag || !mean_mag || !weights) return ADVOC_ERR_NULL;
+  if (spec_in == spec_out) return ADVOC_ERR_UNSUPPORTED;      // a sweep reads the previous iterate of every neighbour
+  const int bins = nfft / 2 + 1;
+  const int Q = (nfft + nhop - 1) / nhop;
+  if (nfft % 2 || L < 1 || L > 16 || nframes > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  if (period < 1 || (period & (period - 1)) || (int64_t)nhop * period % nfft || (2 * Q - 1) * (2 * L - 1) * period > kMaxWeights) return ADVOC_ERR_UNSUPPORTED;
+  const int64_t total = clips * nframes * bins;
+  const int64_t blocks = advoc::ceil_div(total, 256);
+  if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  LwsTables tb = {reinterpret_cast<const float2*>(weights), Q, L, period, nfft, bins};
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  if (Q == 4 && L == 5 && period == 4)
+    hipLaunchKernelGGL((lws_batch_kernel<4, 5, 4>), dim3((unsigned)blocks), dim3(256), 0, advoc::as_stream(stream),
+                       reinterpret_cast<const float2*>(spec_in), reinterpret_cast<float2*>(spec_out), mag, mean_mag,
+                       (int)nframes, threshold, tb, total);
+  else
+    hipLaunchKernelGGL((lws_batch_kernel<0, 0, 0>), dim3((unsigned)blocks), dim3(256), 0, advoc::as_stream(stream),
+                       reinterpret_cast<const float2*>(spec_in), reinterpret_cast<float2*>(spec_out), mag, mean_mag,
+                       (int)nframes, threshold, tb, total);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}

@@ -44,7 +44,8 @@ def vocode_batch(model, specs, spectral_util=None, phase_estimation='gl60', chun
   [n, (T-1)*256 + 1024] in HBM or None).  Per sample exactly what scripts/spectrogram_advoc.py:80-95 /
   models/advoc/melspecVocoder.py:57-83 do (pseudo-inverse, padding to int(T/L)*L + L frames -- a whole
   extra zero chunk when T is a multiple of L --, generator, trim), with every chunk of every sample
-  in one generator batch and Griffin-Lim over all samples at once.  phase_estimation: 'gl<N>' or None."""
+  in one generator batch and phase reconstruction over all samples at once.  phase_estimation: 'lws' (what the
+  reference script runs, scripts/spectrogram_advoc.py:95), 'gl<N>' or None."""
   from advoc_amd import spectral
   su = spectral_util or SpectralUtil(n_mels=model.n_mels, fs=model.audio_fs)
   specs = torch.as_tensor(np.asarray(specs) if not isinstance(specs, torch.Tensor) else specs)
@@ -62,8 +63,10 @@ def vocode_batch(model, specs, spectral_util=None, phase_estimation='gl60', chun
   gen = torch.cat(outs, dim=0).reshape(n, target, X_mag.shape[2])[:, :T].contiguous()
   if phase_estimation is None:
     return gen, None
+  if phase_estimation == 'lws':
+    return gen, spectral.lws_batch(gen.abs().contiguous(), SpectralUtil.NFFT, SpectralUtil.NHOP)
   if phase_estimation[:2] != 'gl':
-    raise NotImplementedError('only Griffin-Lim phase estimation (gl<N>) is built; LWS is third-party')
+    raise ValueError()
   if unit_phase is None:
     unit_phase = torch.rand(gen.shape, device=gen.device)
   wav = spectral.griffin_lim_batch(gen.abs(), SpectralUtil.NFFT, SpectralUtil.NHOP, int(phase_estimation[2:]),

@@ -18,9 +18,12 @@ Two calling conventions, as in the reference:
 The mel filterbank and its pseudo-inverse are float64 host constants computed
 once (reference: librosa.filters.mel + np.linalg.pinv, spectral.py:86-94).
 
-Phase reconstruction (spectral.py:294-326): Griffin-Lim and the inverse STFT run on the GPU
-(advoc_istft_f32 & friends); LWS is the third-party lws library and raises NotImplementedError.
+Phase reconstruction (spectral.py:294-326): Griffin-Lim, LWS and the inverse STFT run on the GPU
+(advoc_istft_f32, advoc_lws_* & friends); LWS restates the published algorithm of the third-party lws library
+(parity unpinned).
 """
+import ctypes
+import math
 from functools import lru_cache
 
 import numpy as np
@@ -484,14 +487,100 @@ def magspec_to_waveform_griffin_lim(X_mag, nfft, nhop, ngl=60):
   return wav[0].cpu().numpy()[:, np.newaxis, np.newaxis].astype(np.float32)
 
 
+# LWS defaults (lws 1.2 `mode='speech'` as far as its documentation states them; restated, parity unpinned)
+LWS_L = 5
+LWS_LOOK_AHEAD = 3
+LWS_NOFUTURE_THRESHOLDS = (1.0, 0.0)
+LWS_ONLINE = (10, 1.0, 0.1)             # iterations, alpha, beta
+LWS_BATCH = (100, 100.0, 0.1, 1.0)      # iterations, alpha, beta, gamma
+
+
+def _lws_tables(nfft, nhop, L):
+  """(weights [2Q-1, 2L-1, P] complex64 device constant, P): the STFT o iSTFT projection kernel alpha_q(p) times the
+  frame rotation exp(-2 pi i r q nhop / nfft), r = (f + p) mod P, P = nfft / gcd(nfft, nhop); evaluated in float64."""
+  P = nfft // math.gcd(nfft, nhop)
+
+  def make():
+    awin = _lws_window_f64(nfft, nhop)
+    q_frames = -(-nfft // nhop)
+    sq = np.zeros(q_frames * nhop, dtype=np.float64)
+    sq[:nfft] = awin * awin
+    swin = awin / np.tile(sq.reshape(q_frames, nhop).sum(axis=0), q_frames)[:nfft]
+    n = np.arange(nfft)
+    W = np.zeros((2 * q_frames - 1, 2 * L - 1, P), dtype=np.complex128)
+    for q in range(-(q_frames - 1), q_frames):
+      sh = np.zeros(nfft)
+      lo, hi = max(0, q * nhop), min(nfft, nfft + q * nhop)
+      if hi > lo:
+        sh[lo:hi] = swin[lo - q * nhop:hi - q * nhop]
+      prod = awin * sh
+      rot = np.exp(-2j * np.pi * ((np.arange(P) * q * nhop) % nfft) / nfft)
+      for p in range(-(L - 1), L):
+        W[q + q_frames - 1, p + L - 1] = np.sum(prod * np.exp(2j * np.pi * p * n / nfft)) / nfft * rot
+    return torch.view_as_real(torch.from_numpy(W.astype(np.complex64))).contiguous()
+  return _device_const(('lwsW', nfft, nhop, L), make), P
+
+
+def lws_spectrogram_batch(spec, nfft, nhop, L=LWS_L, look_ahead=LWS_LOOK_AHEAD,
+                          nofuture_thresholds=LWS_NOFUTURE_THRESHOLDS, online=LWS_ONLINE, batch=LWS_BATCH):
+  """Local Weighted Sums phase reconstruction of a batch of equally long spectrograms, all on the GPU
+  (advoc_amd/csrc/lws.hip).  spec: float32 [clips, T, bins] magnitudes (phases start from nothing) or complex64
+  [clips, T, bins] (its phases are the starting point, as lws.run_lws treats complex input).  Returns complex64
+  [clips, T, bins]."""
+  lib = _lib.load()
+  _lib.require_device(spec)
+  use_init = spec.is_complex()
+  mag = (spec.abs() if use_init else spec.abs()).to(torch.float32).contiguous()
+  clips, T, bins = mag.shape
+  if bins != nfft // 2 + 1:
+    raise ValueError('expected [clips, T, nfft//2+1]')
+  dev = mag.device
+  cur = torch.view_as_real(spec.to(torch.complex64)).contiguous().clone() if use_init else \
+      torch.zeros(clips, T, bins, 2, dtype=torch.float32, device=dev)
+  if clips == 0 or T == 0:
+    return torch.view_as_complex(cur)
+  W, P = _lws_tables(nfft, nhop, L)
+  mean_mag = torch.empty(clips, dtype=torch.float32, device=dev)
+  _lib.check(lib.advoc_lws_mean_mag_f32(_lib.ptr(mag), clips, T * bins, _lib.ptr(mean_mag), _lib.stream()),
+             'advoc_lws_mean_mag_f32')
+  thr = (ctypes.c_float * len(nofuture_thresholds))(*[float(v) for v in nofuture_thresholds])
+  _lib.check(lib.advoc_lws_causal_c64(
+      _lib.ptr(cur), _lib.ptr(mag), _lib.ptr(mean_mag), clips, T, nfft, nhop, _lib.ptr(W), P, L, look_ahead,
+      thr, len(nofuture_thresholds), int(online[0]), float(online[1]), float(online[2]), int(use_init), _lib.stream()),
+      'advoc_lws_causal_c64')
+  nxt = torch.empty_like(cur)
+  for i in range(int(batch[0])):
+    t = float(batch[1]) * math.exp(-float(batch[2]) * float(i) ** float(batch[3]))
+    _lib.check(lib.advoc_lws_batch_c64(_lib.ptr(cur), _lib.ptr(nxt), _lib.ptr(mag), _lib.ptr(mean_mag), clips, T, nfft,
+                                       nhop, _lib.ptr(W), P, L, t, _lib.stream()), 'advoc_lws_batch_c64')
+    cur, nxt = nxt, cur
+  return torch.view_as_complex(cur)
+
+
+def lws_batch(spec, nfft, nhop, **kw):
+  """LWS phases + lws istft for a batch: [clips, T, bins] (float32 magnitudes or complex64) -> float32 waveforms
+  [clips, (T-1)*nhop + nfft] in HBM."""
+  if nfft != 1024:
+    raise _lib.AdvocHipError('the inverse transform runs on the 1024-point kernels only (nfft={})'.format(nfft))
+  return istft_batch(lws_spectrogram_batch(spec, nfft, nhop, **kw), nfft, nhop)
+
+
 def magspec_to_waveform_lws(X_mag, nfft, nhop):
+  """Reference spectral.py:314-326: lws.run_lws + lws.istft.  X_mag: nd-array [T, bins, 1], real magnitudes or --
+  as the reference's own test passes it (tests/test_spectral.py:184,190) -- a complex spectrogram whose phases are the
+  starting point.  Returns nd-array float32 [(T-1)*nhop + nfft, 1, 1].  The phase reconstruction is a restatement of the
+  published LWS algorithm on the GPU in fp32 (the reference runs the third-party lws library in float64): same
+  stages and defaults, not bit-comparable (parity unpinned)."""
   nsamps, nbins, nch = X_mag.shape
   if nch != 1:
     raise NotImplementedError('Can only invert monaural signals')
-  raise NotImplementedError(
-      'magspec_to_waveform_lws: Local Weighted Sums phase reconstruction is the third-party lws 1.2 '
-      'C++ library (not part of /root/reference); use phase_estimation="gl60" (Griffin-Lim runs on '
-      'the GPU) until it is restated (SURVEY.md §8f-1)')
+  X = np.asarray(X_mag)[:, :, 0]
+  if np.iscomplexobj(X):
+    spec = torch.from_numpy(X.astype(np.complex64)).to(_lib.device())[None]
+  else:
+    spec = _to_device_f32(np.abs(X).astype(np.float32))[None]
+  wav = lws_batch(spec, nfft, nhop)
+  return wav[0].cpu().numpy()[:, np.newaxis, np.newaxis].astype(np.float32)
 
 
 def melspec_to_waveform(
@@ -510,7 +599,7 @@ def melspec_to_waveform(
 
   Args:
     X_mel_dbnorm: nd-array float64 [?, mel_num_bins, 1].
-    phase_estimation: 'gl<N>' (Griffin-Lim, N iterations, on the GPU) or 'lws' (third-party: raises).
+    phase_estimation: 'lws' (the reference default; restated on the GPU) or 'gl<N>' (Griffin-Lim, N iterations).
     waveform_len: pad or clip the output to this length.
   Returns:
     nd-array float32 [waveform_len, 1, 1].

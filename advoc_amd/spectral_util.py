@@ -70,11 +70,10 @@ class SpectralUtil(object):
     mel = torch.from_numpy(X_mel.astype(np.float32)).to(_lib.device())
     return spectral.matmul_last(mel, self.invmeltrans)
 
-  def audio_from_mag_spec(self, mag_spec, phase_estimation='gl60'):
-    """Magnitude spectrogram [T, 513, 1] -> waveform float32 [n, 1, 1] (spectral_util.py:45-50).
-    The reference runs lws.run_lws here (third-party C++, not restated); this build estimates
-    phase with Griffin-Lim on the GPU (`gl<N>`), the reference's own alternative
-    (advoc/spectral.py:294-311)."""
+  def audio_from_mag_spec(self, mag_spec, phase_estimation='lws'):
+    """Magnitude spectrogram [T, 513, 1] -> waveform float32 [n, 1, 1] (spectral_util.py:45-50: lws.run_lws + istft).
+    'lws' runs the GPU restatement of LWS (advoc_amd.spectral.magspec_to_waveform_lws, parity unpinned); 'gl<N>'
+    Griffin-Lim, the reference's own alternative (advoc/spectral.py:294-311)."""
     if phase_estimation == 'lws':
       return spectral.magspec_to_waveform_lws(np.asarray(mag_spec), self.NFFT, self.NHOP)
     if phase_estimation[:2] != 'gl':

@@ -251,8 +251,8 @@ def infer(fps, args):
   writes, under WORK_DIR/infer_*, the input / target / generated magnitude spectrograms (.npy) and
   the three audio clips the reference puts into its TensorBoard audio summaries
   (train_evaluate.py:262-281: the real waveform, the vocoded pseudo-inverse "heuristic" and the vocoded
-  generator output) as PCM16 .wav files.  Phase comes from Griffin-Lim (60 iterations, on the GPU)
-  where the reference uses LWS."""
+  generator output) as PCM16 .wav files.  Phase comes from LWS as in the reference (advoc_model.py:262-281 ->
+  spectral_util.py:45-50), the GPU restatement of advoc_amd.spectral."""
   from advoc_amd.model import Modes
   from advoc_amd.spectral_util import SpectralUtil
   infer_dir = os.path.join(args.train_dir, 'infer_{}'.format(args.infer_dataset_name)
@@ -277,7 +277,7 @@ def infer(fps, args):
     np.save(os.path.join(infer_dir, 'batch%06d_target_magspec.npy' % i), x_magspec.cpu().numpy())
     np.save(os.path.join(infer_dir, 'batch%06d_input_magspec.npy' % i), x_inv.cpu().numpy())
     both = torch.cat([x_inv[..., 0], gen[..., 0]], dim=0).abs().contiguous()       # [2b, T, 513]
-    wav = S.griffin_lim_batch(both, spectral.NFFT, spectral.NHOP, 60, torch.rand(both.shape, device=both.device))
+    wav = S.lws_batch(both, spectral.NFFT, spectral.NHOP)
     b = x_inv.shape[0]
     for j in range(b):
       stem = os.path.join(infer_dir, 'batch%06d_clip%02d' % (i, j))

@@ -2,8 +2,8 @@
 
 The reference versions are TF graph ops feeding tf.summary (advoc/util.py:36-62,
 models/melspecgan/util.py:7-37); here they take and return numpy arrays or
-torch tensors.  ``*_to_approx_audio`` defaults to Griffin-Lim (60 iterations) because the
-reference's default, LWS, is a third-party library that is not built here.
+torch tensors.  ``*_to_approx_audio`` defaults to LWS like the reference (the GPU restatement in
+advoc_amd.spectral).
 """
 import numpy as np
 import torch
@@ -35,7 +35,7 @@ def r9y9_melspec_to_uint8_img(x):
   return np.clip(img * 255., 0., 255.).astype(np.uint8)
 
 
-def r9y9_melspec_to_approx_audio(x, fs, waveform_len, n=None, phase_estimation='gl60'):
+def r9y9_melspec_to_approx_audio(x, fs, waveform_len, n=None, phase_estimation='lws'):
   """[B, T, 80, 1] dB-normalised mel -> float32 waveforms [B', waveform_len, 1, 1]."""
   if n is not None:
     x = x[:n]

@@ -98,6 +98,29 @@ int advoc_cabs_f32(const float* spec, float* out, int64_t n, advoc_stream_t stre
  * unit_phase in [0, 1). */
 int advoc_polar_c64(const float* mag, const float* unit_phase, float* spec, int64_t n, advoc_stream_t stream);
 
+/* Local Weighted Sums phase reconstruction: lws.lws(nfft, nhop, mode='speech', perfectrec=False).run_lws(X) reached from
+ * advoc/spectral.py:314-326 and models/advoc/spectral_util.py:45-50.  lws 1.2 is a third-party C++ library outside
+ * /root/reference: these kernels restate the published algorithm (advoc_amd/csrc/lws.hip), parity unpinned.
+ *   weights   [2Q-1][2L-1][period] complex64 (caller-computed, read-only), Q = nfft/nhop, period = nfft / gcd(nfft, nhop):
+ *             alpha_q(p) * exp(-2 pi i r q nhop / nfft) with alpha_q(p) = 1/nfft sum_n awin[n] swin[n - q nhop]
+ *             exp(2 pi i p n / nfft) -- the STFT o iSTFT projection kernel; r = (f + p) mod period
+ *   mean_mag  [clips]: mean magnitude of each clip (advoc_lws_mean_mag_f32); thresholds are multiples of it
+ * advoc_lws_causal_c64: the time-ordered pass (no-future initialisation look_ahead frames ahead, with the host array
+ *   nofuture_thresholds_host of nofuture_steps descending multiples -- the last must be 0 --, then online_iterations
+ *   refinements per frame with thresholds online_alpha * exp(-online_beta * i)); writes spec [clips][nframes][nfft/2+1]
+ *   complex64.  use_init != 0: spec holds starting phases (complex input of run_lws) and frames are not re-initialised.
+ * advoc_lws_batch_c64: ONE sweep of the whole spectrogram from spec_in into spec_out (must differ): bins with
+ *   mag > threshold * mean_mag get mag * phase(local weighted sum), the others are copied. */
+int advoc_lws_mean_mag_f32(const float* mag, int64_t clips, int64_t per_clip, float* mean_mag, advoc_stream_t stream);
+int advoc_lws_causal_c64(float* spec, const float* mag, const float* mean_mag, int64_t clips, int64_t nframes,
+                         int32_t nfft, int32_t nhop, const float* weights, int32_t period, int32_t L,
+                         int32_t look_ahead, const float* nofuture_thresholds_host, int32_t nofuture_steps,
+                         int32_t online_iterations, float online_alpha, float online_beta, int32_t use_init,
+                         advoc_stream_t stream);
+int advoc_lws_batch_c64(const float* spec_in, float* spec_out, const float* mag, const float* mean_mag, int64_t clips,
+                        int64_t nframes, int32_t nfft, int32_t nhop, const float* weights, int32_t period,
+                        int32_t L, float threshold, advoc_stream_t stream);
+
 /* Host helper: fills tw_host[2 * nfft] with the double-precision-evaluated twiddle table the
  * STFT kernels expect (upload it once; it is read-only). */
 int advoc_stft_twiddle_host(float* tw_host, int32_t nfft);

@@ -155,8 +155,8 @@ def test_melspec_to_waveform_surface(S, mono22):
     S.melspec_to_waveform(mel, 22050, 1024, 256, phase_estimation='glx')
   with pytest.raises(NotImplementedError):
     S.melspec_to_waveform(np.zeros((4, 80, 2)), 22050, 1024, 256)
-  with pytest.raises(NotImplementedError):
-    S.melspec_to_waveform(mel, 22050, 1024, 256, phase_estimation='lws')
+  w = S.melspec_to_waveform(mel, 22050, 1024, 256, phase_estimation='lws')       # the reference default: LWS on the GPU
+  assert w.shape[1:] == (1, 1) and w.dtype == np.float32 and np.isfinite(w).all()
 
 
 @gpu

@@ -96,8 +96,10 @@ def test_vocoding_script_writes_wavs(hip, tmp_path):
   np.random.seed(1)
   x = su.audio_from_mag_spec(mag, phase_estimation='gl2')
   assert x.shape == (11 * 256 + 1024, 1, 1) and x.dtype == np.float32
-  with pytest.raises(NotImplementedError):
-    su.audio_from_mag_spec(mag, phase_estimation='lws')
+  x = su.audio_from_mag_spec(mag, phase_estimation='lws')
+  assert x.shape == (11 * 256 + 1024, 1, 1) and x.dtype == np.float32 and np.isfinite(x).all()
+  with pytest.raises(ValueError):
+    su.audio_from_mag_spec(mag, phase_estimation='nope')
 
 
 @gpu
@@ -127,8 +129,8 @@ def test_vocode_batch_equals_per_sample_vocoding(hip):
     assert np.linalg.norm(one[:, :, 0] - gen[i].cpu().numpy()) / np.linalg.norm(one) < 1e-5
   g0, none = vocode_batch(m, specs[:1], phase_estimation=None, chunk_batch=2)
   assert none is None and tuple(g0.shape) == (1, 64, 513)
-  with pytest.raises(NotImplementedError):
-    vocode_batch(m, specs[:1], phase_estimation='lws', chunk_batch=2)
+  g1, w1 = vocode_batch(m, specs[:1], phase_estimation='lws', chunk_batch=2)
+  assert tuple(w1.shape) == (1, 63 * 256 + 1024) and bool(torch.isfinite(w1).all())
 
 
 @gpu

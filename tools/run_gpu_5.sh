@@ -1,3 +1,9 @@
 cd $GRAFT_REPO_ROOT
-for h in 1 0; do echo "H3=$h"; ADVOC_H3=$h timeout 600 python -m pytest tests/test_hip_model.py -q -m gpu -k side_stream 2>&1 | grep -E "AssertionError: \(|passed|failed" | head -5; done
-timeout 3000 python -m pytest tests -q -m gpu --deselect tests/test_hip_model.py::test_side_stream_weight_gradients_equal_serial_execution 2>&1 | tail -15
+timeout 1500 python -m pytest tests/test_hip_lws.py tests/test_hip_inversion.py tests/test_infer.py tests/test_loader.py tests/test_cli.py -q -m gpu -x 2>&1 | tail -15
+python - <<'PY'
+import time, torch, numpy as np
+from advoc_amd import spectral
+mag = torch.rand(32, 256, 513, device='cuda')
+for name, fn in (('lws', lambda: spectral.lws_batch(mag, 1024, 256)), ('gl60', lambda: spectral.griffin_lim_batch(mag, 1024, 256, 60, torch.rand_like(mag)))):
+  fn(); torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); print(name, '%.2f ms / 32 clips' % ((time.perf_counter() - t0) * 1e3))
+PY
