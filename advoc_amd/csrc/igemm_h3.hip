@@ -46,17 +46,21 @@ __device__ __forceinline__ float act_slope(int act) {
   return act == ADVOC_ACT_LRELU02 ? 0.2f : (act == ADVOC_ACT_RELU ? 0.f : 1.f);
 }
 
-template <int MT, int NT, int NS>
+// WGM x 2 wavefronts per workgroup (WGM = 2: 256 threads; WGM = 4: 512 threads, one workgroup per CU with 2-stage tiles of
+// 256 rows -- twice the rows per byte of B streamed)
+template <int MT, int NT, int NS, int WGM_ = 2>
 struct HCfg {
-  static constexpr int WGM = 2, WGN = 2;
+  static constexpr int WGM = WGM_, WGN = 2;
+  static constexpr int WAVES = WGM * WGN, THREADS = 64 * WAVES;
   static constexpr int BM = 32 * MT * WGM, BN = 32 * NT * WGN;
   static constexpr int BK = 32;
   static constexpr int ROWB = 4 * BK;                       // bytes of one tile row: 2 planes x 32 fp16 = one line
   static constexpr int A_TILE = BM * ROWB, B_TILE = BN * ROWB;
   static constexpr int STAGE = A_TILE + B_TILE;             // bytes
-  static constexpr int RGA = BM / 32, CGB = BN / 32;        // 8-row DMA blocks per wave and K tile
+  static constexpr int RGA = BM / (8 * WAVES), CGB = BN / (8 * WAVES);   // 8-row DMA blocks per wave and K tile
   static constexpr int DMA_PER_TILE = RGA + CGB;
-  static constexpr int EPI_BYTES = 4 * 32 * 36 * 4 + 2 * BM * 4;
+  static constexpr int EPI_BYTES = WAVES * 32 * 36 * 4 + 2 * BM * 4;
+  static_assert(BM % (8 * WAVES) == 0 && BN % (8 * WAVES) == 0, "whole DMA blocks per wave");
   static constexpr size_t LDS_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
 };
 
@@ -68,15 +72,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // (the body is a __device__ function behind a one-line kernel: with the body inside the __global__ template itself
 // hipcc's HOST pass silently dropped the kernel handle -- no diagnostic, an undefined symbol at load time)
-template <int MT, int NT, int NS, int ABL = 0>
+template <int MT, int NT, int NS, int WGM, int ABL = 0>
 __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
-  using C = HCfg<MT, NT, NS>;
+  using C = HCfg<MT, NT, NS, WGM>;
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK, WGN = C::WGN;
   constexpr int RGA = C::RGA, CGB = C::CGB;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* smem_b = reinterpret_cast<unsigned char*>(smem);
-  int* s_pix = reinterpret_cast<int*>(smem + 4 * 32 * 36);
+  int* s_pix = reinterpret_cast<int*>(smem + C::WAVES * 32 * 36);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -302,7 +306,7 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
 
   // ---- epilogue (igemm.hip): pixel table, LDS transpose, 16-byte stores with the fused bias / dropout /
   // activation-gradient / two-destination logic ----
-  for (int r = tid; r < BM; r += 256) {
+  for (int r = tid; r < BM; r += C::THREADS) {
     const unsigned m = m0 + r;
     int pix0 = -1, pix1 = -1;
     if (m < M) {
@@ -386,29 +390,30 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
   }
 }
 
-template <int MT, int NT, int NS>
-__global__ __launch_bounds__(256, 2) void gather_gemm_h3_kernel(const GatherGemmParams p) {
-  gather_gemm_h3_body<MT, NT, NS>(p);
+template <int MT, int NT, int NS, int WGM>
+__global__ __launch_bounds__(64 * WGM * 2, 2) void gather_gemm_h3_kernel(const GatherGemmParams p) {
+  gather_gemm_h3_body<MT, NT, NS, WGM>(p);
 }
 // timing experiments only (ADVOC_H3_ABLATE=2..4): 2 no MFMAs (fragment reads kept), 3 no DMA, 4 DMA only
 template <int MT, int NT, int NS, int ABL>
 __global__ __launch_bounds__(256, 2) void gather_gemm_h3_abl_kernel(const GatherGemmParams p) {
-  gather_gemm_h3_body<MT, NT, NS, ABL>(p);
+  gather_gemm_h3_body<MT, NT, NS, 2, ABL>(p);
 }
 
-template <int MT, int NT, int NS>
+template <int MT, int NT, int NS, int WGM = 2>
 int launch_h(const GatherGemmParams& p, hipStream_t stream, const char** name_only, const TailPlan& tail,
              float* tail_ws, int* tail_cnt, int ksplit) {
-  using C = HCfg<MT, NT, NS>;
+  using C = HCfg<MT, NT, NS, WGM>;
   if (name_only) {
     static const std::string name = std::string("gather_gemm_h3_kernel<") + std::to_string(MT) + ", " +
-                                    std::to_string(NT) + ", " + std::to_string(NS) + ">";
+                                    std::to_string(NT) + ", " + std::to_string(NS) +
+                                    (WGM == 2 ? std::string(">") : ", " + std::to_string(WGM) + ">");
     *name_only = name.c_str();
     return ADVOC_OK;
   }
   static const int abl = getenv("ADVOC_H3_ABLATE") ? atoi(getenv("ADVOC_H3_ABLATE")) : 0;
-  auto kern = gather_gemm_h3_kernel<MT, NT, NS>;
-  if (NS == 2 && MT == 2 && NT >= 2) {   // experiments: two instances are enough
+  auto kern = gather_gemm_h3_kernel<MT, NT, NS, WGM>;
+  if constexpr (NS == 2 && MT == 2 && NT >= 2 && WGM == 2) {   // experiments: two instances are enough
     if (abl == 2) kern = gather_gemm_h3_abl_kernel<MT, NT, NS, 2>;
     if (abl == 3) kern = gather_gemm_h3_abl_kernel<MT, NT, NS, 3>;
     if (abl == 4) kern = gather_gemm_h3_abl_kernel<MT, NT, NS, 4>;
@@ -435,22 +440,31 @@ int launch_h(const GatherGemmParams& p, hipStream_t stream, const char** name_on
     grid = dim3((unsigned)(tail.main + tail.rem * tail.split), 1, 1);
   }
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, q);
+  hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), C::LDS_BYTES, stream, q);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }
 
-struct Pick { int mt, nt, ns; };
+struct Pick { int mt, nt, ns, wgm; };
 
 // Tile choice (tools/micro/h3_sweep.py).  ADVOC_H3_TILE=1|2|3 forces 128x128 | 128x256 | 256x128,
 // ADVOC_H3_STAGES=2|3 the LDS stages.
 Pick pick_tile(const GatherGemmParams& p) {
   const Tuning& t = tuning();
   const int N = p.n_total;
-  Pick k = {2, 2, 2};
-  if (N % 128 != 0 || t.h3_tile == 4) k = {2, 1, 2};      // 64-column tiles (48 KiB: three workgroups per CU)
-  else if (t.h3_tile == 2 && N % 256 == 0) k = {2, 4, 2};
-  else if (t.h3_tile == 3) k = {4, 2, 2};
+  Pick k = {2, 2, 2, 2};
+  if (N % 128 != 0 || t.h3_tile == 4) k = {2, 1, 2, 2};      // 64-column tiles (48 KiB: three workgroups per CU)
+  else if (t.h3_tile == 2 && N % 256 == 0) k = {2, 4, 2, 2};
+  else if (t.h3_tile == 3) k = {4, 2, 2, 2};
+  else if (t.h3_tile == 5 && N % 256 == 0) k = {2, 4, 2, 4};  // 256 x 256, 8 waves
+  else if (t.h3_tile == 6) k = {2, 2, 2, 4};                  // 256 x 128, 8 waves
+  else if (t.h3_tile == 0 && N % 256 == 0) {
+    // 256 x 256 on 8 waves (one workgroup per CU) streams half the bytes per flop of 128 x 128 and measured 1.2-1.35x
+    // faster on every launch with >= 2 such tiles per CU (381 vs 284 TFLOP/s on D layer_4); below that the launch would
+    // fall into split-K, whose atomic epilogue on 64 Ki outputs per workgroup costs more than the tile saves
+    const int64_t t256 = ceil_div((int64_t)p.batch * p.gh * p.gw, 256) * (N / 256) * p.nphase;
+    if (t256 >= 512) k = {2, 4, 2, 4};
+  }
   if (t.h3_stages == 2 || t.h3_stages == 3) k.ns = t.h3_stages;
   if (k.ns == 3 && k.mt * k.nt > 4) k.ns = 2;       // 3 x 48 KiB + would not leave room: 128x256 runs two stages
   return k;
@@ -496,7 +510,7 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   const int64_t wq_bytes = round256((int64_t)4 * taps * N * ktot);
   const int64_t i0_bytes = round256(4 * e0), i1_bytes = round256(4 * e1);
   const Pick k = pick_tile(p);
-  const int BM = 64 * k.mt, BN = 64 * k.nt;
+  const int BM = 32 * k.mt * k.wgm, BN = 64 * k.nt;
   const int64_t tiles = ceil_div((int64_t)p.batch * p.gh * p.gw, BM) * (N / BN) * p.nphase;
   const int nkt = ktot / 32 * p.ntaps;
   // Small pixel grids with deep contractions (encoder_5.., decoder_5.. and their gradients) would leave CUs idle:
@@ -555,6 +569,8 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     }
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
   }
+  if (k.wgm == 4 && k.nt == 4) return launch_h<2, 4, 2, 4>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
+  if (k.wgm == 4) return launch_h<2, 2, 2, 4>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
   if (k.mt == 2 && k.nt == 1 && k.ns == 3) return launch_h<2, 1, 3>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
   if (k.mt == 2 && k.nt == 1) return launch_h<2, 1, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
   if (k.mt == 2 && k.nt == 2 && k.ns == 3) return launch_h<2, 2, 3>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);

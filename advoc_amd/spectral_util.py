@@ -45,6 +45,15 @@ class SpectralUtil(object):
   def invmeltrans(self):
     return self._const('inv')
 
+  def extract_training_triple(self, wav):
+    """What the train step consumes per batch (models/advoc/train_evaluate.py:55-56 on top of
+    advoc/loader.py:116-128): waveforms [b, n, 1, 1] in HBM -> (|STFT| [b, T, 513, 1], linear mel [b, T, n_mels, 1],
+    pseudo-inverted magnitudes [b, T, 513, 1]), T = 1 + (n - nfft) // nhop frames (whole frames only)."""
+    mag = spectral.stft_magnitude(wav, self.NFFT, self.NHOP, pad_end=False)
+    mel = spectral.matmul_last(mag[:, :, :, 0], self.meltrans).unsqueeze(-1)
+    inv = spectral.matmul_last(mel[:, :, :, 0], self.invmeltrans).unsqueeze(-1)
+    return mag, mel, inv
+
   def mag_to_mel_linear_spec(self, mag_spec):
     """[B, T, 513, 1] -> [B, T, n_mels, 1]   (spectral_util.py:29-32)."""
     mag_spec = mag_spec.to(_lib.device(), torch.float32)

@@ -27,7 +27,9 @@ Extra objects on the JSON line:
                 MFMA (157.3 TFLOP/s), or, for the split-bf16 kernels, dense bf16 MFMA / 6 partial products
                 (416.7 TFLOP/s algorithmic).  `traffic` = L2-miss bytes per launch of that kernel from the
                 committed rocprofv3 counter passes of this same command (profiles/r02_traffic.json; FETCH_SIZE
-                doubled per the gfx950 correction + WRITE_SIZE), null when not recorded for this workload.
+                doubled per the gfx950 correction + WRITE_SIZE), null when not recorded for this workload.  A launch of
+                an operand-image kernel includes its image passes (amax + fp16 pair image of the activations, weight
+                image): `achieved` prices the whole call, `kernels[..].gemm_only` is not separable by HIP events.
                 `kernels` lists every instance with its share, so the HBM-bound ones can be read too.
   extractor     the HBM-bound leg: waveform -> |STFT| -> mel -> pseudo-inverse, timed per launch with HIP
                 events; algorithmic bytes per clip from SURVEY.md §8d against 8 TB/s.
@@ -52,11 +54,13 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-# Kernels of the split-bf16 path run every fp32 product as SIX bf16 MFMA products (x = x0 + x1 + x2 exactly; the
-# three smallest of the nine partial products are dropped): their roof in ALGORITHMIC fp32 flops is the dense
-# bf16 peak / 6.
+# Kernels of the split paths run every fp32 product as several 16-bit MFMA products with fp32 accumulation: their roof in
+# ALGORITHMIC fp32 flops is the dense bf16 / f16 peak divided by the products per fp32 product --
+#   register-split kernels (x6.h: x = x0 + x1 + x2 in bf16, six of nine partial products)          2500 / 6
+#   operand-image kernels (igemm_h3.hip: x 2^s = h0 + h1 in fp16, three of four partial products)  2500 / 3
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # ibid., "BF16/F16 ~2.5 PF dense"
 X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+H3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
 HBM_PEAK_GBS = 8000.0           # ibid., HBM3E peak BW
 CLIP_FRAMES = 256
 CLIP_SAMPLES = (CLIP_FRAMES - 1) * 256 + 1024   # 66304
@@ -76,10 +80,17 @@ def synth_waveforms(batch, seed, device):
   return x.reshape(batch, CLIP_SAMPLES, 1, 1).to(device)
 
 
+def mfma_pipe(name):
+  """(peak TFLOP/s in algorithmic fp32 flops, description) of the matrix pipe a kernel instance runs on."""
+  if '_h3_kernel<' in name:
+    return H3_PEAK_TFLOPS, 'f16 MFMA, 3 partial products per fp32 product (2500 / 3 TFLOP/s algorithmic)'
+  if name.endswith(', true>') and (name.startswith('gather_gemm_kernel<') or name.startswith('wgrad_mfma_kernel<')):
+    return X6_PEAK_TFLOPS, 'bf16 MFMA, 6 partial products per fp32 product (2500 / 6 TFLOP/s algorithmic)'
+  return FP32_MFMA_PEAK_TFLOPS, 'fp32 MFMA'
+
+
 def is_split_bf16(name):
-  """Kernel instances of the split-bf16 matrix path (priced against 2500 / 6 TFLOP/s)."""
-  return ('x6' in name.split('<')[0]) or (
-      name.endswith(', true>') and (name.startswith('gather_gemm_kernel<') or name.startswith('wgrad_mfma_kernel<')))
+  return mfma_pipe(name)[0] != FP32_MFMA_PEAK_TFLOPS
 
 
 def cpu_baseline(model_small, threads, batch, budget_s, warm=True):
@@ -324,11 +335,11 @@ def roofline_from(prof, model, batch, ms_per_step, prof_steps, verbose):
   tot = sum(v['ms'] for v in rows.values())
   kernels = []
   for k, v in sorted(rows.items(), key=lambda kv: -kv[1]['ms']):
-    mfma = 'mfma' in k or 'gather_gemm' in k or 'x6' in k
+    mfma = 'mfma' in k or 'gather_gemm' in k
     entry = dict(kernel=k, launches_per_step=v['launches'] / prof_steps, share_of_conv_stack=v['ms'] / tot,
                  avg_launch_ms=v['ms'] / v['launches'])
     if mfma and v['flops'] > 0:
-      peak = X6_PEAK_TFLOPS if is_split_bf16(k) else FP32_MFMA_PEAK_TFLOPS
+      peak = mfma_pipe(k)[0]
       entry.update(bound='mfma', achieved=v['flops'] / (v['ms'] * 1e-3) / 1e12, peak=round(peak, 1), unit='TFLOP/s')
     else:
       entry.update(bound='hbm', achieved=v['bytes'] / (v['ms'] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s')
@@ -344,9 +355,7 @@ def roofline_from(prof, model, batch, ms_per_step, prof_steps, verbose):
                   measured='HIP events per launch on %d serial steps right after the timed region' % prof_steps,
                   kernels=kernels[:24])
   if top['bound'] == 'mfma':
-    x6 = is_split_bf16(name)
-    roofline.update(pipe=('bf16 MFMA, 6 partial products per fp32 product (2500 / 6 TFLOP/s algorithmic)' if x6
-                          else 'fp32 MFMA'),
+    roofline.update(pipe=mfma_pipe(name)[1],
                     vs_fp32_mfma_peak=top['achieved'] / FP32_MFMA_PEAK_TFLOPS,
                     flops_per_launch=r['flops'] / r['launches'])
   if verbose:
@@ -371,19 +380,20 @@ def train_leg(torch, model_name, B, steps, warmup, dp, dev, prof_steps):
   dp.attach(model)
   dp.broadcast_parameters(model)
   su = SpectralUtil(n_mels=model.n_mels, fs=model.audio_fs)
-  pool = [synth_waveforms(B, 1234 + 17 * dp.rank + i, dev) for i in range(4)]
-  state = {'i': 0}
+  # a train_loop consumes two batches (D update, then G update): both are extracted by ONE set of launches over
+  # 2B clips (a launch over B clips alone leaves most of the 256 CUs idle), then handed out half by half
+  pool = [synth_waveforms(2 * B, 1234 + 17 * dp.rank + i, dev) for i in range(2)]
+  state = {'i': 0, 'pending': None}
 
   def feed():
+    if state['pending'] is not None:
+      out, state['pending'] = state['pending'], None
+      return out
     wav = pool[state['i'] % len(pool)]
     state['i'] += 1
-    if hasattr(su, 'extract_training_triple'):
-      mag, mel, inv = su.extract_training_triple(wav)
-    else:
-      mag = spectral.stft_magnitude(wav, 1024, 256, pad_end=False)          # [B,256,513,1]
-      mel = su.mag_to_mel_linear_spec(mag)
-      inv = su.mel_linear_to_mag_spec(mel)
-    return inv, mag, wav, mel
+    mag, mel, inv = su.extract_training_triple(wav)
+    state['pending'] = (inv[B:], mag[B:], wav[B:], mel[B:])
+    return inv[:B], mag[:B], wav[:B], mel[:B]
   model(feed)
 
   for _ in range(warmup):
@@ -467,8 +477,8 @@ def main():
 
   extractor = inference = small = loader_res = None
   if dp.rank == 0 and not args.train_only:
-    extractor = extractor_leg(torch, spectral, su, pool[0])
-    mel0 = su.mag_to_mel_linear_spec(spectral.stft_magnitude(pool[0], 1024, 256, pad_end=False))
+    extractor = extractor_leg(torch, spectral, su, pool[0][:B])
+    mel0 = su.mag_to_mel_linear_spec(spectral.stft_magnitude(pool[0][:B], 1024, 256, pad_end=False))
     inference = inference_leg(torch, AdvocSmall if args.model == 'small' else Advoc, Modes, su, mel0)
     inference['joint_sc09'] = joint_leg(torch)
     try:
@@ -511,9 +521,12 @@ def main():
         'scaling': 'weak',
         'vs_baseline': None,
         'dtype': 'f32',
-        'dtype_note': 'fp32 tensors and fp32 accumulation everywhere; the large conv contractions run on the '
-                      'bf16 matrix cores with each fp32 operand split exactly into three bf16 terms (six of the '
-                      'nine partial products): error vs float64 2.5e-7, below the fp32 MFMA path (4e-7)',
+        'dtype_note': 'fp32 tensors and fp32 accumulation everywhere; the large conv contractions run on the 16-bit '
+                      'matrix cores with each fp32 operand written as a sum of 16-bit terms -- forward / backward-data: '
+                      'two fp16 terms of the operand scaled by one power of two per tensor, three of the four partial '
+                      'products (representation and dropped term <= 2^-22 relative); weight gradients: three bf16 '
+                      'terms, six of nine partial products -- measured against float64 at or below the error of the '
+                      'fp32 MFMA chain on the same layers (tests/test_hip_conv.py, tools/micro/h3_numerics.py)',
         'data': 'synthetic',
         'config': {
             'workload': 'AdVoc-%s train_loop (1 D update + 1 G update on fresh batches), LJSpeech '

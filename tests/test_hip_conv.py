@@ -255,7 +255,7 @@ H3 = [
     # deep contraction on a small grid: split-K slices meeting with atomics
     ('h3_deep_small', 0, (2, 8, 9), 512, 0, 128, 0, (2, 2), None, 1, False, 0),
 ]
-H3_VARIANTS = [(1, 2), (1, 3), (2, 2), (3, 2), (4, 2), (4, 3)]
+H3_VARIANTS = [(1, 2), (1, 3), (2, 2), (3, 2), (4, 2), (4, 3), (5, 2), (6, 2)]
 
 
 @gpu
@@ -273,7 +273,7 @@ def test_layer_operand_image_kernels(hip, case, variant, hipenv):
   cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
   y = torch.empty(x0.shape[0], c['oh'], c['out_w'], cout, device=dev)
   L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
-  want_tile = {1: '2, 2', 2: '2, 4', 3: '4, 2', 4: '2, 1'}[tile]
+  want_tile = {1: '2, 2', 2: '2, 4', 3: '4, 2', 4: '2, 1', 5: '2, 4', 6: '2, 2'}[tile]
   cin = x0.shape[3] + (x1.shape[3] if x1 is not None else 0)
   for direction, n_cols, k_ch in ((0, cout, cin), (1, cin, cout)):
     name = L.kernel_name(direction)
@@ -281,8 +281,10 @@ def test_layer_operand_image_kernels(hip, case, variant, hipenv):
       continue                                                   # outside the image path: other kernels, same oracle
     if n_cols % 128:
       want = 'gather_gemm_h3_kernel<2, 1, %d>' % stages          # 64 / 192 columns: 128 x 64 tiles
-    elif tile == 2 and n_cols % 256:
+    elif tile in (2, 5) and n_cols % 256:
       want = 'gather_gemm_h3_kernel<2, 2, %d>' % stages          # 256-column tile impossible: falls to 128 x 128
+    elif tile in (5, 6):
+      want = 'gather_gemm_h3_kernel<%s, 2, 4>' % want_tile       # 8-wave workgroups: 256 x 256 / 256 x 128
     else:
       want = 'gather_gemm_h3_kernel<%s, %d>' % (want_tile, 2 if tile in (2, 3) else stages)
     assert name == want, (direction, name, want)

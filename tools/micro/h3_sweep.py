@@ -32,8 +32,8 @@ def t(fn, reps=10):
   return e0.elapsed_time(e1) / reps * 1e3
 
 
-VARIANTS = [('old', dict(ADVOC_H3=0))] + [('t3_s2', dict(ADVOC_H3=1, ADVOC_H3_TILE=3, ADVOC_H3_STAGES=2))] + [
-    ('t%d_s%d' % (tl, st), dict(ADVOC_H3=1, ADVOC_H3_TILE=tl, ADVOC_H3_STAGES=st)) for tl, st in ((1, 2), (1, 3), (2, 2))]
+VARIANTS = [('t5_256x256', dict(ADVOC_H3=1, ADVOC_H3_TILE=5)), ('t6_256x128', dict(ADVOC_H3=1, ADVOC_H3_TILE=6))] + [
+    ('t%d_s%d' % (tl, st), dict(ADVOC_H3=1, ADVOC_H3_TILE=tl, ADVOC_H3_STAGES=st)) for tl, st in ((1, 2),)]
 
 for name in (sys.argv[1:] or list(SHAPES)):
   L, dy, dx0, dx1 = build(name)

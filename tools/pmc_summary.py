@@ -16,6 +16,7 @@ L2-miss traffic, an upper bound on HBM bytes."""
 import collections
 import csv
 import json
+import os
 import sys
 
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
@@ -41,7 +42,8 @@ def main():
     out[k] = dict(launches=len(fetch[k]), fetch_kib_raw=f, write_kib=w, traffic_bytes=traffic)
     print('| `%s` | %d | %.2f | %.2f | %.1f |' % (k, len(fetch[k]), f / 1024, w / 1024, traffic / 1e6))
   if '--json' in sys.argv:
-    out['_workload'] = dict(model='small', batch=32, command='python bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-only')
+    out['_workload'] = dict(model=os.environ.get('PMC_MODEL', 'regular'), batch=int(os.environ.get('PMC_BATCH', '64')),
+                            command='python bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-only --prof-steps 0')
     json.dump(out, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1, sort_keys=True)
 
 
