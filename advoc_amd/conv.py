@@ -128,8 +128,7 @@ class Layer(object):
     self.struct = s
     # scratch for the two-stage path of the 1-2 channel layers: one buffer per device, shared by
     # all layers (launches are stream-ordered), grown on demand
-    need = max(_lib.load().advoc_conv_workspace_bytes(ctypes.byref(s), 0),
-               _lib.load().advoc_conv_workspace_bytes(ctypes.byref(s), 1))
+    need = max(_lib.load().advoc_conv_workspace_bytes(ctypes.byref(s), d) for d in (0, 1, 2))
     if need > 0 and workspace:
       ws = Layer._workspace_for(x0.device, need)
       s.workspace = ws.data_ptr()

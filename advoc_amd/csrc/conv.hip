@@ -6,6 +6,7 @@
 // Reference graph being replaced: models/advoc/advoc_model.py:25-69 (layer builders),
 // :89-158 (generator), :184-202 (discriminator) and their TF gradients.
 #include "conv_internal.h"
+#include "tuning.h"
 
 namespace advoc {
 
@@ -327,6 +328,13 @@ extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stre
 
 extern "C" int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* L, int32_t direction) {
   if (validate_layer(L) != ADVOC_OK) return 0;
+  if (direction == 2) {      // backward-weight: operand images of the image-based kernel
+    WgradParams w;
+    float dummy = 0.f;
+    if (build_backward_weight(L, &dummy, &dummy, w) != ADVOC_OK || !wgrad_h3_eligible(w)) return 0;
+    int64_t a, b, c, d;
+    return 256 + wgrad_h3_operand_bytes(w.P, w.batch, &a, &b) + wgrad_h3_operand_bytes(w.Q, w.batch, &c, &d);
+  }
   GatherGemmParams p;
   bool b_kn;
   float dummy = 0.f;
@@ -377,7 +385,27 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
     rc = (cb % 32 == 0 && p.ntaps * ca <= 32) ? launch_wgrad_thin_mfma(p, as_stream(stream)) : ADVOC_ERR_UNSUPPORTED;
     if (rc == ADVOC_ERR_UNSUPPORTED) rc = launch_wgrad_thin(p, as_stream(stream));   // odd channel counts / wide tap spans
   } else {
-    rc = launch_wgrad_mfma(p, as_stream(stream));
+    rc = ADVOC_ERR_UNSUPPORTED;
+    if (wgrad_h3_eligible(p)) {
+      // operand images in the caller's workspace: [P header 128 B][Q header 128 B][P image][Q image]
+      int64_t pb0, pb1, qb0, qb1;
+      const int64_t pbytes = wgrad_h3_operand_bytes(p.P, p.batch, &pb0, &pb1);
+      const int64_t qbytes = wgrad_h3_operand_bytes(p.Q, p.batch, &qb0, &qb1);
+      if (L->workspace && L->workspace_bytes >= 256 + pbytes + qbytes) {
+        char* ws = reinterpret_cast<char*>(L->workspace);
+        unsigned* hp = reinterpret_cast<unsigned*>(ws);
+        unsigned* hq = reinterpret_cast<unsigned*>(ws + 128);
+        uint16_t* ip = reinterpret_cast<uint16_t*>(ws + 256);
+        uint16_t* iq = reinterpret_cast<uint16_t*>(ws + 256 + pbytes);
+        rc = ADVOC_OK;
+        if (!tuning().h3_skip_prep) {      // (micro-benchmarks reuse the images of the previous call)
+          rc = wgrad_h3_make_image(p.P, p.batch, ip, hp, as_stream(stream));
+          if (rc == ADVOC_OK) rc = wgrad_h3_make_image(p.Q, p.batch, iq, hq, as_stream(stream));
+        }
+        if (rc == ADVOC_OK) rc = launch_wgrad_h3(p, ip, hp, iq, hq, as_stream(stream));
+      }
+    }
+    if (rc == ADVOC_ERR_UNSUPPORTED) rc = launch_wgrad_mfma(p, as_stream(stream));
   }
   if (rc != ADVOC_OK) return rc;
   if (db)
@@ -418,8 +446,14 @@ extern "C" int advoc_conv_kernel_name(const advoc_conv_layer* L, int32_t directi
     if (ca <= 2)
       rc = (cb % 32 == 0 && p.ntaps * ca <= 32) ? launch_wgrad_thin_mfma(p, nullptr, &name)
                                                 : launch_wgrad_thin(p, nullptr, &name);
-    else
-      rc = launch_wgrad_mfma(p, nullptr, &name);
+    else {
+      int64_t a, b, c, d;
+      rc = ADVOC_ERR_UNSUPPORTED;
+      if (wgrad_h3_eligible(p) && L->workspace &&
+          L->workspace_bytes >= 256 + wgrad_h3_operand_bytes(p.P, p.batch, &a, &b) + wgrad_h3_operand_bytes(p.Q, p.batch, &c, &d))
+        rc = launch_wgrad_h3(p, nullptr, nullptr, nullptr, nullptr, nullptr, &name);
+      if (rc == ADVOC_ERR_UNSUPPORTED) rc = launch_wgrad_mfma(p, nullptr, &name);
+    }
   } else {
     return ADVOC_ERR_UNSUPPORTED;
   }

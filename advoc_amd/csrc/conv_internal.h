@@ -59,6 +59,14 @@ int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream,
 int launch_wgrad_thin(const WgradParams& p, hipStream_t stream,
                       const char** name_only = nullptr);   // P has <= 2 channels
 
+// Operand-image weight gradient (wgrad_h3.hip): both operands as fp16 pair images.  *_make_image writes one operand's
+// image (source 1 behind source 0 at its 256-byte-rounded size) and {amax, 2^-s} header; *_operand_bytes sizes it.
+bool wgrad_h3_eligible(const WgradParams& p);
+int64_t wgrad_h3_operand_bytes(const Operand& o, int batch, int64_t* b0, int64_t* b1);
+int wgrad_h3_make_image(const Operand& o, int batch, uint16_t* img, unsigned* hdr, hipStream_t stream);
+int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned* p_hdr, const uint16_t* q_img,
+                    const unsigned* q_hdr, hipStream_t stream, const char** name_only = nullptr);
+
 int launch_wgrad_thin_mfma(const WgradParams& p, hipStream_t stream,
                            const char** name_only = nullptr);   // P <= 2 channels, Q % 32, on MFMA
 

@@ -1,0 +1,302 @@
+// Weight gradient on operand images: dw[tap][a][b] = sum_g P[g s + d(tap)][a] Q[g][b] with both operands read as fp16
+// pair images (image.hip) -- the images the forward (activations) and backward-data (output gradients) launches of the
+// same layer have already written.  Replaces TF Conv2DBackpropFilter for the layers of
+// models/advoc/advoc_model.py:25-69 whose operands are >= 32 channels wide.
+//
+// The register-split kernel of wgrad.hip spends its issue slots converting: every operand element is split into bf16
+// terms and packed again for every tap that reads it (41 % of its wave cycles issue VALU work, the matrix pipe is busy
+// 35 %).  Here nothing is converted:
+//   * GEMM view as in wgrad.hip: rows = (tap, channel of P), 128 per workgroup; columns = channel of Q, 128 per
+//     workgroup; the reduction axis is the pixel grid, cut into chunks over workgroups (fp32 atomics into the zeroed
+//     dw), 32 grid points per K tile;
+//   * a K tile is DMA'd (buffer_load ... lds) as [32-channel block][32 pixels][128 B]: one instruction = 8 pixels x one
+//     128-byte K slice of the image (both fp16 planes of 32 channels = one cache line).  A tap shifts the gathered
+//     operand's pixel, out-of-range pixels get an offset beyond num_records and arrive as zeros;
+//   * the MFMA wants 8 consecutive PIXELS of one channel per lane, the tile holds 32 consecutive channels per pixel:
+//     ds_read_b64_tr_b16 transposes on the way out of LDS (16 lanes read a [4 pixels][16 channels] block, 8 bytes per
+//     lane, and each lane receives the 4 pixels of its own channel -- probed on gfx950, tools/micro/tr_probe.hip); the
+//     two planes of a pixel row are stored swapped on pixels 2, 3 (mod 4), applied to the DMA source address, which makes
+//     the 4-row x 64-byte reads of a half wave conflict-free;
+//   * three fp16 products per fp32 product (a0 b1, a1 b0, a0 b0), fp32 accumulation, exact power-of-two unscaling.
+#include <stdlib.h>
+
+#include <string>
+
+#include "conv_internal.h"
+#include "tuning.h"
+#include "x6.h"
+
+namespace advoc {
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_void_p;
+
+constexpr int WK = 32;              // grid points per K tile
+constexpr int BLK = WK * 128;       // bytes of one 32-channel block of a K tile
+constexpr int STAGE = 8 * BLK;      // 4 row blocks of P + 4 column blocks of Q
+
+struct WgradImages {
+  const uint16_t* p0; const uint16_t* p1;   // images of the two sources of P (p1 null: single source)
+  const uint16_t* q0; const uint16_t* q1;
+  int p0_bytes, p1_bytes, q0_bytes, q1_bytes;
+  const unsigned* p_hdr; const unsigned* q_hdr;   // {amax bits, 2^-s}
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, const WgradImages im, int tiles_n,
+                                                          int tiles, int chunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int vblock;
+  {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, slot = b >> 3;
+    vblock = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int zchunk = vblock / tiles;
+  const int tile_id = vblock - zchunk * tiles;
+  const int a0 = (tile_id / tiles_n) * 128;
+  const int b0 = (tile_id % tiles_n) * 128;
+  const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
+  const int rows_total = p.ntaps * ca;
+  const int M = p.batch * p.gh * p.gw;                 // < 2^31 (launcher)
+  const int g_begin = zchunk * chunk;
+  const int g_end = g_begin + chunk < M ? g_begin + chunk : M;
+  const int nkt = (g_end - g_begin + WK - 1) / WK;
+
+  // ---- this wave's DMA blocks: P row block `wave` (one tap, one 32-channel slice), Q column block `wave` ----
+  const int lpix = lane >> 3, lpos = lane & 7;         // pixel within an 8-pixel group, 16-byte position in the row
+  const int row0 = a0 + wave * 32;
+  const bool p_live = row0 < rows_total;
+  const int tap_i = p_live ? row0 / ca : 0;
+  const int p_ch = p_live ? row0 - tap_i * ca : 0;     // first channel of the slice (concatenated view)
+  const int tp = p.tap[tap_i];
+  const int dy = (int)(int8_t)(tp & 0xff), dx = (int)(int8_t)((tp >> 8) & 0xff);
+  const bool p_second = p_ch >= p.P.c0;
+  const int p_c = p_second ? p.P.c1 : p.P.c0, p_pitch = p_second ? p.P.pitch1 : p.P.pitch0;
+  const int p_choff = (p_second ? p_ch - p.P.c0 : p_ch) * 4;          // bytes: 2 planes x 2 B per channel
+  const int q_ch = b0 + wave * 32;
+  const bool q_live = q_ch < cb;
+  const bool q_second = q_live && q_ch >= p.Q.c0;
+  const int q_c = q_second ? p.Q.c1 : p.Q.c0, q_pitch = q_second ? p.Q.pitch1 : p.Q.pitch0;
+  const int q_choff = (q_second ? q_ch - p.Q.c0 : (q_live ? q_ch : 0)) * 4;
+  const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(p_second ? im.p1 : im.p0), 0, p_second ? im.p1_bytes : im.p0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(q_second ? im.q1 : im.q0), 0, q_second ? im.q1_bytes : im.q0_bytes, 0x00020000);
+  // chunk position q of pixel row r holds chunk q ^ (4 if r & 2): the two planes swapped on rows 2, 3 (mod 4)
+  const int lchunk16 = (lpos ^ (((lpix >> 1) & 1) << 2)) * 16;
+
+  // grid point of each of this lane's 4 pixel slots (pixel lpix + 8 s of the K tile), tracked incrementally
+  int gy[4], gx[4], gi[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const unsigned g = (unsigned)(g_begin + lpix + 8 * s);
+    const unsigned t = g / (unsigned)p.gw;
+    gx[s] = (int)(g - t * (unsigned)p.gw);
+    gi[s] = (int)(t / (unsigned)p.gh);
+    gy[s] = (int)(t - (unsigned)gi[s] * (unsigned)p.gh);
+  }
+  const int step_q = WK / p.gw, step_r = WK - step_q * p.gw;       // 32 grid points = step_q rows + step_r points
+  int g_lane = g_begin + lpix;                                       // grid index of slot 0
+
+#define ADVOC_WH3_ISSUE(ST)                                                                              \
+  {                                                                                                      \
+    unsigned char* st_ = wsm + (ST) * STAGE;                                                             \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                      \
+      const bool in_ = g_lane + 8 * s < g_end;                                                           \
+      const int py_ = gy[s] * p.sy + dy, px_ = gx[s] * p.sx + dx;                                        \
+      const bool pok_ = in_ && p_live && (unsigned)py_ < (unsigned)p.P.h && (unsigned)px_ < (unsigned)p.P.w; \
+      const int pv_ = pok_ ? ((gi[s] * p.P.h + py_) * p_pitch + px_) * p_c * 4 + p_choff + lchunk16 : (int)0x80000000; \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (lds_void_p)(st_ + wave * BLK + s * 1024), 16, pv_, 0, 0, 0);   \
+      const bool qok_ = in_ && q_live;                                                                   \
+      const int qv_ = qok_ ? ((gi[s] * p.Q.h + gy[s]) * q_pitch + gx[s]) * q_c * 4 + q_choff + lchunk16 : (int)0x80000000; \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_p)(st_ + (4 + wave) * BLK + s * 1024), 16, qv_, 0, 0, 0); \
+      /* advance the slot by one K tile */                                                               \
+      gx[s] += step_r; gy[s] += step_q;                                                                  \
+      if (gx[s] >= p.gw) { gx[s] -= p.gw; gy[s] += 1; }                                                  \
+      while (gy[s] >= p.gh) { gy[s] -= p.gh; gi[s] += 1; }                                               \
+    }                                                                                                    \
+    g_lane += WK;                                                                                        \
+  }
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposing fragment reads: lane -> channel lane % 32 of a 32-channel block, pixels 8 (lane / 32) + 4 h + 0..3 of a
+  // 16-pixel K step.  A 16-lane group reads [4 pixels][16 channels]: lane ll at pixel ll / 4, channels 4 (ll % 4)..+3.
+  const int ll = lane & 15;
+  const int tr_base = ((lane >> 5) * 8 + (ll >> 2)) * 128 + ((lane >> 4) & 1) * 32 + (ll & 3) * 8;
+  const int tr_flip = ((ll >> 3) & 1) * 64;        // rows 2, 3 of the 4-pixel block hold the planes swapped
+  const int tr_pl0 = tr_base + tr_flip, tr_pl1 = tr_base + (64 - tr_flip);
+
+#define ADVOC_WH3_FRAG(BASE, PLOFF, KS, H) \
+  __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)((BASE) + (PLOFF) + ((KS) * 16 + (H) * 4) * 128))
+
+#define ADVOC_WH3_COMPUTE(ST)                                                                            \
+  {                                                                                                      \
+    const unsigned char* Pb = wsm + (ST) * STAGE;                                                        \
+    const unsigned char* Qb = Pb + 4 * BLK;                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                   \
+      f16x8 af[2][2], bq[2][2];                                                                          \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
+        const unsigned char* b_ = Pb + (wm * 2 + i) * BLK;                                               \
+        const short4v a00 = ADVOC_WH3_FRAG(b_, tr_pl0, ks, 0), a01 = ADVOC_WH3_FRAG(b_, tr_pl0, ks, 1);    \
+        const short4v a10 = ADVOC_WH3_FRAG(b_, tr_pl1, ks, 0), a11 = ADVOC_WH3_FRAG(b_, tr_pl1, ks, 1);    \
+        af[i][0] = __builtin_bit_cast(f16x8, __builtin_shufflevector(a00, a01, 0, 1, 2, 3, 4, 5, 6, 7));                            \
+        af[i][1] = __builtin_bit_cast(f16x8, __builtin_shufflevector(a10, a11, 0, 1, 2, 3, 4, 5, 6, 7));                            \
+      }                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
+        const unsigned char* b_ = Qb + (wn * 2 + j) * BLK;                                               \
+        const short4v b00 = ADVOC_WH3_FRAG(b_, tr_pl0, ks, 0), b01 = ADVOC_WH3_FRAG(b_, tr_pl0, ks, 1);    \
+        const short4v b10 = ADVOC_WH3_FRAG(b_, tr_pl1, ks, 0), b11 = ADVOC_WH3_FRAG(b_, tr_pl1, ks, 1);    \
+        bq[j][0] = __builtin_bit_cast(f16x8, __builtin_shufflevector(b00, b01, 0, 1, 2, 3, 4, 5, 6, 7));                            \
+        bq[j][1] = __builtin_bit_cast(f16x8, __builtin_shufflevector(b10, b11, 0, 1, 2, 3, 4, 5, 6, 7));                            \
+      }                                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bq[j][1], acc[i][j], 0, 0, 0);    \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bq[j][0], acc[i][j], 0, 0, 0);    \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bq[j][0], acc[i][j], 0, 0, 0);    \
+        }                                                                                                \
+    }                                                                                                    \
+  }
+
+  // ---- K loop: two LDS stages, one barrier per K tile (igemm_h3.hip) ----
+  ADVOC_WH3_ISSUE(0);
+  for (int kt = 0; kt < nkt; kt += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      ADVOC_WH3_ISSUE(u ^ 1);
+      if (kt + u < nkt) ADVOC_WH3_COMPUTE(u);
+    }
+  }
+#undef ADVOC_WH3_ISSUE
+#undef ADVOC_WH3_COMPUTE
+#undef ADVOC_WH3_FRAG
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const float unscale = __uint_as_float(im.p_hdr[1]) * __uint_as_float(im.q_hdr[1]);
+  const int half = lane >> 5, l32 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    // a 32-row MFMA tile never straddles a tap (ca % 32 == 0): one tap lookup per tile
+    const int r0 = a0 + (wm * 2 + i) * 32;
+    if (r0 >= rows_total) continue;
+    const int t_ = r0 / ca;
+    float* out = p.dw + ((int64_t)(p.tap[t_] >> 16) * ca + (r0 - t_ * ca)) * cb;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int b = b0 + (wn * 2 + j) * 32 + l32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int a = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (b < cb) unsafeAtomicAdd(out + (int64_t)a * cb + b, acc[i][j][r] * unscale);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool wgrad_h3_eligible(const WgradParams& p) {
+  const Tuning& t = tuning();
+  if (!t.wgrad_h3 || !t.h3 || !t.igemm_x6) return false;
+  const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
+  if (ca % 32 || cb % 32 || p.P.c0 % 32 || p.Q.c0 % 32) return false;
+  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  if (M > 0x3fffffffLL || M < t.wgrad_h3_min_m || p.gw < 1) return false;
+  if ((int64_t)p.ntaps * ca * cb < 128 * 128) return false;
+  const int64_t lim = 0x7fffffffLL;
+  const int64_t ep0 = (int64_t)p.batch * p.P.h * p.P.pitch0 * p.P.c0, ep1 = (int64_t)p.batch * p.P.h * p.P.pitch1 * p.P.c1;
+  const int64_t eq0 = (int64_t)p.batch * p.Q.h * p.Q.pitch0 * p.Q.c0, eq1 = (int64_t)p.batch * p.Q.h * p.Q.pitch1 * p.Q.c1;
+  if (4 * ep0 > lim || 4 * ep1 > lim || 4 * eq0 > lim || 4 * eq1 > lim) return false;
+  return true;
+}
+
+int64_t wgrad_h3_operand_bytes(const Operand& o, int batch, int64_t* b0, int64_t* b1) {
+  *b0 = ((int64_t)4 * batch * o.h * o.pitch0 * o.c0 + 255) / 256 * 256;
+  *b1 = ((int64_t)4 * batch * o.h * o.pitch1 * o.c1 + 255) / 256 * 256;
+  return *b0 + *b1;
+}
+
+// Makes the image of one operand (both sources, one scale) at `img` / `hdr`.
+int wgrad_h3_make_image(const Operand& o, int batch, uint16_t* img, unsigned* hdr, hipStream_t stream) {
+  int64_t b0, b1;
+  wgrad_h3_operand_bytes(o, batch, &b0, &b1);
+  const int64_t e0 = (int64_t)batch * o.h * o.pitch0 * o.c0, e1 = (int64_t)batch * o.h * o.pitch1 * o.c1;
+  hipError_t e = hipMemsetAsync(hdr, 0, 8, stream);
+  if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  int rc = launch_amax(o.p0, e0, o.c0, o.scale, o.shift, o.act, o.mask, o.mask_scale, hdr, stream);
+  if (rc != ADVOC_OK) return rc;
+  const float* sc1 = o.scale ? o.scale + o.c0 : nullptr;
+  const float* sh1 = o.shift ? o.shift + o.c0 : nullptr;
+  if (e1) {
+    rc = launch_amax(o.p1, e1, o.c1, sc1, sh1, o.act, nullptr, 0.f, hdr, stream);
+    if (rc != ADVOC_OK) return rc;
+  }
+  rc = launch_pair_image(o.p0, img, e0, o.c0, o.scale, o.shift, o.act, o.mask, o.mask_scale, hdr, stream);
+  if (rc != ADVOC_OK) return rc;
+  if (e1) rc = launch_pair_image(o.p1, reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(img) + b0), e1, o.c1, sc1, sh1,
+                                 o.act, nullptr, 0.f, hdr, stream);
+  return rc;
+}
+
+// p_img / q_img: images of P and Q (source 1 follows source 0 at the 256-byte-rounded size of source 0), hdr: their
+// {amax, 2^-s} words; the caller has filled them (wgrad_h3_make_image or an earlier forward / backward-data launch).
+int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned* p_hdr, const uint16_t* q_img,
+                    const unsigned* q_hdr, hipStream_t stream, const char** name_only) {
+  if (!wgrad_h3_eligible(p)) return ADVOC_ERR_UNSUPPORTED;
+  if (name_only) { *name_only = "wgrad_h3_kernel"; return ADVOC_OK; }
+  if (!p_img || !q_img || !p_hdr || !q_hdr) return ADVOC_ERR_NULL;
+  const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
+  if (!p.accumulate) {
+    hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
+    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  }
+  int64_t pb0, pb1, qb0, qb1;
+  wgrad_h3_operand_bytes(p.P, p.batch, &pb0, &pb1);
+  wgrad_h3_operand_bytes(p.Q, p.batch, &qb0, &qb1);
+  WgradImages im = {};
+  im.p0 = p_img; im.p1 = p.P.c1 ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(p_img) + pb0) : nullptr;
+  im.q0 = q_img; im.q1 = p.Q.c1 ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(q_img) + qb0) : nullptr;
+  im.p0_bytes = (int)((int64_t)4 * p.batch * p.P.h * p.P.pitch0 * p.P.c0);
+  im.p1_bytes = (int)((int64_t)4 * p.batch * p.P.h * p.P.pitch1 * p.P.c1);
+  im.q0_bytes = (int)((int64_t)4 * p.batch * p.Q.h * p.Q.pitch0 * p.Q.c0);
+  im.q1_bytes = (int)((int64_t)4 * p.batch * p.Q.h * p.Q.pitch1 * p.Q.c1);
+  im.p_hdr = p_hdr; im.q_hdr = q_hdr;
+  const int tiles_m = (p.ntaps * ca + 127) / 128, tiles_n = (cb + 127) / 128;
+  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  static const int64_t resident = 2 * (int64_t)device_cu_count();      // 64 KiB of LDS: two workgroups per CU
+  const int64_t tiles = (int64_t)tiles_m * tiles_n;
+  int64_t ksplit = ceil_div(resident, tiles);
+  if (M / ksplit >= 4096) ksplit = ceil_div(2 * resident, tiles);
+  const int64_t max_split = ceil_div(M, 8 * WK);
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit < 1) ksplit = 1;
+  int64_t chunk = ceil_div(ceil_div(M, ksplit), WK) * WK;
+  ksplit = ceil_div(M, chunk);
+  if (chunk > 0x3fffffffLL || tiles * ksplit > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+  if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(wgrad_h3_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), 2 * STAGE, stream, p, im, tiles_n,
+                     (int)tiles, (int)chunk);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+}  // namespace advoc

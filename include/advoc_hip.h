@@ -210,7 +210,7 @@ typedef struct advoc_conv_layer {
   int64_t workspace_bytes;
 } advoc_conv_layer;
 
-/* Scratch the layer can use for `direction` (0 forward, 1 backward-data); 0 when it needs none. */
+/* Scratch the layer can use for `direction` (0 forward, 1 backward-data, 2 backward-weight); 0 when it needs none. */
 int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* layer, int32_t direction);
 
 /* Forward.  Replaces TF Conv2D / Conv2DBackpropInput(+BiasAdd, activations, concat, dropout)

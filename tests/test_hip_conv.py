@@ -292,6 +292,28 @@ def test_layer_operand_image_kernels(hip, case, variant, hipenv):
 
 
 @gpu
+@pytest.mark.parametrize('case', H3, ids=[c[0] for c in H3])
+def test_layer_operand_image_weight_gradient(hip, case, hipenv):
+  """wgrad_h3.hip: both operands from fp16 pair images, transposing LDS reads; every H3 shape (taps that leave the
+  image, two sources, strides, dropout on the gradient operand) against the float64 oracle."""
+  from advoc_amd import conv
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_WGRAD_H3_MIN_M=1)
+  c = build_case(case)
+  dev = torch.device('cuda')
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w = c['w'].to(dev)
+  cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+  y = torch.empty(x0.shape[0], c['oh'], c['out_w'], cout, device=dev)
+  L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
+  assert L.kernel_name(2) == 'wgrad_h3_kernel', L.kernel_name(2)
+  test_layer_all_directions(hip, case)
+  hipenv(ADVOC_WGRAD_H3=0)
+  L2 = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
+  assert 'h3' not in L2.kernel_name(2)
+
+
+@gpu
 def test_operand_image_kernel_with_batchnorm_prologue(hip, hipenv):
   """The image pass applies the producer's batch-norm affine and the dropout that follows it (in_scale / in_shift /
   in_mask of advoc_conv_layer) before the split: compare with the fp32 MFMA path on the same layer."""
