@@ -74,6 +74,11 @@ class Layer(object):
 
   profiler = None   # set to a LaunchProfiler to time every launch
   _workspaces = {}
+  # True: the caller guarantees that between a forward() and the backward_weight() that follows it the layer's inputs
+  # are unchanged, and that backward_data(dy) / backward_weight(dy) of one step see the same dy contents (the train
+  # step of advoc_amd.model does): the operand images forward / backward_data leave behind are then read again by
+  # backward_weight instead of being rebuilt.  False (default, stand-alone use): every call builds what it reads.
+  reuse_images = False
 
   @staticmethod
   def _workspace_for(device, nbytes):
@@ -134,6 +139,21 @@ class Layer(object):
       s.workspace = ws.data_ptr()
       s.workspace_bytes = ws.numel() * 4
       self.tensors = self.tensors + (ws,)
+    # persistent operand images (advoc_conv_layer.x_img / dy_img): only where the image-based weight gradient applies
+    self._img = []
+    self._x_current = False
+    self._dy_current_ptr = None
+    if workspace:
+      for which, img_field, hdr_field in ((0, 'x_img', 'x_hdr'), (1, 'dy_img', 'dy_hdr')):
+        nbytes = _lib.load().advoc_conv_image_bytes(ctypes.byref(s), which)
+        if nbytes > 0:
+          img = torch.empty(nbytes // 2, dtype=torch.int16, device=x0.device)
+          hdr = torch.zeros(2, dtype=torch.int32, device=x0.device)
+          setattr(s, img_field, img.data_ptr())
+          setattr(s, hdr_field, hdr.data_ptr())
+          self._img += [img, hdr]
+      self.tensors = self.tensors + tuple(self._img)
+    s.img_flags = 0
     self._names = {}
     lw = s.x0.w
     grid = (y.shape[1] * s.y.w) if kind == CONV else (x0.shape[1] * lw)
@@ -161,6 +181,8 @@ class Layer(object):
   def forward(self):
     self._run(0, lambda: _lib.check(
         _lib.load().advoc_conv_forward(ctypes.byref(self.struct), _lib.stream()), 'advoc_conv_forward'))
+    # the image-based forward kernel has just left the input image in x_img
+    self._x_current = bool(self.struct.x_img) and 'h3' in self.kernel_name(0)
     return self.y
 
   def backward_data(self, dy, dx0=None, dx1=None, accum0=False, accum1=False):
@@ -175,15 +197,22 @@ class Layer(object):
     self._run(1, lambda: _lib.check(_lib.load().advoc_conv_backward_data(
         ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dx0), _lib.ptr(dx1), int(accum0),
         int(accum1), _lib.stream()), 'advoc_conv_backward_data'))
+    self._dy_current_ptr = dy.data_ptr() if (self.struct.dy_img and 'h3' in self.kernel_name(1)) else None
 
   def backward_weight(self, dy, dw, db=None, accumulate=False):
     _lib.require_device(dy)
     _lib.require_device(dw)
     if tuple(dw.shape) != tuple(self.weight.shape):
       raise _lib.AdvocHipError('dw shape mismatch')
+    flags = 0
+    if self.reuse_images:
+      flags = (1 if self._x_current else 0) | (2 if self._dy_current_ptr == dy.data_ptr() else 0)
+    self.struct.img_flags = flags
     self._run(2, lambda: _lib.check(_lib.load().advoc_conv_backward_weight(
         ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dw), None, int(accumulate), _lib.stream()),
         'advoc_conv_backward_weight'))
+    self.struct.img_flags = 0
+    self._dy_current_ptr = None          # one use per backward_data: the next step's dy lives at the same address
     if db is not None:
       _lib.require_device(db)
       call = lambda: _lib.check(_lib.load().advoc_conv_backward_bias(      # noqa: E731

@@ -323,7 +323,18 @@ extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stre
   bool b_kn;
   rc = build_forward(L, p, b_kn);
   if (rc != ADVOC_OK) return rc;
+  p.a_img_out = L->x_img; p.a_hdr_out = L->x_img ? L->x_hdr : nullptr;
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
+}
+
+extern "C" int64_t advoc_conv_image_bytes(const advoc_conv_layer* L, int32_t which) {
+  if (validate_layer(L) != ADVOC_OK || which < 0 || which > 1) return 0;
+  WgradParams w;
+  float dummy = 0.f;
+  if (build_backward_weight(L, &dummy, &dummy, w) != ADVOC_OK || !wgrad_h3_eligible(w)) return 0;
+  const bool p_is_inputs = w.P.p0 == L->x0.p;
+  int64_t a, b;
+  return wgrad_h3_operand_bytes((which == 0) == p_is_inputs ? w.P : w.Q, w.batch, &a, &b);
 }
 
 extern "C" int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* L, int32_t direction) {
@@ -363,6 +374,7 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
   bool b_kn;
   rc = build_backward_data(L, dy, dx0, dx1, accum0, accum1, p, b_kn);
   if (rc != ADVOC_OK) return rc;
+  p.a_img_out = L->dy_img; p.a_hdr_out = L->dy_img ? L->dy_hdr : nullptr;
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
 
@@ -387,22 +399,31 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
   } else {
     rc = ADVOC_ERR_UNSUPPORTED;
     if (wgrad_h3_eligible(p)) {
-      // operand images in the caller's workspace: [P header 128 B][Q header 128 B][P image][Q image]
+      // operand images: the layer's persistent ones when they are current (left by this step's forward /
+      // backward-data call), else made here -- into the persistent buffer if there is one, else into the workspace
+      // ([P header 128 B][Q header 128 B][P image][Q image])
       int64_t pb0, pb1, qb0, qb1;
       const int64_t pbytes = wgrad_h3_operand_bytes(p.P, p.batch, &pb0, &pb1);
       const int64_t qbytes = wgrad_h3_operand_bytes(p.Q, p.batch, &qb0, &qb1);
-      if (L->workspace && L->workspace_bytes >= 256 + pbytes + qbytes) {
+      const bool p_is_inputs = p.P.p0 == L->x0.p;
+      struct Home { uint16_t* img; unsigned* hdr; bool current; };
+      const Home in_home = {L->x_img, L->x_img ? L->x_hdr : nullptr, (L->img_flags & ADVOC_IMG_X_CURRENT) != 0};
+      const Home dy_home = {L->dy_img, L->dy_img ? L->dy_hdr : nullptr, (L->img_flags & ADVOC_IMG_DY_CURRENT) != 0};
+      Home hp = p_is_inputs ? in_home : dy_home, hq = p_is_inputs ? dy_home : in_home;
+      int64_t ws_need = 256 + (hp.img ? 0 : pbytes) + (hq.img ? 0 : qbytes);
+      if ((hp.img && hq.img) || (L->workspace && L->workspace_bytes >= ws_need)) {
         char* ws = reinterpret_cast<char*>(L->workspace);
-        unsigned* hp = reinterpret_cast<unsigned*>(ws);
-        unsigned* hq = reinterpret_cast<unsigned*>(ws + 128);
-        uint16_t* ip = reinterpret_cast<uint16_t*>(ws + 256);
-        uint16_t* iq = reinterpret_cast<uint16_t*>(ws + 256 + pbytes);
+        if (!hp.img) { hp = {reinterpret_cast<uint16_t*>(ws + 256), reinterpret_cast<unsigned*>(ws), false}; }
+        if (!hq.img) {
+          hq = {reinterpret_cast<uint16_t*>(ws + 256 + (hp.img == reinterpret_cast<uint16_t*>(ws + 256) ? pbytes : 0)),
+                reinterpret_cast<unsigned*>(ws + 128), false};
+        }
         rc = ADVOC_OK;
         if (!tuning().h3_skip_prep) {      // (micro-benchmarks reuse the images of the previous call)
-          rc = wgrad_h3_make_image(p.P, p.batch, ip, hp, as_stream(stream));
-          if (rc == ADVOC_OK) rc = wgrad_h3_make_image(p.Q, p.batch, iq, hq, as_stream(stream));
+          if (!hp.current) rc = wgrad_h3_make_image(p.P, p.batch, hp.img, hp.hdr, as_stream(stream));
+          if (rc == ADVOC_OK && !hq.current) rc = wgrad_h3_make_image(p.Q, p.batch, hq.img, hq.hdr, as_stream(stream));
         }
-        if (rc == ADVOC_OK) rc = launch_wgrad_h3(p, ip, hp, iq, hq, as_stream(stream));
+        if (rc == ADVOC_OK) rc = launch_wgrad_h3(p, hp.img, hp.hdr, hq.img, hq.hdr, as_stream(stream));
       }
     }
     if (rc == ADVOC_ERR_UNSUPPORTED) rc = launch_wgrad_mfma(p, as_stream(stream));

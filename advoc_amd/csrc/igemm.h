@@ -77,6 +77,9 @@ struct GatherGemmParams {
   int a0_img_bytes, a1_img_bytes;
   const unsigned* a_hdr;
   const unsigned* b_hdr;
+  // caller-provided home of the A image / header (persistent per-layer buffers); null: the launch workspace
+  uint16_t* a_img_out;
+  unsigned* a_hdr_out;
   // ---- tail split (filled in by the launcher, see launch_cfg) ----
   int tail_main;           // > 0: 1-D launch; tiles [0, tail_main) whole, the rest in tail_split K slices each
   int tail_split;

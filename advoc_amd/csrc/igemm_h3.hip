@@ -530,11 +530,14 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   if (!scratch || scratch_bytes < need) return ADVOC_ERR_UNSUPPORTED;
   p.k_order = tuning().igemm_korder >= 0 ? tuning().igemm_korder : 1;
   char* ws = reinterpret_cast<char*>(scratch);
-  unsigned* hdr_a = reinterpret_cast<unsigned*>(ws);
-  unsigned* hdr_b = hdr_a + 2;
+  unsigned* hdr_b = reinterpret_cast<unsigned*>(ws) + 2;
+  unsigned* hdr_a = p.a_hdr_out ? p.a_hdr_out : reinterpret_cast<unsigned*>(ws);
   uint16_t* wq = reinterpret_cast<uint16_t*>(ws + hdr_bytes);
-  uint16_t* img0 = reinterpret_cast<uint16_t*>(ws + hdr_bytes + wq_bytes);
-  uint16_t* img1 = reinterpret_cast<uint16_t*>(ws + hdr_bytes + wq_bytes + i0_bytes);
+  // the A image: in the layer's persistent buffer when it has one (the weight-gradient call of the same step reads it
+  // again, wgrad_h3.hip), else in the workspace; source 1 follows source 0 at its 256-byte-rounded size either way
+  char* img_home = p.a_img_out ? reinterpret_cast<char*>(p.a_img_out) : ws + hdr_bytes + wq_bytes;
+  uint16_t* img0 = reinterpret_cast<uint16_t*>(img_home);
+  uint16_t* img1 = reinterpret_cast<uint16_t*>(img_home + i0_bytes);
   p.a_hdr = hdr_a; p.b_hdr = hdr_b;
   p.wq = wq;
   p.wq_taps = taps;
@@ -547,7 +550,8 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   if (!name_only && tuning().h3_skip_prep) {
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
   } else if (!name_only) {
-    hipError_t e = hipMemsetAsync(hdr_a, 0, 16, stream);
+    hipError_t e = hipMemsetAsync(hdr_a, 0, 8, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(hdr_b, 0, 8, stream);
     if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
     int rc = launch_pair_weights(p.w, wq, taps, N, ktot, b_kn, hdr_b, stream);
     if (rc != ADVOC_OK) return rc;

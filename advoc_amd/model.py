@@ -441,6 +441,10 @@ class Advoc(Model):
     else:
       st['d_layers_2b'], _ = d_layers(0, 2 * B)
     st['g_d_target'] = torch.zeros(2 * B, T, F, 1, **f32)
+    # inside the train step a layer's inputs do not change between its forward and its weight gradient, and backward_data /
+    # backward_weight of a layer see the same gradient tensor: the operand images are made once per tensor and step
+    for lay in list(L.values()) + st['d_layers_fake'] + st.get('d_layers_real', []) + st.get('d_layers_2b', []):
+      lay.reuse_images = True
 
   # ------------------------------------------------------------------------------------------
   # batch-norm plumbing
@@ -655,10 +659,11 @@ class Advoc(Model):
         g = st['g_d_act'][i][lo:hi]
         if i in bns:
           self._bn_backward(bns[i], g, accumulate=acc)
-        with self._wgrad_ctx():
-          layers[i].backward_weight(g, DG[s + '/kernel'], DG[s + '/bias'], accumulate=acc)
+        # backward-data first: it leaves the fp16 pair image of g behind, which the weight gradient reads again
         if i > 0:
           layers[i].backward_data(g, st['g_d_act'][i - 1][lo:hi])
+        with self._wgrad_ctx():
+          layers[i].backward_weight(g, DG[s + '/kernel'], DG[s + '/bias'], accumulate=acc)
     self._join_wgrad()
     self._adam('d')
     st['last_counts_d'] = n
@@ -744,34 +749,34 @@ class Advoc(Model):
     s = 'generator/decoder_1/conv2d_transpose'
     st['g_sent'] = 0
     st['g_grad'].zero_()       # one fill for the whole arena; the kernels below accumulate into it
+    last_idx = dec[-1][0] if dec else None
+    GL['decoder_1'].backward_data(g_out, gd[last_idx] if dec else ge[-1], ge[0])
     with self._wgrad_ctx():
       GL['decoder_1'].backward_weight(g_out, GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
       self._g_grads_ready(self._last_param_of('generator/decoder_1'))
-    last_idx = dec[-1][0] if dec else None
-    GL['decoder_1'].backward_data(g_out, gd[last_idx] if dec else ge[-1], ge[0])
     for j in range(len(dec) - 1, -1, -1):
       idx = dec[j][0]
       s = 'generator/decoder_%d/conv2d_transpose' % idx
       lay = GL['decoder_%d' % idx]
       if 'decoder_%d' % idx in gbn:
         self._bn_backward(gbn['decoder_%d' % idx], gd[idx], accumulate=True)
-      with self._wgrad_ctx():
-        lay.backward_weight(gd[idx], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
-        self._g_grads_ready(self._last_param_of('generator/decoder_%d' % idx))
       if j == 0:
         lay.backward_data(gd[idx], ge[-1])
       else:
         lay.backward_data(gd[idx], gd[dec[j - 1][0]], ge[idx - 1])
+      with self._wgrad_ctx():
+        lay.backward_weight(gd[idx], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
+        self._g_grads_ready(self._last_param_of('generator/decoder_%d' % idx))
     for i in range(len(e) - 1, -1, -1):
       s = 'generator/encoder_%d/conv2d' % (i + 1)
       lay = GL['encoder_%d' % (i + 1)]
       if 'encoder_%d' % (i + 1) in gbn:
         self._bn_backward(gbn['encoder_%d' % (i + 1)], ge[i], accumulate=True)
+      if i > 0:
+        lay.backward_data(ge[i], ge[i - 1], accum0=True)
       with self._wgrad_ctx():
         lay.backward_weight(ge[i], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
         self._g_grads_ready(self._last_param_of('generator/encoder_%d' % (i + 1)))
-      if i > 0:
-        lay.backward_data(ge[i], ge[i - 1], accum0=True)
     self._join_wgrad()
     self._adam('g')
     self.step += 1

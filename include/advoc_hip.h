@@ -208,7 +208,26 @@ typedef struct advoc_conv_layer {
    * between calls, one buffer can serve every layer on a stream. */
   float* workspace;
   int64_t workspace_bytes;
+  /* optional persistent operand images (caller-owned device memory, 256-byte aligned; NULL = none).  The image-based
+   * kernels read fp16 pair images of the layer's input (after its fused transform) and of the output gradient; with
+   * these buffers the forward call leaves the input image (and its 8-byte header {largest magnitude, 2^-s}) in x_img /
+   * x_hdr and the backward-data call the image of dy in dy_img / dy_hdr, and the backward-weight call of the same step
+   * reads them instead of making its own: img_flags bit 0 = x_img is current (the inputs have not changed since the
+   * forward call that filled it), bit 1 = dy_img is current (filled by a backward-data call with the same dy).  Sizes:
+   * advoc_conv_image_bytes(); headers 8 bytes each.  Without the buffers the images live in `workspace` per call. */
+  uint16_t* x_img;
+  uint32_t* x_hdr;
+  uint16_t* dy_img;
+  uint32_t* dy_hdr;
+  int32_t img_flags;
 } advoc_conv_layer;
+
+#define ADVOC_IMG_X_CURRENT 1
+#define ADVOC_IMG_DY_CURRENT 2
+
+/* Bytes of the persistent operand image `which` (0: inputs, 1: output gradient) the layer can use; 0 when the layer's
+ * shapes are outside the image-based kernels. */
+int64_t advoc_conv_image_bytes(const advoc_conv_layer* layer, int32_t which);
 
 /* Scratch the layer can use for `direction` (0 forward, 1 backward-data, 2 backward-weight); 0 when it needs none. */
 int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* layer, int32_t direction);
