@@ -67,6 +67,7 @@ PROTOTYPES = {
     'advoc_mel_dbnorm_f32': (ctypes.c_int, [_p, _i64, _f32, _f32, _f32, _p]),
     'advoc_conv_workspace_bytes': (_i64, [_p, _i32]),
     'advoc_conv_image_bytes': (_i64, [_p, _i32]),
+    'advoc_conv_make_image': (ctypes.c_int, [_p, _i32, _p, _p]),
     'advoc_conv_forward': (ctypes.c_int, [_p, _p]),
     'advoc_conv_backward_data': (ctypes.c_int, [_p, _p, _p, _p, _i32, _i32, _p]),
     'advoc_conv_backward_weight': (ctypes.c_int, [_p, _p, _p, _p, _i32, _p]),

@@ -324,7 +324,21 @@ extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stre
   rc = build_forward(L, p, b_kn);
   if (rc != ADVOC_OK) return rc;
   p.a_img_out = L->x_img; p.a_hdr_out = L->x_img ? L->x_hdr : nullptr;
+  p.a_img_current = (L->img_flags & ADVOC_IMG_X_CURRENT) != 0;
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
+}
+
+extern "C" int advoc_conv_make_image(const advoc_conv_layer* L, int32_t which, const float* dy, advoc_stream_t stream) {
+  int rc = validate_layer(L);
+  if (rc != ADVOC_OK) return rc;
+  if (which < 0 || which > 1 || (which == 1 && !dy)) return ADVOC_ERR_NULL;
+  uint16_t* img = which == 0 ? L->x_img : L->dy_img;
+  unsigned* hdr = which == 0 ? L->x_hdr : L->dy_hdr;
+  if (!img || !hdr) return ADVOC_ERR_NULL;
+  Operand o;
+  if (which == 0) operand_from_inputs(L, o); else operand_from_dy(L, dy, o);
+  if ((o.c0 % 32) || (o.c1 % 32)) return ADVOC_ERR_UNSUPPORTED;
+  return wgrad_h3_make_image(o, L->x0.n, img, hdr, as_stream(stream));
 }
 
 extern "C" int64_t advoc_conv_image_bytes(const advoc_conv_layer* L, int32_t which) {
@@ -375,6 +389,7 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
   rc = build_backward_data(L, dy, dx0, dx1, accum0, accum1, p, b_kn);
   if (rc != ADVOC_OK) return rc;
   p.a_img_out = L->dy_img; p.a_hdr_out = L->dy_img ? L->dy_hdr : nullptr;
+  p.a_img_current = (L->img_flags & ADVOC_IMG_DY_CURRENT) != 0;
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
 

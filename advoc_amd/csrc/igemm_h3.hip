@@ -406,8 +406,7 @@ int launch_h(const GatherGemmParams& p, hipStream_t stream, const char** name_on
   using C = HCfg<MT, NT, NS, WGM>;
   if (name_only) {
     static const std::string name = std::string("gather_gemm_h3_kernel<") + std::to_string(MT) + ", " +
-                                    std::to_string(NT) + ", " + std::to_string(NS) +
-                                    (WGM == 2 ? std::string(">") : ", " + std::to_string(WGM) + ">");
+                                    std::to_string(NT) + ", " + std::to_string(NS) + ", " + std::to_string(WGM) + ">";
     *name_only = name.c_str();
     return ADVOC_OK;
   }
@@ -550,11 +549,12 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   if (!name_only && tuning().h3_skip_prep) {
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
   } else if (!name_only) {
-    hipError_t e = hipMemsetAsync(hdr_a, 0, 8, stream);
+    hipError_t e = (p.a_img_out && p.a_img_current) ? hipSuccess : hipMemsetAsync(hdr_a, 0, 8, stream);
     if (e == hipSuccess) e = hipMemsetAsync(hdr_b, 0, 8, stream);
     if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
     int rc = launch_pair_weights(p.w, wq, taps, N, ktot, b_kn, hdr_b, stream);
     if (rc != ADVOC_OK) return rc;
+    if (!(p.a_img_out && p.a_img_current)) {
     // one scale for the whole A operand: the largest magnitude over both sources of a channel concat
     rc = launch_amax(p.a0, e0, p.c0, p.in_scale, p.in_shift, p.in_act, p.a_mask, p.a_mask_scale, hdr_a, stream);
     if (rc != ADVOC_OK) return rc;
@@ -570,6 +570,7 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     if (e1) {
       rc = launch_pair_image(p.a1, img1, e1, p.c1, sc1, sh1, p.in_act, nullptr, 0.f, hdr_a, stream);
       if (rc != ADVOC_OK) return rc;
+    }
     }
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
   }

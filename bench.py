@@ -27,9 +27,10 @@ Extra objects on the JSON line:
                 MFMA (157.3 TFLOP/s), or, for the split-bf16 kernels, dense bf16 MFMA / 6 partial products
                 (416.7 TFLOP/s algorithmic).  `traffic` = L2-miss bytes per launch of that kernel from the
                 committed rocprofv3 counter passes of this same command (profiles/r02_traffic.json; FETCH_SIZE
-                doubled per the gfx950 correction + WRITE_SIZE), null when not recorded for this workload.  A launch of
-                an operand-image kernel includes its image passes (amax + fp16 pair image of the activations, weight
-                image): `achieved` prices the whole call, `kernels[..].gemm_only` is not separable by HIP events.
+                doubled per the gfx950 correction + WRITE_SIZE), null when not recorded for this workload.  The operand-image
+                passes (amax_kernel + pair_image_kernel) that precede an image-based GEMM are launched and timed on their
+                own during the instrumented steps (`operand_images(...)` in `kernels`); the small weight-image kernels
+                stay inside the GEMM's call.
                 `kernels` lists every instance with its share, so the HBM-bound ones can be read too.
   extractor     the HBM-bound leg: waveform -> |STFT| -> mel -> pseudo-inverse, timed per launch with HIP
                 events; algorithmic bytes per clip from SURVEY.md §8d against 8 TB/s.
@@ -82,7 +83,7 @@ def synth_waveforms(batch, seed, device):
 
 def mfma_pipe(name):
   """(peak TFLOP/s in algorithmic fp32 flops, description) of the matrix pipe a kernel instance runs on."""
-  if '_h3_kernel<' in name:
+  if '_h3_kernel' in name:
     return H3_PEAK_TFLOPS, 'f16 MFMA, 3 partial products per fp32 product (2500 / 3 TFLOP/s algorithmic)'
   if name.endswith(', true>') and (name.startswith('gather_gemm_kernel<') or name.startswith('wgrad_mfma_kernel<')):
     return X6_PEAK_TFLOPS, 'bf16 MFMA, 6 partial products per fp32 product (2500 / 6 TFLOP/s algorithmic)'
@@ -335,7 +336,7 @@ def roofline_from(prof, model, batch, ms_per_step, prof_steps, verbose):
   tot = sum(v['ms'] for v in rows.values())
   kernels = []
   for k, v in sorted(rows.items(), key=lambda kv: -kv[1]['ms']):
-    mfma = 'mfma' in k or 'gather_gemm' in k
+    mfma = 'mfma' in k or 'gather_gemm' in k or 'wgrad_h3' in k
     entry = dict(kernel=k, launches_per_step=v['launches'] / prof_steps, share_of_conv_stack=v['ms'] / tot,
                  avg_launch_ms=v['ms'] / v['launches'])
     if mfma and v['flops'] > 0:

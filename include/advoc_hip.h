@@ -213,7 +213,8 @@ typedef struct advoc_conv_layer {
    * these buffers the forward call leaves the input image (and its 8-byte header {largest magnitude, 2^-s}) in x_img /
    * x_hdr and the backward-data call the image of dy in dy_img / dy_hdr, and the backward-weight call of the same step
    * reads them instead of making its own: img_flags bit 0 = x_img is current (the inputs have not changed since the
-   * forward call that filled it), bit 1 = dy_img is current (filled by a backward-data call with the same dy).  Sizes:
+   * call that filled it), bit 1 = dy_img is current (filled by a call with the same dy).  A forward / backward-data call
+   * that finds its bit set skips its image passes too (advoc_conv_make_image fills a buffer on its own).  Sizes:
    * advoc_conv_image_bytes(); headers 8 bytes each.  Without the buffers the images live in `workspace` per call. */
   uint16_t* x_img;
   uint32_t* x_hdr;
@@ -228,6 +229,9 @@ typedef struct advoc_conv_layer {
 /* Bytes of the persistent operand image `which` (0: inputs, 1: output gradient) the layer can use; 0 when the layer's
  * shapes are outside the image-based kernels. */
 int64_t advoc_conv_image_bytes(const advoc_conv_layer* layer, int32_t which);
+/* Builds the persistent operand image `which` (0: x_img from the layer's inputs; 1: dy_img from `dy`) on its own: the
+ * magnitude pass and the fp16 pair image pass of advoc_amd/csrc/image.hip.  ADVOC_ERR_NULL without the buffer. */
+int advoc_conv_make_image(const advoc_conv_layer* layer, int32_t which, const float* dy, advoc_stream_t stream);
 
 /* Scratch the layer can use for `direction` (0 forward, 1 backward-data, 2 backward-weight); 0 when it needs none. */
 int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* layer, int32_t direction);

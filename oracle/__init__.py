@@ -11,7 +11,10 @@ Pinning status ("Oracle"):
                     (tests/test_spectral.py:33-46,74-76) and the r9y9 fixture.  Its iSTFT /
                     Griffin-Lim part reproduces the reference's Griffin-Lim constants
                     (tests/test_spectral.py:200-203) to 0.1 % with scipy's resampler standing in
-                    for librosa's (8-decimal pin NOT reproducible); LWS is not restated.
+                    for librosa's (8-decimal pin NOT reproducible).
+  * lws_np       -- PARITY UNPINNED: lws 1.2 (third-party C++) is not part of /root/reference; the published
+                    LWS algorithm restated.  The one reachable reference number (run_lws from the true complex
+                    spectrogram, tests/test_spectral.py:190,207: 4.24e-4) is met in order of magnitude (5.7e-4).
   * audioio      -- pinned against outputs of the reference's advoc/audioio.py
                     imported in the build container (tests/golden/make_golden.py).
   * advoc_torch  -- PARITY UNPINNED: the reference holds no test or golden

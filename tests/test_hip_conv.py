@@ -280,13 +280,13 @@ def test_layer_operand_image_kernels(hip, case, variant, hipenv):
     if k_ch % 32 or n_cols % 64 or x0.shape[3] % 32:
       continue                                                   # outside the image path: other kernels, same oracle
     if n_cols % 128:
-      want = 'gather_gemm_h3_kernel<2, 1, %d>' % stages          # 64 / 192 columns: 128 x 64 tiles
+      want = 'gather_gemm_h3_kernel<2, 1, %d, 2>' % stages          # 64 / 192 columns: 128 x 64 tiles
     elif tile in (2, 5) and n_cols % 256:
-      want = 'gather_gemm_h3_kernel<2, 2, %d>' % stages          # 256-column tile impossible: falls to 128 x 128
+      want = 'gather_gemm_h3_kernel<2, 2, %d, 2>' % stages          # 256-column tile impossible: falls to 128 x 128
     elif tile in (5, 6):
       want = 'gather_gemm_h3_kernel<%s, 2, 4>' % want_tile       # 8-wave workgroups: 256 x 256 / 256 x 128
     else:
-      want = 'gather_gemm_h3_kernel<%s, %d>' % (want_tile, 2 if tile in (2, 3) else stages)
+      want = 'gather_gemm_h3_kernel<%s, %d, 2>' % (want_tile, 2 if tile in (2, 3) else stages)
     assert name == want, (direction, name, want)
   test_layer_all_directions(hip, case)
 

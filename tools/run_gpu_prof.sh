@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 OUT=gpurun_out/prof_r02; rm -rf $OUT; mkdir -p $OUT
-CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-only --prof-steps 0"
+CMD="env ADVOC_WGRAD_STREAM=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-only --prof-steps 0"
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1; echo trace rc=$?
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1; echo fetch rc=$?
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1; echo write rc=$?
