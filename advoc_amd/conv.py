@@ -79,6 +79,10 @@ class Layer(object):
   # step of advoc_amd.model does): the operand images forward / backward_data leave behind are then read again by
   # backward_weight instead of being rebuilt.  False (default, stand-alone use): every call builds what it reads.
   reuse_images = False
+  # True: consecutive calls on this layer see data of the same scale (the train step): after the first (exact, two-pass)
+  # image of a buffer, later images are built in ONE pass with the scale taken from the previous image's largest
+  # magnitude (ADVOC_IMG_*_DELAYED, 2^6 of head room; csrc/image.hip).  False (default): always the exact two-pass form.
+  delayed_scale = False
 
   @staticmethod
   def _workspace_for(device, nbytes):
@@ -143,12 +147,14 @@ class Layer(object):
     self._img = []
     self._x_current = False
     self._dy_current_ptr = None
+    self._x_built = False          # x_img / dy_img have held an image before (their headers carry its magnitude)
+    self._dy_built = False
     if workspace:
       for which, img_field, hdr_field in ((0, 'x_img', 'x_hdr'), (1, 'dy_img', 'dy_hdr')):
         nbytes = _lib.load().advoc_conv_image_bytes(ctypes.byref(s), which)
         if nbytes > 0:
           img = torch.empty(nbytes // 2, dtype=torch.int16, device=x0.device)
-          hdr = torch.zeros(2, dtype=torch.int32, device=x0.device)
+          hdr = torch.zeros(4, dtype=torch.int32, device=x0.device)
           setattr(s, img_field, img.data_ptr())
           setattr(s, hdr_field, hdr.data_ptr())
           self._img += [img, hdr]
@@ -189,16 +195,28 @@ class Layer(object):
       return 0
     src = [t for t in (self.x0, self.x1) if t is not None] if which == 0 else [dy]
     nbytes = sum(12.0 * t.numel() for t in src)           # read twice (magnitude pass, image pass), 4 B written
+    self.struct.img_flags = self._delayed_bits()
     prof.timed('operand_images(amax_kernel + pair_image_kernel)', 0.0, nbytes, lambda: _lib.check(
         _lib.load().advoc_conv_make_image(ctypes.byref(self.struct), which, _lib.ptr(dy), _lib.stream()),
         'advoc_conv_make_image'))
+    if which == 0:
+      self._x_built = True
+    else:
+      self._dy_built = True
     return 1 if which == 0 else 2
 
+  def _delayed_bits(self):
+    if not self.delayed_scale:
+      return 0
+    return (4 if self._x_built else 0) | (8 if self._dy_built else 0)
+
   def forward(self):
-    self.struct.img_flags = self._timed_image(0)
+    self.struct.img_flags = self._timed_image(0) | self._delayed_bits()
     self._run(0, lambda: _lib.check(
         _lib.load().advoc_conv_forward(ctypes.byref(self.struct), _lib.stream()), 'advoc_conv_forward'))
     self.struct.img_flags = 0
+    if self.struct.x_img and 'h3' in self.kernel_name(0):
+      self._x_built = True
     # the image-based forward kernel has just left the input image in x_img
     self._x_current = bool(self.struct.x_img) and 'h3' in self.kernel_name(0)
     return self.y
@@ -212,11 +230,13 @@ class Layer(object):
         _lib.require_device(d)
         if x is None or tuple(d.shape) != tuple(x.shape):
           raise _lib.AdvocHipError('dx must have the shape of the matching input')
-    self.struct.img_flags = self._timed_image(1, dy)
+    self.struct.img_flags = self._timed_image(1, dy) | self._delayed_bits()
     self._run(1, lambda: _lib.check(_lib.load().advoc_conv_backward_data(
         ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dx0), _lib.ptr(dx1), int(accum0),
         int(accum1), _lib.stream()), 'advoc_conv_backward_data'))
     self.struct.img_flags = 0
+    if self.struct.dy_img and 'h3' in self.kernel_name(1):
+      self._dy_built = True
     self._dy_current_ptr = dy.data_ptr() if (self.struct.dy_img and 'h3' in self.kernel_name(1)) else None
 
   def backward_weight(self, dy, dw, db=None, accumulate=False):
@@ -227,11 +247,14 @@ class Layer(object):
     flags = 0
     if self.reuse_images:
       flags = (1 if self._x_current else 0) | (2 if self._dy_current_ptr == dy.data_ptr() else 0)
-    self.struct.img_flags = flags
+    self.struct.img_flags = flags | self._delayed_bits()
     self._run(2, lambda: _lib.check(_lib.load().advoc_conv_backward_weight(
         ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dw), None, int(accumulate), _lib.stream()),
         'advoc_conv_backward_weight'))
     self.struct.img_flags = 0
+    if 'h3' in self.kernel_name(2):        # the image-based weight gradient has (re)built whatever was not current
+      self._x_built = self._x_built or bool(self.struct.x_img)
+      self._dy_built = self._dy_built or bool(self.struct.dy_img)
     self._dy_current_ptr = None          # one use per backward_data: the next step's dy lives at the same address
     if db is not None:
       _lib.require_device(db)

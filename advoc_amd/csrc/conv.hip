@@ -325,6 +325,7 @@ extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stre
   if (rc != ADVOC_OK) return rc;
   p.a_img_out = L->x_img; p.a_hdr_out = L->x_img ? L->x_hdr : nullptr;
   p.a_img_current = (L->img_flags & ADVOC_IMG_X_CURRENT) != 0;
+  p.a_img_delayed = (L->img_flags & ADVOC_IMG_X_DELAYED) != 0;
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
 
@@ -338,7 +339,8 @@ extern "C" int advoc_conv_make_image(const advoc_conv_layer* L, int32_t which, c
   Operand o;
   if (which == 0) operand_from_inputs(L, o); else operand_from_dy(L, dy, o);
   if ((o.c0 % 32) || (o.c1 % 32)) return ADVOC_ERR_UNSUPPORTED;
-  return wgrad_h3_make_image(o, L->x0.n, img, hdr, as_stream(stream));
+  const bool delayed = (L->img_flags & (which == 0 ? ADVOC_IMG_X_DELAYED : ADVOC_IMG_DY_DELAYED)) != 0;
+  return wgrad_h3_make_image(o, L->x0.n, img, hdr, delayed, as_stream(stream));
 }
 
 extern "C" int64_t advoc_conv_image_bytes(const advoc_conv_layer* L, int32_t which) {
@@ -390,6 +392,7 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
   if (rc != ADVOC_OK) return rc;
   p.a_img_out = L->dy_img; p.a_hdr_out = L->dy_img ? L->dy_hdr : nullptr;
   p.a_img_current = (L->img_flags & ADVOC_IMG_DY_CURRENT) != 0;
+  p.a_img_delayed = (L->img_flags & ADVOC_IMG_DY_DELAYED) != 0;
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
 
@@ -421,22 +424,24 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
       const int64_t pbytes = wgrad_h3_operand_bytes(p.P, p.batch, &pb0, &pb1);
       const int64_t qbytes = wgrad_h3_operand_bytes(p.Q, p.batch, &qb0, &qb1);
       const bool p_is_inputs = p.P.p0 == L->x0.p;
-      struct Home { uint16_t* img; unsigned* hdr; bool current; };
-      const Home in_home = {L->x_img, L->x_img ? L->x_hdr : nullptr, (L->img_flags & ADVOC_IMG_X_CURRENT) != 0};
-      const Home dy_home = {L->dy_img, L->dy_img ? L->dy_hdr : nullptr, (L->img_flags & ADVOC_IMG_DY_CURRENT) != 0};
+      struct Home { uint16_t* img; unsigned* hdr; bool current; bool delayed; };
+      const Home in_home = {L->x_img, L->x_img ? L->x_hdr : nullptr, (L->img_flags & ADVOC_IMG_X_CURRENT) != 0,
+                            (L->img_flags & ADVOC_IMG_X_DELAYED) != 0};
+      const Home dy_home = {L->dy_img, L->dy_img ? L->dy_hdr : nullptr, (L->img_flags & ADVOC_IMG_DY_CURRENT) != 0,
+                            (L->img_flags & ADVOC_IMG_DY_DELAYED) != 0};
       Home hp = p_is_inputs ? in_home : dy_home, hq = p_is_inputs ? dy_home : in_home;
       int64_t ws_need = 256 + (hp.img ? 0 : pbytes) + (hq.img ? 0 : qbytes);
       if ((hp.img && hq.img) || (L->workspace && L->workspace_bytes >= ws_need)) {
         char* ws = reinterpret_cast<char*>(L->workspace);
-        if (!hp.img) { hp = {reinterpret_cast<uint16_t*>(ws + 256), reinterpret_cast<unsigned*>(ws), false}; }
+        if (!hp.img) { hp = {reinterpret_cast<uint16_t*>(ws + 256), reinterpret_cast<unsigned*>(ws), false, false}; }
         if (!hq.img) {
           hq = {reinterpret_cast<uint16_t*>(ws + 256 + (hp.img == reinterpret_cast<uint16_t*>(ws + 256) ? pbytes : 0)),
-                reinterpret_cast<unsigned*>(ws + 128), false};
+                reinterpret_cast<unsigned*>(ws + 128), false, false};
         }
         rc = ADVOC_OK;
         if (!tuning().h3_skip_prep) {      // (micro-benchmarks reuse the images of the previous call)
-          if (!hp.current) rc = wgrad_h3_make_image(p.P, p.batch, hp.img, hp.hdr, as_stream(stream));
-          if (rc == ADVOC_OK && !hq.current) rc = wgrad_h3_make_image(p.Q, p.batch, hq.img, hq.hdr, as_stream(stream));
+          if (!hp.current) rc = wgrad_h3_make_image(p.P, p.batch, hp.img, hp.hdr, hp.delayed, as_stream(stream));
+          if (rc == ADVOC_OK && !hq.current) rc = wgrad_h3_make_image(p.Q, p.batch, hq.img, hq.hdr, hq.delayed, as_stream(stream));
         }
         if (rc == ADVOC_OK) rc = launch_wgrad_h3(p, hp.img, hp.hdr, hq.img, hq.hdr, as_stream(stream));
       }

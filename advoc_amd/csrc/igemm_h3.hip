@@ -549,28 +549,17 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   if (!name_only && tuning().h3_skip_prep) {
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
   } else if (!name_only) {
-    hipError_t e = (p.a_img_out && p.a_img_current) ? hipSuccess : hipMemsetAsync(hdr_a, 0, 8, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(hdr_b, 0, 8, stream);
+    hipError_t e = hipMemsetAsync(hdr_b, 0, 8, stream);
     if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
     int rc = launch_pair_weights(p.w, wq, taps, N, ktot, b_kn, hdr_b, stream);
     if (rc != ADVOC_OK) return rc;
     if (!(p.a_img_out && p.a_img_current)) {
-    // one scale for the whole A operand: the largest magnitude over both sources of a channel concat
-    rc = launch_amax(p.a0, e0, p.c0, p.in_scale, p.in_shift, p.in_act, p.a_mask, p.a_mask_scale, hdr_a, stream);
-    if (rc != ADVOC_OK) return rc;
-    const float* sc1 = p.in_scale ? p.in_scale + p.c0 : nullptr;
-    const float* sh1 = p.in_shift ? p.in_shift + p.c0 : nullptr;
-    if (e1) {
-      rc = launch_amax(p.a1, e1, p.c1, sc1, sh1, p.in_act, nullptr, 0.f, hdr_a, stream);
+      // one scale for the whole A operand: the largest magnitude over both sources of a channel concat
+      const ImageSource s0 = {p.a0, e0, p.c0, p.in_scale, p.in_shift, p.in_act, p.a_mask, p.a_mask_scale};
+      const ImageSource s1 = {p.a1, e1, p.c1, p.in_scale ? p.in_scale + p.c0 : nullptr,
+                              p.in_shift ? p.in_shift + p.c0 : nullptr, p.in_act, nullptr, 0.f};
+      rc = make_operand_image(s0, s1, img0, hdr_a, p.a_img_out && p.a_img_delayed, stream);
       if (rc != ADVOC_OK) return rc;
-    }
-    rc = launch_pair_image(p.a0, img0, e0, p.c0, p.in_scale, p.in_shift, p.in_act, p.a_mask, p.a_mask_scale, hdr_a,
-                           stream);
-    if (rc != ADVOC_OK) return rc;
-    if (e1) {
-      rc = launch_pair_image(p.a1, img1, e1, p.c1, sc1, sh1, p.in_act, nullptr, 0.f, hdr_a, stream);
-      if (rc != ADVOC_OK) return rc;
-    }
     }
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
   }

@@ -111,20 +111,49 @@ __device__ __forceinline__ float up_scale(unsigned amax_bits) {
   return __uint_as_float((unsigned)(s + 127) << 23);
 }
 
+// Delayed scaling (DELAYED): the scale comes from the largest magnitude of the PREVIOUS image written to this buffer
+// (hdr[2]), placed at [2^9, 2^10) -- 2^6 of head room before fp16 overflows, and still 22 significant bits for every
+// element within 2^12 of the largest -- while this pass records its own largest magnitude in hdr[0] for the next one:
+// one pass over the tensor instead of two.  Values beyond the head room saturate at +-65504 and are counted in hdr[3].
+__device__ __forceinline__ float up_scale_delayed(unsigned prev_bits) {
+  const int e = (int)((prev_bits >> 23) & 0xffu);
+  if (e == 0 || e == 255) return 1.f;
+  int s = 9 - (e - 127);
+  s = s > 120 ? 120 : (s < -120 ? -120 : s);
+  return __uint_as_float((unsigned)(s + 127) << 23);
+}
+
+// hdr[0] <- 0, hdr[2] <- old hdr[0]: the image about to be written becomes "current", the last one "previous"
+__global__ void rotate_hdr_kernel(unsigned* __restrict__ hdr) {
+  hdr[2] = hdr[0];
+  hdr[0] = 0u;
+}
+
 // one thread = 8 consecutive channels of one pixel: two float4 loads, two 16-byte stores.
-// hdr[0] = amax bits (input), hdr[1] = 2^-s as float bits (output, written by the first thread).
+// hdr[0] = amax bits (input; DELAYED: accumulated here), hdr[1] = 2^-s as float bits (output, written by the first thread).
+template <bool DELAYED>
 __global__ __launch_bounds__(256) void pair_image_kernel(const float* __restrict__ x, __half* __restrict__ img,
                                                          int64_t n8, int c, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float slope,
                                                          const uint8_t* __restrict__ mask, float mask_scale,
                                                          unsigned* __restrict__ hdr) {
-  const float up = up_scale(hdr[0]);
+  const float up = DELAYED ? up_scale_delayed(hdr[2]) : up_scale(hdr[0]);
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = __float_as_uint(1.f / up);     // exact: a power of two
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float vmax = 0.f;
+  int sat = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
     const int64_t e = i * 8;
     float v[8];
     load8(x, e, c, scale, shift, slope, mask, mask_scale, v);
+    if (DELAYED) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        vmax = fmaxf(vmax, fabsf(v[j]));
+        const float a = v[j] * up;
+        if (fabsf(a) > 65504.f) { v[j] = copysignf(65504.f, a) / up; ++sat; }
+      }
+    }
     __half2 h0[4], h1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -137,6 +166,18 @@ __global__ __launch_bounds__(256) void pair_image_kernel(const float* __restrict
     __half* o = img + (e >> 5) * 64 + ((e >> 3) & 3) * 8;
     *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(h0);
     *reinterpret_cast<uint4*>(o + 32) = *reinterpret_cast<const uint4*>(h1);
+  }
+  if (DELAYED) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      if (vmax > 0.f) atomicMax(hdr, __float_as_uint(vmax));
+    }
+    if (sat) atomicAdd(hdr + 3, (unsigned)sat);
   }
 }
 
@@ -221,15 +262,45 @@ int launch_amax(const float* x, int64_t elems, int c, const float* scale, const 
 }
 
 int launch_pair_image(const float* x, uint16_t* img, int64_t elems, int c, const float* scale, const float* shift,
-                      int act, const uint8_t* mask, float mask_scale, unsigned* hdr, hipStream_t stream) {
+                      int act, const uint8_t* mask, float mask_scale, unsigned* hdr, bool delayed, hipStream_t stream) {
   if (!x || !img || !hdr) return ADVOC_ERR_NULL;
   if (elems <= 0) return ADVOC_OK;
   if (c % 32 || elems % 32) return ADVOC_ERR_UNSUPPORTED;
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(pair_image_kernel, dim3(grid_for(elems / 8, 256)), dim3(256), 0, stream, x,
-                     reinterpret_cast<__half*>(img), elems / 8, c, scale, shift, slope_of(act), mask, mask_scale, hdr);
+  if (delayed)
+    hipLaunchKernelGGL(pair_image_kernel<true>, dim3(grid_for(elems / 8, 256)), dim3(256), 0, stream, x,
+                       reinterpret_cast<__half*>(img), elems / 8, c, scale, shift, slope_of(act), mask, mask_scale, hdr);
+  else
+    hipLaunchKernelGGL(pair_image_kernel<false>, dim3(grid_for(elems / 8, 256)), dim3(256), 0, stream, x,
+                       reinterpret_cast<__half*>(img), elems / 8, c, scale, shift, slope_of(act), mask, mask_scale, hdr);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
+}
+
+// One GEMM operand (one or two channel-concatenated sources, ONE scale) -> image at `img` (source 1 behind source 0 at
+// its 256-byte-rounded size) and header `hdr` (16 bytes, caller-owned, persistent across calls for delayed scaling).
+int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* img, unsigned* hdr, bool delayed,
+                       hipStream_t stream) {
+  const int64_t b0 = (4 * s0.elems + 255) / 256 * 256;
+  uint16_t* img1 = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(img) + b0);
+  int rc = ADVOC_OK;
+  if (delayed) {
+    ADVOC_CLEAR_LAUNCH_ERROR();
+    hipLaunchKernelGGL(rotate_hdr_kernel, dim3(1), dim3(1), 0, stream, hdr);
+    ADVOC_RETURN_IF_LAUNCH_FAILED();
+  } else {
+    hipError_t e = hipMemsetAsync(hdr, 0, 8, stream);
+    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    rc = launch_amax(s0.x, s0.elems, s0.c, s0.scale, s0.shift, s0.act, s0.mask, s0.mask_scale, hdr, stream);
+    if (rc == ADVOC_OK && s1.elems)
+      rc = launch_amax(s1.x, s1.elems, s1.c, s1.scale, s1.shift, s1.act, s1.mask, s1.mask_scale, hdr, stream);
+    if (rc != ADVOC_OK) return rc;
+  }
+  rc = launch_pair_image(s0.x, img, s0.elems, s0.c, s0.scale, s0.shift, s0.act, s0.mask, s0.mask_scale, hdr, delayed, stream);
+  if (rc == ADVOC_OK && s1.elems)
+    rc = launch_pair_image(s1.x, img1, s1.elems, s1.c, s1.scale, s1.shift, s1.act, s1.mask, s1.mask_scale, hdr, delayed,
+                           stream);
+  return rc;
 }
 
 int launch_split_weights(const float* w, uint16_t* wq, int taps, int n_total, int n_valid, int ktot, bool b_kn,

@@ -233,25 +233,12 @@ int64_t wgrad_h3_operand_bytes(const Operand& o, int batch, int64_t* b0, int64_t
 }
 
 // Makes the image of one operand (both sources, one scale) at `img` / `hdr`.
-int wgrad_h3_make_image(const Operand& o, int batch, uint16_t* img, unsigned* hdr, hipStream_t stream) {
-  int64_t b0, b1;
-  wgrad_h3_operand_bytes(o, batch, &b0, &b1);
+int wgrad_h3_make_image(const Operand& o, int batch, uint16_t* img, unsigned* hdr, bool delayed, hipStream_t stream) {
   const int64_t e0 = (int64_t)batch * o.h * o.pitch0 * o.c0, e1 = (int64_t)batch * o.h * o.pitch1 * o.c1;
-  hipError_t e = hipMemsetAsync(hdr, 0, 8, stream);
-  if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
-  int rc = launch_amax(o.p0, e0, o.c0, o.scale, o.shift, o.act, o.mask, o.mask_scale, hdr, stream);
-  if (rc != ADVOC_OK) return rc;
-  const float* sc1 = o.scale ? o.scale + o.c0 : nullptr;
-  const float* sh1 = o.shift ? o.shift + o.c0 : nullptr;
-  if (e1) {
-    rc = launch_amax(o.p1, e1, o.c1, sc1, sh1, o.act, nullptr, 0.f, hdr, stream);
-    if (rc != ADVOC_OK) return rc;
-  }
-  rc = launch_pair_image(o.p0, img, e0, o.c0, o.scale, o.shift, o.act, o.mask, o.mask_scale, hdr, stream);
-  if (rc != ADVOC_OK) return rc;
-  if (e1) rc = launch_pair_image(o.p1, reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(img) + b0), e1, o.c1, sc1, sh1,
-                                 o.act, nullptr, 0.f, hdr, stream);
-  return rc;
+  const ImageSource s0 = {o.p0, e0, o.c0, o.scale, o.shift, o.act, o.mask, o.mask_scale};
+  const ImageSource s1 = {o.p1, e1, o.c1, o.scale ? o.scale + o.c0 : nullptr, o.shift ? o.shift + o.c0 : nullptr, o.act,
+                          nullptr, 0.f};
+  return make_operand_image(s0, s1, img, hdr, delayed, stream);
 }
 
 // p_img / q_img: images of P and Q (source 1 follows source 0 at the 256-byte-rounded size of source 0), hdr: their

@@ -33,7 +33,25 @@ int launch_amax(const float* x, int64_t elems, int c, const float* scale, const 
 // act(scale * x + shift) * mask * mask_scale of `elems` fp32 values (channels innermost, c % 32 == 0) as 128-byte
 // K slices img[elems / 32][plane][32] fp16, scaled by the power of two derived from hdr[0]
 int launch_pair_image(const float* x, uint16_t* img, int64_t elems, int c, const float* scale, const float* shift,
-                      int act, const uint8_t* mask, float mask_scale, unsigned* hdr, hipStream_t stream);
+                      int act, const uint8_t* mask, float mask_scale, unsigned* hdr, bool delayed, hipStream_t stream);
+// One GEMM operand = one or two channel-concatenated sources under ONE scale.  make_operand_image writes the image
+// (source 1 behind source 0 at its 256-byte-rounded size) and the 16-byte header {[0] largest magnitude of this image,
+// [1] 2^-s, [2] largest magnitude of the previous image in this buffer, [3] saturated values}.  delayed == false: the
+// exact two-pass form (magnitude pass, then image pass, largest magnitude at [2^13, 2^14)).  delayed == true (the
+// header must hold a previous image's magnitude): ONE pass, scale from the previous image's magnitude placed at
+// [2^9, 2^10), this image's magnitude recorded for the next call (image.hip).
+struct ImageSource {
+  const float* x;
+  int64_t elems;
+  int c;
+  const float* scale;
+  const float* shift;
+  int act;
+  const uint8_t* mask;
+  float mask_scale;
+};
+int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* img, unsigned* hdr, bool delayed,
+                       hipStream_t stream);
 // weights [tap][k][n] (b_kn) or [tap][n][k] -> wq[tap][n_total][ktot / 32][plane][32] fp16 (amax pass included;
 // hdr[0] must be zero on entry)
 int launch_pair_weights(const float* w, uint16_t* wq, int taps, int n_total, int ktot, bool b_kn, unsigned* hdr,

@@ -445,6 +445,7 @@ class Advoc(Model):
     # backward_weight of a layer see the same gradient tensor: the operand images are made once per tensor and step
     for lay in list(L.values()) + st['d_layers_fake'] + st.get('d_layers_real', []) + st.get('d_layers_2b', []):
       lay.reuse_images = True
+      lay.delayed_scale = os.environ.get('ADVOC_DELAYED_SCALE', '1') == '1'
 
   # ------------------------------------------------------------------------------------------
   # batch-norm plumbing

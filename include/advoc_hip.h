@@ -215,7 +215,7 @@ typedef struct advoc_conv_layer {
    * reads them instead of making its own: img_flags bit 0 = x_img is current (the inputs have not changed since the
    * call that filled it), bit 1 = dy_img is current (filled by a call with the same dy).  A forward / backward-data call
    * that finds its bit set skips its image passes too (advoc_conv_make_image fills a buffer on its own).  Sizes:
-   * advoc_conv_image_bytes(); headers 8 bytes each.  Without the buffers the images live in `workspace` per call. */
+   * advoc_conv_image_bytes(); headers 16 bytes each.  Without the buffers the images live in `workspace` per call. */
   uint16_t* x_img;
   uint32_t* x_hdr;
   uint16_t* dy_img;
@@ -225,6 +225,12 @@ typedef struct advoc_conv_layer {
 
 #define ADVOC_IMG_X_CURRENT 1
 #define ADVOC_IMG_DY_CURRENT 2
+/* the header of the buffer holds the largest magnitude of an image written to it before (an earlier call on data of the
+ * same scale, e.g. the previous train step): the image may be built in ONE pass with the scale derived from that
+ * magnitude (2^6 of head room; beyond it values saturate and are counted in header word 3) instead of a magnitude pass
+ * followed by the image pass.  Never set on the first call for a buffer. */
+#define ADVOC_IMG_X_DELAYED 4
+#define ADVOC_IMG_DY_DELAYED 8
 
 /* Bytes of the persistent operand image `which` (0: inputs, 1: output gradient) the layer can use; 0 when the layer's
  * shapes are outside the image-based kernels. */

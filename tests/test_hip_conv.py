@@ -523,3 +523,44 @@ RANDOM = _random_cases(28, seed=2024)
 @pytest.mark.parametrize('case', RANDOM, ids=[c[0] for c in RANDOM])
 def test_random_layer_shapes(hip, case):
   test_layer_all_directions(hip, case)
+
+
+@gpu
+def test_delayed_scale_images_match_the_exact_two_pass_form(hip, hipenv):
+  """Layer.delayed_scale: after the first (exact) image of a buffer, later images take their power-of-two scale from the
+  previous image's largest magnitude (one pass instead of two).  Data of the same scale gives the same results to
+  round-off; data 32 x larger still fits the head room; the headers report no saturation."""
+  from advoc_amd import conv
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_WGRAD_H3_MIN_M=1)
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(21)
+  x = torch.randn(3, 16, 33, 128, generator=g).to(dev)
+  w = (torch.randn(4, 4, 128, 256, generator=g) * 0.05).to(dev)
+  dy = torch.randn(3, 8, 17, 256, generator=g).to(dev)
+
+  def run(layer, scale):
+    xs = x * scale
+    layer.x0.copy_(xs)
+    layer.forward()
+    dx = torch.zeros_like(x)
+    layer.backward_data(dy * scale, dx)
+    dw = torch.zeros_like(w)
+    layer.backward_weight(dy * scale, dw)
+    return layer.y.clone(), dx, dw
+
+  def make(delayed):
+    y = torch.empty(3, 8, 17, 256, device=dev)
+    L = conv.Layer(conv.CONV, x.clone(), y, w, None, stride=(2, 2), pad=(1, 1), in_act=conv.ACT_LRELU)
+    L.delayed_scale = delayed
+    L.reuse_images = True
+    assert 'h3' in L.kernel_name(0) and 'h3' in L.kernel_name(1) and 'h3' in L.kernel_name(2)
+    return L
+  exact, delayed = make(False), make(True)
+  for scale in (1.0, 0.7, 32.0, 0.05):
+    ye, dxe, dwe = run(exact, scale)
+    yd, dxd, dwd = run(delayed, scale)
+    for a, b in ((yd, ye), (dxd, dxe), (dwd, dwe)):
+      assert rel(a, b) < 2e-6, (scale, rel(a, b))
+  hdr_x, hdr_dy = delayed._img[1].cpu(), delayed._img[3].cpu()
+  assert int(hdr_x[3]) == 0 and int(hdr_dy[3]) == 0          # nothing saturated
+  assert int(hdr_x[2]) != 0                                    # the one-pass form really ran (a previous magnitude exists)
