@@ -194,8 +194,10 @@ class Layer(object):
     if 'h3' not in self.kernel_name(0 if which == 0 else 1):
       return 0
     src = [t for t in (self.x0, self.x1) if t is not None] if which == 0 else [dy]
-    nbytes = sum(12.0 * t.numel() for t in src)           # read twice (magnitude pass, image pass), 4 B written
     self.struct.img_flags = self._delayed_bits()
+    one_pass = bool(self.struct.img_flags & (4 if which == 0 else 8)) and (self._x_built if which == 0 else self._dy_built)
+    # exact scaling reads the source twice (magnitude pass, image pass); delayed scaling once; 4 B written either way
+    nbytes = sum((8.0 if one_pass else 12.0) * t.numel() for t in src)
     prof.timed('operand_images(amax_kernel + pair_image_kernel)', 0.0, nbytes, lambda: _lib.check(
         _lib.load().advoc_conv_make_image(ctypes.byref(self.struct), which, _lib.ptr(dy), _lib.stream()),
         'advoc_conv_make_image'))

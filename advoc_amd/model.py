@@ -511,6 +511,20 @@ class Advoc(Model):
     if 'global_step' in state:
       self.step = int(state['global_step'])
 
+  def image_saturations(self):
+    """Elements that exceeded the fp16 range of a delayed-scale operand image (conv.Layer.delayed_scale) and were
+    clamped, summed over all layers since the buffers were allocated.  0 in a healthy run: a non-zero value means a
+    tensor grew more than 64 x from one step to the next.  Synchronises; call it at summary time, not per step."""
+    st = self._built
+    if not st:
+      return 0
+    layers = list(st.get('g_layers', {}).values()) + st.get('d_layers_fake', []) + st.get('d_layers_real', []) \
+        + st.get('d_layers_2b', [])
+    hdrs = [h for lay in layers for h in lay._img[1::2]]
+    if not hdrs:
+      return 0
+    return int(torch.stack([h[3].to(torch.int64) for h in hdrs]).sum().item())
+
   def optimizer_state(self):
     st = self._built
     return {k: st[k].detach().clone() for k in ('g_m', 'g_v', 'd_m', 'd_v')}, (st['g_t'], st['d_t'])
@@ -628,6 +642,36 @@ class Advoc(Model):
     st['d_cond'][:B].copy_(x)
     st['d_cond'][B:].copy_(x)
     st['d_target'][:B].copy_(target)
+    st['last_batch'] = batch
+
+  def media_summaries(self, max_outputs=3):
+    """The image / audio summaries of advoc_model.py:258-281 for the batch of the last step: (images, audio), both
+    {name: numpy array}.  Images are [n, 513 (high frequencies on top), T] -- tf.image.rot90 of [n, T, F, 1]; audio is the
+    phase reconstruction (SpectralUtil.audio_from_mag_spec) of clip 0's input / target / generated spectrogram plus the
+    source waveform.  Synchronises and runs the vocoder back end: call it at summary time only."""
+    import numpy as np
+    st = self._built
+    if not st or 'last_batch' not in st:
+      return {}, {}
+    B = st['B']
+    n = min(max_outputs, B)
+
+    def rot90(t):                      # [n, T, F, 1] -> [n, F, T], counter-clockwise: row 0 = last column
+      return np.ascontiguousarray(np.flip(t[:n, :, :, 0].detach().cpu().numpy().transpose(0, 2, 1), axis=1))
+    x, target, gen = st['x_in'], st['d_target'][:B], st['gen_out']
+    images = dict(input_magspec=rot90(x), generated_magspec=rot90(gen), target_magspec=rot90(target))
+    batch = st['last_batch']
+    if len(batch) > 3 and batch[3] is not None:
+      images['input_melspec'] = rot90(torch.as_tensor(batch[3]))
+    audio = {}
+    if getattr(self, 'spectral', None) is None:
+      from advoc_amd.spectral_util import SpectralUtil
+      self.spectral = SpectralUtil()
+    for name, t in (('input_audio', x), ('target_audio', target), ('gen_audio', gen)):
+      audio[name] = np.asarray(self.spectral.audio_from_mag_spec(t[0].detach().cpu().numpy()), dtype=np.float32).reshape(1, -1)
+    if len(batch) > 2 and batch[2] is not None:
+      audio['target_x_wav'] = torch.as_tensor(batch[2])[:n].detach().cpu().numpy().reshape(n, -1)
+    return images, audio
 
   def d_step(self, batch):
     """One discriminator update on `batch` (advoc_model.py:238,257): G forward, D on real and on

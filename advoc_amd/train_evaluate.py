@@ -50,6 +50,8 @@ def latest_checkpoint(train_dir):
     m = re.search(r'model_checkpoint_path:\s*"([^"]+)"', text)
     name = m.group(1) if m else text
   fp = name if os.path.isabs(name) else os.path.join(train_dir, name)
+  if os.path.isfile(fp + '.pt'):       # a TF-format export (ADVOC_EXPORT_TF_CKPT=1) sits next to the native file
+    return fp + '.pt'
   from advoc_amd import tf_checkpoint
   if os.path.isfile(fp) or tf_checkpoint.is_tf_checkpoint(fp):
     return fp
@@ -87,13 +89,52 @@ def save_checkpoint(train_dir, model, generator_only=False, name=None, max_to_ke
   tmp = os.path.join(train_dir, name + '.tmp')
   torch.save(state, tmp)
   os.replace(tmp, os.path.join(train_dir, name))
+  index_text = name
+  if os.environ.get('ADVOC_EXPORT_TF_CKPT') == '1' and name.endswith('.pt'):
+    # also as a TensorFlow tensor bundle + CheckpointState index, so that the reference (tf.train.Saver.restore /
+    # tf.train.latest_checkpoint, train_evaluate.py:60-66,131) can load weights trained here
+    prefix = export_tf_checkpoint(os.path.join(train_dir, name[:-3]), model, generator_only=generator_only)
+    base = os.path.basename(prefix)
+    index_text = 'model_checkpoint_path: "{0}"\nall_model_checkpoint_paths: "{0}"\n'.format(base)
   with open(os.path.join(train_dir, 'checkpoint.tmp'), 'w') as f:
-    f.write(name)
+    f.write(index_text)
   os.replace(os.path.join(train_dir, 'checkpoint.tmp'), os.path.join(train_dir, 'checkpoint'))
   stem = name[:name.rfind('-') + 1] if '-' in name else None
   if stem and max_to_keep:
     _prune(train_dir, stem + '*.pt', max_to_keep)
   return os.path.join(train_dir, name)
+
+
+def export_tf_checkpoint(prefix, model, generator_only=False):
+  """Writes the model as a TensorFlow tensor bundle `prefix`.index / .data-00000-of-00001 (advoc_amd.tf_checkpoint):
+  variables under their TF names and layouts, `global_step` (int64), and -- unless generator_only -- the Adam slots as
+  tf.train.AdamOptimizer names them (`<var>/Adam`, `<var>/Adam_1`, `beta1_power`, `beta2_power` for the optimizer
+  built first, the generator's at advoc_model.py:250-255, `..._1` for the discriminator's).  The slot names are
+  inferred from TF's conventions, not verified against a TF-written checkpoint (none is reachable here); minimize() order there: generator first.  Returns the
+  prefix."""
+  import numpy as np
+  from advoc_amd import tf_checkpoint
+  sd = model.state_dict()
+  out = {}
+  for k, v in sd.items():
+    if k == 'global_step':
+      continue
+    if generator_only and not k.startswith('generator'):
+      continue
+    out[k] = v.detach().cpu().numpy().astype(np.float32)
+  out['global_step'] = np.asarray(int(model.step), dtype=np.int64)
+  if not generator_only and getattr(model, '_built', None):
+    st = model._built
+    for net, suffix in (('g', ''), ('d', '_1')):
+      arena = st[net + '_arena']
+      for slot, tf_slot in (('_m', 'Adam'), ('_v', 'Adam_1')):
+        for k, v in arena.views(st[net + slot]).items():
+          out['%s/%s' % (k, tf_slot)] = v.detach().cpu().numpy().astype(np.float32)
+      t = st[net + '_t']
+      out['beta1_power' + suffix] = np.asarray(model._beta1 ** t, dtype=np.float32)
+      out['beta2_power' + suffix] = np.asarray(model._beta2 ** t, dtype=np.float32)
+  tf_checkpoint.write_checkpoint(prefix, out)
+  return prefix
 
 
 def restore_checkpoint(fp, model, with_optimizer=True):
@@ -180,9 +221,17 @@ def train(fps, args):
     now = time.time()
     if dp.rank == 0 and now - last_summary >= args.train_summary_every_nsecs:
       rec = dict(step=_step, time=now, **model.losses())
+      sat = model.image_saturations()
+      if sat:
+        rec['operand_image_saturations'] = sat
+        print('WARNING: {} operand-image elements left the fp16 head room (set ADVOC_DELAYED_SCALE=0)'.format(sat))
       log.write(json.dumps(rec) + '\n')
       log.flush()
-      events.add_scalars(model.losses(), _step, wall_time=now)      # tags as advoc_model.py:263-266
+      events.add_scalars(model.losses(), _step, wall_time=now)      # tags as advoc_model.py:272-275
+      if os.environ.get('ADVOC_MEDIA_SUMMARIES', '1') == '1':        # image / audio summaries (advoc_model.py:258-281)
+        images, audio = model.media_summaries()
+        events.add_images(images, _step, wall_time=now)
+        events.add_audio(audio, _step, model.audio_fs, wall_time=now)
       last_summary = now
     if dp.rank == 0 and now - last_ckpt >= args.train_ckpt_every_nsecs:
       save_checkpoint(args.train_dir, model)

@@ -91,6 +91,13 @@ def test_train_resume_eval_infer_end_to_end(hip, tmp_path, capsys):
   from advoc_amd.tb_events import read_events
   ev = read_events(_glob.glob(os.path.join(work, 'events.out.tfevents.*'))[0])
   assert ev[-1][0] == 3 and abs(ev[-1][1]['gen_loss_total'] - recs[-1]['gen_loss_total']) < 1e-4 * abs(recs[-1]['gen_loss_total'])
+  # image / audio summaries of advoc_model.py:258-281 in the same file
+  media = read_events(_glob.glob(os.path.join(work, 'events.out.tfevents.*'))[0], kinds=('image', 'audio'))
+  tags = set(t for _, v in media for t in v)
+  assert {'generated_magspec/image/0', 'target_magspec/image/0', 'input_magspec/image/0', 'input_melspec/image/0',
+          'gen_audio/audio/0', 'input_audio/audio/0', 'target_audio/audio/0', 'target_x_wav/audio/0'} <= tags
+  im = [v for _, v in media if 'input_melspec/image/0' in v][0]
+  assert (im['input_melspec/image/0']['height'], im['input_magspec/image/0']['height']) == (80, 513)
   # resume: continues from step 3
   TE.main(['train', work] + common + ['--max_steps', '5'])
   assert 'Restoring from' in capsys.readouterr().out

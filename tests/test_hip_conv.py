@@ -564,3 +564,35 @@ def test_delayed_scale_images_match_the_exact_two_pass_form(hip, hipenv):
   hdr_x, hdr_dy = delayed._img[1].cpu(), delayed._img[3].cpu()
   assert int(hdr_x[3]) == 0 and int(hdr_dy[3]) == 0          # nothing saturated
   assert int(hdr_x[2]) != 0                                    # the one-pass form really ran (a previous magnitude exists)
+
+
+@gpu
+def test_delayed_scale_counts_what_leaves_the_head_room(hip, hipenv):
+  """A tensor that grows 1000 x between two steps exceeds the one-pass image's head room (>= 64 x): the elements are
+  clamped to the fp16 range and COUNTED in header word 3 (model.image_saturations() reports the sum); the step after
+  that is exact again because the header now carries the new magnitude."""
+  from advoc_amd import conv
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_WGRAD_H3_MIN_M=1)
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(22)
+  x = torch.randn(2, 16, 33, 128, generator=g).to(dev)
+  w = (torch.randn(4, 4, 128, 256, generator=g) * 0.05).to(dev)
+
+  def make(delayed):
+    y = torch.empty(2, 8, 17, 256, device=dev)
+    L = conv.Layer(conv.CONV, x.clone(), y, w, None, stride=(2, 2), pad=(1, 1))
+    L.delayed_scale, L.reuse_images = delayed, True
+    return L
+  exact, delayed = make(False), make(True)
+  for L in (exact, delayed):
+    L.forward()                                   # first image: exact for both
+  for L in (exact, delayed):
+    L.x0.copy_(x * 1000.0)
+    L.forward()
+  sat = int(delayed._img[1].cpu()[3])
+  assert sat > 0                                  # clamped and counted ...
+  assert rel(delayed.y, exact.y) > 1e-4           # ... and visibly so
+  for L in (exact, delayed):
+    L.forward()                                   # header now holds the new magnitude
+  assert int(delayed._img[1].cpu()[3]) == sat
+  assert rel(delayed.y, exact.y) < 2e-6
