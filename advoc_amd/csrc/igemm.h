@@ -112,4 +112,19 @@ int* tail_counter_slot();
 int launch_gather_gemm_h3(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const char** name_only,
                            float* scratch, int64_t scratch_bytes, int64_t* scratch_query);
 
+// Patch variant for stride-1 gathers (igemm_patch.hip): a workgroup owns a 16 x 16 patch of grid points of one image
+// and loads its input halo once per K slice.  patch_plan: 0 = not a patch launch, else the number of phases a
+// workgroup fuses (4: sub-pixel phases of 2x2 taps, 1: a 4x4 stride-1 gather) with the geometry filled in.  The
+// launcher expects the operand images / headers of launch_gather_gemm_h3 in `p`.
+struct PatchGeom {
+  int dy0, dx0;      // smallest tap offsets: halo pixel (0, 0) is input (gy0 + dy0, gx0 + dx0)
+  int hh, hw;        // halo rows / columns
+  int py, px;        // patches per image along y / x
+  int nblocks;       // 8-pixel DMA blocks of the halo
+  int ablate;        // timing experiments only (ADVOC_H3_PATCH_ABLATE bits: 1 no DMA, 2 no MFMA, 4 no barrier); 0 in use
+};
+int patch_plan(const GatherGemmParams& p, PatchGeom* g);
+int launch_patch_gemm_h3(const GatherGemmParams& p, const PatchGeom& g, int nph, hipStream_t stream,
+                         const char** name_only);
+
 }  // namespace advoc

@@ -509,20 +509,22 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   const int64_t wq_bytes = round256((int64_t)4 * taps * N * ktot);
   const int64_t i0_bytes = round256(4 * e0), i1_bytes = round256(4 * e1);
   const Pick k = pick_tile(p);
+  PatchGeom geom;
+  const int patch_nph = patch_plan(p, &geom);       // stride-1 gathers: igemm_patch.hip
   const int BM = 32 * k.mt * k.wgm, BN = 64 * k.nt;
   const int64_t tiles = ceil_div((int64_t)p.batch * p.gh * p.gw, BM) * (N / BN) * p.nphase;
   const int nkt = ktot / 32 * p.ntaps;
   // Small pixel grids with deep contractions (encoder_5.., decoder_5.. and their gradients) would leave CUs idle:
   // split K until the launch holds ~4 workgroups per CU, keeping >= 8 K tiles per slice (igemm.hip does the same)
   int ksplit = 1;
-  if (tiles < 512 && tuning().igemm_splitk) {
+  if (!patch_nph && tiles < 512 && tuning().igemm_splitk) {
     ksplit = (int)ceil_div((int64_t)1024, tiles);
     if (ksplit > nkt / 8) ksplit = nkt / 8;
     if (ksplit > 16) ksplit = 16;
     if (ksplit < 1) ksplit = 1;
   }
   TailPlan tail;
-  if (ksplit == 1) tail = plan_tail(tiles, nkt);
+  if (ksplit == 1 && !patch_nph) tail = plan_tail(tiles, nkt);
   const int64_t tail_bytes = (int64_t)sizeof(float) * tail.rem * tail.split * BM * BN;
   const int64_t need = hdr_bytes + wq_bytes + i0_bytes + i1_bytes;
   if (scratch_query) { *scratch_query = need + tail_bytes; return ADVOC_OK; }
@@ -563,6 +565,7 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     }
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
   }
+  if (patch_nph) return launch_patch_gemm_h3(p, geom, patch_nph, stream, name_only);
   if (k.wgm == 4 && k.nt == 4) return launch_h<2, 4, 2, 4>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
   if (k.wgm == 4) return launch_h<2, 2, 2, 4>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
   if (k.mt == 2 && k.nt == 1 && k.ns == 3) return launch_h<2, 1, 3>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);

@@ -1,0 +1,484 @@
+// Patch gather-GEMM on operand images: the stride-1 gathers of the model (transposed-conv forward and conv
+// backward-data as four sub-pixel phases of 2x2 taps; the 4x4 stride-1 convolution of the discriminator's layer_4
+// in both directions) with the A operand read ONCE per workgroup instead of once per tap.
+//
+// Same arithmetic and operand images as igemm_h3.hip (fp16 pairs, three MFMA products per fp32 product, replaces the
+// cuDNN / Eigen Conv2DBackpropInput / Conv2D kernels TF1 runs for models/advoc/advoc_model.py:25-69,185-199).  What
+// differs is the tile: igemm_h3.hip walks K = (tap, channel slice) and fetches a fresh [rows x 128 B] A tile for every
+// tap -- with stride-1 gathers the same input pixel is fetched 4 (2x2 phases, x4 phases) or 16 (4x4) times by one
+// workgroup and the launch is bound by the L2 -> LDS volume.  Here a workgroup owns a 16 x 16 PATCH
+// of grid points of one image:
+//   * per 32-channel K slice the patch's input HALO ((16 + e) x (16 + e) pixels, e = 2 or 3; one 128-byte line per
+//     pixel) goes global -> LDS once (LDS-DMA, zero padding from the descriptor's range check) and serves every tap
+//     and every phase: the A fragment of tap (dy, dx) is the same LDS rows shifted by dy * halo_width + dx;
+//   * the K loop is (slice, tap step); a step streams ONE 256-row x 128-byte B tile (2 LDS stages) -- four phases x 64
+//     output channels of tap t of each phase (NPH = 4), or 256 output channels of tap t (NPH = 1) -- and runs 48
+//     MFMAs per wave on it; the halo of the NEXT slice arrives in pieces during the steps of the current one
+//     (2 halo buffers);
+//   * 8 waves, each a 128-point x 64-column accumulator (4 x 2 blocks of 32 x 32): wave -> (half of the patch,
+//     phase | column quarter).  1024 output pixels x 64 channels (NPH = 4) or 256 x 256 (NPH = 1) per workgroup;
+//   * L2 -> LDS bytes per K-slice: ~41 KiB of halo + 4 x 32 KiB of weights for 4.2 algorithmic MFLOP x 4
+//     (10 B / kFLOP) against 46 (128 x 64 tile), 31 (128 x 128) and 15.6 (256 x 256) of igemm_h3.hip.
+// LDS rows are 128 bytes; chunk c of the halo pixel in halo column x sits at position c ^ ((x >> 1) & 7).  A
+// ds_read_b128 is served in four fixed 16-lane groups that are NOT contiguous ({0-3, 12-15, 20-27}, ...): with 32-point
+// blocks of 2 patch rows x 16 columns a group is columns {0-3, 12-15} of one row and {4-11} of the next, i.e. 16
+// different columns, and (address bit 7, position) -- the 16-byte slot of the 256-byte bank row -- is different for
+// each of them whatever the tap offset and the halo width (a swizzle by the linear pixel index is 2-way conflicted
+// whenever the halo width is not a multiple of 16: measured 450 -> ... TFLOP/s with the DMAs ablated).
+#include <string>
+
+#include "common.h"
+#include "igemm.h"
+#include "tuning.h"
+
+namespace advoc {
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_void_p;
+
+__device__ __forceinline__ float act_slope_p(int act) {
+  return act == ADVOC_ACT_LRELU02 ? 0.2f : (act == ADVOC_ACT_RELU ? 0.f : 1.f);
+}
+
+// W = 4 wavefronts: ONE per SIMD, 512 registers each (256 of them accumulators), fragments double-buffered in registers
+// and prefetched across the barrier.  W = 8: two per SIMD, 256 registers each, half the accumulator rows per wave.
+template <int NPH, int W>
+struct PCfg {
+  static constexpr int WAVES = W, THREADS = 64 * W;
+  static constexpr int NST = NPH == 4 ? 4 : 16;            // tap steps per K slice
+  static constexpr int BN = NPH == 4 ? 64 : 256;           // output channels per workgroup
+  static constexpr int MT = (NPH == 4 && W == 4) ? 8 : 4;  // 32-point blocks per wave
+  static constexpr int NT = (NPH == 1 && W == 4) ? 4 : 2;  // 32-column blocks per wave
+  static constexpr bool CARRY = W == 4;                    // next step's first A fragments fetched before the barrier
+  static constexpr bool DOUBLE_B = W == 4;                 // B fragments of both k steps in registers at once (W = 8: the
+                                                           // second set costs the 16 registers that tip the loop into scratch)
+  static constexpr int HALO_BLOCKS = NPH == 4 ? 41 : 46;   // 8-pixel DMA blocks: 18 x 18 = 324 | 19 x 19 = 361 pixels
+  static constexpr int HPS = NPH == 4 ? (W == 4 ? 3 : 2) : 1;   // halo DMA slots per wave and step
+  static constexpr int BPW = 32 / W;                       // B DMA blocks (8 rows) per wave and step
+  static constexpr int HALO_BYTES = HALO_BLOCKS * 1024;
+  static constexpr int B_STAGE = 256 * 128;
+  static constexpr int OFF_B = 2 * HALO_BYTES;
+  static constexpr int OFF_DUMMY = OFF_B + 2 * B_STAGE;
+  static constexpr int LDS_BYTES = OFF_DUMMY + 1024;
+  static constexpr int PTS_W = 32 * MT;                    // grid points per wave
+  static constexpr int EPI_BYTES = WAVES * (32 * 36 * 4 + 2 * PTS_W * 4);
+  static_assert(WAVES * NST * HPS >= HALO_BLOCKS, "every halo block has a DMA slot");
+  static_assert(LDS_BYTES <= 160 * 1024 && EPI_BYTES <= LDS_BYTES, "LDS budget");
+};
+
+// BWD = 0: forward epilogue (bias, dropout mask on the result, one destination); BWD = 1: backward-data epilogue
+// (activation gradient at the pre-activation value, the consumer's BN affine / dropout mask, accumulate, two
+// destinations)
+template <int NPH, int W, int BWD>
+__device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, const PatchGeom& g) {
+  using C = PCfg<NPH, W>;
+  constexpr int NST = C::NST, BN = C::BN, HPS = C::HPS, MT = C::MT, NT = C::NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* smem_b = reinterpret_cast<unsigned char*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // wave -> (part wm of the patch's points, phase, first of its columns):
+  //   NPH = 4: W = 4: (all 256 points, phase = wave);  W = 8: (half wave / 4, phase = wave % 4);  64 columns either way
+  //   NPH = 1: W = 4: (half wave / 2, column half wave % 2);  W = 8: (half wave / 4, column quarter wave % 4)
+  const int wm = W == 8 ? wave >> 2 : (NPH == 4 ? 0 : wave >> 1);
+  const int phase = NPH == 4 ? (wave & 3) : 0;
+  const int ncol0 = NPH == 4 ? 0 : (W == 8 ? (wave & 3) * 64 : (wave & 1) * 128);
+  const int brow0 = NPH == 4 ? phase * 64 : ncol0;         // first B-stage row of the wave's columns
+  const int b_phase = NPH == 4 ? wave * (256 / W) / 64 : 0;   // phase of the B rows this wave LOADS
+  const int ppi = g.py * g.px;                       // patches per image
+  const int npatch = p.batch * ppi;
+  const int ktot = p.c0 + p.c1;
+  const int nslices = ktot / 32;
+  constexpr int hw = NPH == 4 ? 18 : 19;             // halo width (patch_plan takes only gathers of exactly this extent):
+  const int hpix = g.hh * hw;                        // compile-time, so that block i of a fragment read is an immediate offset
+
+  const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(p.a0_img), 0, p.a0_img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(p.a1_img ? p.a1_img : p.a0_img), 0, p.a1_img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(p.wq), 0, p.wq_taps * p.n_total * ktot * 4, 0x00020000);
+
+  const int lrow = lane >> 3, lpos = lane & 7;
+  constexpr int hmagic = (65536 + hw - 1) / hw;      // h / hw == (h * hmagic) >> 16 for h < 512, hw <= 19
+  const int half = lane >> 5, l32 = lane & 31;
+  // halo pixel of this lane's row in the wave's first 32-point block (2 patch rows x 16 columns) for tap (0, 0); block
+  // i is 2 i halo rows further
+  const int h_base = (wm * 8 + (l32 >> 4)) * hw + (l32 & 15);
+  // fragment chunk (plane, k step, half) = 4 plane + 2 ks + half sits at position chunk ^ swizzle = (half ^ swizzle) ^
+  // (4 plane + 2 ks): one byte offset per row, the (plane, ks) part is an XOR with a constant
+  const int bfrag = (brow0 + l32) * 128 + ((half ^ ((l32 >> 1) & 7)) * 16);
+  const float gslope = act_slope_p(p.grad_act);
+  // the tap tables of the wave's compute phase and of the phase whose B rows it loads, one tap per lane: read back with
+  // v_readlane inside the K loop (an s_load there would put an lgkmcnt(0) wait -- SMEM returns out of order -- in front
+  // of every step's LDS reads)
+  const int tapv_c = p.tap[phase][lane & (kMaxTaps - 1)];
+  const int tapv_b = p.tap[b_phase][lane & (kMaxTaps - 1)];
+  const int src_c0 = p.c0, src_c1 = p.c1, src_p0 = p.a0_pitch, src_p1 = p.a1_pitch;
+  const int abl = g.ablate;       // timing experiments only (ADVOC_H3_PATCH_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier
+
+  // ---- persistent workgroups: the launch holds one workgroup per CU; XCD x walks its own contiguous range of tiles
+  // (column tile slowest, so the workgroups an XCD runs together stream the same weights), and the stores of one
+  // tile's epilogue drain while the next tile's operands arrive ----
+  const int ntiles = npatch * (p.n_total / BN);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int tq_ = ntiles >> 3, tr_ = ntiles & 7;
+  const int t_lo = xcd < tr_ ? xcd * (tq_ + 1) : tr_ * (tq_ + 1) + (xcd - tr_) * tq_;
+  const int t_hi = t_lo + tq_ + (xcd < tr_ ? 1 : 0);
+
+  for (int tile = t_lo + slot; tile < t_hi; tile += per_xcd) {
+  const int nt = tile / npatch;
+  const int pid = tile - nt * npatch;
+  const int img = pid / ppi;
+  const int pin = pid - img * ppi;
+  const int gy0 = (pin / g.px) * 16, gx0 = (pin % g.px) * 16;
+  const int n0 = nt * BN;
+
+  // ---- B DMA lanes: the wave loads stage rows (256 / W) wave .. in 8-row blocks; stage row q holds (phase q / 64,
+  // column q % 64) for NPH = 4, column q for NPH = 1.  Block k is 8 k rows further (that part goes into the scalar
+  // offset); the swizzle of row q, (q >> 1) & 7, is lrow >> 1 for even k and that ^ 4 for odd k ----
+  int b_off[2];
+  {
+    const int q = wave * (256 / W) + lrow;
+    const int col = NPH == 4 ? (q & 63) : q;
+    const int rowb = ((n0 + col) * ktot) * 4;
+    b_off[0] = rowb + ((lpos ^ (lrow >> 1)) * 16);
+    b_off[1] = rowb + ((lpos ^ (lrow >> 1) ^ 4) * 16);
+  }
+
+  // Halo pieces of K slice SL (channels [32 SL, 32 SL + 32) of the concatenated sources) that step T carries, into
+  // halo buffer HB.  Slots beyond the halo write zeros into a dummy KiB (out-of-range offset: no memory traffic).
+#define ADVOC_P3_HALO(SL, T, HB)                                                                          \
+  {                                                                                                       \
+    const int k0_ = (SL) * 32;                                                                            \
+    const bool second_ = k0_ >= p.c0;                                                                     \
+    const int c_ = second_ ? src_c1 : src_c0, pitch_ = second_ ? src_p1 : src_p0;                         \
+    const int kk_ = second_ ? k0_ - p.c0 : k0_;                                                           \
+    _Pragma("unroll") for (int j = 0; j < HPS; ++j) {                                                     \
+      const int blk_ = ((T) * C::WAVES + wave) * HPS + j;                                                 \
+      int lr_ = lrow;                                                                                     \
+      asm volatile("" : "+v"(lr_));  /* recompute per use: hoisted out of the K loop these cost a VGPR per slot */ \
+      const int h_ = blk_ * 8 + lr_;                                                                      \
+      const int hy_ = (h_ * hmagic) >> 16;                                                                \
+      const int hx_ = h_ - hy_ * hw;                                                                      \
+      const int iy_ = gy0 + hy_ + g.dy0, ix_ = gx0 + hx_ + g.dx0;                                         \
+      const bool ok_ = h_ < hpix && (unsigned)iy_ < (unsigned)p.in_h && (unsigned)ix_ < (unsigned)p.in_w; \
+      const int voff_ = ok_ ? (((img * p.a_h + iy_) * pitch_ + ix_) * c_ + kk_) * 4 +                     \
+                                  ((lpos ^ ((hx_ >> 1) & 7)) * 16)                                        \
+                            : (int)0x80000000;                                                            \
+      unsigned char* d_ = blk_ < g.nblocks ? smem_b + (HB) * C::HALO_BYTES + blk_ * 1024                  \
+                                           : smem_b + C::OFF_DUMMY;                                       \
+      if (abl & 1) continue;                                                                              \
+      if (second_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_void_p)(d_), 16, voff_, 0, 0, 0); \
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (lds_void_p)(d_), 16, voff_, 0, 0, 0);         \
+    }                                                                                                     \
+  }
+
+  // The B tile of (slice SL, tap step T) into stage ST
+#define ADVOC_P3_B(SL, T, ST)                                                                             \
+  {                                                                                                       \
+    const int wtap_ = __builtin_amdgcn_readlane(tapv_b, (T)) >> 16;                                       \
+    const int wslab_ = (wtap_ * p.n_total * ktot + (SL) * 32) * 4;                                        \
+    _Pragma("unroll") for (int k = 0; k < C::BPW; ++k) {                                                  \
+      unsigned char* d_ = smem_b + C::OFF_B + (ST) * C::B_STAGE + (wave * C::BPW + k) * 1024;             \
+      if (!(abl & 1))                                                                                     \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_p)(d_), 16, b_off[k & 1],                \
+                                                 wslab_ + k * 8 * ktot * 4, 0, 0);                        \
+    }                                                                                                     \
+  }
+
+  // A fragments of tap step T, k step KS, from halo buffer HB into REG[MT][2]
+#define ADVOC_P3_LOAD_A(REG, HB, T, KS)                                                                   \
+  {                                                                                                       \
+    const int tp_ = __builtin_amdgcn_readlane(tapv_c, (T));                                               \
+    const int dxo_ = (int)(int8_t)((tp_ >> 8) & 0xff) - g.dx0;                                            \
+    const int toff_ = ((int)(int8_t)(tp_ & 0xff) - g.dy0) * hw + dxo_;                                    \
+    const unsigned char* Hx = smem_b + (HB) * C::HALO_BYTES;                                              \
+    const int sl_ = ((half ^ ((((l32 & 15) + dxo_) >> 1) & 7)) ^ (2 * (KS))) * 16;                        \
+    const int ad_ = (h_base + toff_) * 128 + sl_;                                                         \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                        \
+      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                    \
+        REG[i][pl] = *reinterpret_cast<const f16x8*>(Hx + (ad_ ^ (4 * pl * 16)) + i * (2 * hw * 128));    \
+  }
+#define ADVOC_P3_LOAD_B(REG, ST, KS)                                                                      \
+  {                                                                                                       \
+    const unsigned char* Bx = smem_b + C::OFF_B + (ST) * C::B_STAGE;                                      \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                        \
+      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                    \
+        REG[j][pl] = *reinterpret_cast<const f16x8*>(Bx + (bfrag ^ ((4 * pl + 2 * (KS)) * 16)) + j * 32 * 128); \
+  }
+  // three fp16 products per 32x32x16 block, small terms first (a0 b1, a1 b0, a0 b0); product-major so that consecutive
+  // MFMAs write different accumulators
+#define ADVOC_P3_MFMA(AR, BR)                                                                             \
+  if (abl & 2) {                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(AR[i][0]), "v"(AR[i][1]));       \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(BR[j][0]), "v"(BR[j][1]));       \
+  } else {                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                        \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AR[i][0], BR[j][1], acc[i][j], 0, 0, 0);       \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                        \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AR[i][1], BR[j][0], acc[i][j], 0, 0, 0);       \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                        \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AR[i][0], BR[j][0], acc[i][j], 0, 0, 0);       \
+  }
+
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue: the whole halo of slice 0, the B tile of step 0 ----
+#pragma unroll
+  for (int t = 0; t < NST; ++t) ADVOC_P3_HALO(0, t, 0);
+  ADVOC_P3_B(0, 0, 0);
+
+  // ---- K loop: one barrier per step.  Wait for the own DMAs of this step's B tile (and, at a slice boundary, of the
+  // halo), barrier (everyone's data landed, everyone finished the step before), issue the next step's B tile into the
+  // stage just vacated and a piece of the next slice's halo, then compute.  NST is even: stage = step parity.
+  // Fragments are double-buffered in registers: the second k step's are fetched under the MFMAs of the first; the
+  // halo of the running slice has been in LDS since the slice began, so the A fragments of the NEXT step's first k
+  // step are fetched under the MFMAs of the second (a0 is carried across the barrier) and only the B fragments wait
+  // for the barrier. ----
+  f16x8 a0[MT][2], a1[MT][2], b0[NT][2], b1[NT][2];
+  for (int s = 0; s < nslices; ++s) {
+    const int hb = s & 1;
+    const bool more = s + 1 < nslices;
+    for (int t = 0; t < NST; t += 2) {
+      // step t (stage 0)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!(abl & 4)) __builtin_amdgcn_s_barrier();
+      ADVOC_P3_B(s, t + 1, 1);
+      if (more) ADVOC_P3_HALO(s + 1, t, hb ^ 1);
+      if (!C::CARRY || t == 0) ADVOC_P3_LOAD_A(a0, hb, t, 0);
+      ADVOC_P3_LOAD_B(b0, 0, 0);
+      ADVOC_P3_LOAD_A(a1, hb, t, 1);
+      if (C::DOUBLE_B) ADVOC_P3_LOAD_B(b1, 0, 1);
+      ADVOC_P3_MFMA(a0, b0);
+      if (C::CARRY) ADVOC_P3_LOAD_A(a0, hb, t + 1, 0);
+      if (C::DOUBLE_B) {
+        ADVOC_P3_MFMA(a1, b1);
+      } else {
+        ADVOC_P3_LOAD_B(b0, 0, 1);
+        ADVOC_P3_MFMA(a1, b0);
+      }
+      // step t + 1 (stage 1)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!(abl & 4)) __builtin_amdgcn_s_barrier();
+      if (t + 2 < NST) {
+        ADVOC_P3_B(s, t + 2, 0);
+      } else if (more) {
+        ADVOC_P3_B(s + 1, 0, 0);
+      }
+      if (more) ADVOC_P3_HALO(s + 1, t + 1, hb ^ 1);
+      if (!C::CARRY) ADVOC_P3_LOAD_A(a0, hb, t + 1, 0);
+      ADVOC_P3_LOAD_B(b0, 1, 0);
+      ADVOC_P3_LOAD_A(a1, hb, t + 1, 1);
+      if (C::DOUBLE_B) ADVOC_P3_LOAD_B(b1, 1, 1);
+      ADVOC_P3_MFMA(a0, b0);
+      if (C::CARRY && t + 2 < NST) ADVOC_P3_LOAD_A(a0, hb, t + 2, 0);
+      if (C::DOUBLE_B) {
+        ADVOC_P3_MFMA(a1, b1);
+      } else {
+        ADVOC_P3_LOAD_B(b0, 1, 1);
+        ADVOC_P3_MFMA(a1, b0);
+      }
+    }
+  }
+#undef ADVOC_P3_HALO
+#undef ADVOC_P3_B
+#undef ADVOC_P3_LOAD_A
+#undef ADVOC_P3_LOAD_B
+#undef ADVOC_P3_MFMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- epilogue (igemm_h3.hip's, per wave): pixel table of the wave's points for its phase, LDS transpose,
+  // 16-byte stores with the fused bias / dropout / activation-gradient / two-destination logic ----
+  constexpr int PW_ = C::PTS_W;
+  int* s_pix = reinterpret_cast<int*>(smem + C::WAVES * 32 * 36) + wave * 2 * PW_;
+  for (int r = lane; r < PW_; r += 64) {
+    const int pt = wm * PW_ + r;
+    const int gy = gy0 + (pt >> 4), gx = gx0 + (pt & 15);
+    int pix0 = -1, pix1 = -1;
+    if (gy < p.gh && gx < p.gw) {
+      const int oy = gy * p.osy + p.ooy[phase], ox = gx * p.osx + p.oox[phase];
+      if (oy < p.out_h && ox < p.out_w) {
+        pix0 = (img * p.out_h + oy) * p.d[0].pitch + ox;
+        pix1 = (img * p.out_h + oy) * p.d[1].pitch + ox;
+      }
+    }
+    s_pix[r] = pix0;
+    s_pix[PW_ + r] = pix1;
+  }
+  wave_lds_sync();
+
+  const float unscale = __uint_as_float(p.a_hdr[1]) * __uint_as_float(p.b_hdr[1]);   // exact: powers of two
+  constexpr int LDT = 36;
+  float* T = smem + wave * (32 * LDT);
+  const int trow = lane >> 3, tq = lane & 7;
+  const bool use_grad = BWD && p.grad_act != ADVOC_ACT_NONE;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    // destination of this column block (channels [0, n_split) -> d[0], the rest -> d[1]) and its per-channel vectors
+    const int nt0 = n0 + ncol0 + j * 32;
+    const int di = nt0 >= p.n_split ? 1 : 0;
+    float* const dp = di ? p.d[1].p : p.d[0].p;
+    if (dp == nullptr) continue;
+    const float* const d_xpre = di ? p.d[1].xpre : p.d[0].xpre;
+    const uint8_t* const d_gmask = di ? p.d[1].gmask : p.d[0].gmask;
+    const float d_gmask_scale = di ? p.d[1].gmask_scale : p.d[0].gmask_scale;
+    const int d_c = di ? p.d[1].c : p.d[0].c;
+    const bool d_accum = (di ? p.d[1].accum : p.d[0].accum) != 0;
+    const int ch = (di ? nt0 - p.n_split : nt0) + 4 * tq;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!BWD && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + nt0 + 4 * tq);
+    float4 gs4 = make_float4(1.f, 1.f, 1.f, 1.f), gh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* const gsc = di ? p.d[1].gscale : p.d[0].gscale;
+    const float* const gsh = di ? p.d[1].gshift : p.d[0].gshift;
+    if (BWD && gsc) {
+      gs4 = *reinterpret_cast<const float4*>(gsc + ch);
+      gh4 = *reinterpret_cast<const float4*>(gsh + ch);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      // ALL global loads of the block (pre-activation values, masks, the value to add to) are issued before anything is
+      // used or stored: loads and stores retire through one in-order counter here, so a load placed after a store
+      // waits for the store's round trip, and the plain per-row load -> wait -> store chain costs one memory latency
+      // per 16 bytes (measured: 2/3 of the time of the 64-column backward-data launches).  Rows that store nothing
+      // load from pixel 0.
+      int off[4];
+      float4 xp[4], old[4];
+      uchar4 mk[4];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int pix = s_pix[di * PW_ + i * 32 + trow + 8 * ps];
+        off[ps] = pix < 0 ? -1 : pix * d_c + ch;
+        const int lo = pix < 0 ? ch : off[ps];
+        if (BWD) {
+          if (use_grad) xp[ps] = *reinterpret_cast<const float4*>(d_xpre + lo);
+          if (d_gmask) mk[ps] = *reinterpret_cast<const uchar4*>(d_gmask + lo);
+          if (d_accum) old[ps] = *reinterpret_cast<const float4*>(dp + lo);
+        } else {
+          if (p.y_mask) mk[ps] = *reinterpret_cast<const uchar4*>(p.y_mask + lo);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * half) * LDT + l32] = acc[i][j][r];
+      wave_lds_sync();
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        float4 v = *reinterpret_cast<const float4*>(T + (trow + 8 * ps) * LDT + 4 * tq);
+        v.x = fmaf(v.x, unscale, bias4.x); v.y = fmaf(v.y, unscale, bias4.y);
+        v.z = fmaf(v.z, unscale, bias4.z); v.w = fmaf(v.w, unscale, bias4.w);
+        if (!BWD && p.y_mask) {
+          v.x *= mk[ps].x * p.y_mask_scale; v.y *= mk[ps].y * p.y_mask_scale;
+          v.z *= mk[ps].z * p.y_mask_scale; v.w *= mk[ps].w * p.y_mask_scale;
+        }
+        if (use_grad) {
+          float4 x = xp[ps];
+          x.x = x.x * gs4.x + gh4.x; x.y = x.y * gs4.y + gh4.y; x.z = x.z * gs4.z + gh4.z; x.w = x.w * gs4.w + gh4.w;
+          v.x *= x.x > 0.f ? 1.f : gslope; v.y *= x.y > 0.f ? 1.f : gslope;
+          v.z *= x.z > 0.f ? 1.f : gslope; v.w *= x.w > 0.f ? 1.f : gslope;
+        }
+        if (BWD && d_gmask) {
+          v.x *= mk[ps].x * d_gmask_scale; v.y *= mk[ps].y * d_gmask_scale;
+          v.z *= mk[ps].z * d_gmask_scale; v.w *= mk[ps].w * d_gmask_scale;
+        }
+        if (BWD && d_accum) {
+          v.x += old[ps].x; v.y += old[ps].y; v.z += old[ps].z; v.w += old[ps].w;
+        }
+        if (off[ps] >= 0) *reinterpret_cast<float4*>(dp + off[ps]) = v;
+      }
+      wave_lds_sync();
+    }
+  }
+  __syncthreads();          // the next tile's DMAs overwrite the LDS this epilogue read
+  }  // tiles
+}
+
+template <int NPH, int BWD>
+__global__ __launch_bounds__(512, 1) void patch_gemm_h3_kernel(const GatherGemmParams p, const PatchGeom g) {
+  patch_gemm_h3_body<NPH, 8, BWD>(p, g);
+}
+
+template <int NPH, int BWD>
+int launch_patch(const GatherGemmParams& p, const PatchGeom& g, hipStream_t stream, const char** name_only) {
+  using C = PCfg<NPH, 8>;
+  const Tuning& t = tuning();
+  if (name_only) {
+    static const std::string name = std::string("patch_gemm_h3_kernel<") + std::to_string(NPH) + ", " +
+                                    std::to_string(BWD) + ">";
+    *name_only = name.c_str();
+    return ADVOC_OK;
+  }
+  auto kern = patch_gemm_h3_kernel<NPH, BWD>;
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+  if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }
+  // workgroups in whole rows of the 8 XCDs; persistent (default; ADVOC_H3_PATCH_PERSIST=0 for one tile per workgroup):
+  // one per CU (160 KB of LDS each), every workgroup walks tiles -- 2-4 % faster on every layer of the model
+  const int64_t tiles = (int64_t)p.batch * g.py * g.px * (p.n_total / C::BN);
+  int64_t wgs = (tiles + 7) / 8 * 8;
+  if (t.h3_patch_persist) {
+    const int64_t cus = device_cu_count() / 8 * 8;
+    if (wgs > cus && cus >= 8) wgs = cus;
+  }
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(C::THREADS), C::LDS_BYTES, stream, p, g);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+}  // namespace
+
+// 0: not a patch launch; else NPH (4 | 1) with `g` filled in
+int patch_plan(const GatherGemmParams& p, PatchGeom* g) {
+  const Tuning& t = tuning();
+  if (!t.h3_patch) return 0;
+  if (p.sy != 1 || p.sx != 1) return 0;
+  int nph = 0;
+  if (p.nphase == 4 && p.ntaps == 4 && p.osy == 2 && p.osx == 2 && p.n_total % 64 == 0) nph = 4;
+  else if (p.nphase == 1 && p.ntaps == 16 && p.osy == 1 && p.osx == 1 && p.n_total % 256 == 0) nph = 1;
+  if (!nph) return 0;
+  int dy0 = 127, dy1 = -127, dx0 = 127, dx1 = -127;
+  for (int ph = 0; ph < p.nphase; ++ph)
+    for (int i = 0; i < p.ntaps; ++i) {
+      const int dy = (int)(int8_t)(p.tap[ph][i] & 0xff), dx = (int)(int8_t)((p.tap[ph][i] >> 8) & 0xff);
+      dy0 = dy < dy0 ? dy : dy0; dy1 = dy > dy1 ? dy : dy1;
+      dx0 = dx < dx0 ? dx : dx0; dx1 = dx > dx1 ? dx : dx1;
+    }
+  const int e = nph == 4 ? 2 : 3;                 // the kernels are compiled for halos of exactly (16 + e) x (16 + e)
+  if (dy1 - dy0 != e || dx1 - dx0 != e) return 0;
+  if (p.gh < 16 || p.gw < 16) return 0;
+  g->dy0 = dy0; g->dx0 = dx0;
+  g->hh = 16 + (dy1 - dy0); g->hw = 16 + (dx1 - dx0);
+  g->py = (p.gh + 15) / 16; g->px = (p.gw + 15) / 16;
+  g->nblocks = (g->hh * g->hw + 7) / 8;
+  g->ablate = t.h3_patch_ablate;
+  // rows the patches add beyond the grid are computed and thrown away
+  if ((int64_t)g->py * g->px * 256 * 100 > (int64_t)p.gh * p.gw * 125) return 0;
+  const int bn = nph == 4 ? 64 : 256;
+  const int64_t wgs = (int64_t)p.batch * g->py * g->px * (p.n_total / bn);
+  if (wgs < t.h3_patch_min_wgs) return 0;
+  return nph;
+}
+
+int launch_patch_gemm_h3(const GatherGemmParams& p, const PatchGeom& g, int nph, hipStream_t stream,
+                         const char** name_only) {
+  // the backward-data description is the one with an activation gradient or a second / accumulating destination
+  const bool bwd = p.grad_act != ADVOC_ACT_NONE || p.d[0].xpre || p.d[1].p || p.d[0].accum;
+  if (nph == 4) return bwd ? launch_patch<4, 1>(p, g, stream, name_only) : launch_patch<4, 0>(p, g, stream, name_only);
+  return bwd ? launch_patch<1, 1>(p, g, stream, name_only) : launch_patch<1, 0>(p, g, stream, name_only);
+}
+
+}  // namespace advoc

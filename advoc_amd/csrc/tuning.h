@@ -22,6 +22,10 @@ struct Tuning {
   int h3_stages;        // ADVOC_H3_STAGES      2 | 3 LDS stages forced
   int h3_skip_prep;     // ADVOC_H3_SKIP_PREP   1: (micro-benchmarks only) reuse the images already in the workspace
   int h3_min_tiles;     // ADVOC_H3_MIN_TILES   smallest launch (128-row x 128-column tiles) that takes the image path
+  int h3_patch;         // ADVOC_H3_PATCH       0: stride-1 gathers stay on the per-tap tiles of igemm_h3.hip
+  int h3_patch_min_wgs; // ADVOC_H3_PATCH_MIN_WGS  smallest launch (workgroups) that takes the patch kernel
+  int h3_patch_persist; // ADVOC_H3_PATCH_PERSIST  0: one tile per workgroup instead of one workgroup per CU walking tiles
+  int h3_patch_ablate;  // ADVOC_H3_PATCH_ABLATE  timing experiments: bits 1 no DMA, 2 no MFMA, 4 no barrier (results are garbage)
 };
 
 const Tuning& tuning();

@@ -257,6 +257,52 @@ H3 = [
 ]
 H3_VARIANTS = [(1, 2), (1, 3), (2, 2), (3, 2), (4, 2), (4, 3), (5, 2), (6, 2)]
 
+# Patch kernels (igemm_patch.hip): the stride-1 gathers -- four fused sub-pixel phases (transposed-conv forward, conv
+# backward-data) and the 4x4 stride-1 conv in both directions -- on grids that are not multiples of the 16 x 16 patch,
+# with two sources and a trimmed column, dropout on either side, several column tiles.  (direction, kernel) expected:
+PATCH = [
+    (('p3_dec_skip',  1, (2, 31, 30), 64, 64, 128, 1, (2, 2), (1, 1), 2, True, 0), {0: 'patch_gemm_h3_kernel<4, 0>'}),
+    (('p3_dec_clip',  1, (3, 30, 31), 96, 0, 64, 0, (2, 2), (1, 1), 2, False, 1), {0: 'patch_gemm_h3_kernel<4, 0>'}),
+    (('p3_enc_bwd',   0, (2, 62, 60), 64, 0, 128, 0, (2, 2), None, 1, False, 0), {1: 'patch_gemm_h3_kernel<4, 1>'}),
+    (('p3_enc_bwd_odd', 0, (2, 61, 59), 128, 0, 64, 0, (2, 2), None, 1, True, 0), {1: 'patch_gemm_h3_kernel<4, 1>'}),
+    (('p3_d4',        0, (2, 32, 31), 256, 0, 256, 0, (1, 1), (1, 1), 1, False, 0),
+     {0: 'patch_gemm_h3_kernel<1, 0>', 1: 'patch_gemm_h3_kernel<1, 1>'}),
+    (('p3_d4_wide',   0, (1, 29, 33), 64, 0, 512, 0, (1, 1), (1, 1), 1, True, 0), {0: 'patch_gemm_h3_kernel<1, 0>'}),
+]
+
+
+@gpu
+@pytest.mark.parametrize('persist', [1, 0], ids=['persistent', 'tile_per_wg'])
+@pytest.mark.parametrize('case,want', PATCH, ids=[c[0][0] for c in PATCH])
+def test_layer_patch_kernels(hip, case, want, persist, hipenv):
+  from advoc_amd import conv
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1, ADVOC_H3_PATCH_PERSIST=persist)
+  c = build_case(case)
+  dev = torch.device('cuda')
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w = c['w'].to(dev)
+  cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+  y = torch.empty(x0.shape[0], c['oh'], c['out_w'], cout, device=dev)
+  L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
+  for direction, name in want.items():
+    assert L.kernel_name(direction) == name, (direction, L.kernel_name(direction))
+  test_layer_all_directions(hip, case)
+  # and the per-tap tiles on the same shapes agree with it far below the oracle tolerance
+  outs = {}
+  for patch in (1, 0):
+    hipenv(ADVOC_H3_PATCH=patch)
+    L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
+    if patch == 0:
+      assert not any('patch' in L.kernel_name(d) for d in (0, 1))
+    L.forward()
+    dx0 = torch.zeros_like(x0)
+    dx1 = torch.zeros_like(x1) if x1 is not None else None
+    L.backward_data(c['dy'].to(dev), dx0, dx1)
+    outs[patch] = (y.clone(), dx0[:, :, :c['in_w']].clone())
+  for a, b in zip(outs[1], outs[0]):
+    assert rel(a, b) < 2e-6, rel(a, b)
+
 
 @gpu
 @pytest.mark.parametrize('variant', H3_VARIANTS, ids=['t%d_s%d' % v for v in H3_VARIANTS])

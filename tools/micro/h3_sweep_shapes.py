@@ -12,6 +12,16 @@ SHAPES = {
     'd4':    (0, 128, 32, 64, 256, 0, 512, (1, 1), 0, 1),
     'dec4':  (1, 64, 16, 33, 512, 512, 256, (2, 2), 1, 2),
     'dec3':  (1, 64, 32, 65, 256, 256, 128, (2, 2), 1, 2),
+    # model geometry (AdVoc-full, B=64; D on 2B): the stride-1 gathers igemm_patch.hip takes
+    'dec2m': (1, 64, 64, 128, 128, 128, 64, (2, 2), 1, 2),      # decoder_2 forward: 64 output channels
+    'dec3m': (1, 64, 32, 64, 256, 256, 128, (2, 2), 1, 2),
+    'dec4m': (1, 64, 16, 32, 512, 512, 256, (2, 2), 1, 2),
+    'enc2m': (0, 64, 128, 256, 64, 0, 128, (2, 2), 0, 1),       # backward-data: 64 columns, phases over a 64 x 128 grid
+    'enc3m': (0, 64, 64, 128, 128, 0, 256, (2, 2), 0, 1),
+    'enc4m': (0, 64, 32, 64, 256, 0, 512, (2, 2), 0, 1),
+    'd2m':   (0, 128, 128, 256, 64, 0, 128, (2, 2), 0, 1),
+    'd3m':   (0, 128, 64, 128, 128, 0, 256, (2, 2), 0, 1),
+    'd4b':   (0, 64, 32, 64, 256, 0, 512, (1, 1), 0, 1),        # layer_4 on the B-clip pass of the G step
 }
 
 
@@ -36,3 +46,25 @@ def build(name):
   return L, dy, dx0, dx1
 
 
+
+
+def setenv(**kw):
+  from advoc_amd import _lib
+  for k, v in kw.items():
+    if v is None:
+      os.environ.pop(k, None)
+    else:
+      os.environ[k] = str(v)
+  _lib.reload_env()
+
+
+def timed_us(fn, reps=10):
+  for _ in range(2):
+    fn()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    fn()
+  e1.record()
+  torch.cuda.synchronize()
+  return e0.elapsed_time(e1) / reps * 1e3
