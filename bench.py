@@ -336,7 +336,7 @@ def roofline_from(prof, model, batch, ms_per_step, prof_steps, verbose):
   tot = sum(v['ms'] for v in rows.values())
   kernels = []
   for k, v in sorted(rows.items(), key=lambda kv: -kv[1]['ms']):
-    mfma = 'mfma' in k or 'gather_gemm' in k or 'wgrad_h3' in k
+    mfma = 'mfma' in k or 'gather_gemm' in k or 'wgrad_h3' in k or 'patch_gemm' in k
     entry = dict(kernel=k, launches_per_step=v['launches'] / prof_steps, share_of_conv_stack=v['ms'] / tot,
                  avg_launch_ms=v['ms'] / v['launches'])
     if mfma and v['flops'] > 0:
