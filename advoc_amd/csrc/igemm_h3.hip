@@ -342,48 +342,64 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
     if (p.bias && (ks_idx == 0 || !atomic_split)) bias4 = *reinterpret_cast<const float4*>(p.bias + nt0 + 4 * tq);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+      // ALL global loads of the block (pre-activation values, masks, the value to add to) are issued before anything is
+      // used or stored: loads and stores retire through one in-order counter, so a load placed after a store waits for
+      // the store's round trip -- the per-row load -> wait -> store chain costs one memory latency per 16 bytes
+      // (igemm_patch.hip measured it).  Rows that store nothing load from pixel 0.
+      int off[4];
+      float4 xp[4], old[4];
+      uchar4 ymk[4], gmk[4];
+      const bool use_grad = p.grad_act != ADVOC_ACT_NONE;
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int pix = s_pix[di * BM + (wm * MT + i) * 32 + trow + 8 * ps];
+        off[ps] = pix < 0 ? -1 : pix * d.c + ch;
+        const int lo = pix < 0 ? ch : off[ps];
+        if (p.y_mask) ymk[ps] = *reinterpret_cast<const uchar4*>(p.y_mask + lo);
+        if (use_grad) xp[ps] = *reinterpret_cast<const float4*>(d.xpre + lo);
+        if (d.gmask) gmk[ps] = *reinterpret_cast<const uchar4*>(d.gmask + lo);
+        if (d.accum && !atomic_split) old[ps] = *reinterpret_cast<const float4*>(d.p + lo);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * half) * LDT + l32] = acc[i][j][r];
       wave_lds_sync();
+      float4 gs = make_float4(1.f, 1.f, 1.f, 1.f), gh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (use_grad && d.gscale) {
+        gs = *reinterpret_cast<const float4*>(d.gscale + ch);
+        gh = *reinterpret_cast<const float4*>(d.gshift + ch);
+      }
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
-        const int row = trow + 8 * ps;
-        const int pix = s_pix[di * BM + (wm * MT + i) * 32 + row];
-        if (pix < 0) continue;
-        const int off = pix * d.c + ch;
-        float4 v = *reinterpret_cast<const float4*>(T + row * LDT + 4 * tq);
+        if (off[ps] < 0) continue;
+        float4 v = *reinterpret_cast<const float4*>(T + (trow + 8 * ps) * LDT + 4 * tq);
         v.x = fmaf(v.x, unscale, bias4.x); v.y = fmaf(v.y, unscale, bias4.y);
         v.z = fmaf(v.z, unscale, bias4.z); v.w = fmaf(v.w, unscale, bias4.w);
         if (p.y_mask) {
-          const uchar4 mk = *reinterpret_cast<const uchar4*>(p.y_mask + off);
+          const uchar4 mk = ymk[ps];
           v.x *= mk.x * p.y_mask_scale; v.y *= mk.y * p.y_mask_scale;
           v.z *= mk.z * p.y_mask_scale; v.w *= mk.w * p.y_mask_scale;
         }
-        if (p.grad_act != ADVOC_ACT_NONE) {
-          float4 x = *reinterpret_cast<const float4*>(d.xpre + off);
-          if (d.gscale) {
-            const float4 gs = *reinterpret_cast<const float4*>(d.gscale + ch);
-            const float4 gh = *reinterpret_cast<const float4*>(d.gshift + ch);
-            x.x = x.x * gs.x + gh.x; x.y = x.y * gs.y + gh.y; x.z = x.z * gs.z + gh.z; x.w = x.w * gs.w + gh.w;
-          }
+        if (use_grad) {
+          float4 x = xp[ps];
+          x.x = x.x * gs.x + gh.x; x.y = x.y * gs.y + gh.y; x.z = x.z * gs.z + gh.z; x.w = x.w * gs.w + gh.w;
           v.x *= x.x > 0.f ? 1.f : gslope; v.y *= x.y > 0.f ? 1.f : gslope;
           v.z *= x.z > 0.f ? 1.f : gslope; v.w *= x.w > 0.f ? 1.f : gslope;
         }
         if (d.gmask) {
-          const uchar4 mk = *reinterpret_cast<const uchar4*>(d.gmask + off);
+          const uchar4 mk = gmk[ps];
           v.x *= mk.x * d.gmask_scale; v.y *= mk.y * d.gmask_scale;
           v.z *= mk.z * d.gmask_scale; v.w *= mk.w * d.gmask_scale;
         }
+        float* const dst = d.p + off[ps];
         if (atomic_split) {
-          unsafeAtomicAdd(d.p + off, v.x); unsafeAtomicAdd(d.p + off + 1, v.y);
-          unsafeAtomicAdd(d.p + off + 2, v.z); unsafeAtomicAdd(d.p + off + 3, v.w);
+          unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + 1, v.y);
+          unsafeAtomicAdd(dst + 2, v.z); unsafeAtomicAdd(dst + 3, v.w);
           continue;
         }
         if (d.accum) {
-          const float4 o = *reinterpret_cast<const float4*>(d.p + off);
-          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          v.x += old[ps].x; v.y += old[ps].y; v.z += old[ps].z; v.w += old[ps].w;
         }
-        *reinterpret_cast<float4*>(d.p + off) = v;
+        *reinterpret_cast<float4*>(dst) = v;
       }
       wave_lds_sync();
     }
