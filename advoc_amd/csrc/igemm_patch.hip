@@ -54,14 +54,16 @@ struct PCfg {
   static constexpr bool CARRY = W == 4;                    // next step's first A fragments fetched before the barrier
   static constexpr bool DOUBLE_B = W == 4;                 // B fragments of both k steps in registers at once (W = 8: the
                                                            // second set costs the 16 registers that tip the loop into scratch)
-  static constexpr int HALO_BLOCKS = NPH == 4 ? 41 : 46;   // 8-pixel DMA blocks: 18 x 18 = 324 | 19 x 19 = 361 pixels
+  static constexpr int HW = NPH == 4 ? 18 : 19;            // halo width = height (patch_plan takes only gathers of this extent)
+  static constexpr int HP = NPH == 4 ? 18 : 20;            // halo row pitch in LDS, EVEN: address bit 7 (the half of the
+                                                           // 256-byte bank row) must follow the column's parity
+  static constexpr int HALO_BLOCKS = (HW * HP + 7) / 8;    // 8-pixel DMA blocks: 41 | 48
   static constexpr int HPS = NPH == 4 ? (W == 4 ? 3 : 2) : 1;   // halo DMA slots per wave and step
   static constexpr int BPW = 32 / W;                       // B DMA blocks (8 rows) per wave and step
   static constexpr int HALO_BYTES = HALO_BLOCKS * 1024;
   static constexpr int B_STAGE = 256 * 128;
   static constexpr int OFF_B = 2 * HALO_BYTES;
-  static constexpr int OFF_DUMMY = OFF_B + 2 * B_STAGE;
-  static constexpr int LDS_BYTES = OFF_DUMMY + 1024;
+  static constexpr int LDS_BYTES = OFF_B + 2 * B_STAGE;     // 146 KiB | 160 KiB
   static constexpr int PTS_W = 32 * MT;                    // grid points per wave
   static constexpr int EPI_BYTES = WAVES * (32 * 36 * 4 + 2 * PTS_W * 4);
   static_assert(WAVES * NST * HPS >= HALO_BLOCKS, "every halo block has a DMA slot");
@@ -93,8 +95,8 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const int npatch = p.batch * ppi;
   const int ktot = p.c0 + p.c1;
   const int nslices = ktot / 32;
-  constexpr int hw = NPH == 4 ? 18 : 19;             // halo width (patch_plan takes only gathers of exactly this extent):
-  const int hpix = g.hh * hw;                        // compile-time, so that block i of a fragment read is an immediate offset
+  constexpr int hw = C::HP;                          // halo row pitch: compile-time, so that block i of a fragment read is an
+  constexpr int hpix = C::HW * C::HP;                // immediate offset
 
   const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(p.a0_img), 0, p.a0_img_bytes, 0x00020000);
@@ -104,7 +106,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       const_cast<uint16_t*>(p.wq), 0, p.wq_taps * p.n_total * ktot * 4, 0x00020000);
 
   const int lrow = lane >> 3, lpos = lane & 7;
-  constexpr int hmagic = (65536 + hw - 1) / hw;      // h / hw == (h * hmagic) >> 16 for h < 512, hw <= 19
+  constexpr int hmagic = (65536 + hw - 1) / hw;      // h / hw == (h * hmagic) >> 16 for h < 512, hw <= 20
   const int half = lane >> 5, l32 = lane & 31;
   // halo pixel of this lane's row in the wave's first 32-point block (2 patch rows x 16 columns) for tap (0, 0); block
   // i is 2 i halo rows further
@@ -119,7 +121,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const int tapv_c = p.tap[phase][lane & (kMaxTaps - 1)];
   const int tapv_b = p.tap[b_phase][lane & (kMaxTaps - 1)];
   const int src_c0 = p.c0, src_c1 = p.c1, src_p0 = p.a0_pitch, src_p1 = p.a1_pitch;
-  const int abl = g.ablate;       // timing experiments only (ADVOC_H3_PATCH_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier
+  // ADVOC_H3_PATCH_ABLATE bits, timing experiments: 1 no DMA, 2 no MFMA, 4 no barrier (results are garbage); 8 / 16: DMA
+  // issue position inside a step (patch_plan picks the default), 32: DMAs at the top of the step
+  const int abl = g.ablate;
 
   // ---- persistent workgroups: the launch holds one workgroup per CU; XCD x walks its own contiguous range of tiles
   // (column tile slowest, so the workgroups an XCD runs together stream the same weights), and the stores of one
@@ -151,7 +155,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   }
 
   // Halo pieces of K slice SL (channels [32 SL, 32 SL + 32) of the concatenated sources) that step T carries, into
-  // halo buffer HB.  Slots beyond the halo write zeros into a dummy KiB (out-of-range offset: no memory traffic).
+  // halo buffer HB.  Slots beyond the halo issue nothing (every wait in the K loop is vmcnt(0): no counting to keep).
 #define ADVOC_P3_HALO(SL, T, HB)                                                                          \
   {                                                                                                       \
     const int k0_ = (SL) * 32;                                                                            \
@@ -166,13 +170,13 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       const int hy_ = (h_ * hmagic) >> 16;                                                                \
       const int hx_ = h_ - hy_ * hw;                                                                      \
       const int iy_ = gy0 + hy_ + g.dy0, ix_ = gx0 + hx_ + g.dx0;                                         \
-      const bool ok_ = h_ < hpix && (unsigned)iy_ < (unsigned)p.in_h && (unsigned)ix_ < (unsigned)p.in_w; \
+      const bool ok_ = h_ < hpix && hx_ < C::HW && (unsigned)iy_ < (unsigned)p.in_h &&                    \
+                       (unsigned)ix_ < (unsigned)p.in_w;                                                  \
       const int voff_ = ok_ ? (((img * p.a_h + iy_) * pitch_ + ix_) * c_ + kk_) * 4 +                     \
                                   ((lpos ^ ((hx_ >> 1) & 7)) * 16)                                        \
                             : (int)0x80000000;                                                            \
-      unsigned char* d_ = blk_ < g.nblocks ? smem_b + (HB) * C::HALO_BYTES + blk_ * 1024                  \
-                                           : smem_b + C::OFF_DUMMY;                                       \
-      if (abl & 1) continue;                                                                              \
+      unsigned char* d_ = smem_b + (HB) * C::HALO_BYTES + blk_ * 1024;                                    \
+      if (blk_ >= C::HALO_BLOCKS || (abl & 1)) continue;                                                  \
       if (second_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_void_p)(d_), 16, voff_, 0, 0, 0); \
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (lds_void_p)(d_), 16, voff_, 0, 0, 0);         \
     }                                                                                                     \
@@ -257,13 +261,23 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       // step t (stage 0)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!(abl & 4)) __builtin_amdgcn_s_barrier();
-      ADVOC_P3_B(s, t + 1, 1);
-      if (more) ADVOC_P3_HALO(s + 1, t, hb ^ 1);
+      if (!(abl & 24)) {
+        ADVOC_P3_B(s, t + 1, 1);
+        if (more) ADVOC_P3_HALO(s + 1, t, hb ^ 1);
+      }
       if (!C::CARRY || t == 0) ADVOC_P3_LOAD_A(a0, hb, t, 0);
       ADVOC_P3_LOAD_B(b0, 0, 0);
       ADVOC_P3_LOAD_A(a1, hb, t, 1);
       if (C::DOUBLE_B) ADVOC_P3_LOAD_B(b1, 0, 1);
+      if (abl & 8) {
+        ADVOC_P3_B(s, t + 1, 1);
+        if (more) ADVOC_P3_HALO(s + 1, t, hb ^ 1);
+      }
       ADVOC_P3_MFMA(a0, b0);
+      if (abl & 16) {
+        ADVOC_P3_B(s, t + 1, 1);
+        if (more) ADVOC_P3_HALO(s + 1, t, hb ^ 1);
+      }
       if (C::CARRY) ADVOC_P3_LOAD_A(a0, hb, t + 1, 0);
       if (C::DOUBLE_B) {
         ADVOC_P3_MFMA(a1, b1);
@@ -274,17 +288,35 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       // step t + 1 (stage 1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!(abl & 4)) __builtin_amdgcn_s_barrier();
-      if (t + 2 < NST) {
-        ADVOC_P3_B(s, t + 2, 0);
-      } else if (more) {
-        ADVOC_P3_B(s + 1, 0, 0);
+      if (!(abl & 24)) {
+        if (t + 2 < NST) {
+          ADVOC_P3_B(s, t + 2, 0);
+        } else if (more) {
+          ADVOC_P3_B(s + 1, 0, 0);
+        }
+        if (more) ADVOC_P3_HALO(s + 1, t + 1, hb ^ 1);
       }
-      if (more) ADVOC_P3_HALO(s + 1, t + 1, hb ^ 1);
       if (!C::CARRY) ADVOC_P3_LOAD_A(a0, hb, t + 1, 0);
       ADVOC_P3_LOAD_B(b0, 1, 0);
       ADVOC_P3_LOAD_A(a1, hb, t + 1, 1);
       if (C::DOUBLE_B) ADVOC_P3_LOAD_B(b1, 1, 1);
+      if (abl & 8) {
+        if (t + 2 < NST) {
+          ADVOC_P3_B(s, t + 2, 0);
+        } else if (more) {
+          ADVOC_P3_B(s + 1, 0, 0);
+        }
+        if (more) ADVOC_P3_HALO(s + 1, t + 1, hb ^ 1);
+      }
       ADVOC_P3_MFMA(a0, b0);
+      if (abl & 16) {
+        if (t + 2 < NST) {
+          ADVOC_P3_B(s, t + 2, 0);
+        } else if (more) {
+          ADVOC_P3_B(s + 1, 0, 0);
+        }
+        if (more) ADVOC_P3_HALO(s + 1, t + 1, hb ^ 1);
+      }
       if (C::CARRY && t + 2 < NST) ADVOC_P3_LOAD_A(a0, hb, t + 2, 0);
       if (C::DOUBLE_B) {
         ADVOC_P3_MFMA(a1, b1);
@@ -461,10 +493,13 @@ int patch_plan(const GatherGemmParams& p, PatchGeom* g) {
   if (dy1 - dy0 != e || dx1 - dx0 != e) return 0;
   if (p.gh < 16 || p.gw < 16) return 0;
   g->dy0 = dy0; g->dx0 = dx0;
-  g->hh = 16 + (dy1 - dy0); g->hw = 16 + (dx1 - dx0);
+  g->hh = 16 + e; g->hw = 16 + e;
   g->py = (p.gh + 15) / 16; g->px = (p.gw + 15) / 16;
   g->nblocks = (g->hh * g->hw + 7) / 8;
-  g->ablate = t.h3_patch_ablate;
+  // bits 8 / 16: where in a step the DMAs of the next one are issued -- after the step's fragment reads / after its first
+  // MFMA group (measured: +4-5 % on the four-phase kernel, neutral on the 4x4 one; at the top of the step the DMA's LDS
+  // writes collide with the fragment reads that follow the barrier)
+  g->ablate = t.h3_patch_ablate ? t.h3_patch_ablate : (nph == 4 ? 16 : 8);
   // rows the patches add beyond the grid are computed and thrown away
   if ((int64_t)g->py * g->px * 256 * 100 > (int64_t)p.gh * p.gw * 125) return 0;
   const int bn = nph == 4 ? 64 : 256;

@@ -12,7 +12,7 @@ for spec in (sys.argv[1:] or ['d4:f', 'dec2m:f', 'dec4m:f', 'enc2m:d']):
   fn = L.forward if d != 'd' else (lambda: L.backward_data(dy, dx0, dx1))
   for waves in (8,):
     row = []
-    for abl in (0, 1, 2, 3, 4, 5, 6):
+    for abl in (0, 8, 16, 0, 8, 16):
       setenv(ADVOC_H3_PATCH=1, ADVOC_H3_PATCH_ABLATE=0, ADVOC_H3_SKIP_PREP=None)
       fn()
       setenv(ADVOC_H3_SKIP_PREP=1, ADVOC_H3_PATCH_ABLATE=abl)
