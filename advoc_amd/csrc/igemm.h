@@ -121,7 +121,7 @@ struct PatchGeom {
   int hh, hw;        // halo rows / columns
   int py, px;        // patches per image along y / x
   int nblocks;       // 8-pixel DMA blocks of the halo
-  int ablate;        // ADVOC_H3_PATCH_ABLATE bits: 1 no DMA, 2 no MFMA, 4 no barrier (timing experiments); 8 | 16: DMA issue position
+  int ablate;        // timing experiments only (ADVOC_H3_PATCH_ABLATE bits: 1 no DMA, 2 no MFMA, 4 no barrier); 0 in use
 };
 int patch_plan(const GatherGemmParams& p, PatchGeom* g);
 int launch_patch_gemm_h3(const GatherGemmParams& p, const PatchGeom& g, int nph, hipStream_t stream,

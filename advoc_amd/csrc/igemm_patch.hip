@@ -60,6 +60,10 @@ struct PCfg {
   static constexpr int HALO_BLOCKS = (HW * HP + 7) / 8;    // 8-pixel DMA blocks: 41 | 48
   static constexpr int HPS = NPH == 4 ? (W == 4 ? 3 : 2) : 1;   // halo DMA slots per wave and step
   static constexpr int BPW = 32 / W;                       // B DMA blocks (8 rows) per wave and step
+  // where in a step the DMAs of the next one are issued: 1 after the step's fragment reads, 2 after its first MFMA group
+  // (measured with a run-time switch: +4-5 % on the four-phase kernel, neutral on the 4x4 one; at the top of the step, 0,
+  // the DMA's LDS writes collide with the fragment reads that follow the barrier)
+  static constexpr int DMA_POS = NPH == 4 ? 2 : 1;
   static constexpr int HALO_BYTES = HALO_BLOCKS * 1024;
   static constexpr int B_STAGE = 256 * 128;
   static constexpr int OFF_B = 2 * HALO_BYTES;
@@ -121,9 +125,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const int tapv_c = p.tap[phase][lane & (kMaxTaps - 1)];
   const int tapv_b = p.tap[b_phase][lane & (kMaxTaps - 1)];
   const int src_c0 = p.c0, src_c1 = p.c1, src_p0 = p.a0_pitch, src_p1 = p.a1_pitch;
-  // ADVOC_H3_PATCH_ABLATE bits, timing experiments: 1 no DMA, 2 no MFMA, 4 no barrier (results are garbage); 8 / 16: DMA
-  // issue position inside a step (patch_plan picks the default), 32: DMAs at the top of the step
-  const int abl = g.ablate;
+  const int abl = g.ablate;       // timing experiments only (ADVOC_H3_PATCH_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier
 
   // ---- persistent workgroups: the launch holds one workgroup per CU; XCD x walks its own contiguous range of tiles
   // (column tile slowest, so the workgroups an XCD runs together stream the same weights), and the stores of one
@@ -134,6 +136,8 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const int t_lo = xcd < tr_ ? xcd * (tq_ + 1) : tr_ * (tq_ + 1) + (xcd - tr_) * tq_;
   const int t_hi = t_lo + tq_ + (xcd < tr_ ? 1 : 0);
 
+  // (the backward-data instances take ONE tile per workgroup: with the K loop's per-lane constants kept alive across the
+  // epilogue for a next tile, their epilogue -- accumulators + the block's prefetched operands -- spills)
   for (int tile = t_lo + slot; tile < t_hi; tile += per_xcd) {
   const int nt = tile / npatch;
   const int pid = tile - nt * npatch;
@@ -261,7 +265,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       // step t (stage 0)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!(abl & 4)) __builtin_amdgcn_s_barrier();
-      if (!(abl & 24)) {
+      if (C::DMA_POS == 0) {
         ADVOC_P3_B(s, t + 1, 1);
         if (more) ADVOC_P3_HALO(s + 1, t, hb ^ 1);
       }
@@ -269,12 +273,12 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       ADVOC_P3_LOAD_B(b0, 0, 0);
       ADVOC_P3_LOAD_A(a1, hb, t, 1);
       if (C::DOUBLE_B) ADVOC_P3_LOAD_B(b1, 0, 1);
-      if (abl & 8) {
+      if (C::DMA_POS == 1) {
         ADVOC_P3_B(s, t + 1, 1);
         if (more) ADVOC_P3_HALO(s + 1, t, hb ^ 1);
       }
       ADVOC_P3_MFMA(a0, b0);
-      if (abl & 16) {
+      if (C::DMA_POS == 2) {
         ADVOC_P3_B(s, t + 1, 1);
         if (more) ADVOC_P3_HALO(s + 1, t, hb ^ 1);
       }
@@ -288,7 +292,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       // step t + 1 (stage 1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!(abl & 4)) __builtin_amdgcn_s_barrier();
-      if (!(abl & 24)) {
+      if (C::DMA_POS == 0) {
         if (t + 2 < NST) {
           ADVOC_P3_B(s, t + 2, 0);
         } else if (more) {
@@ -300,7 +304,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       ADVOC_P3_LOAD_B(b0, 1, 0);
       ADVOC_P3_LOAD_A(a1, hb, t + 1, 1);
       if (C::DOUBLE_B) ADVOC_P3_LOAD_B(b1, 1, 1);
-      if (abl & 8) {
+      if (C::DMA_POS == 1) {
         if (t + 2 < NST) {
           ADVOC_P3_B(s, t + 2, 0);
         } else if (more) {
@@ -309,7 +313,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
         if (more) ADVOC_P3_HALO(s + 1, t + 1, hb ^ 1);
       }
       ADVOC_P3_MFMA(a0, b0);
-      if (abl & 16) {
+      if (C::DMA_POS == 2) {
         if (t + 2 < NST) {
           ADVOC_P3_B(s, t + 2, 0);
         } else if (more) {
@@ -434,6 +438,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       wave_lds_sync();
     }
   }
+  if (BWD) break;
   __syncthreads();          // the next tile's DMAs overwrite the LDS this epilogue read
   }  // tiles
 }
@@ -461,7 +466,7 @@ int launch_patch(const GatherGemmParams& p, const PatchGeom& g, hipStream_t stre
   // one per CU (160 KB of LDS each), every workgroup walks tiles -- 2-4 % faster on every layer of the model
   const int64_t tiles = (int64_t)p.batch * g.py * g.px * (p.n_total / C::BN);
   int64_t wgs = (tiles + 7) / 8 * 8;
-  if (t.h3_patch_persist) {
+  if (t.h3_patch_persist && !BWD) {
     const int64_t cus = device_cu_count() / 8 * 8;
     if (wgs > cus && cus >= 8) wgs = cus;
   }
@@ -496,10 +501,7 @@ int patch_plan(const GatherGemmParams& p, PatchGeom* g) {
   g->hh = 16 + e; g->hw = 16 + e;
   g->py = (p.gh + 15) / 16; g->px = (p.gw + 15) / 16;
   g->nblocks = (g->hh * g->hw + 7) / 8;
-  // bits 8 / 16: where in a step the DMAs of the next one are issued -- after the step's fragment reads / after its first
-  // MFMA group (measured: +4-5 % on the four-phase kernel, neutral on the 4x4 one; at the top of the step the DMA's LDS
-  // writes collide with the fragment reads that follow the barrier)
-  g->ablate = t.h3_patch_ablate ? t.h3_patch_ablate : (nph == 4 ? 16 : 8);
+  g->ablate = t.h3_patch_ablate;
   // rows the patches add beyond the grid are computed and thrown away
   if ((int64_t)g->py * g->px * 256 * 100 > (int64_t)p.gh * p.gw * 125) return 0;
   const int bn = nph == 4 ? 64 : 256;

@@ -37,7 +37,19 @@ typedef __attribute__((address_space(3))) void* lds_void_p;
 
 constexpr int WK = 32;              // grid points per K tile
 constexpr int BLK = WK * 128;       // bytes of one 32-channel block of a K tile
-constexpr int STAGE = 8 * BLK;      // 4 row blocks of P + 4 column blocks of Q
+
+// WGM x 2 wavefronts, each MT x NT blocks of 32 x 32: 128 x 128 on 4 waves (two workgroups per CU) or 256 x 256 on 8
+// (one per CU, 128 KiB of LDS; half the L2 -> LDS bytes per flop -- the 128 x 128 tile runs at the DMA rate, like the
+// same tile of igemm_h3.hip).  Every wave loads one 32-row block of P and one 32-column block of Q per K tile.
+template <int WGM_, int NT_>
+struct WCfg {
+  static constexpr int WGM = WGM_, MT = 2, NT = NT_;
+  static constexpr int WAVES = 2 * WGM, THREADS = 64 * WAVES;
+  static constexpr int PB = WGM * MT, QB = 2 * NT;            // 32-row / 32-column blocks per workgroup
+  static constexpr int ROWS = 32 * PB, COLS = 32 * QB;
+  static constexpr int STAGE = (PB + QB) * BLK;
+  static_assert(PB == WAVES && QB == WAVES, "one P block and one Q block per wave");
+};
 
 struct WgradImages {
   const uint16_t* p0; const uint16_t* p1;   // images of the two sources of P (p1 null: single source)
@@ -46,8 +58,11 @@ struct WgradImages {
   const unsigned* p_hdr; const unsigned* q_hdr;   // {amax bits, 2^-s}
 };
 
-__global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, const WgradImages im, int tiles_n,
-                                                          int tiles, int chunk) {
+template <int WGM, int NT>
+__device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradImages& im, int tiles_n, int tiles,
+                                              int chunk) {
+  using C = WCfg<WGM, NT>;
+  constexpr int STAGE = C::STAGE, MT = C::MT;
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,8 +75,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, c
   }
   const int zchunk = vblock / tiles;
   const int tile_id = vblock - zchunk * tiles;
-  const int a0 = (tile_id / tiles_n) * 128;
-  const int b0 = (tile_id % tiles_n) * 128;
+  const int a0 = (tile_id / tiles_n) * C::ROWS;
+  const int b0 = (tile_id % tiles_n) * C::COLS;
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   const int rows_total = p.ntaps * ca;
   const int M = p.batch * p.gh * p.gw;                 // < 2^31 (launcher)
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, c
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (lds_void_p)(st_ + wave * BLK + s * 1024), 16, pv_, 0, 0, 0);   \
       const bool qok_ = in_ && q_live;                                                                   \
       const int qv_ = qok_ ? ((gi[s] * p.Q.h + gy[s]) * q_pitch + gx[s]) * q_c * 4 + q_choff + lchunk16 : (int)0x80000000; \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_p)(st_ + (4 + wave) * BLK + s * 1024), 16, qv_, 0, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_p)(st_ + (C::PB + wave) * BLK + s * 1024), 16, qv_, 0, 0, 0); \
       /* advance the slot by one K tile */                                                               \
       gx[s] += step_r; gy[s] += step_q;                                                                  \
       if (gx[s] >= p.gw) { gx[s] -= p.gw; gy[s] += 1; }                                                  \
@@ -125,11 +140,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, c
     g_lane += WK;                                                                                        \
   }
 
-  floatx16 acc[2][2];
+  floatx16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -146,25 +161,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, c
 #define ADVOC_WH3_COMPUTE(ST)                                                                            \
   {                                                                                                      \
     const unsigned char* Pb = wsm + (ST) * STAGE;                                                        \
-    const unsigned char* Qb = Pb + 4 * BLK;                                                              \
+    const unsigned char* Qb = Pb + C::PB * BLK;                                                          \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                   \
-      f16x8 af[2][2], bq[2][2];                                                                          \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
-        const unsigned char* b_ = Pb + (wm * 2 + i) * BLK;                                               \
+      f16x8 af[MT][2], bq[NT][2];                                                                        \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                   \
+        const unsigned char* b_ = Pb + (wm * MT + i) * BLK;                                              \
         const short4v a00 = ADVOC_WH3_FRAG(b_, tr_pl0, ks, 0), a01 = ADVOC_WH3_FRAG(b_, tr_pl0, ks, 1);    \
         const short4v a10 = ADVOC_WH3_FRAG(b_, tr_pl1, ks, 0), a11 = ADVOC_WH3_FRAG(b_, tr_pl1, ks, 1);    \
         af[i][0] = __builtin_bit_cast(f16x8, __builtin_shufflevector(a00, a01, 0, 1, 2, 3, 4, 5, 6, 7));                            \
         af[i][1] = __builtin_bit_cast(f16x8, __builtin_shufflevector(a10, a11, 0, 1, 2, 3, 4, 5, 6, 7));                            \
       }                                                                                                  \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
-        const unsigned char* b_ = Qb + (wn * 2 + j) * BLK;                                               \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                   \
+        const unsigned char* b_ = Qb + (wn * NT + j) * BLK;                                              \
         const short4v b00 = ADVOC_WH3_FRAG(b_, tr_pl0, ks, 0), b01 = ADVOC_WH3_FRAG(b_, tr_pl0, ks, 1);    \
         const short4v b10 = ADVOC_WH3_FRAG(b_, tr_pl1, ks, 0), b11 = ADVOC_WH3_FRAG(b_, tr_pl1, ks, 1);    \
         bq[j][0] = __builtin_bit_cast(f16x8, __builtin_shufflevector(b00, b01, 0, 1, 2, 3, 4, 5, 6, 7));                            \
         bq[j][1] = __builtin_bit_cast(f16x8, __builtin_shufflevector(b10, b11, 0, 1, 2, 3, 4, 5, 6, 7));                            \
       }                                                                                                  \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                 \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bq[j][1], acc[i][j], 0, 0, 0);    \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bq[j][0], acc[i][j], 0, 0, 0);    \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bq[j][0], acc[i][j], 0, 0, 0);    \
@@ -191,15 +206,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, c
   const float unscale = __uint_as_float(im.p_hdr[1]) * __uint_as_float(im.q_hdr[1]);
   const int half = lane >> 5, l32 = lane & 31;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MT; ++i) {
     // a 32-row MFMA tile never straddles a tap (ca % 32 == 0): one tap lookup per tile
-    const int r0 = a0 + (wm * 2 + i) * 32;
+    const int r0 = a0 + (wm * MT + i) * 32;
     if (r0 >= rows_total) continue;
     const int t_ = r0 / ca;
     float* out = p.dw + ((int64_t)(p.tap[t_] >> 16) * ca + (r0 - t_ * ca)) * cb;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int b = b0 + (wn * 2 + j) * 32 + l32;
+    for (int j = 0; j < NT; ++j) {
+      const int b = b0 + (wn * NT + j) * 32 + l32;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int a = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -207,6 +222,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, c
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, const WgradImages im, int tiles_n,
+                                                          int tiles, int chunk) {
+  wgrad_h3_body<2, 2>(p, im, tiles_n, tiles, chunk);
+}
+__global__ __launch_bounds__(512, 2) void wgrad_h3_256_kernel(const WgradParams p, const WgradImages im, int tiles_n,
+                                                              int tiles, int chunk) {
+  wgrad_h3_body<4, 4>(p, im, tiles_n, tiles, chunk);
+}
+
+// 256 x 256 tiles when both matrix dimensions divide and the pixel grid is long enough to give every workgroup (one per
+// CU) a few thousand grid points (ADVOC_WGRAD_H3_TILE=1 | 2 forces 128 | 256)
+bool wgrad_big_tile(const WgradParams& p) {
+  const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
+  if ((p.ntaps * ca) % 256 || cb % 256) return false;
+  const int force = tuning().wgrad_h3_tile;
+  if (force) return force == 2;
+  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  const int64_t tiles = (int64_t)(p.ntaps * ca / 256) * (cb / 256);
+  return M * tiles >= (int64_t)2048 * device_cu_count();
 }
 
 }  // namespace
@@ -246,7 +282,8 @@ int wgrad_h3_make_image(const Operand& o, int batch, uint16_t* img, unsigned* hd
 int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned* p_hdr, const uint16_t* q_img,
                     const unsigned* q_hdr, hipStream_t stream, const char** name_only) {
   if (!wgrad_h3_eligible(p)) return ADVOC_ERR_UNSUPPORTED;
-  if (name_only) { *name_only = "wgrad_h3_kernel"; return ADVOC_OK; }
+  const bool big = wgrad_big_tile(p);
+  if (name_only) { *name_only = big ? "wgrad_h3_256_kernel" : "wgrad_h3_kernel"; return ADVOC_OK; }
   if (!p_img || !q_img || !p_hdr || !q_hdr) return ADVOC_ERR_NULL;
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   if (!p.accumulate) {
@@ -264,9 +301,11 @@ int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned*
   im.q0_bytes = (int)((int64_t)4 * p.batch * p.Q.h * p.Q.pitch0 * p.Q.c0);
   im.q1_bytes = (int)((int64_t)4 * p.batch * p.Q.h * p.Q.pitch1 * p.Q.c1);
   im.p_hdr = p_hdr; im.q_hdr = q_hdr;
-  const int tiles_m = (p.ntaps * ca + 127) / 128, tiles_n = (cb + 127) / 128;
+  const int edge = big ? 256 : 128;
+  const int tiles_m = (p.ntaps * ca + edge - 1) / edge, tiles_n = (cb + edge - 1) / edge;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
-  static const int64_t resident = 2 * (int64_t)device_cu_count();      // 64 KiB of LDS: two workgroups per CU
+  // 64 KiB of LDS: two workgroups per CU; 128 KiB: one
+  const int64_t resident = (big ? 1 : 2) * (int64_t)device_cu_count();
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
   int64_t ksplit = ceil_div(resident, tiles);
   if (M / ksplit >= 4096) ksplit = ceil_div(2 * resident, tiles);
@@ -276,12 +315,20 @@ int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned*
   int64_t chunk = ceil_div(ceil_div(M, ksplit), WK) * WK;
   ksplit = ceil_div(M, chunk);
   if (chunk > 0x3fffffffLL || tiles * ksplit > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  constexpr int lds128 = 2 * WCfg<2, 2>::STAGE, lds256 = 2 * WCfg<4, 4>::STAGE;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
+  static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_256_kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
   if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }
+  if (attr2 != hipSuccess) { note_hip_error(attr2); return ADVOC_ERR_HIP; }
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(wgrad_h3_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), 2 * STAGE, stream, p, im, tiles_n,
-                     (int)tiles, (int)chunk);
+  if (big)
+    hipLaunchKernelGGL(wgrad_h3_256_kernel, dim3((unsigned)(tiles * ksplit)), dim3(512), lds256, stream, p,
+                       im, tiles_n, (int)tiles, (int)chunk);
+  else
+    hipLaunchKernelGGL(wgrad_h3_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), lds128, stream, p, im,
+                       tiles_n, (int)tiles, (int)chunk);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }

@@ -83,7 +83,7 @@ def synth_waveforms(batch, seed, device):
 
 def mfma_pipe(name):
   """(peak TFLOP/s in algorithmic fp32 flops, description) of the matrix pipe a kernel instance runs on."""
-  if '_h3_kernel' in name:
+  if '_h3_kernel' in name or '_h3_256_kernel' in name:
     return H3_PEAK_TFLOPS, 'f16 MFMA, 3 partial products per fp32 product (2500 / 3 TFLOP/s algorithmic)'
   if name.endswith(', true>') and (name.startswith('gather_gemm_kernel<') or name.startswith('wgrad_mfma_kernel<')):
     return X6_PEAK_TFLOPS, 'bf16 MFMA, 6 partial products per fp32 product (2500 / 6 TFLOP/s algorithmic)'

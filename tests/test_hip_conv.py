@@ -359,6 +359,28 @@ def test_layer_operand_image_weight_gradient(hip, case, hipenv):
   assert 'h3' not in L2.kernel_name(2)
 
 
+WG256 = [c for c in H3 if c[0] in ('h3_enc', 'h3_dec_skip', 'h3_dec_first')]      # (the others: 128 / 384 columns)
+
+
+@gpu
+@pytest.mark.parametrize('case', WG256, ids=[c[0] for c in WG256])
+def test_layer_operand_image_weight_gradient_256_tile(hip, case, hipenv):
+  """wgrad_h3_256_kernel (256 x 256 on 8 waves, what the large layers of the model run): forced onto the small H3
+  shapes whose matrix dimensions divide by 256, all directions against the float64 oracle."""
+  from advoc_amd import conv
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_WGRAD_H3_MIN_M=1, ADVOC_WGRAD_H3_TILE=2)
+  c = build_case(case)
+  dev = torch.device('cuda')
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w = c['w'].to(dev)
+  cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+  y = torch.empty(x0.shape[0], c['oh'], c['out_w'], cout, device=dev)
+  L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
+  assert L.kernel_name(2) == 'wgrad_h3_256_kernel', L.kernel_name(2)
+  test_layer_all_directions(hip, case)
+
+
 @gpu
 def test_operand_image_kernel_with_batchnorm_prologue(hip, hipenv):
   """The image pass applies the producer's batch-norm affine and the dropout that follows it (in_scale / in_shift /

@@ -38,13 +38,18 @@ for name in (sys.argv[1:] or list(SHAPES)):
   us_old = t(fn)
   old = dw.clone()
   name_old = L.kernel_name(2)
-  setenv(ADVOC_WGRAD_H3=1)
-  L._names = {}
-  us_all = t(fn)
-  new = dw.clone()
-  setenv(ADVOC_H3_SKIP_PREP=1)
-  us_new = t(fn)
-  setenv(ADVOC_H3_SKIP_PREP=None)
-  rel = float((new.double() - old.double()).norm() / old.double().norm())
-  print('%-5s %-36s %8.1f us %6.1f TF | %-16s %8.1f us %6.1f TF (with images %8.1f us)  rel diff %.1e' % (
-      name, name_old, us_old, L.flops / us_old / 1e6, L.kernel_name(2), us_new, L.flops / us_new / 1e6, us_all, rel), flush=True)
+  line = '%-6s %-36s %8.1f us %6.1f TF |' % (name, name_old, us_old, L.flops / us_old / 1e6)
+  for tile in (1, 2):
+    setenv(ADVOC_WGRAD_H3=1, ADVOC_WGRAD_H3_TILE=tile)
+    L._names = {}
+    us_all = t(fn)
+    new = dw.clone()
+    setenv(ADVOC_H3_SKIP_PREP=1)
+    us_new = t(fn)
+    setenv(ADVOC_H3_SKIP_PREP=None)
+    rel = float((new.double() - old.double()).norm() / old.double().norm())
+    line += ' %-20s %8.1f us %6.1f TF (with images %8.1f us) rel %.1e |' % (L.kernel_name(2), us_new, L.flops / us_new / 1e6, us_all, rel)
+  setenv(ADVOC_WGRAD_H3_TILE=None)
+  print(line, flush=True)
+  del L, dy, dx0, dx1, dw
+  torch.cuda.empty_cache()
