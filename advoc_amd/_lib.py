@@ -63,6 +63,7 @@ PROTOTYPES = {
     'advoc_lws_causal_c64': (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p, _i32, _i32, _f32, _f32, _i32, _p]),
     'advoc_lws_batch_c64': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _f32, _p]),
     'advoc_matmul_nt_f32': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
+    'advoc_mel_pinv_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     'advoc_tanh_affine_f32': (ctypes.c_int, [_p, _p, _i64, _f32, _f32, _p]),
     'advoc_mel_dbnorm_f32': (ctypes.c_int, [_p, _i64, _f32, _f32, _f32, _p]),
     'advoc_conv_workspace_bytes': (_i64, [_p, _i32]),
@@ -127,6 +128,9 @@ def load():
 def reload_env():
   """Makes the library re-read its ADVOC_* diagnostic switches from os.environ (it caches them on first use)."""
   load().advoc_tuning_reload()
+
+
+ERR_UNSUPPORTED = -2       # ADVOC_ERR_UNSUPPORTED (include/advoc_hip.h)
 
 
 def check(rc, what=''):

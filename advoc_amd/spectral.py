@@ -292,6 +292,53 @@ def matmul_last(x, w_dev):
   return out.reshape(tuple(x.shape[:-1]) + (N,))
 
 
+def mel_and_inverse(mag, meltrans_dev, invmeltrans_dev, packed=None):
+  """mag [..., bins] (device f32) -> (mag W^T [..., n_mels], (mag W^T) P^T [..., bins]) in one launch
+  (advoc_mel_pinv_f32): the chain models/advoc/train_evaluate.py:55-56 builds from spectral_util.py:29-43.  packed:
+  (runs int32 [n_mels, 2], packed weights f32, pseudo-inverse transposed [n_mels, bins]) on the device, as
+  pack_filterbank makes them (made here from the dense matrices when not given).  Falls back to two projections for
+  shapes the fused kernel does not take."""
+  bins, n_mels = mag.shape[-1], meltrans_dev.shape[0]
+  if packed is None:
+    packed = pack_filterbank(meltrans_dev.cpu().numpy(), invmeltrans_dev.cpu().numpy(), mag.device)
+  runs, wp, inv_t = packed
+  x2 = mag.reshape(-1, bins).contiguous()
+  mel = torch.empty((x2.shape[0], n_mels), dtype=torch.float32, device=mag.device)
+  inv = torch.empty((x2.shape[0], bins), dtype=torch.float32, device=mag.device)
+  rc = _lib.load().advoc_mel_pinv_f32(_lib.ptr(x2), _lib.ptr(wp), _lib.ptr(runs), _lib.ptr(inv_t), _lib.ptr(mel),
+                                      _lib.ptr(inv), x2.shape[0], bins, n_mels, int(wp.numel()), _lib.stream())
+  if rc == _lib.ERR_UNSUPPORTED:
+    mel = matmul_last(mag, meltrans_dev)
+    return mel, matmul_last(mel, invmeltrans_dev)
+  _lib.check(rc, 'advoc_mel_pinv_f32')
+  lead = tuple(mag.shape[:-1])
+  return mel.reshape(lead + (n_mels,)), inv.reshape(lead + (bins,))
+
+
+def pack_filterbank(meltrans_np, invmeltrans_np, device):
+  """(runs, packed weights, transposed pseudo-inverse) of advoc_mel_pinv_f32 as device tensors: every row of the
+  filterbank [n_mels, bins] as its run of non-zero weights, padded with zeros to a multiple of 4."""
+  w = np.asarray(meltrans_np, dtype=np.float32)
+  runs = band_runs(w)
+  parts = []
+  for m, (lo, hi) in enumerate(runs):
+    seg = w[m, lo:hi]
+    parts.append(np.concatenate([seg, np.zeros((-len(seg)) % 4, dtype=np.float32)]))
+  wp = np.concatenate(parts) if parts else np.zeros(0, dtype=np.float32)
+  inv_t = np.ascontiguousarray(np.asarray(invmeltrans_np, dtype=np.float32).T)
+  return (torch.from_numpy(runs).to(device), torch.from_numpy(wp).to(device), torch.from_numpy(inv_t).to(device))
+
+
+def band_runs(meltrans_np):
+  """[n_mels, 2] int32: first bin and one past the last bin with a non-zero weight in each filterbank row."""
+  out = np.zeros((meltrans_np.shape[0], 2), dtype=np.int32)
+  for m, row in enumerate(np.asarray(meltrans_np)):
+    nz = np.flatnonzero(row)
+    if len(nz):
+      out[m] = (nz[0], nz[-1] + 1)
+  return out
+
+
 def _device_melbank(fs, nfft, mel_min, mel_max, mel_num_bins):
   key = ('mel', fs, nfft, mel_min, mel_max, mel_num_bins)
   return _device_const(key, lambda: torch.from_numpy(create_mel_filterbank(

@@ -33,8 +33,11 @@ class SpectralUtil(object):
     dev = _lib.device()
     key = (name, dev.index)
     if key not in self._dev:
-      src = self.meltrans_np if name == 'mel' else self.invmeltrans_np
-      self._dev[key] = torch.from_numpy(src.astype(np.float32)).to(dev).contiguous()
+      if name == 'packed':
+        self._dev[key] = spectral.pack_filterbank(self.meltrans_np, self.invmeltrans_np, dev)
+      else:
+        src = self.meltrans_np if name == 'mel' else self.invmeltrans_np
+        self._dev[key] = torch.from_numpy(src.astype(np.float32)).to(dev).contiguous()
     return self._dev[key]
 
   @property
@@ -50,9 +53,9 @@ class SpectralUtil(object):
     advoc/loader.py:116-128): waveforms [b, n, 1, 1] in HBM -> (|STFT| [b, T, 513, 1], linear mel [b, T, n_mels, 1],
     pseudo-inverted magnitudes [b, T, 513, 1]), T = 1 + (n - nfft) // nhop frames (whole frames only)."""
     mag = spectral.stft_magnitude(wav, self.NFFT, self.NHOP, pad_end=False)
-    mel = spectral.matmul_last(mag[:, :, :, 0], self.meltrans).unsqueeze(-1)
-    inv = spectral.matmul_last(mel[:, :, :, 0], self.invmeltrans).unsqueeze(-1)
-    return mag, mel, inv
+    # both projections in one pass over the magnitudes (csrc/melpinv.hip)
+    mel, inv = spectral.mel_and_inverse(mag[:, :, :, 0], self.meltrans, self.invmeltrans, packed=self._const('packed'))
+    return mag, mel.unsqueeze(-1), inv.unsqueeze(-1)
 
   def mag_to_mel_linear_spec(self, mag_spec):
     """[B, T, 513, 1] -> [B, T, n_mels, 1]   (spectral_util.py:29-32)."""

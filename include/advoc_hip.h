@@ -139,6 +139,22 @@ int advoc_stft_c64(const float* wav, int64_t batch, int64_t nsamps, const float*
 int advoc_matmul_nt_f32(const float* x, const float* w, float* out, int64_t rows, int32_t k,
                         int32_t n, advoc_stream_t stream);
 
+/* mel[r, m] = sum_k mag[r, k] * W[m, k]  and  inv[r, k] = sum_m mel[r, m] * inv_wt[m, k]  in one pass over mag:
+ * the mag -> mel -> pseudo-inverted mag chain models/advoc/train_evaluate.py:55-56 builds for every training batch out
+ * of models/advoc/spectral_util.py:29-43 (two tf.tensordot / tf.matmul launches there, two advoc_matmul_nt_f32 here
+ * before).  The mel filterbank W [n_mels, bins] is triangular and is passed as its RUNS: band_lo_hi[m] = {first bin,
+ * one past the last bin} with a non-zero weight in row m, mel_wp = the runs' weights W[m, lo .. hi) back to back, every
+ * run padded with zeros to a multiple of 4 floats (zeros inside a run are multiplied, bins outside it skipped).
+ *   mag [rows, bins]  mel_wp [packed_weights]  band_lo_hi [n_mels, 2] int32  inv_wt [n_mels, bins] (the pseudo-inverse
+ *   [bins, n_mels] of spectral_util.py:26-27 TRANSPOSED: the kernel reads it along the bins)
+ *   mel_out [rows, n_mels]  inv_out [rows, bins]        float32, dense row-major, device memory
+ * packed_weights = floats in mel_wp (a multiple of 4).
+ * bins = 513, n_mels = 80 (the reference's extractor) and packed_weights <= 4096; anything else:
+ * ADVOC_ERR_UNSUPPORTED, use advoc_matmul_nt_f32 twice. */
+int advoc_mel_pinv_f32(const float* mag, const float* mel_wp, const int32_t* band_lo_hi, const float* inv_wt,
+                       float* mel_out, float* inv_out, int64_t rows, int32_t bins, int32_t n_mels,
+                       int32_t packed_weights, advoc_stream_t stream);
+
 /* y[i] = tanh(x[i]) * scale + shift (x == y allowed).  Replaces tf.nn.tanh + feats_denorm at the end of
  * the MelspecGAN generator, models/melspecgan/conv2d.py:139 and util.py:11-12 (scale = shift = 0.5). */
 int advoc_tanh_affine_f32(const float* x, float* y, int64_t n, float scale, float shift,

@@ -279,3 +279,35 @@ def test_stft_random_lengths_and_hops(S, case):
   gc = S.stft_tf(x, 1024, hop, pad_end=pad_end).cpu().numpy()
   wc = O.stft_tf(x, 1024, hop, pad_end=pad_end)
   assert gc.shape == wc.shape and (wc.size == 0 or rel_l2(gc, wc) < 1e-5)
+
+
+@gpu
+def test_fused_mel_and_pseudo_inverse_matches_the_two_projections(hip):
+  """advoc_mel_pinv_f32 (csrc/melpinv.hip): mag -> (mel, pinv(mel)) in one launch, against the float64 products of the
+  oracle's filterbanks and against the two advoc_matmul_nt_f32 launches it replaces; row counts that are not multiples
+  of the 32-frame tile; the training triple uses it."""
+  from advoc_amd import spectral
+  from advoc_amd.spectral_util import SpectralUtil
+  from oracle import spectral_np as S
+  su = SpectralUtil()
+  W = S.create_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80)
+  P = S.create_inverse_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80)
+  bands = spectral.band_runs(W.astype(np.float32))
+  assert (bands[:, 1] > bands[:, 0]).all() and bands[:, 1].max() <= 513
+  for rows in (1, 31, 32, 33, 1000):
+    g = torch.Generator().manual_seed(rows)
+    mag = (torch.rand(rows, 513, generator=g) * 30.0).cuda()
+    mel, inv = spectral.mel_and_inverse(mag, su.meltrans, su.invmeltrans, packed=su._const('packed') if rows != 31 else None)
+    mel64 = mag.double().cpu().numpy() @ W.T
+    inv64 = mel64 @ P.T
+    assert np.abs(mel.cpu().numpy() - mel64).max() < 1e-5 * np.abs(mel64).max()
+    assert np.abs(inv.cpu().numpy() - inv64).max() < 2e-5 * np.abs(inv64).max()
+    mel2 = spectral.matmul_last(mag, su.meltrans)
+    inv2 = spectral.matmul_last(mel2, su.invmeltrans)
+    assert float((mel - mel2).abs().max()) < 1e-5 * float(mel2.abs().max())
+    assert float((inv - inv2).abs().max()) < 2e-5 * float(inv2.abs().max())
+  wav = (torch.rand(3, 1024 + 256 * 9, 1, 1) - 0.5).cuda()
+  mag, mel, inv = su.extract_training_triple(wav)
+  assert mag.shape == (3, 10, 513, 1) and mel.shape == (3, 10, 80, 1) and inv.shape == (3, 10, 513, 1)
+  ref = su.mel_linear_to_mag_spec(su.mag_to_mel_linear_spec(mag))
+  assert float((inv - ref).abs().max()) < 2e-5 * float(ref.abs().max())
