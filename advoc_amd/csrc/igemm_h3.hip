@@ -477,8 +477,16 @@ Pick pick_tile(const GatherGemmParams& p) {
     // 256 x 256 on 8 waves (one workgroup per CU) streams half the bytes per flop of 128 x 128 and measured 1.2-1.35x
     // faster on every launch with >= 2 such tiles per CU (381 vs 284 TFLOP/s on D layer_4); below that the launch would
     // fall into split-K, whose atomic epilogue on 64 Ki outputs per workgroup costs more than the tile saves
+    // (re-measured without split-K, tools/micro/deep_sweep.py: from ONE such tile per CU on it is already 1.2 x the
+    // 128 x 128 tile -- 422 vs 522 us on encoder_4 forward, 424 vs 526 on decoder_5 forward)
     const int64_t t256 = ceil_div((int64_t)p.batch * p.gh * p.gw, 256) * (N / 256) * p.nphase;
-    if (t256 >= 512) k = {2, 4, 2, 4};
+    if (t256 >= device_cu_count()) k = {2, 4, 2, 4};
+  }
+  if (t.h3_tile == 0 && k.wgm == 2 && k.nt == 2) {
+    // under one round of 128 x 128 tiles (two per CU) the 128 x 64 tile (three per CU) fills the chip better:
+    // 1.04-1.2 x on the deep layers (encoder_5 / decoder_6 forward, encoder_6 / decoder_6 backward-data)
+    const int64_t t128 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * (N / 128) * p.nphase;
+    if (t128 < 2 * device_cu_count()) k = {2, 1, 2, 2};
   }
   if (t.h3_stages == 2 || t.h3_stages == 3) k.ns = t.h3_stages;
   if (k.ns == 3 && k.mt * k.nt > 4) k.ns = 2;       // 3 x 48 KiB + would not leave room: 128x256 runs two stages
@@ -532,9 +540,12 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   const int nkt = ktot / 32 * p.ntaps;
   // Small pixel grids with deep contractions (encoder_5.., decoder_5.. and their gradients) would leave CUs idle:
   // split K until the launch holds ~4 workgroups per CU, keeping >= 8 K tiles per slice (igemm.hip does the same)
+  // (measured, tools/micro/deep_sweep.py / profiles/r02_deep_sweep.txt: with these kernels the atomic epilogue + the
+  // zero-fill cost more than idle CUs down to a quarter of the chip -- encoder_6 backward-data 278 -> 116 us, decoder_6
+  // forward 365 -> 213 us, encoder_5 forward 487 -> 393 us without the split; and never on 64 Ki-output tiles)
   int ksplit = 1;
-  if (!patch_nph && tiles < 512 && tuning().igemm_splitk) {
-    ksplit = (int)ceil_div((int64_t)1024, tiles);
+  if (!patch_nph && tiles < device_cu_count() / 2 && k.wgm == 2 && tuning().igemm_splitk) {
+    ksplit = (int)ceil_div((int64_t)device_cu_count(), tiles);
     if (ksplit > nkt / 8) ksplit = nkt / 8;
     if (ksplit > 16) ksplit = 16;
     if (ksplit < 1) ksplit = 1;

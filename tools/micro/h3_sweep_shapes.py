@@ -22,6 +22,12 @@ SHAPES = {
     'd2m':   (0, 128, 128, 256, 64, 0, 128, (2, 2), 0, 1),
     'd3m':   (0, 128, 64, 128, 128, 0, 256, (2, 2), 0, 1),
     'd4b':   (0, 64, 32, 64, 256, 0, 512, (1, 1), 0, 1),        # layer_4 on the B-clip pass of the G step
+    # the deep layers (few grid points, 16-33 MB of weights): split-K launches
+    'enc5m': (0, 64, 16, 33, 512, 0, 512, (2, 2), 0, 1),
+    'enc6m': (0, 64, 8, 17, 512, 0, 512, (2, 2), 0, 1),
+    'dec5m': (1, 64, 8, 17, 512, 512, 512, (2, 2), 1, 2),
+    'dec6m': (1, 64, 4, 9, 512, 512, 512, (2, 2), 1, 2),
+    'enc4o': (0, 64, 32, 65, 256, 0, 512, (2, 2), 0, 1),        # encoder_4 at the model's odd width
 }
 
 
