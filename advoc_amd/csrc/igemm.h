@@ -113,15 +113,21 @@ int launch_gather_gemm_h3(const GatherGemmParams& p, bool b_kn, hipStream_t stre
                            float* scratch, int64_t scratch_bytes, int64_t* scratch_query);
 
 // Patch variant for stride-1 gathers (igemm_patch.hip): a workgroup owns a 16 x 16 patch of grid points of one image
-// and loads its input halo once per K slice.  patch_plan: 0 = not a patch launch, else the number of phases a
-// workgroup fuses (4: sub-pixel phases of 2x2 taps, 1: a 4x4 stride-1 gather) with the geometry filled in.  The
-// launcher expects the operand images / headers of launch_gather_gemm_h3 in `p`.
+// and loads its input halo once per K slice.  patch_plan: 0 = not a patch launch, else the kernel form (4: four fused
+// sub-pixel phases of 2x2 taps, 1: a 4x4 stride-1 gather, 2 | 3: a 4x4 stride-2 gather as four parity planes with 256 |
+// 128 columns per workgroup) with the geometry filled in.  The launcher expects the operand images / headers of
+// launch_gather_gemm_h3 in `p`.
 struct PatchGeom {
   int dy0, dx0;      // smallest tap offsets: halo pixel (0, 0) is input (gy0 + dy0, gx0 + dx0)
   int hh, hw;        // halo rows / columns
   int py, px;        // patches per image along y / x
   int nblocks;       // 8-pixel DMA blocks of the halo
   int ablate;        // timing experiments only (ADVOC_H3_PATCH_ABLATE bits: 1 no DMA, 2 no MFMA, 4 no barrier); 0 in use
+  // stride-2 gathers as four parity planes of the input (nph 2 | 3): plane (py, px) holds input pixels (2 y + py, 2 x + px);
+  // s2_a0y[py] / s2_a0x[px] = smallest plane-row / plane-column offset of the plane's taps (its halo origin),
+  // s2_tap[4 (2 py + px) + t] = (row offset - s2_a0y) | (column offset - s2_a0x) << 8 | weight tap << 16
+  int s2_a0y[2], s2_a0x[2];
+  int s2_tap[16];
 };
 int patch_plan(const GatherGemmParams& p, PatchGeom* g);
 int launch_patch_gemm_h3(const GatherGemmParams& p, const PatchGeom& g, int nph, hipStream_t stream,

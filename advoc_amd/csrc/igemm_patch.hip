@@ -42,32 +42,42 @@ __device__ __forceinline__ float act_slope_p(int act) {
   return act == ADVOC_ACT_LRELU02 ? 0.2f : (act == ADVOC_ACT_RELU ? 0.f : 1.f);
 }
 
-// W = 4 wavefronts: ONE per SIMD, 512 registers each (256 of them accumulators), fragments double-buffered in registers
-// and prefetched across the barrier.  W = 8: two per SIMD, 256 registers each, half the accumulator rows per wave.
+// NPH selects the gather a workgroup fuses:
+//   4  four sub-pixel phases of 2x2 taps (transposed-conv forward, conv backward-data): 256 points x 4 phases x 64 columns
+//   1  one 4x4 stride-1 gather (layer_4 both directions): 256 points x 256 columns
+//   2  one 4x4 STRIDE-2 gather (conv forward, transposed-conv backward-data) as four PARITY PLANES of the input, each a
+//      2x2-tap stride-1 gather over the output grid: the K loop walks (channel slice, plane), the halo of a slice is the
+//      17 x 17 pixels of ONE plane -- every other pixel of the ordinary image, de-interleaved by the DMA's source
+//      addresses, so the planes exist in LDS only: 256 points x 256 columns
+//   3  as 2 with 128 columns (the 128-channel layers): 8 waves = 4 point quarters x 2 column halves
+// (W = 4 wavefronts, one per SIMD with 512 registers and register-carried fragments, was built and measured 0.85-1.0 x
+// the 8-wave form: the code paths are kept behind CARRY / DOUBLE_B, only W = 8 is instantiated.)
 template <int NPH, int W>
 struct PCfg {
+  static constexpr bool S2 = NPH == 2 || NPH == 3;
   static constexpr int WAVES = W, THREADS = 64 * W;
-  static constexpr int NST = NPH == 4 ? 4 : 16;            // tap steps per K slice
-  static constexpr int BN = NPH == 4 ? 64 : 256;           // output channels per workgroup
-  static constexpr int MT = (NPH == 4 && W == 4) ? 8 : 4;  // 32-point blocks per wave
+  static constexpr int NST = NPH == 1 ? 16 : 4;            // tap steps per K slice
+  static constexpr int BN = NPH == 4 ? 64 : (NPH == 3 ? 128 : 256);   // output channels per workgroup
+  static constexpr int BROWS = NPH == 3 ? 128 : 256;       // rows of a B stage (NPH = 4: four phases x 64 columns)
+  static constexpr int MT = NPH == 3 ? 2 : ((NPH == 4 && W == 4) ? 8 : 4);   // 32-point blocks per wave
   static constexpr int NT = (NPH == 1 && W == 4) ? 4 : 2;  // 32-column blocks per wave
   static constexpr bool CARRY = W == 4;                    // next step's first A fragments fetched before the barrier
   static constexpr bool DOUBLE_B = W == 4;                 // B fragments of both k steps in registers at once (W = 8: the
                                                            // second set costs the 16 registers that tip the loop into scratch)
-  static constexpr int HW = NPH == 4 ? 18 : 19;            // halo width = height (patch_plan takes only gathers of this extent)
-  static constexpr int HP = NPH == 4 ? 18 : 20;            // halo row pitch in LDS, EVEN: address bit 7 (the half of the
+  static constexpr int HW = NPH == 4 ? 18 : (NPH == 1 ? 19 : 17);   // halo width = height (patch_plan takes only these)
+  static constexpr int HP = NPH == 1 ? 20 : 18;            // halo row pitch in LDS, EVEN: address bit 7 (the half of the
                                                            // 256-byte bank row) must follow the column's parity
-  static constexpr int HALO_BLOCKS = (HW * HP + 7) / 8;    // 8-pixel DMA blocks: 41 | 48
-  static constexpr int HPS = NPH == 4 ? (W == 4 ? 3 : 2) : 1;   // halo DMA slots per wave and step
-  static constexpr int BPW = 32 / W;                       // B DMA blocks (8 rows) per wave and step
+  static constexpr int HALO_BLOCKS = (HW * HP + 7) / 8;    // 8-pixel DMA blocks: 41 | 48 | 39
+  static constexpr int HPS = NPH == 1 ? 1 : (W == 4 ? 3 : 2);   // halo DMA slots per wave and step
+  static constexpr int BPW = BROWS / 8 / W;                // B DMA blocks (8 rows) per wave and step
   // where in a step the DMAs of the next one are issued: 1 after the step's fragment reads, 2 after its first MFMA group
   // (measured with a run-time switch: +4-5 % on the four-phase kernel, neutral on the 4x4 one; at the top of the step, 0,
   // the DMA's LDS writes collide with the fragment reads that follow the barrier)
-  static constexpr int DMA_POS = NPH == 4 ? 2 : 1;
+  static constexpr int DMA_POS = NPH == 1 ? 1 : 2;
   static constexpr int HALO_BYTES = HALO_BLOCKS * 1024;
-  static constexpr int B_STAGE = 256 * 128;
+  static constexpr int B_STAGE = BROWS * 128;
   static constexpr int OFF_B = 2 * HALO_BYTES;
-  static constexpr int LDS_BYTES = OFF_B + 2 * B_STAGE;     // 146 KiB | 160 KiB
+  static constexpr int LDS_BYTES = OFF_B + 2 * B_STAGE;     // 146 | 160 | 142 | 110 KiB
   static constexpr int PTS_W = 32 * MT;                    // grid points per wave
   static constexpr int EPI_BYTES = WAVES * (32 * 36 * 4 + 2 * PTS_W * 4);
   static_assert(WAVES * NST * HPS >= HALO_BLOCKS, "every halo block has a DMA slot");
@@ -87,18 +97,19 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // wave -> (part wm of the patch's points, phase, first of its columns):
-  //   NPH = 4: W = 4: (all 256 points, phase = wave);  W = 8: (half wave / 4, phase = wave % 4);  64 columns either way
-  //   NPH = 1: W = 4: (half wave / 2, column half wave % 2);  W = 8: (half wave / 4, column quarter wave % 4)
-  const int wm = W == 8 ? wave >> 2 : (NPH == 4 ? 0 : wave >> 1);
+  // wave -> (part wm of the patch's points, phase, first of its columns), W = 8:
+  //   NPH = 4: (half wave / 4, phase = wave % 4), 64 columns;  NPH = 1, 2: (half wave / 4, column quarter wave % 4);
+  //   NPH = 3: (quarter wave / 2, column half wave % 2)
+  constexpr bool S2 = C::S2;
+  const int wm = NPH == 3 ? wave >> 1 : (W == 8 ? wave >> 2 : (NPH == 4 ? 0 : wave >> 1));
   const int phase = NPH == 4 ? (wave & 3) : 0;
-  const int ncol0 = NPH == 4 ? 0 : (W == 8 ? (wave & 3) * 64 : (wave & 1) * 128);
+  const int ncol0 = NPH == 4 ? 0 : (NPH == 3 ? (wave & 1) * 64 : (W == 8 ? (wave & 3) * 64 : (wave & 1) * 128));
   const int brow0 = NPH == 4 ? phase * 64 : ncol0;         // first B-stage row of the wave's columns
   const int b_phase = NPH == 4 ? wave * (256 / W) / 64 : 0;   // phase of the B rows this wave LOADS
   const int ppi = g.py * g.px;                       // patches per image
   const int npatch = p.batch * ppi;
   const int ktot = p.c0 + p.c1;
-  const int nslices = ktot / 32;
+  const int nslices = (S2 ? 4 : 1) * (ktot / 32);      // S2: K slice s = (channel slice s / 4, parity plane s % 4)
   constexpr int hw = C::HP;                          // halo row pitch: compile-time, so that block i of a fragment read is an
   constexpr int hpix = C::HW * C::HP;                // immediate offset
 
@@ -114,7 +125,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const int half = lane >> 5, l32 = lane & 31;
   // halo pixel of this lane's row in the wave's first 32-point block (2 patch rows x 16 columns) for tap (0, 0); block
   // i is 2 i halo rows further
-  const int h_base = (wm * 8 + (l32 >> 4)) * hw + (l32 & 15);
+  const int h_base = (wm * (C::PTS_W / 16) + (l32 >> 4)) * hw + (l32 & 15);
   // fragment chunk (plane, k step, half) = 4 plane + 2 ks + half sits at position chunk ^ swizzle = (half ^ swizzle) ^
   // (4 plane + 2 ks): one byte offset per row, the (plane, ks) part is an XOR with a constant
   const int bfrag = (brow0 + l32) * 128 + ((half ^ ((l32 >> 1) & 7)) * 16);
@@ -122,8 +133,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // the tap tables of the wave's compute phase and of the phase whose B rows it loads, one tap per lane: read back with
   // v_readlane inside the K loop (an s_load there would put an lgkmcnt(0) wait -- SMEM returns out of order -- in front
   // of every step's LDS reads)
-  const int tapv_c = p.tap[phase][lane & (kMaxTaps - 1)];
-  const int tapv_b = p.tap[b_phase][lane & (kMaxTaps - 1)];
+  // (S2: one table for all waves, entry 4 plane + t, offsets already relative to the plane's halo origin)
+  const int tapv_c = S2 ? g.s2_tap[lane & (kMaxTaps - 1)] : p.tap[phase][lane & (kMaxTaps - 1)];
+  const int tapv_b = S2 ? tapv_c : p.tap[b_phase][lane & (kMaxTaps - 1)];
   const int src_c0 = p.c0, src_c1 = p.c1, src_p0 = p.a0_pitch, src_p1 = p.a1_pitch;
   const int abl = g.ablate;       // timing experiments only (ADVOC_H3_PATCH_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier
 
@@ -151,7 +163,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // offset); the swizzle of row q, (q >> 1) & 7, is lrow >> 1 for even k and that ^ 4 for odd k ----
   int b_off[2];
   {
-    const int q = wave * (256 / W) + lrow;
+    const int q = wave * (C::BROWS / W) + lrow;
     const int col = NPH == 4 ? (q & 63) : q;
     const int rowb = ((n0 + col) * ktot) * 4;
     b_off[0] = rowb + ((lpos ^ (lrow >> 1)) * 16);
@@ -162,7 +174,8 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // halo buffer HB.  Slots beyond the halo issue nothing (every wait in the K loop is vmcnt(0): no counting to keep).
 #define ADVOC_P3_HALO(SL, T, HB)                                                                          \
   {                                                                                                       \
-    const int k0_ = (SL) * 32;                                                                            \
+    const int k0_ = (S2 ? (SL) >> 2 : (SL)) * 32;                                                         \
+    const int ppy_ = ((SL) >> 1) & 1, ppx_ = (SL) & 1;        /* S2: parity plane of the slice */           \
     const bool second_ = k0_ >= p.c0;                                                                     \
     const int c_ = second_ ? src_c1 : src_c0, pitch_ = second_ ? src_p1 : src_p0;                         \
     const int kk_ = second_ ? k0_ - p.c0 : k0_;                                                           \
@@ -173,7 +186,8 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       const int h_ = blk_ * 8 + lr_;                                                                      \
       const int hy_ = (h_ * hmagic) >> 16;                                                                \
       const int hx_ = h_ - hy_ * hw;                                                                      \
-      const int iy_ = gy0 + hy_ + g.dy0, ix_ = gx0 + hx_ + g.dx0;                                         \
+      const int iy_ = S2 ? 2 * (gy0 + hy_ + g.s2_a0y[ppy_]) + ppy_ : gy0 + hy_ + g.dy0;                    \
+      const int ix_ = S2 ? 2 * (gx0 + hx_ + g.s2_a0x[ppx_]) + ppx_ : gx0 + hx_ + g.dx0;                    \
       const bool ok_ = h_ < hpix && hx_ < C::HW && (unsigned)iy_ < (unsigned)p.in_h &&                    \
                        (unsigned)ix_ < (unsigned)p.in_w;                                                  \
       const int voff_ = ok_ ? (((img * p.a_h + iy_) * pitch_ + ix_) * c_ + kk_) * 4 +                     \
@@ -189,8 +203,8 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // The B tile of (slice SL, tap step T) into stage ST
 #define ADVOC_P3_B(SL, T, ST)                                                                             \
   {                                                                                                       \
-    const int wtap_ = __builtin_amdgcn_readlane(tapv_b, (T)) >> 16;                                       \
-    const int wslab_ = (wtap_ * p.n_total * ktot + (SL) * 32) * 4;                                        \
+    const int wtap_ = __builtin_amdgcn_readlane(tapv_b, S2 ? ((SL) & 3) * 4 + (T) : (T)) >> 16;           \
+    const int wslab_ = (wtap_ * p.n_total * ktot + (S2 ? (SL) >> 2 : (SL)) * 32) * 4;                     \
     _Pragma("unroll") for (int k = 0; k < C::BPW; ++k) {                                                  \
       unsigned char* d_ = smem_b + C::OFF_B + (ST) * C::B_STAGE + (wave * C::BPW + k) * 1024;             \
       if (!(abl & 1))                                                                                     \
@@ -202,9 +216,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // A fragments of tap step T, k step KS, from halo buffer HB into REG[MT][2]
 #define ADVOC_P3_LOAD_A(REG, HB, T, KS)                                                                   \
   {                                                                                                       \
-    const int tp_ = __builtin_amdgcn_readlane(tapv_c, (T));                                               \
-    const int dxo_ = (int)(int8_t)((tp_ >> 8) & 0xff) - g.dx0;                                            \
-    const int toff_ = ((int)(int8_t)(tp_ & 0xff) - g.dy0) * hw + dxo_;                                    \
+    const int tp_ = __builtin_amdgcn_readlane(tapv_c, S2 ? (s & 3) * 4 + (T) : (T));                      \
+    const int dxo_ = S2 ? (tp_ >> 8) & 0xff : (int)(int8_t)((tp_ >> 8) & 0xff) - g.dx0;                   \
+    const int toff_ = (S2 ? tp_ & 0xff : (int)(int8_t)(tp_ & 0xff) - g.dy0) * hw + dxo_;                  \
     const unsigned char* Hx = smem_b + (HB) * C::HALO_BYTES;                                              \
     const int sl_ = ((half ^ ((((l32 & 15) + dxo_) >> 1) & 7)) ^ (2 * (KS))) * 16;                        \
     const int ad_ = (h_base + toff_) * 128 + sl_;                                                         \
@@ -482,29 +496,56 @@ int launch_patch(const GatherGemmParams& p, const PatchGeom& g, hipStream_t stre
 int patch_plan(const GatherGemmParams& p, PatchGeom* g) {
   const Tuning& t = tuning();
   if (!t.h3_patch) return 0;
-  if (p.sy != 1 || p.sx != 1) return 0;
   int nph = 0;
-  if (p.nphase == 4 && p.ntaps == 4 && p.osy == 2 && p.osx == 2 && p.n_total % 64 == 0) nph = 4;
-  else if (p.nphase == 1 && p.ntaps == 16 && p.osy == 1 && p.osx == 1 && p.n_total % 256 == 0) nph = 1;
+  if (p.sy == 1 && p.sx == 1 && p.nphase == 4 && p.ntaps == 4 && p.osy == 2 && p.osx == 2 && p.n_total % 64 == 0) nph = 4;
+  else if (p.sy == 1 && p.sx == 1 && p.nphase == 1 && p.ntaps == 16 && p.osy == 1 && p.osx == 1 && p.n_total % 256 == 0)
+    nph = 1;
+  else if (t.h3_patch_s2 && p.sy == 2 && p.sx == 2 && p.nphase == 1 && p.ntaps == 16 && p.osy == 1 && p.osx == 1 &&
+           p.n_total % 128 == 0)
+    nph = p.n_total % 256 == 0 ? 2 : 3;
   if (!nph) return 0;
-  int dy0 = 127, dy1 = -127, dx0 = 127, dx1 = -127;
-  for (int ph = 0; ph < p.nphase; ++ph)
-    for (int i = 0; i < p.ntaps; ++i) {
-      const int dy = (int)(int8_t)(p.tap[ph][i] & 0xff), dx = (int)(int8_t)((p.tap[ph][i] >> 8) & 0xff);
-      dy0 = dy < dy0 ? dy : dy0; dy1 = dy > dy1 ? dy : dy1;
-      dx0 = dx < dx0 ? dx : dx0; dx1 = dx > dx1 ? dx : dx1;
-    }
-  const int e = nph == 4 ? 2 : 3;                 // the kernels are compiled for halos of exactly (16 + e) x (16 + e)
-  if (dy1 - dy0 != e || dx1 - dx0 != e) return 0;
   if (p.gh < 16 || p.gw < 16) return 0;
-  g->dy0 = dy0; g->dx0 = dx0;
-  g->hh = 16 + e; g->hw = 16 + e;
+  *g = PatchGeom{};
+  if (nph >= 2 && nph <= 3) {
+    // every tap (dy, dx) reads input (2 gy + dy, 2 gx + dx) = pixel (gy + a, gx + b) of plane (py, px), dy = 2 a + py
+    int cnt[4] = {0, 0, 0, 0};
+    int ay[16], ax[16];
+    g->s2_a0y[0] = g->s2_a0y[1] = g->s2_a0x[0] = g->s2_a0x[1] = 127;
+    for (int i = 0; i < 16; ++i) {
+      const int dy = (int)(int8_t)(p.tap[0][i] & 0xff), dx = (int)(int8_t)((p.tap[0][i] >> 8) & 0xff);
+      const int py = dy & 1, px = dx & 1;                  // (two's complement: -1 & 1 == 1)
+      ay[i] = (dy - py) / 2; ax[i] = (dx - px) / 2;
+      g->s2_a0y[py] = ay[i] < g->s2_a0y[py] ? ay[i] : g->s2_a0y[py];
+      g->s2_a0x[px] = ax[i] < g->s2_a0x[px] ? ax[i] : g->s2_a0x[px];
+    }
+    for (int i = 0; i < 16; ++i) {
+      const int dy = (int)(int8_t)(p.tap[0][i] & 0xff), dx = (int)(int8_t)((p.tap[0][i] >> 8) & 0xff);
+      const int py = dy & 1, px = dx & 1, pl = 2 * py + px;
+      const int ry = ay[i] - g->s2_a0y[py], rx = ax[i] - g->s2_a0x[px];
+      if (cnt[pl] >= 4 || ry < 0 || ry > 1 || rx < 0 || rx > 1) return 0;     // 2x2 taps per plane: 17 x 17 halos
+      g->s2_tap[4 * pl + cnt[pl]++] = ry | (rx << 8) | ((p.tap[0][i] >> 16) << 16);
+    }
+    if (cnt[0] != 4 || cnt[1] != 4 || cnt[2] != 4 || cnt[3] != 4) return 0;
+    g->hh = g->hw = 17;
+  } else {
+    int dy0 = 127, dy1 = -127, dx0 = 127, dx1 = -127;
+    for (int ph = 0; ph < p.nphase; ++ph)
+      for (int i = 0; i < p.ntaps; ++i) {
+        const int dy = (int)(int8_t)(p.tap[ph][i] & 0xff), dx = (int)(int8_t)((p.tap[ph][i] >> 8) & 0xff);
+        dy0 = dy < dy0 ? dy : dy0; dy1 = dy > dy1 ? dy : dy1;
+        dx0 = dx < dx0 ? dx : dx0; dx1 = dx > dx1 ? dx : dx1;
+      }
+    const int e = nph == 4 ? 2 : 3;                 // the kernels are compiled for halos of exactly (16 + e) x (16 + e)
+    if (dy1 - dy0 != e || dx1 - dx0 != e) return 0;
+    g->dy0 = dy0; g->dx0 = dx0;
+    g->hh = 16 + e; g->hw = 16 + e;
+  }
   g->py = (p.gh + 15) / 16; g->px = (p.gw + 15) / 16;
   g->nblocks = (g->hh * g->hw + 7) / 8;
   g->ablate = t.h3_patch_ablate;
   // rows the patches add beyond the grid are computed and thrown away
   if ((int64_t)g->py * g->px * 256 * 100 > (int64_t)p.gh * p.gw * 125) return 0;
-  const int bn = nph == 4 ? 64 : 256;
+  const int bn = nph == 4 ? 64 : (nph == 3 ? 128 : 256);
   const int64_t wgs = (int64_t)p.batch * g->py * g->px * (p.n_total / bn);
   if (wgs < t.h3_patch_min_wgs) return 0;
   return nph;
@@ -515,6 +556,8 @@ int launch_patch_gemm_h3(const GatherGemmParams& p, const PatchGeom& g, int nph,
   // the backward-data description is the one with an activation gradient or a second / accumulating destination
   const bool bwd = p.grad_act != ADVOC_ACT_NONE || p.d[0].xpre || p.d[1].p || p.d[0].accum;
   if (nph == 4) return bwd ? launch_patch<4, 1>(p, g, stream, name_only) : launch_patch<4, 0>(p, g, stream, name_only);
+  if (nph == 2) return bwd ? launch_patch<2, 1>(p, g, stream, name_only) : launch_patch<2, 0>(p, g, stream, name_only);
+  if (nph == 3) return bwd ? launch_patch<3, 1>(p, g, stream, name_only) : launch_patch<3, 0>(p, g, stream, name_only);
   return bwd ? launch_patch<1, 1>(p, g, stream, name_only) : launch_patch<1, 0>(p, g, stream, name_only);
 }
 

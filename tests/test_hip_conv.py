@@ -268,6 +268,16 @@ PATCH = [
     (('p3_d4',        0, (2, 32, 31), 256, 0, 256, 0, (1, 1), (1, 1), 1, False, 0),
      {0: 'patch_gemm_h3_kernel<1, 0>', 1: 'patch_gemm_h3_kernel<1, 1>'}),
     (('p3_d4_wide',   0, (1, 29, 33), 64, 0, 512, 0, (1, 1), (1, 1), 1, True, 0), {0: 'patch_gemm_h3_kernel<1, 0>'}),
+    # stride-2 gathers as four parity planes of the input (<2, .>: 256 columns per workgroup, <3, .>: 128): conv forward on
+    # even and odd input sizes (SAME padding), transposed-conv backward-data into two destinations
+    (('p3_s2_enc',    0, (2, 62, 60), 64, 0, 256, 0, (2, 2), None, 1, False, 0),
+     {0: 'patch_gemm_h3_kernel<2, 0>', 1: 'patch_gemm_h3_kernel<4, 1>'}),
+    (('p3_s2_enc_odd', 0, (2, 61, 59), 32, 0, 128, 0, (2, 2), None, 1, True, 0), {0: 'patch_gemm_h3_kernel<3, 0>'}),
+    (('p3_s2_enc_pad', 0, (1, 62, 64), 96, 0, 384, 0, (2, 2), (1, 1), 0, False, 0), {0: 'patch_gemm_h3_kernel<3, 0>'}),
+    (('p3_s2_dec_bwd', 1, (2, 31, 30), 128, 128, 64, 1, (2, 2), (1, 1), 2, True, 0),
+     {0: 'patch_gemm_h3_kernel<4, 0>', 1: 'patch_gemm_h3_kernel<2, 1>'}),
+    (('p3_s2_dec_bwd128', 1, (3, 30, 31), 128, 0, 64, 0, (2, 2), (1, 1), 2, False, 1),
+     {0: 'patch_gemm_h3_kernel<4, 0>', 1: 'patch_gemm_h3_kernel<3, 1>'}),
 ]
 
 

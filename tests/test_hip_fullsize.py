@@ -100,12 +100,13 @@ def test_three_directions_are_one_trilinear_form(hip, model, case):
   L, x0, x1, w, b, y, dy, W = build(case, act=0)
   if model == 'full64' and case[0] in ('encoder_2', 'encoder_3', 'encoder_4', 'decoder_5', 'decoder_4', 'decoder_3',
                                        'layer_2', 'layer_3', 'layer_4'):
-    # the launches that dominate the configs[2] step run on the operand-image kernels: the per-tap tiles of
-    # igemm_h3.hip for the stride-2 gathers, the patch kernels of igemm_patch.hip for the stride-1 ones (transposed-conv
-    # forward / conv backward-data on grids of at least 16 x 16 points, layer_4 in both directions)
-    # (decoder_4 / encoder_4 gather over 16 x 33 points: 16 x 16 patches would compute 1.45 x the grid)
-    patch_fwd = case[0] in ('decoder_3', 'layer_4')
-    patch_bwd = case[0] in ('encoder_2', 'encoder_3', 'layer_2', 'layer_3', 'layer_4')
+    # the launches that dominate the configs[2] step run on the operand-image kernels: the patch kernels of
+    # igemm_patch.hip wherever the grid has at least 16 x 16 points that 16 x 16 patches cover with < 25 % waste (four
+    # fused sub-pixel phases, the 4x4 stride-1 conv, the stride-2 gathers as parity planes), the per-tap tiles of
+    # igemm_h3.hip for the rest (decoder_4 / encoder_4 gather over 16 x 33 points: patches would compute 1.45 x the
+    # grid; decoder_5 / encoder_5 over 8 x 17)
+    patch_fwd = case[0] in ('encoder_2', 'encoder_3', 'decoder_3', 'layer_2', 'layer_3', 'layer_4')
+    patch_bwd = case[0] in ('encoder_2', 'encoder_3', 'decoder_3', 'layer_2', 'layer_3', 'layer_4')
     for d, patch in ((0, patch_fwd), (1, patch_bwd)):
       want = 'patch_gemm_h3_kernel' if patch else 'gather_gemm_h3_kernel'
       assert want in L.kernel_name(d), (d, L.kernel_name(d))

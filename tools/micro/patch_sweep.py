@@ -8,13 +8,14 @@ import torch
 from h3_sweep_shapes import build, setenv, timed_us
 
 DEFAULT = ['dec2m:f', 'dec3m:f', 'dec4m:f', 'enc2m:d', 'enc3m:d', 'enc4m:d', 'd2m:d', 'd3m:d', 'd4:fd', 'd4b:fd']
+S2 = ['enc2m:f', 'enc3m:f', 'd2m:f', 'd3m:f', 'dec2m:d', 'dec3m:d', 'enc4m:f', 'dec4m:d']     # stride-2 gathers (parity planes)
 
 
 def rel(a, b):
   return float((a.double() - b.double()).norm() / b.double().norm())
 
 
-for spec in (sys.argv[1:] or DEFAULT):
+for spec in (S2 if sys.argv[1:] == ['s2'] else (sys.argv[1:] or DEFAULT)):
   name, _, dirs = spec.partition(':')
   dirs = dirs or 'fd'
   L, dy, dx0, dx1 = build(name)
