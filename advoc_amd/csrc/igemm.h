@@ -47,6 +47,7 @@ struct GatherGemmParams {
   float a_mask_scale;
   // ---- grid / taps ----
   int batch, gh, gw;
+  int gx_off;              // the launch covers grid columns [gx_off, gx_off + gw) (igemm_h3.hip only; 0 elsewhere)
   int sy, sx;
   int nphase, ntaps;
   int tap[kMaxPhases][kMaxTaps];  // (dy & 0xff) | (dx & 0xff) << 8 | wtap << 16
@@ -121,6 +122,7 @@ struct PatchGeom {
   int dy0, dx0;      // smallest tap offsets: halo pixel (0, 0) is input (gy0 + dy0, gx0 + dx0)
   int hh, hw;        // halo rows / columns
   int py, px;        // patches per image along y / x
+  int rem;           // > 0: the patches cover grid columns [0, 16 px) only, the last `rem` (<= 4) columns go to a per-tap launch
   int nblocks;       // 8-pixel DMA blocks of the halo
   int ablate;        // timing experiments only (ADVOC_H3_PATCH_ABLATE bits: 1 no DMA, 2 no MFMA, 4 no barrier); 0 in use
   // stride-2 gathers as four parity planes of the input (nph 2 | 3): plane (py, px) holds input pixels (2 y + py, 2 x + px);

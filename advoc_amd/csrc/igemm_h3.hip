@@ -129,7 +129,7 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
     const int gx = (int)(mm - t * (unsigned)p.gw);
     const int img = (int)(t / (unsigned)p.gh);
     const int gy = (int)(t - (unsigned)img * (unsigned)p.gh);
-    a_x[g] = gx * p.sx;
+    a_x[g] = (gx + p.gx_off) * p.sx;
     a_y[g] = gy * p.sy;
     const int gc = lpos ^ ((r >> 1) & 7);
     a_b0[g] = (((img * p.a_h + a_y[g]) * p.a0_pitch + a_x[g]) * p.c0) * 4 + gc * 16;     // bytes into the image
@@ -314,7 +314,7 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
       const int gx = (int)(m - t * (unsigned)p.gw);
       const int img = (int)(t / (unsigned)p.gh);
       const int gy = (int)(t - (unsigned)img * (unsigned)p.gh);
-      const int oy = gy * p.osy + p.ooy[phase], ox = gx * p.osx + p.oox[phase];
+      const int oy = gy * p.osy + p.ooy[phase], ox = (gx + p.gx_off) * p.osx + p.oox[phase];
       if (oy < p.out_h && ox < p.out_w) {
         pix0 = (img * p.out_h + oy) * p.d[0].pitch + ox;
         pix1 = (img * p.out_h + oy) * p.d[1].pitch + ox;
@@ -446,8 +446,13 @@ int launch_h(const GatherGemmParams& p, hipStream_t stream, const char** name_on
     for (int i = 0; i < 2; ++i) {
       const GemmDest& d = p.d[i];
       if (d.p == nullptr || d.accum) continue;
-      hipError_t e = hipMemset2DAsync(d.p, sizeof(float) * (size_t)d.pitch * d.c, 0,
-                                      sizeof(float) * (size_t)p.out_w * d.c, (size_t)p.batch * p.out_h, stream);
+      // (a launch over grid columns [gx_off, gx_off + gw) only owns the output columns those map to)
+      const int col0 = p.gx_off * p.osx;
+      int cols = p.out_w - col0;
+      if (p.gx_off && cols > p.gw * p.osx) cols = p.gw * p.osx;
+      if (cols <= 0) continue;
+      hipError_t e = hipMemset2DAsync(d.p + (size_t)col0 * d.c, sizeof(float) * (size_t)d.pitch * d.c, 0,
+                                      sizeof(float) * (size_t)cols * d.c, (size_t)p.batch * p.out_h, stream);
       if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
     }
   } else if (tail.split > 1 && tail_ws && tail_cnt) {
@@ -592,7 +597,25 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     }
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
   }
-  if (patch_nph) return launch_patch_gemm_h3(p, geom, patch_nph, stream, name_only);
+  if (patch_nph) {
+    if (geom.rem == 0) return launch_patch_gemm_h3(p, geom, patch_nph, stream, name_only);
+    // grid width = 16 px + a few columns (the model's 33 / 65 / 129 / 257-wide grids): the patches take the multiple of
+    // 16, a per-tap launch the remaining columns -- a whole patch column for 1 of 16 columns costs 1.1-1.5 x the work
+    GatherGemmParams pm = p;
+    pm.gw = geom.px * 16;
+    const int rc = launch_patch_gemm_h3(pm, geom, patch_nph, stream, name_only);
+    if (rc != ADVOC_OK || name_only) return rc;
+    GatherGemmParams pr = p;
+    pr.gw = geom.rem;
+    pr.gx_off = geom.px * 16;
+    // few rows, the whole contraction: split K over workgroups until the chip is covered twice
+    const int64_t rtiles = ceil_div((int64_t)pr.batch * pr.gh * pr.gw, 128) * (N / 64) * pr.nphase;
+    int rsplit = (int)ceil_div((int64_t)2 * device_cu_count(), rtiles);
+    if (rsplit > nkt / 8) rsplit = nkt / 8;
+    if (rsplit > 16) rsplit = 16;
+    if (rsplit < 1 || !tuning().igemm_splitk) rsplit = 1;
+    return launch_h<2, 1, 2>(pr, stream, nullptr, TailPlan(), nullptr, nullptr, rsplit);
+  }
   if (k.wgm == 4 && k.nt == 4) return launch_h<2, 4, 2, 4>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
   if (k.wgm == 4) return launch_h<2, 2, 2, 4>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
   if (k.mt == 2 && k.nt == 1 && k.ns == 3) return launch_h<2, 1, 3>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);

@@ -541,10 +541,16 @@ int patch_plan(const GatherGemmParams& p, PatchGeom* g) {
     g->hh = 16 + e; g->hw = 16 + e;
   }
   g->py = (p.gh + 15) / 16; g->px = (p.gw + 15) / 16;
+  int gw_cov = p.gw;
+  if (t.h3_patch_rem && p.gw >= 32 && p.gw % 16 >= 1 && p.gw % 16 <= 4) {      // 16 px + a few columns: see the launcher
+    g->px = p.gw / 16;
+    g->rem = p.gw % 16;
+    gw_cov = g->px * 16;
+  }
   g->nblocks = (g->hh * g->hw + 7) / 8;
   g->ablate = t.h3_patch_ablate;
   // rows the patches add beyond the grid are computed and thrown away
-  if ((int64_t)g->py * g->px * 256 * 100 > (int64_t)p.gh * p.gw * 125) return 0;
+  if ((int64_t)g->py * g->px * 256 * 100 > (int64_t)p.gh * gw_cov * 125) return 0;
   const int bn = nph == 4 ? 64 : (nph == 3 ? 128 : 256);
   const int64_t wgs = (int64_t)p.batch * g->py * g->px * (p.n_total / bn);
   if (wgs < t.h3_patch_min_wgs) return 0;

@@ -278,6 +278,13 @@ PATCH = [
      {0: 'patch_gemm_h3_kernel<4, 0>', 1: 'patch_gemm_h3_kernel<2, 1>'}),
     (('p3_s2_dec_bwd128', 1, (3, 30, 31), 128, 0, 64, 0, (2, 2), (1, 1), 2, False, 1),
      {0: 'patch_gemm_h3_kernel<4, 0>', 1: 'patch_gemm_h3_kernel<3, 1>'}),
+    # grids of 16 n + 1..3 columns (the model's 33 / 65 / 129): patches over the multiple of 16, a per-tap launch over
+    # the remaining columns
+    (('p3_rem_dec',   1, (2, 16, 33), 64, 64, 128, 1, (2, 2), (1, 1), 2, True, 0),
+     {0: 'patch_gemm_h3_kernel<4, 0>', 1: 'patch_gemm_h3_kernel<3, 1>'}),
+    (('p3_rem_enc',   0, (2, 32, 65), 64, 0, 256, 0, (2, 2), None, 1, False, 0),
+     {0: 'patch_gemm_h3_kernel<2, 0>', 1: 'patch_gemm_h3_kernel<4, 1>'}),
+    (('p3_rem_d4',    0, (1, 33, 36), 64, 0, 256, 0, (1, 1), (1, 1), 1, True, 0), {0: 'patch_gemm_h3_kernel<1, 0>'}),
 ]
 
 

@@ -103,10 +103,10 @@ def test_three_directions_are_one_trilinear_form(hip, model, case):
     # the launches that dominate the configs[2] step run on the operand-image kernels: the patch kernels of
     # igemm_patch.hip wherever the grid has at least 16 x 16 points that 16 x 16 patches cover with < 25 % waste (four
     # fused sub-pixel phases, the 4x4 stride-1 conv, the stride-2 gathers as parity planes), the per-tap tiles of
-    # igemm_h3.hip for the rest (decoder_4 / encoder_4 gather over 16 x 33 points: patches would compute 1.45 x the
-    # grid; decoder_5 / encoder_5 over 8 x 17)
-    patch_fwd = case[0] in ('encoder_2', 'encoder_3', 'decoder_3', 'layer_2', 'layer_3', 'layer_4')
-    patch_bwd = case[0] in ('encoder_2', 'encoder_3', 'decoder_3', 'layer_2', 'layer_3', 'layer_4')
+    # igemm_h3.hip for the rest (decoder_5 / encoder_5 gather over 8 x 17 points).  The model's 33 / 65 / 129-wide grids
+    # are 16 n + 1 columns: the patches take the 16 n, a per-tap launch the last column.
+    patch_fwd = case[0] in ('encoder_2', 'encoder_3', 'encoder_4', 'decoder_4', 'decoder_3', 'layer_2', 'layer_3', 'layer_4')
+    patch_bwd = case[0] in ('encoder_2', 'encoder_3', 'encoder_4', 'decoder_4', 'decoder_3', 'layer_2', 'layer_3', 'layer_4')
     for d, patch in ((0, patch_fwd), (1, patch_bwd)):
       want = 'patch_gemm_h3_kernel' if patch else 'gather_gemm_h3_kernel'
       assert want in L.kernel_name(d), (d, L.kernel_name(d))
