@@ -608,12 +608,16 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     GatherGemmParams pr = p;
     pr.gw = geom.rem;
     pr.gx_off = geom.px * 16;
-    // few rows, the whole contraction: split K over workgroups until the chip is covered twice
+    // few rows, the whole contraction: split K over workgroups (zero fill + atomics) only when the contraction is long
+    // and the launch would leave most of the chip idle
     const int64_t rtiles = ceil_div((int64_t)pr.batch * pr.gh * pr.gw, 128) * (N / 64) * pr.nphase;
-    int rsplit = (int)ceil_div((int64_t)2 * device_cu_count(), rtiles);
-    if (rsplit > nkt / 8) rsplit = nkt / 8;
-    if (rsplit > 16) rsplit = 16;
-    if (rsplit < 1 || !tuning().igemm_splitk) rsplit = 1;
+    int rsplit = 1;
+    if (nkt >= 64 && rtiles < device_cu_count() && tuning().igemm_splitk) {
+      rsplit = (int)ceil_div((int64_t)device_cu_count(), rtiles);
+      if (rsplit > nkt / 16) rsplit = nkt / 16;
+      if (rsplit > 16) rsplit = 16;
+      if (rsplit < 1) rsplit = 1;
+    }
     return launch_h<2, 1, 2>(pr, stream, nullptr, TailPlan(), nullptr, nullptr, rsplit);
   }
   if (k.wgm == 4 && k.nt == 4) return launch_h<2, 4, 2, 4>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
