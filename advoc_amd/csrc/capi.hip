@@ -59,7 +59,7 @@ Tuning read_env() {
   t.h3_tile = env_int("ADVOC_H3_TILE", 0);
   t.h3_stages = env_int("ADVOC_H3_STAGES", 0);
   t.h3_skip_prep = env_int("ADVOC_H3_SKIP_PREP", 0);
-  t.h3_min_tiles = env_int("ADVOC_H3_MIN_TILES", 128);
+  t.h3_min_tiles = env_int("ADVOC_H3_MIN_TILES", 4);
   t.h3_patch = env_int("ADVOC_H3_PATCH", 1);
   t.h3_patch_min_wgs = env_int("ADVOC_H3_PATCH_MIN_WGS", 256);
   t.h3_patch_s2 = env_int("ADVOC_H3_PATCH_S2", 1);

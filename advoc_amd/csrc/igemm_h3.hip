@@ -90,7 +90,7 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
   const int ntn = p.n_total / BN;
   int tile, phase, ks_idx = blockIdx.y, ks_cnt = gridDim.y, tail_tile = -1;
   {
-    const bool tail_mode = p.tail_main > 0;
+    const bool tail_mode = p.tail_split > 1;       // tail_main == 0: EVERY tile is cut into K slices
     const int nb = tail_mode ? p.tail_main : (int)gridDim.x, b = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = b & 7, slot = b >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;   // bijective for any nb
@@ -549,14 +549,25 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   // zero-fill cost more than idle CUs down to a quarter of the chip -- encoder_6 backward-data 278 -> 116 us, decoder_6
   // forward 365 -> 213 us, encoder_5 forward 487 -> 393 us without the split; and never on 64 Ki-output tiles)
   int ksplit = 1;
-  if (!patch_nph && tiles < device_cu_count() / 2 && k.wgm == 2 && tuning().igemm_splitk) {
+  TailPlan tail;
+  if (!patch_nph && tiles < device_cu_count() && tiles <= 256 && k.wgm == 2 && tuning().igemm_splitk) {
+    // Few tiles, deep contraction (the 8 x 17-point layers and below): every tile is cut into K slices that meet in the
+    // WORKSPACE -- the tail-split mechanism with no whole tiles: the last slice to arrive sums the parked partial tiles
+    // in slice order and runs the ordinary epilogue (no zero fill, no atomics, bias and activation gradient fused as
+    // usual; <= 256 tiles: one arrival counter each)
+    int split = (int)ceil_div((int64_t)2 * device_cu_count(), tiles);
+    if (split > nkt / 8) split = nkt / 8;
+    if (split > 16) split = 16;
+    if (split >= 2) { tail.main = 0; tail.rem = (int)tiles; tail.split = split; }
+  }
+  if (tail.split < 2 && !patch_nph && tiles < device_cu_count() / 2 && k.wgm == 2 && tuning().igemm_splitk) {
+    // (without a workspace the slices meet in the destination with atomics, as in igemm.hip)
     ksplit = (int)ceil_div((int64_t)device_cu_count(), tiles);
     if (ksplit > nkt / 8) ksplit = nkt / 8;
     if (ksplit > 16) ksplit = 16;
     if (ksplit < 1) ksplit = 1;
   }
-  TailPlan tail;
-  if (ksplit == 1 && !patch_nph) tail = plan_tail(tiles, nkt);
+  if (tail.split < 2 && ksplit == 1 && !patch_nph) tail = plan_tail(tiles, nkt);
   const int64_t tail_bytes = (int64_t)sizeof(float) * tail.rem * tail.split * BM * BN;
   const int64_t need = hdr_bytes + wq_bytes + i0_bytes + i1_bytes;
   if (scratch_query) { *scratch_query = need + tail_bytes; return ADVOC_OK; }

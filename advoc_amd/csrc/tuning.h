@@ -22,7 +22,8 @@ struct Tuning {
   int h3_tile;          // ADVOC_H3_TILE        1: 128x128, 2: 128x256, 3: 256x128, 4: 128x64 forced
   int h3_stages;        // ADVOC_H3_STAGES      2 | 3 LDS stages forced
   int h3_skip_prep;     // ADVOC_H3_SKIP_PREP   1: (micro-benchmarks only) reuse the images already in the workspace
-  int h3_min_tiles;     // ADVOC_H3_MIN_TILES   smallest launch (128-row x 128-column tiles) that takes the image path
+  int h3_min_tiles;     // ADVOC_H3_MIN_TILES   smallest launch (128-row x 128-column tiles) that takes the image path (4: with the
+                        //                      workspace K split the image kernels beat the r1 ones down to the 1 x 3-point layers)
   int h3_patch;         // ADVOC_H3_PATCH       0: stride-1 gathers stay on the per-tap tiles of igemm_h3.hip
   int h3_patch_min_wgs; // ADVOC_H3_PATCH_MIN_WGS  smallest launch (workgroups) that takes the patch kernel
   int h3_patch_s2;      // ADVOC_H3_PATCH_S2    0: stride-2 gathers stay on the per-tap tiles (no parity-plane patch kernel)

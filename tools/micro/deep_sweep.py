@@ -6,9 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from h3_sweep_shapes import build, setenv, timed_us
 
-VARIANTS = [('default', {}), ('nosplit', dict(ADVOC_IGEMM_SPLITK=0)), ('t128', dict(ADVOC_H3_TILE=1)),
-            ('t256', dict(ADVOC_H3_TILE=5)), ('t128x64', dict(ADVOC_H3_TILE=4)), ('min32', dict(ADVOC_H3_MIN_TILES=32))]
-for name in (sys.argv[1:] or ['enc5m', 'enc6m', 'dec5m', 'dec6m', 'enc4o']):
+VARIANTS = [('default', {}), ('nosplit', dict(ADVOC_IGEMM_SPLITK=0)), ('min32', dict(ADVOC_H3_MIN_TILES=32)),
+            ('min8', dict(ADVOC_H3_MIN_TILES=8)), ('min1', dict(ADVOC_H3_MIN_TILES=1))]
+for name in (sys.argv[1:] or ['enc5m', 'enc6m', 'enc7m', 'enc8m', 'dec5m', 'dec6m', 'dec7m', 'dec8m']):
   L, dy, dx0, dx1 = build(name)
   for d, tag in ((0, 'fwd '), (1, 'bwdD')):
     fn = L.forward if d == 0 else (lambda: L.backward_data(dy, dx0, dx1))

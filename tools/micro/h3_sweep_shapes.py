@@ -28,6 +28,10 @@ SHAPES = {
     'dec5m': (1, 64, 8, 17, 512, 512, 512, (2, 2), 1, 2),
     'dec6m': (1, 64, 4, 9, 512, 512, 512, (2, 2), 1, 2),
     'enc4o': (0, 64, 32, 65, 256, 0, 512, (2, 2), 0, 1),        # encoder_4 at the model's odd width
+    'enc7m': (0, 64, 4, 9, 512, 0, 512, (2, 2), 0, 1),
+    'enc8m': (0, 64, 2, 5, 512, 0, 512, (2, 2), 0, 1),
+    'dec7m': (1, 64, 2, 5, 512, 512, 512, (2, 2), 1, 2),
+    'dec8m': (1, 64, 1, 3, 512, 0, 512, (2, 2), 0, 2),
 }
 
 
