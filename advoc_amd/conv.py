@@ -161,6 +161,8 @@ class Layer(object):
       self.tensors = self.tensors + tuple(self._img)
     s.img_flags = 0
     self._names = {}
+    self._db_done_for = None
+    self._bias_fusable = bool(_lib.load().advoc_conv_bias_fusable(ctypes.byref(s)))
     lw = s.x0.w
     grid = (y.shape[1] * s.y.w) if kind == CONV else (x0.shape[1] * lw)
     self.flops = 2.0 * x0.shape[0] * grid * kh * kw * cin * cout
@@ -223,7 +225,10 @@ class Layer(object):
     self._x_current = bool(self.struct.x_img) and 'h3' in self.kernel_name(0)
     return self.y
 
-  def backward_data(self, dy, dx0=None, dx1=None, accum0=False, accum1=False):
+  def backward_data(self, dy, dx0=None, dx1=None, accum0=False, accum1=False, db=None, db_accumulate=True):
+    """dx0 / dx1 <- gradient w.r.t. the inputs.  db (optional): the bias gradient buffer of this layer -- where the call
+    builds the image of dy (image kernels, advoc_conv_bias_fusable) the per-channel sums are taken in the same pass and
+    the backward_weight call that follows with the same dy skips its bias kernel."""
     _lib.require_device(dy)
     if tuple(dy.shape) != tuple(self.y.shape):
       raise _lib.AdvocHipError('dy shape {} != y shape {}'.format(tuple(dy.shape), tuple(self.y.shape)))
@@ -232,11 +237,21 @@ class Layer(object):
         _lib.require_device(d)
         if x is None or tuple(d.shape) != tuple(x.shape):
           raise _lib.AdvocHipError('dx must have the shape of the matching input')
+    self._db_done_for = None
+    fuse_db = db is not None and self._bias_fusable and 'h3' in self.kernel_name(1)
+    if fuse_db:
+      _lib.require_device(db)
+      if not db_accumulate:
+        db.zero_()
+      self.struct.db_fused = _lib.ptr(db)
     self.struct.img_flags = self._timed_image(1, dy) | self._delayed_bits()
     self._run(1, lambda: _lib.check(_lib.load().advoc_conv_backward_data(
         ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dx0), _lib.ptr(dx1), int(accum0),
         int(accum1), _lib.stream()), 'advoc_conv_backward_data'))
     self.struct.img_flags = 0
+    if fuse_db:
+      self.struct.db_fused = None
+      self._db_done_for = dy.data_ptr()
     if self.struct.dy_img and 'h3' in self.kernel_name(1):
       self._dy_built = True
     self._dy_current_ptr = dy.data_ptr() if (self.struct.dy_img and 'h3' in self.kernel_name(1)) else None
@@ -258,7 +273,9 @@ class Layer(object):
       self._x_built = self._x_built or bool(self.struct.x_img)
       self._dy_built = self._dy_built or bool(self.struct.dy_img)
     self._dy_current_ptr = None          # one use per backward_data: the next step's dy lives at the same address
-    if db is not None:
+    db_done = getattr(self, '_db_done_for', None) == dy.data_ptr()
+    self._db_done_for = None
+    if db is not None and not db_done:
       _lib.require_device(db)
       call = lambda: _lib.check(_lib.load().advoc_conv_backward_bias(      # noqa: E731
           ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(db), int(accumulate), _lib.stream()),

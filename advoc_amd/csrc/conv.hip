@@ -7,6 +7,7 @@
 // :89-158 (generator), :184-202 (discriminator) and their TF gradients.
 #include "conv_internal.h"
 #include "tuning.h"
+#include "x6.h"
 
 namespace advoc {
 
@@ -329,6 +330,11 @@ extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stre
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
 
+extern "C" int advoc_conv_bias_fusable(const advoc_conv_layer* L) {
+  if (validate_layer(L) != ADVOC_OK) return 0;
+  return L->dy_img && L->dy_hdr && image_colsum_ok(L->y.c) ? 1 : 0;
+}
+
 extern "C" int advoc_conv_make_image(const advoc_conv_layer* L, int32_t which, const float* dy, advoc_stream_t stream) {
   int rc = validate_layer(L);
   if (rc != ADVOC_OK) return rc;
@@ -340,7 +346,11 @@ extern "C" int advoc_conv_make_image(const advoc_conv_layer* L, int32_t which, c
   if (which == 0) operand_from_inputs(L, o); else operand_from_dy(L, dy, o);
   if ((o.c0 % 32) || (o.c1 % 32)) return ADVOC_ERR_UNSUPPORTED;
   const bool delayed = (L->img_flags & (which == 0 ? ADVOC_IMG_X_DELAYED : ADVOC_IMG_DY_DELAYED)) != 0;
-  return wgrad_h3_make_image(o, L->x0.n, img, hdr, delayed, as_stream(stream));
+  // (the replica table of the bias-gradient sums sits where launch_gather_gemm_h3 keeps it: behind the 256-byte
+  // header block of the workspace)
+  float* table = L->workspace && L->workspace_bytes >= 256 + kColsumBytes
+                     ? reinterpret_cast<float*>(reinterpret_cast<char*>(L->workspace) + 256) : nullptr;
+  return wgrad_h3_make_image(o, L->x0.n, img, hdr, delayed, as_stream(stream), which == 1 ? L->db_fused : nullptr, table);
 }
 
 extern "C" int64_t advoc_conv_image_bytes(const advoc_conv_layer* L, int32_t which) {
@@ -393,6 +403,7 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
   p.a_img_out = L->dy_img; p.a_hdr_out = L->dy_img ? L->dy_hdr : nullptr;
   p.a_img_current = (L->img_flags & ADVOC_IMG_DY_CURRENT) != 0;
   p.a_img_delayed = (L->img_flags & ADVOC_IMG_DY_DELAYED) != 0;
+  p.a_colsum = L->dy_img ? L->db_fused : nullptr;       // the bias gradient rides in the dy image pass (igemm_h3.hip)
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
 

@@ -63,7 +63,8 @@ int launch_wgrad_thin(const WgradParams& p, hipStream_t stream,
 // image (source 1 behind source 0 at its 256-byte-rounded size) and {amax, 2^-s} header; *_operand_bytes sizes it.
 bool wgrad_h3_eligible(const WgradParams& p);
 int64_t wgrad_h3_operand_bytes(const Operand& o, int batch, int64_t* b0, int64_t* b1);
-int wgrad_h3_make_image(const Operand& o, int batch, uint16_t* img, unsigned* hdr, bool delayed, hipStream_t stream);
+int wgrad_h3_make_image(const Operand& o, int batch, uint16_t* img, unsigned* hdr, bool delayed, hipStream_t stream,
+                        float* colsum0 = nullptr, float* colsum_table = nullptr);
 int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned* p_hdr, const uint16_t* q_img,
                     const unsigned* q_hdr, hipStream_t stream, const char** name_only = nullptr);
 

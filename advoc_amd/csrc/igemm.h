@@ -83,6 +83,8 @@ struct GatherGemmParams {
   unsigned* a_hdr_out;
   int a_img_current;       // != 0: a_img_out / a_hdr_out already hold this operand's image (skip the image passes)
   int a_img_delayed;       // != 0: a_hdr_out holds the magnitude of a previous image of this operand: one-pass image
+  float* a_colsum;         // != null: the image pass of source 0 adds its per-channel sums over the logical pixels here (the
+                           // bias gradient, when A is an output gradient); only honoured where image_colsum_ok(c0)
   // ---- tail split (filled in by the launcher, see launch_cfg) ----
   int tail_main;           // > 0: 1-D launch; tiles [0, tail_main) whole, the rest in tail_split K slices each
   int tail_split;

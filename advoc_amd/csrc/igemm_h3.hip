@@ -534,7 +534,7 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   const int ktot = p.c0 + p.c1, N = p.n_total;
   const int taps = weight_taps_of(p);
   const int64_t e0 = (int64_t)p.batch * p.a_h * p.a0_pitch * p.c0, e1 = (int64_t)p.batch * p.a_h * p.a1_pitch * p.c1;
-  const int64_t hdr_bytes = 256;
+  const int64_t hdr_bytes = 256 + kColsumBytes;       // operand headers + the bias-gradient replica table (image.hip)
   const int64_t wq_bytes = round256((int64_t)4 * taps * N * ktot);
   const int64_t i0_bytes = round256(4 * e0), i1_bytes = round256(4 * e1);
   const Pick k = pick_tile(p);
@@ -603,7 +603,9 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
       const ImageSource s0 = {p.a0, e0, p.c0, p.in_scale, p.in_shift, p.in_act, p.a_mask, p.a_mask_scale};
       const ImageSource s1 = {p.a1, e1, p.c1, p.in_scale ? p.in_scale + p.c0 : nullptr,
                               p.in_shift ? p.in_shift + p.c0 : nullptr, p.in_act, nullptr, 0.f};
-      rc = make_operand_image(s0, s1, img0, hdr_a, p.a_img_out && p.a_img_delayed, stream);
+      rc = make_operand_image(s0, s1, img0, hdr_a, p.a_img_out && p.a_img_delayed, stream,
+                              p.a_colsum && image_colsum_ok(p.c0) ? p.a_colsum : nullptr, p.in_w, p.a0_pitch,
+                              reinterpret_cast<float*>(ws + 256));
       if (rc != ADVOC_OK) return rc;
     }
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();

@@ -129,15 +129,39 @@ __global__ void rotate_hdr_kernel(unsigned* __restrict__ hdr) {
   hdr[0] = 0u;
 }
 
+// out[ch] += sum over the replicas of table[r][ch]
+__global__ void colsum_reduce_kernel(const float* __restrict__ table, float* __restrict__ out, int c) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float t = 0.f;
+  for (int r = 0; r < kColsumReplicas; ++r) t += table[(size_t)r * c + ch];
+  out[ch] += t;
+}
+
 // one thread = 8 consecutive channels of one pixel: two float4 loads, two 16-byte stores.
 // hdr[0] = amax bits (input; DELAYED: accumulated here), hdr[1] = 2^-s as float bits (output, written by the first thread).
-template <bool DELAYED>
+template <bool DELAYED, bool COLSUM = false>
 __global__ __launch_bounds__(256) void pair_image_kernel(const float* __restrict__ x, __half* __restrict__ img,
                                                          int64_t n8, int c, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float slope,
                                                          const uint8_t* __restrict__ mask, float mask_scale,
-                                                         unsigned* __restrict__ hdr) {
+                                                         unsigned* __restrict__ hdr, float* __restrict__ colsum,
+                                                         int w_log, int w_pitch) {
   const float up = DELAYED ? up_scale_delayed(hdr[2]) : up_scale(hdr[0]);
+  // colsum != null: also accumulate the per-channel sums of the transformed values over the LOGICAL pixels (the bias
+  // gradient of the layer whose output gradient this is, models/advoc/advoc_model.py: tf.gradients w.r.t. the conv
+  // biases) -- the launcher guarantees that the block size and the grid stride are multiples of c / 8, so a thread
+  // keeps ONE group of 8 channels for the whole loop
+  // (COLSUM is a template parameter: the plain instances keep the registers and the code of the image pass alone)
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // logical column of this thread's pixel, advanced without divisions: the pixel index grows by stride / (c / 8) per trip
+  int xcol = 0, xstep = 0;
+  if (COLSUM) {
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int groups = c >> 3;
+    xcol = (int)((i0 / groups) % w_pitch);
+    xstep = (int)(((int64_t)gridDim.x * blockDim.x / groups) % w_pitch);
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = __float_as_uint(1.f / up);     // exact: a power of two
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   float vmax = 0.f;
@@ -146,6 +170,14 @@ __global__ __launch_bounds__(256) void pair_image_kernel(const float* __restrict
     const int64_t e = i * 8;
     float v[8];
     load8(x, e, c, scale, shift, slope, mask, mask_scale, v);
+    if (COLSUM) {
+      if (xcol < w_log) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += v[j];
+      }
+      xcol += xstep;
+      if (xcol >= w_pitch) xcol -= w_pitch;
+    }
     if (DELAYED) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -178,6 +210,24 @@ __global__ __launch_bounds__(256) void pair_image_kernel(const float* __restrict
       if (vmax > 0.f) atomicMax(hdr, __float_as_uint(vmax));
     }
     if (sat) atomicAdd(hdr + 3, (unsigned)sat);
+  }
+  if (COLSUM) {
+    __shared__ float s_cs[256][9];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_cs[threadIdx.x][j] = cs[j];
+    __syncthreads();
+    const int groups = c >> 3;                       // <= 128, divides 256
+    if ((int)threadIdx.x < groups) {
+      float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int m = threadIdx.x; m < 256; m += groups)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] += s_cs[m][j];
+#pragma unroll
+      // (into one of kColsumReplicas copies: thousands of blocks adding to the SAME c addresses serialise in the L2 --
+      // measured 0.2 ms per launch; colsum_reduce_kernel folds the copies afterwards)
+      for (int j = 0; j < 8; ++j)
+        unsafeAtomicAdd(colsum + (size_t)(blockIdx.x & (kColsumReplicas - 1)) * c + threadIdx.x * 8 + j, t[j]);
+    }
   }
 }
 
@@ -261,26 +311,39 @@ int launch_amax(const float* x, int64_t elems, int c, const float* scale, const 
   return ADVOC_OK;
 }
 
+bool image_colsum_ok(int c) { return c >= 32 && c <= 1024 && 256 % (c / 8) == 0 && c % 8 == 0; }
+
 int launch_pair_image(const float* x, uint16_t* img, int64_t elems, int c, const float* scale, const float* shift,
-                      int act, const uint8_t* mask, float mask_scale, unsigned* hdr, bool delayed, hipStream_t stream) {
+                      int act, const uint8_t* mask, float mask_scale, unsigned* hdr, bool delayed, hipStream_t stream,
+                      float* colsum_out, int w_log, int w_pitch, float* colsum_table) {
   if (!x || !img || !hdr) return ADVOC_ERR_NULL;
   if (elems <= 0) return ADVOC_OK;
   if (c % 32 || elems % 32) return ADVOC_ERR_UNSUPPORTED;
+  if (colsum_out && (!image_colsum_ok(c) || w_pitch <= 0 || !colsum_table)) return ADVOC_ERR_UNSUPPORTED;
+  float* colsum = colsum_out ? colsum_table : nullptr;
+  if (colsum) {
+    hipError_t e = hipMemsetAsync(colsum_table, 0, sizeof(float) * kColsumReplicas * (size_t)c, stream);
+    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  }
   ADVOC_CLEAR_LAUNCH_ERROR();
-  if (delayed)
-    hipLaunchKernelGGL(pair_image_kernel<true>, dim3(grid_for(elems / 8, 256)), dim3(256), 0, stream, x,
-                       reinterpret_cast<__half*>(img), elems / 8, c, scale, shift, slope_of(act), mask, mask_scale, hdr);
-  else
-    hipLaunchKernelGGL(pair_image_kernel<false>, dim3(grid_for(elems / 8, 256)), dim3(256), 0, stream, x,
-                       reinterpret_cast<__half*>(img), elems / 8, c, scale, shift, slope_of(act), mask, mask_scale, hdr);
+  // (256 threads per block: block size and grid stride are multiples of c / 8 whenever image_colsum_ok(c))
+  auto kern = delayed ? (colsum ? pair_image_kernel<true, true> : pair_image_kernel<true, false>)
+                      : (colsum ? pair_image_kernel<false, true> : pair_image_kernel<false, false>);
+  hipLaunchKernelGGL(kern, dim3(grid_for(elems / 8, 256)), dim3(256), 0, stream, x, reinterpret_cast<__half*>(img),
+                     elems / 8, c, scale, shift, slope_of(act), mask, mask_scale, hdr, colsum, w_log, w_pitch);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
+  if (colsum) {
+    ADVOC_CLEAR_LAUNCH_ERROR();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, colsum_table, colsum_out, c);
+    ADVOC_RETURN_IF_LAUNCH_FAILED();
+  }
   return ADVOC_OK;
 }
 
 // One GEMM operand (one or two channel-concatenated sources, ONE scale) -> image at `img` (source 1 behind source 0 at
 // its 256-byte-rounded size) and header `hdr` (16 bytes, caller-owned, persistent across calls for delayed scaling).
 int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* img, unsigned* hdr, bool delayed,
-                       hipStream_t stream) {
+                       hipStream_t stream, float* colsum0, int w_log, int w_pitch, float* colsum_table) {
   const int64_t b0 = (4 * s0.elems + 255) / 256 * 256;
   uint16_t* img1 = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(img) + b0);
   int rc = ADVOC_OK;
@@ -296,10 +359,11 @@ int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* i
       rc = launch_amax(s1.x, s1.elems, s1.c, s1.scale, s1.shift, s1.act, s1.mask, s1.mask_scale, hdr, stream);
     if (rc != ADVOC_OK) return rc;
   }
-  rc = launch_pair_image(s0.x, img, s0.elems, s0.c, s0.scale, s0.shift, s0.act, s0.mask, s0.mask_scale, hdr, delayed, stream);
+  rc = launch_pair_image(s0.x, img, s0.elems, s0.c, s0.scale, s0.shift, s0.act, s0.mask, s0.mask_scale, hdr, delayed, stream,
+                         colsum0, w_log, w_pitch, colsum_table);
   if (rc == ADVOC_OK && s1.elems)
     rc = launch_pair_image(s1.x, img1, s1.elems, s1.c, s1.scale, s1.shift, s1.act, s1.mask, s1.mask_scale, hdr, delayed,
-                           stream);
+                           stream, nullptr, 0, 0, nullptr);
   return rc;
 }
 

@@ -269,12 +269,14 @@ int64_t wgrad_h3_operand_bytes(const Operand& o, int batch, int64_t* b0, int64_t
 }
 
 // Makes the image of one operand (both sources, one scale) at `img` / `hdr`.
-int wgrad_h3_make_image(const Operand& o, int batch, uint16_t* img, unsigned* hdr, bool delayed, hipStream_t stream) {
+int wgrad_h3_make_image(const Operand& o, int batch, uint16_t* img, unsigned* hdr, bool delayed, hipStream_t stream,
+                        float* colsum0, float* colsum_table) {
   const int64_t e0 = (int64_t)batch * o.h * o.pitch0 * o.c0, e1 = (int64_t)batch * o.h * o.pitch1 * o.c1;
   const ImageSource s0 = {o.p0, e0, o.c0, o.scale, o.shift, o.act, o.mask, o.mask_scale};
   const ImageSource s1 = {o.p1, e1, o.c1, o.scale ? o.scale + o.c0 : nullptr, o.shift ? o.shift + o.c0 : nullptr, o.act,
                           nullptr, 0.f};
-  return make_operand_image(s0, s1, img, hdr, delayed, stream);
+  return make_operand_image(s0, s1, img, hdr, delayed, stream,
+                            colsum0 && colsum_table && image_colsum_ok(o.c0) ? colsum0 : nullptr, o.w, o.pitch0, colsum_table);
 }
 
 // p_img / q_img: images of P and Q (source 1 follows source 0 at the 256-byte-rounded size of source 0), hdr: their

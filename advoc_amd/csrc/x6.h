@@ -33,7 +33,8 @@ int launch_amax(const float* x, int64_t elems, int c, const float* scale, const 
 // act(scale * x + shift) * mask * mask_scale of `elems` fp32 values (channels innermost, c % 32 == 0) as 128-byte
 // K slices img[elems / 32][plane][32] fp16, scaled by the power of two derived from hdr[0]
 int launch_pair_image(const float* x, uint16_t* img, int64_t elems, int c, const float* scale, const float* shift,
-                      int act, const uint8_t* mask, float mask_scale, unsigned* hdr, bool delayed, hipStream_t stream);
+                      int act, const uint8_t* mask, float mask_scale, unsigned* hdr, bool delayed, hipStream_t stream,
+                      float* colsum = nullptr, int w_log = 0, int w_pitch = 0, float* colsum_table = nullptr);
 // One GEMM operand = one or two channel-concatenated sources under ONE scale.  make_operand_image writes the image
 // (source 1 behind source 0 at its 256-byte-rounded size) and the 16-byte header {[0] largest magnitude of this image,
 // [1] 2^-s, [2] largest magnitude of the previous image in this buffer, [3] saturated values}.  delayed == false: the
@@ -50,8 +51,15 @@ struct ImageSource {
   const uint8_t* mask;
   float mask_scale;
 };
+// colsum0 != null: the image pass of source 0 also adds its per-channel sums over the logical pixels (x < w_log of rows
+// w_pitch pixels apart) to colsum0[c] -- the bias gradient when the operand is an output gradient (image_colsum_ok(c))
+// colsum_table: kColsumBytes of scratch (the sums are collected in kColsumReplicas copies first)
 int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* img, unsigned* hdr, bool delayed,
-                       hipStream_t stream);
+                       hipStream_t stream, float* colsum0 = nullptr, int w_log = 0, int w_pitch = 0,
+                       float* colsum_table = nullptr);
+bool image_colsum_ok(int c);
+constexpr int kColsumReplicas = 64;
+constexpr int64_t kColsumBytes = (int64_t)kColsumReplicas * 1024 * 4;
 // weights [tap][k][n] (b_kn) or [tap][n][k] -> wq[tap][n_total][ktot / 32][plane][32] fp16 (amax pass included;
 // hdr[0] must be zero on entry)
 int launch_pair_weights(const float* w, uint16_t* wq, int taps, int n_total, int ktot, bool b_kn, unsigned* hdr,

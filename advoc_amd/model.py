@@ -706,7 +706,7 @@ class Advoc(Model):
           self._bn_backward(bns[i], g, accumulate=acc)
         # backward-data first: it leaves the fp16 pair image of g behind, which the weight gradient reads again
         if i > 0:
-          layers[i].backward_data(g, st['g_d_act'][i - 1][lo:hi])
+          layers[i].backward_data(g, st['g_d_act'][i - 1][lo:hi], db=DG[s + '/bias'], db_accumulate=acc)
         with self._wgrad_ctx():
           layers[i].backward_weight(g, DG[s + '/kernel'], DG[s + '/bias'], accumulate=acc)
     self._join_wgrad()
@@ -806,9 +806,9 @@ class Advoc(Model):
       if 'decoder_%d' % idx in gbn:
         self._bn_backward(gbn['decoder_%d' % idx], gd[idx], accumulate=True)
       if j == 0:
-        lay.backward_data(gd[idx], ge[-1])
+        lay.backward_data(gd[idx], ge[-1], db=GG[s + '/bias'])
       else:
-        lay.backward_data(gd[idx], gd[dec[j - 1][0]], ge[idx - 1])
+        lay.backward_data(gd[idx], gd[dec[j - 1][0]], ge[idx - 1], db=GG[s + '/bias'])
       with self._wgrad_ctx():
         lay.backward_weight(gd[idx], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
         self._g_grads_ready(self._last_param_of('generator/decoder_%d' % idx))
@@ -818,7 +818,7 @@ class Advoc(Model):
       if 'encoder_%d' % (i + 1) in gbn:
         self._bn_backward(gbn['encoder_%d' % (i + 1)], ge[i], accumulate=True)
       if i > 0:
-        lay.backward_data(ge[i], ge[i - 1], accum0=True)
+        lay.backward_data(ge[i], ge[i - 1], accum0=True, db=GG[s + '/bias'])
       with self._wgrad_ctx():
         lay.backward_weight(ge[i], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
         self._g_grads_ready(self._last_param_of('generator/encoder_%d' % (i + 1)))

@@ -237,7 +237,17 @@ typedef struct advoc_conv_layer {
   uint16_t* dy_img;
   uint32_t* dy_hdr;
   int32_t img_flags;
+  /* optional: the bias gradient rides in the pass that builds the output-gradient image.  When non-null, a
+   * backward-data call (or advoc_conv_make_image(which = 1)) that BUILDS dy_img also ADDS sum over the logical pixels
+   * of dy (times the forward dropout mask, as advoc_conv_backward_bias) to db_fused[cout] -- the caller zeroes it
+   * first if it does not accumulate, and skips advoc_conv_backward_bias.  Only where advoc_conv_bias_fusable() says
+   * so and the backward-data call runs on the image kernels (advoc_conv_kernel_name); ignored otherwise. */
+  float* db_fused;
 } advoc_conv_layer;
+
+/* 1: the layer's output-gradient image pass can carry the bias gradient (db_fused above): dy_img present and cout such
+ * that a thread of the image pass keeps one group of 8 channels (32 <= cout <= 1024, 256 % (cout / 8) == 0) */
+int advoc_conv_bias_fusable(const advoc_conv_layer* layer);
 
 #define ADVOC_IMG_X_CURRENT 1
 #define ADVOC_IMG_DY_CURRENT 2

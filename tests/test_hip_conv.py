@@ -681,3 +681,45 @@ def test_delayed_scale_counts_what_leaves_the_head_room(hip, hipenv):
     L.forward()                                   # header now holds the new magnitude
   assert int(delayed._img[1].cpu()[3]) == sat
   assert rel(delayed.y, exact.y) < 2e-6
+
+
+@gpu
+@pytest.mark.parametrize('case', [c for c in H3 if c[0] in ('h3_enc', 'h3_dec_skip')] +
+                         [('bias_n192', 0, (3, 16, 33), 64, 0, 192, 0, (2, 2), None, 1, True, 0)] +
+                         [c[0] for c in PATCH if c[0][0] in ('p3_dec_skip', 'p3_enc_bwd_odd', 'p3_rem_dec')],
+                         ids=lambda c: c[0])
+def test_bias_gradient_rides_in_the_output_gradient_image_pass(hip, case, hipenv):
+  """backward_data(..., db=...) on the image kernels: the per-channel sums of dy (times the forward dropout mask, logical
+  columns only) are taken by the pass that writes dy's fp16 pair image, the following backward_weight skips its bias
+  kernel; same numbers as advoc_conv_backward_bias and the float64 oracle, with and without accumulation, in exact and
+  in delayed-scale image mode.  192 output channels (256 % 24 != 0): not fusable, the bias kernel runs as before."""
+  from advoc_amd import conv
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1, ADVOC_WGRAD_H3_MIN_M=1)
+  c = build_case(case)
+  dev = torch.device('cuda')
+  _, _, _, _, db_o = oracle_layer(c['kind'], c['x0'], c['x1'], c['in_w'], c['w'], c['b'], c['stride'], c['pad'], c['act'],
+                                  c['mask'], c['keep'], c['out_w'], c['dy'])
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w, b, dy = c['w'].to(dev), c['b'].to(dev), c['dy'].to(dev)
+  mask = c['mask'].to(dev) if c['mask'] is not None else None
+  cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+  y = torch.empty(x0.shape[0], c['oh'], c['out_w'], cout, device=dev)
+  L = conv.Layer(c['kind'], x0, y, w, b, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'],
+                 drop_mask=mask, drop_scale=1 / c['keep'] if mask is not None else 0.)
+  L.reuse_images = True
+  L.delayed_scale = True
+  assert 'h3' in L.kernel_name(1)
+  assert L._bias_fusable == (256 % (cout // 8) == 0)
+  L.forward()
+  dx0 = torch.zeros_like(x0)
+  dx1 = torch.zeros_like(x1) if x1 is not None else None
+  for rep in range(3):                      # first call: exact two-pass image; then the delayed one-pass form
+    db = torch.full_like(b, 5.0)
+    dw = torch.zeros_like(w)
+    L.backward_data(dy, dx0, dx1, db=db, db_accumulate=(rep == 2))
+    if L._bias_fusable:
+      assert L._db_done_for == dy.data_ptr()
+      assert rel(db - (5.0 if rep == 2 else 0.0), db_o) < TOL, (rep, rel(db, db_o))     # already there
+    L.backward_weight(dy, dw, db, accumulate=(rep == 2))
+    assert rel(db - (5.0 if rep == 2 else 0.0), db_o) < TOL, (rep, rel(db, db_o))
