@@ -120,22 +120,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(p.wq), 0, p.wq_taps * p.n_total * ktot * 4, 0x00020000);
 
-  const int lrow = lane >> 3, lpos = lane & 7;
-  constexpr int hmagic = (65536 + hw - 1) / hw;      // h / hw == (h * hmagic) >> 16 for h < 512, hw <= 20
-  const int half = lane >> 5, l32 = lane & 31;
-  // halo pixel of this lane's row in the wave's first 32-point block (2 patch rows x 16 columns) for tap (0, 0); block
-  // i is 2 i halo rows further
-  const int h_base = (wm * (C::PTS_W / 16) + (l32 >> 4)) * hw + (l32 & 15);
-  // fragment chunk (plane, k step, half) = 4 plane + 2 ks + half sits at position chunk ^ swizzle = (half ^ swizzle) ^
-  // (4 plane + 2 ks): one byte offset per row, the (plane, ks) part is an XOR with a constant
-  const int bfrag = (brow0 + l32) * 128 + ((half ^ ((l32 >> 1) & 7)) * 16);
   const float gslope = act_slope_p(p.grad_act);
-  // the tap tables of the wave's compute phase and of the phase whose B rows it loads, one tap per lane: read back with
-  // v_readlane inside the K loop (an s_load there would put an lgkmcnt(0) wait -- SMEM returns out of order -- in front
-  // of every step's LDS reads)
-  // (S2: one table for all waves, entry 4 plane + t, offsets already relative to the plane's halo origin)
-  const int tapv_c = S2 ? g.s2_tap[lane & (kMaxTaps - 1)] : p.tap[phase][lane & (kMaxTaps - 1)];
-  const int tapv_b = S2 ? tapv_c : p.tap[b_phase][lane & (kMaxTaps - 1)];
   const int src_c0 = p.c0, src_c1 = p.c1, src_p0 = p.a0_pitch, src_p1 = p.a1_pitch;
   const int abl = g.ablate;       // timing experiments only (ADVOC_H3_PATCH_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier
 
@@ -151,6 +136,26 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // (the backward-data instances take ONE tile per workgroup: with the K loop's per-lane constants kept alive across the
   // epilogue for a next tile, their epilogue -- accumulators + the block's prefetched operands -- spills)
   for (int tile = t_lo + slot; tile < t_hi; tile += per_xcd) {
+  // The per-lane constants of the K loop are derived from an OPAQUE copy of the lane id inside the tile loop: hoisted out
+  // of it they would stay alive across the epilogue, whose accumulators + prefetched operands then spill (80-230
+  // registers in the backward-data instances).
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  const int lrow = ln >> 3, lpos = ln & 7;
+  constexpr int hmagic = (65536 + hw - 1) / hw;      // h / hw == (h * hmagic) >> 16 for h < 512, hw <= 20
+  const int half = ln >> 5, l32 = ln & 31;
+  // halo pixel of this lane's row in the wave's first 32-point block (2 patch rows x 16 columns) for tap (0, 0); block
+  // i is 2 i halo rows further
+  const int h_base = (wm * (C::PTS_W / 16) + (l32 >> 4)) * hw + (l32 & 15);
+  // fragment chunk (plane, k step, half) = 4 plane + 2 ks + half sits at position chunk ^ swizzle = (half ^ swizzle) ^
+  // (4 plane + 2 ks): one byte offset per row, the (plane, ks) part is an XOR with a constant
+  const int bfrag = (brow0 + l32) * 128 + ((half ^ ((l32 >> 1) & 7)) * 16);
+  // the tap tables of the wave's compute phase and of the phase whose B rows it loads, one tap per lane: read back with
+  // v_readlane inside the K loop (an s_load there would put an lgkmcnt(0) wait -- SMEM returns out of order -- in front
+  // of every step's LDS reads).  (S2: one table for all waves, entry 4 plane + t, offsets already relative to the
+  // plane's halo origin)
+  const int tapv_c = S2 ? g.s2_tap[ln & (kMaxTaps - 1)] : p.tap[phase][ln & (kMaxTaps - 1)];
+  const int tapv_b = S2 ? tapv_c : p.tap[b_phase][ln & (kMaxTaps - 1)];
   const int nt = tile / npatch;
   const int pid = tile - nt * npatch;
   const int img = pid / ppi;
@@ -354,9 +359,12 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 
   // ---- epilogue (igemm_h3.hip's, per wave): pixel table of the wave's points for its phase, LDS transpose,
   // 16-byte stores with the fused bias / dropout / activation-gradient / two-destination logic ----
+  int le = lane;
+  asm volatile("" : "+v"(le));
+  const int half_e = le >> 5, l32_e = le & 31;
   constexpr int PW_ = C::PTS_W;
   int* s_pix = reinterpret_cast<int*>(smem + C::WAVES * 32 * 36) + wave * 2 * PW_;
-  for (int r = lane; r < PW_; r += 64) {
+  for (int r = le; r < PW_; r += 64) {
     const int pt = wm * PW_ + r;
     const int gy = gy0 + (pt >> 4), gx = gx0 + (pt & 15);
     int pix0 = -1, pix1 = -1;
@@ -375,7 +383,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const float unscale = __uint_as_float(p.a_hdr[1]) * __uint_as_float(p.b_hdr[1]);   // exact: powers of two
   constexpr int LDT = 36;
   float* T = smem + wave * (32 * LDT);
-  const int trow = lane >> 3, tq = lane & 7;
+  const int trow = le >> 3, tq = le & 7;
   const bool use_grad = BWD && p.grad_act != ADVOC_ACT_NONE;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -423,7 +431,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * half) * LDT + l32] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * half_e) * LDT + l32_e] = acc[i][j][r];
       wave_lds_sync();
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
