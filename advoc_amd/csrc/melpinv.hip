@@ -4,17 +4,29 @@
 // them for every training batch (the "x_inverted" input of the generator).
 //
 // The two advoc_matmul_nt_f32 launches it replaces run an LDS-tiled FMA kernel (34 TFLOP/s) and read the 2 KiB rows
-// twice; here a workgroup owns 32 frames (band_lo_hi must describe at most 4 096 weights in total: the caller checks):
-//   * the 32 x 513 magnitudes go to LDS once (66 KB);
+// twice.  Here one PERSISTENT workgroup per CU walks tiles of 32 frames (band_lo_hi must describe at most 2 048 weights
+// in total: the caller checks):
+//   * the tile's 32 x 513 magnitudes go to LDS once, by LDS-DMA (66 KB); the next tile's are fetched under the current
+//     tile's MFMAs;
 //   * the filterbank is triangular -- every band is a short run of bins -- so the mel projection is ~1 000 FMAs per
 //     frame on the vector ALUs; the caller passes the runs' weights PACKED back to back (each run padded with zeros to
-//     a multiple of 4), a few KB that live in LDS;
-//   * the 32 x 80 mel tile stays in LDS and is the A operand of the pseudo-inverse on the fp32 matrix cores
-//     (v_mfma_f32_32x32x2_f32, 40 k-steps per 32 x 32 output block, 17 blocks over 8 waves); P arrives TRANSPOSED
-//     ([80][513]) so that the 32 lanes of a k-step read 128 contiguous bytes of L2 (with P as stored, [513][80], the
-//     same fragment is 32 different cache lines per instruction: measured 0.59 ms instead of ... for 131 072 frames);
+//     a multiple of 4), a few KB that live in LDS for the whole launch;
+//   * the 32 x 80 mel tile (in LDS, over the magnitudes it came from) is the A operand of the pseudo-inverse on the
+//     fp32 matrix cores (v_mfma_f32_32x32x2_f32, 40 k-steps per 32 x 32 output block, 17 blocks over 8 waves); the
+//     pseudo-inverse is the STATIONARY operand: every wave keeps the columns of its 2-3 output blocks in registers for
+//     the whole launch (P arrives transposed, [80][513], so that this one-time load reads 128 contiguous bytes per
+//     k-step; re-fetched per tile it was 680 four-byte loads per tile, more vector-memory instructions than everything
+//     else together);
 //   * algorithmic HBM bytes per frame: 2 052 read + 320 + 2 052 written.
+// Measured for 131 072 frames (tools/micro/melpinv_time.py): 223 us (2.6 TB/s algorithmic) against 650-680 us for the
+// two projection launches; steps on the way: per-lane (frame, band) with the band fastest 580 us, load -> ds_write loop
+// 560, DMA + packed weights 328, 8 waves + prefetched operand 271, persistent + stationary operand 223.  The floor is
+// ~100 us of HBM time next to ~90 us of fp32 MFMA time.
 #include "common.h"
+
+#ifndef ADVOC_MELPINV_WAVES
+#define ADVOC_MELPINV_WAVES 8
+#endif
 
 namespace {
 
@@ -25,116 +37,138 @@ constexpr int kBins = 513, kMels = 80, kFrames = 32;
 constexpr int kMagPitch = 513;         // floats per LDS row of magnitudes: the tile is a linear copy (LDS-DMA)
 constexpr int kMelPitch = 81;          // floats per LDS row of the mel tile (odd: the A-fragment reads walk rows)
 constexpr int kNBlocks = (kBins + 31) / 32;   // 17 output blocks of 32 bins
-constexpr int kWaves = 8, kThreads = 64 * kWaves;   // 2 workgroups per CU: 4 waves per SIMD to hide the L2 / LDS latencies
+constexpr int kWaves = ADVOC_MELPINV_WAVES, kThreads = 64 * kWaves;   // one persistent workgroup per CU
 constexpr int kMagFloats = (kFrames * kBins + 63) / 64 * 64;   // the DMA writes whole 64-lane blocks
-constexpr int kMaxW = 4096;            // packed filterbank weights the kernel takes (the reference's bank has ~1 100)
+constexpr int kMaxW = 2048;            // packed filterbank weights the kernel takes (the reference's bank has ~1 100)
 
-__global__ __launch_bounds__(kThreads, 2) void mel_pinv_kernel(const float* __restrict__ mag, const float* __restrict__ mel_wp,
+__global__ __launch_bounds__(kThreads, 1) void mel_pinv_kernel(const float* __restrict__ mag, const float* __restrict__ mel_wp,
                                                           const int2* __restrict__ band, const float* __restrict__ inv_wt,
                                                           float* __restrict__ mel_out, float* __restrict__ inv_out,
-                                                          int64_t rows, int packed) {
+                                                          int64_t rows, int packed, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_mag = sm;                                   // [32][513] + slack to a whole DMA block
-  float* s_mel = sm + kMagFloats;                      // [32][81]
+  float* s_mel = sm;                                   // [32][81], over the magnitudes once the mel phase has read them
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t r0 = (int64_t)blockIdx.x * kFrames;
-  const int nrows = rows - r0 < kFrames ? (int)(rows - r0) : kFrames;
-  float* s_w = s_mel + kFrames * kMelPitch;            // the filterbank's runs of weights, packed (<= kMaxW floats)
+  float* s_w = sm + kMagFloats;                        // the filterbank's runs of weights, packed (<= kMaxW floats)
   int* s_band = reinterpret_cast<int*>(s_w + kMaxW);   // [3][80]: first bin, run length / 4, offset into s_w
+  const int l32 = lane & 31, half = lane >> 5;
 
-  // ---- magnitudes and packed weights -> LDS by LDS-DMA (buffer_load_dword ... lds: 256 contiguous bytes per
-  // instruction, no registers, every instruction of a thread in flight at once; a plain load -> ds_write loop waits one
-  // memory latency per iteration: 0.56 ms for 131 072 frames).  The tile is a linear copy, row pitch 513 floats: the 32
-  // frames of a band step fall on 32 different banks.  Rows past the end of the tensor are beyond num_records and
-  // arrive as zeros, and so does the slack behind the tile (the padded runs may read up to 3 floats of it). ----
+  const int64_t bytes = rows * kBins * 4;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(mag), 0, bytes > 0xffffffffLL ? (int)0xffffffff : (int)bytes, 0x00020000);
+  // Magnitudes of tile T -> LDS by LDS-DMA (buffer_load_dword ... lds: 256 contiguous bytes per instruction, no
+  // registers, every instruction of a thread in flight at once; a plain load -> ds_write loop waits one memory latency
+  // per iteration: 0.56 ms for 131 072 frames).  The tile is a linear copy, row pitch 513 floats: the 32 frames of a
+  // band step fall on 32 different banks.  Rows past the end of the tensor are beyond num_records and arrive as zeros,
+  // and so does the slack behind the tile (the padded runs may read up to 3 floats of it).
+#define ADVOC_MP_LOAD(T)                                                                                 \
+  {                                                                                                      \
+    const unsigned base_ = (unsigned)((int64_t)(T) * kFrames * kBins * 4);       /* < 2^32 (launcher) */  \
+    for (int c = wave; c < kMagFloats / 64; c += kWaves) {                                               \
+      const bool in_tile_ = c * 64 + lane < kFrames * kBins;                                             \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_p)(s_mag + c * 64), 4,                      \
+                                               in_tile_ ? (int)(base_ + (unsigned)(c * 64 + lane) * 4u)  \
+                                                        : (int)0xffffffff, 0, 0, 0);                     \
+    }                                                                                                    \
+  }
+
+  // ---- once per workgroup (it walks tiles): the packed filterbank runs -> LDS, the pseudo-inverse columns of this
+  // wave's output blocks -> REGISTERS (the stationary operand: re-fetching them per tile was 680 four-byte loads per
+  // tile, more vector-memory instructions than everything else together) ----
+  int tile = blockIdx.x;
+  if (tile < ntiles) ADVOC_MP_LOAD(tile);
   {
-    const int64_t bytes = rows * kBins * 4;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(mag), 0, bytes > 0xffffffffLL ? (int)0xffffffff : (int)bytes, 0x00020000);
-    const int64_t base = r0 * kBins * 4;                // < 2^32 (launcher)
-    for (int c = wave; c < kMagFloats / 64; c += kWaves) {
-      const unsigned off = (unsigned)base + (unsigned)(c * 64 + lane) * 4u;
-      const bool in_tile = c * 64 + lane < kFrames * kBins;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_p)(s_mag + c * 64), 4,
-                                               in_tile ? (int)off : (int)0xffffffff, 0, 0, 0);
-    }
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(mel_wp), 0, packed * 4, 0x00020000);
     for (int c = wave; c * 64 < packed; c += kWaves)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_p)(s_w + c * 64), 4, (c * 64 + lane) * 4, 0, 0, 0);
   }
-  // meanwhile: the runs (first bin, length) and their offsets in the packed array
   if (tid < kMels) {
-    const int2 b = band[tid];
-    s_band[tid] = b.x;
-    s_band[kMels + tid] = (b.y - b.x + 3) >> 2;         // runs are padded to multiples of 4 with zero weights
+    const int2 bnd = band[tid];
+    s_band[tid] = bnd.x;
+    s_band[kMels + tid] = (bnd.y - bnd.x + 3) >> 2;     // runs are padded to multiples of 4 with zero weights
+  }
+  constexpr int kBPW = (kNBlocks + kWaves - 1) / kWaves;      // output blocks per wave: 3 (wave 0) or 2
+  float b[kBPW][kMels / 2];                            // lane (l32, half): P^T[k = 2 j + half][n = 32 nb + l32]
+#pragma unroll
+  for (int q = 0; q < kBPW; ++q) {
+    const int n = (wave + q * kWaves) * 32 + l32;
+    const float* pcol = inv_wt + (n < kBins ? n : kBins - 1) + half * kBins;
+#pragma unroll
+    for (int j = 0; j < kMels / 2; ++j) b[q][j] = wave + q * kWaves < kNBlocks ? pcol[(2 * j) * kBins] : 0.f;
   }
   __syncthreads();
-  if (tid < kMels) {                                   // offset of run m (independent LDS reads)
+  if (tid < kMels) {                                   // offset of run m in the packed array (independent LDS reads)
     int off = 0;
     for (int m = 0; m < tid; ++m) off += s_band[kMels + m];
     s_band[2 * kMels + tid] = off * 4;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 
-  // ---- mel = mag W^T on the bands' runs of bins.  Thread -> (band, frame) with the FRAME fastest: the 32 lanes of a
-  // half wave share one band, so its weights are an LDS broadcast and the run length is uniform ----
-  for (int o = tid; o < kFrames * kMels; o += kThreads) {
-    const int m = o >> 5, f = o & 31;
-    const int lo = s_band[m], n4 = s_band[kMels + m], wo = s_band[2 * kMels + m];
-    const float* x = s_mag + f * kMagPitch + lo;
-    const float* w = s_w + wo;
-    float acc = 0.f;
-    for (int k = 0; k < n4; ++k) {
-      const float x0 = x[4 * k], x1 = x[4 * k + 1], x2 = x[4 * k + 2], x3 = x[4 * k + 3];
-      const float4 w4 = *reinterpret_cast<const float4*>(w + 4 * k);
-      acc = fmaf(x0, w4.x, acc); acc = fmaf(x1, w4.y, acc); acc = fmaf(x2, w4.z, acc); acc = fmaf(x3, w4.w, acc);
-    }
-    s_mel[f * kMelPitch + m] = acc;
-  }
-  __syncthreads();
-  {
-    float* dst = mel_out + r0 * kMels;                  // the tile's 32 x 80 outputs are contiguous
-    for (int i = tid; i < nrows * kMels; i += kThreads) dst[i] = s_mel[(i / kMels) * kMelPitch + (i % kMels)];
-  }
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = (int64_t)tile * kFrames;
+    const int nrows = rows - r0 < kFrames ? (int)(rows - r0) : kFrames;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
-  // ---- inv = mel P^T: fp32 MFMA 32x32x2.  Lane (l32, half): A[m = l32][k = 2 j + half], B[k = 2 j + half][n = l32] ----
-  const int l32 = lane & 31, half = lane >> 5;
-  float a[kMels / 2];
+    // ---- mel = mag W^T on the bands' runs of bins.  Thread -> (band, frame) with the FRAME fastest: the 32 lanes of a
+    // half wave share one band, so its weights are an LDS broadcast and the run length is uniform ----
+    constexpr int kOutPerThread = (kFrames * kMels + kThreads - 1) / kThreads;
+    float macc[kOutPerThread];
 #pragma unroll
-  for (int j = 0; j < kMels / 2; ++j) a[j] = s_mel[l32 * kMelPitch + 2 * j + half];
-  // the B operand of the NEXT block is fetched under the MFMAs of the current one
-  float b[kMels / 2], bn[kMels / 2];
-  {
-    const int n = wave * 32 + l32;
-    const float* pcol = inv_wt + (n < kBins ? n : kBins - 1) + half * kBins;      // P^T[k = half][n]
-#pragma unroll
-    for (int j = 0; j < kMels / 2; ++j) b[j] = pcol[(2 * j) * kBins];              // k = 2 j + half
-  }
-  for (int nb = wave; nb < kNBlocks; nb += kWaves) {
-    const int n = nb * 32 + l32;
-    if (nb + kWaves < kNBlocks) {
-      const int nn = n + kWaves * 32;
-      const float* pcol = inv_wt + (nn < kBins ? nn : kBins - 1) + half * kBins;
-#pragma unroll
-      for (int j = 0; j < kMels / 2; ++j) bn[j] = pcol[(2 * j) * kBins];
+    for (int t = 0; t < kOutPerThread; ++t) {
+      const int o = tid + t * kThreads;
+      float acc = 0.f;
+      if (o < kFrames * kMels) {
+        const int m = o >> 5, f = o & 31;
+        const int lo = s_band[m], n4 = s_band[kMels + m], wo = s_band[2 * kMels + m];
+        const float* x = s_mag + f * kMagPitch + lo;
+        const float* w = s_w + wo;
+        for (int k = 0; k < n4; ++k) {
+          const float x0 = x[4 * k], x1 = x[4 * k + 1], x2 = x[4 * k + 2], x3 = x[4 * k + 3];
+          const float4 w4 = *reinterpret_cast<const float4*>(w + 4 * k);
+          acc = fmaf(x0, w4.x, acc); acc = fmaf(x1, w4.y, acc); acc = fmaf(x2, w4.z, acc); acc = fmaf(x3, w4.w, acc);
+        }
+      }
+      macc[t] = acc;
     }
-    floatx16 acc;
+    __syncthreads();                                    // every read of the magnitudes is done: the mel tile takes their place
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = 0; t < kOutPerThread; ++t) {
+      const int o = tid + t * kThreads;
+      if (o < kFrames * kMels) s_mel[(o & 31) * kMelPitch + (o >> 5)] = macc[t];
+    }
+    __syncthreads();
+    {
+      float* dst = mel_out + r0 * kMels;                // the tile's 32 x 80 outputs are contiguous
+      for (int i = tid; i < nrows * kMels; i += kThreads) dst[i] = s_mel[(i / kMels) * kMelPitch + (i % kMels)];
+    }
+
+    // ---- inv = mel P^T: fp32 MFMA 32x32x2.  Lane (l32, half): A[m = l32][k = 2 j + half] ----
+    float a[kMels / 2];
 #pragma unroll
-    for (int j = 0; j < kMels / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
-    if (n < kBins) {
+    for (int j = 0; j < kMels / 2; ++j) a[j] = s_mel[l32 * kMelPitch + 2 * j + half];
+    __syncthreads();                                    // the mel tile is in registers: the next tile's magnitudes may land
+    if (tile + (int)gridDim.x < ntiles) ADVOC_MP_LOAD(tile + (int)gridDim.x);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (f < nrows) inv_out[(r0 + f) * kBins + n] = acc[r];
+    for (int q = 0; q < kBPW; ++q) {
+      const int nb = wave + q * kWaves;
+      if (nb >= kNBlocks) break;
+      floatx16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < kMels / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[q][j], acc, 0, 0, 0);
+      const int n = nb * 32 + l32;
+      if (n < kBins) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (f < nrows) inv_out[(r0 + f) * kBins + n] = acc[r];
+        }
       }
     }
-#pragma unroll
-    for (int j = 0; j < kMels / 2; ++j) b[j] = bn[j];
   }
+#undef ADVOC_MP_LOAD
 }
 
 }  // namespace
@@ -149,14 +183,27 @@ extern "C" int advoc_mel_pinv_f32(const float* mag, const float* mel_wp, const i
   if (rows == 0) return ADVOC_OK;
   const int64_t blocks = advoc::ceil_div(rows, kFrames);
   if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
-  constexpr int lds = (kMagFloats + kFrames * kMelPitch + kMaxW + 3 * kMels) * (int)sizeof(float);
+  constexpr int lds = (kMagFloats + kMaxW + 3 * kMels) * (int)sizeof(float);
+  static_assert(kFrames * kMelPitch <= kMagFloats && lds <= 160 * 1024, "LDS budget");
   if (rows * kBins * 4 > 0xffffffffLL) return ADVOC_ERR_UNSUPPORTED;         // 32-bit buffer offsets
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_pinv_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (attr != hipSuccess) { advoc::note_hip_error(attr); return ADVOC_ERR_HIP; }
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(mel_pinv_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, advoc::as_stream(stream), mag, mel_wp,
-                     reinterpret_cast<const int2*>(band_lo_hi), inv_wt, mel_out, inv_out, rows, (int)packed_weights);
+  // persistent workgroups: one per CU (the stationary operand takes the registers), each walks tiles (blockIdx,
+  // blockIdx + grid, ...) and fetches the next tile's magnitudes under the current tile's MFMAs
+  static const int resident = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    int n = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    (void)hipGetLastError();
+    return n > 0 ? n : 256;
+  }();
+  const int64_t grid = blocks < resident ? blocks : resident;
+  hipLaunchKernelGGL(mel_pinv_kernel, dim3((unsigned)grid), dim3(kThreads), lds, advoc::as_stream(stream), mag, mel_wp,
+                     reinterpret_cast<const int2*>(band_lo_hi), inv_wt, mel_out, inv_out, rows, (int)packed_weights,
+                     (int)blocks);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }

@@ -149,7 +149,7 @@ int advoc_matmul_nt_f32(const float* x, const float* w, float* out, int64_t rows
  *   [bins, n_mels] of spectral_util.py:26-27 TRANSPOSED: the kernel reads it along the bins)
  *   mel_out [rows, n_mels]  inv_out [rows, bins]        float32, dense row-major, device memory
  * packed_weights = floats in mel_wp (a multiple of 4).
- * bins = 513, n_mels = 80 (the reference's extractor) and packed_weights <= 4096; anything else:
+ * bins = 513, n_mels = 80 (the reference's extractor) and packed_weights <= 2048; anything else:
  * ADVOC_ERR_UNSUPPORTED, use advoc_matmul_nt_f32 twice. */
 int advoc_mel_pinv_f32(const float* mag, const float* mel_wp, const int32_t* band_lo_hi, const float* inv_wt,
                        float* mel_out, float* inv_out, int64_t rows, int32_t bins, int32_t n_mels,
