@@ -12,16 +12,21 @@
 //     frame on the vector ALUs; the caller passes the runs' weights PACKED back to back (each run padded with zeros to
 //     a multiple of 4), a few KB that live in LDS for the whole launch;
 //   * the 32 x 80 mel tile (in LDS, over the magnitudes it came from) is the A operand of the pseudo-inverse on the
-//     fp32 matrix cores (v_mfma_f32_32x32x2_f32, 40 k-steps per 32 x 32 output block, 17 blocks over 8 waves); the
-//     pseudo-inverse is the STATIONARY operand: every wave keeps the columns of its 2-3 output blocks in registers for
+//     f16 matrix cores with igemm_h3.hip's arithmetic: every mel ROW under its own power-of-two scale as an fp16 pair,
+//     every pseudo-inverse COLUMN likewise, three products per 32x32x16 step (a0 b1 + a1 b0 + a0 b0), fp32
+//     accumulation, exact unscaling per row and column -- 15 MFMAs of 32 cycles per 32 x 32 output block (17 blocks
+//     over 8 waves) where v_mfma_f32_32x32x2_f32 takes 40 of 64; error against float64 below 5e-6 of the row's
+//     largest output for rows from 1e-6 to 1e3 in one tile (tests/test_hip_spectral.py).  The pseudo-inverse is the STATIONARY operand: every wave keeps the columns of its 2-3 output blocks in registers for
 //     the whole launch (P arrives transposed, [80][513], so that this one-time load reads 128 contiguous bytes per
 //     k-step; re-fetched per tile it was 680 four-byte loads per tile, more vector-memory instructions than everything
 //     else together);
 //   * algorithmic HBM bytes per frame: 2 052 read + 320 + 2 052 written.
-// Measured for 131 072 frames (tools/micro/melpinv_time.py): 223 us (2.6 TB/s algorithmic) against 650-680 us for the
+// Measured for 131 072 frames (tools/micro/melpinv_time.py): 168 us (3.5 TB/s algorithmic) against 650-680 us for the
 // two projection launches; steps on the way: per-lane (frame, band) with the band fastest 580 us, load -> ds_write loop
-// 560, DMA + packed weights 328, 8 waves + prefetched operand 271, persistent + stationary operand 223.  The floor is
-// ~100 us of HBM time next to ~90 us of fp32 MFMA time.
+// 560, DMA + packed weights 328, 8 waves + prefetched operand 271, persistent + stationary operand 223 (fp32 MFMA: ~90 us
+// of matrix-pipe time per launch), fp16 pairs 168 us = 3.5 TB/s algorithmic.  The floor is ~100 us of HBM time.
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 #ifndef ADVOC_MELPINV_WAVES
@@ -31,6 +36,7 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_void_p;
 
 constexpr int kBins = 513, kMels = 80, kFrames = 32;
@@ -40,6 +46,27 @@ constexpr int kNBlocks = (kBins + 31) / 32;   // 17 output blocks of 32 bins
 constexpr int kWaves = ADVOC_MELPINV_WAVES, kThreads = 64 * kWaves;   // one persistent workgroup per CU
 constexpr int kMagFloats = (kFrames * kBins + 63) / 64 * 64;   // the DMA writes whole 64-lane blocks
 constexpr int kMaxW = 2048;            // packed filterbank weights the kernel takes (the reference's bank has ~1 100)
+
+// power of two that takes `amax` into [2^13, 2^14) (1 for zero / non-finite): x * up = h0 + h1 in fp16 to 2^-22 of amax
+__device__ __forceinline__ float pair_scale(float amax) {
+  const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  if (e == 0 || e == 255) return 1.f;
+  int sh = 13 - (e - 127);
+  sh = sh > 120 ? 120 : (sh < -120 ? -120 : sh);
+  return __uint_as_float((unsigned)(sh + 127) << 23);
+}
+__device__ __forceinline__ void pair_split8(const float* v, float up, f16x8& h0, f16x8& h1) {
+  __half2 p0[4], p1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i] * up, b = v[2 * i + 1] * up;
+    const __half a0 = __float2half_rn(a), b0 = __float2half_rn(b);
+    p0[i] = __halves2half2(a0, b0);
+    p1[i] = __halves2half2(__float2half_rn(a - __half2float(a0)), __float2half_rn(b - __half2float(b0)));
+  }
+  h0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(p0));
+  h1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(p1));
+}
 
 __global__ __launch_bounds__(kThreads, 1) void mel_pinv_kernel(const float* __restrict__ mag, const float* __restrict__ mel_wp,
                                                           const int2* __restrict__ band, const float* __restrict__ inv_wt,
@@ -89,13 +116,32 @@ __global__ __launch_bounds__(kThreads, 1) void mel_pinv_kernel(const float* __re
     s_band[kMels + tid] = (bnd.y - bnd.x + 3) >> 2;     // runs are padded to multiples of 4 with zero weights
   }
   constexpr int kBPW = (kNBlocks + kWaves - 1) / kWaves;      // output blocks per wave: 3 (wave 0) or 2
-  float b[kBPW][kMels / 2];                            // lane (l32, half): P^T[k = 2 j + half][n = 32 nb + l32]
+  constexpr int kSteps = kMels / 16;                   // 5 MFMA k-steps of 16 mel bands
+  // lane (l32, half) of a 32x32x16 MFMA holds k = 16 s + 8 half + 0..7 of row / column l32.  The pseudo-inverse column
+  // of output bin n as an fp16 PAIR under its own power-of-two scale (igemm_h3.hip's arithmetic: x 2^s = h0 + h1 to
+  // 2^-22, three products a0 b1 + a1 b0 + a0 b0, fp32 accumulation, exact unscaling): 15 MFMAs of 32 cycles per output
+  // block instead of 40 fp32 MFMAs of 64
+  f16x8 b0[kBPW][kSteps], b1[kBPW][kSteps];
+  float inv_sb[kBPW];
 #pragma unroll
   for (int q = 0; q < kBPW; ++q) {
     const int n = (wave + q * kWaves) * 32 + l32;
-    const float* pcol = inv_wt + (n < kBins ? n : kBins - 1) + half * kBins;
+    const bool live = wave + q * kWaves < kNBlocks;
+    const float* pcol = inv_wt + (n < kBins ? n : kBins - 1);
+    float v[kSteps][8];
+    float amax = 0.f;
 #pragma unroll
-    for (int j = 0; j < kMels / 2; ++j) b[q][j] = wave + q * kWaves < kNBlocks ? pcol[(2 * j) * kBins] : 0.f;
+    for (int st = 0; st < kSteps; ++st)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[st][i] = live ? pcol[(16 * st + 8 * half + i) * kBins] : 0.f;
+        amax = fmaxf(amax, fabsf(v[st][i]));
+      }
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));       // the other half of the column's 80 values
+    const float up = pair_scale(amax);
+    inv_sb[q] = 1.f / up;
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) pair_split8(v[st], up, b0[q][st], b1[q][st]);
   }
   __syncthreads();
   if (tid < kMels) {                                   // offset of run m in the packed array (independent LDS reads)
@@ -143,10 +189,29 @@ __global__ __launch_bounds__(kThreads, 1) void mel_pinv_kernel(const float* __re
       for (int i = tid; i < nrows * kMels; i += kThreads) dst[i] = s_mel[(i / kMels) * kMelPitch + (i % kMels)];
     }
 
-    // ---- inv = mel P^T: fp32 MFMA 32x32x2.  Lane (l32, half): A[m = l32][k = 2 j + half] ----
-    float a[kMels / 2];
+    // ---- inv = mel P^T on the f16 matrix cores: the mel row of frame l32 as an fp16 pair under the ROW's own scale ----
+    f16x8 a0[kSteps], a1[kSteps];
+    float inv_sa;
+    {
+      float v[kSteps][8];
+      float amax = 0.f;
 #pragma unroll
-    for (int j = 0; j < kMels / 2; ++j) a[j] = s_mel[l32 * kMelPitch + 2 * j + half];
+      for (int st = 0; st < kSteps; ++st)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[st][i] = s_mel[l32 * kMelPitch + 16 * st + 8 * half + i];
+          amax = fmaxf(amax, fabsf(v[st][i]));
+        }
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      const float up = pair_scale(amax);
+      inv_sa = 1.f / up;
+#pragma unroll
+      for (int st = 0; st < kSteps; ++st) pair_split8(v[st], up, a0[st], a1[st]);
+    }
+    // accumulator register r of this lane is frame f(r) = (r & 3) + 8 (r >> 2) + 4 half: its row's unscale factor
+    float unrow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) unrow[r] = __shfl(inv_sa, (r & 3) + 8 * (r >> 2) + 4 * half, 64);
     __syncthreads();                                    // the mel tile is in registers: the next tile's magnitudes may land
     if (tile + (int)gridDim.x < ntiles) ADVOC_MP_LOAD(tile + (int)gridDim.x);
 #pragma unroll
@@ -157,13 +222,17 @@ __global__ __launch_bounds__(kThreads, 1) void mel_pinv_kernel(const float* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int j = 0; j < kMels / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[q][j], acc, 0, 0, 0);
+      for (int st = 0; st < kSteps; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[st], b1[q][st], acc, 0, 0, 0);
+#pragma unroll
+      for (int st = 0; st < kSteps; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[st], b0[q][st], acc, 0, 0, 0);
+#pragma unroll
+      for (int st = 0; st < kSteps; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[st], b0[q][st], acc, 0, 0, 0);
       const int n = nb * 32 + l32;
       if (n < kBins) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (f < nrows) inv_out[(r0 + f) * kBins + n] = acc[r];
+          if (f < nrows) inv_out[(r0 + f) * kBins + n] = acc[r] * (unrow[r] * inv_sb[q]);
         }
       }
     }
