@@ -89,8 +89,17 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
 // weights: plain max |w| (any layout)
 __global__ __launch_bounds__(256) void amax_flat_kernel(const float* __restrict__ w, int64_t n, unsigned* __restrict__ amax) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(w[i]));
+  // 16-byte loads over the aligned body (weight tensors come from 16-byte aligned arena entries; checked), the tail
+  // element by element
+  const int64_t n4 = (reinterpret_cast<uintptr_t>(w) & 15) == 0 ? n >> 2 : 0;
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  for (int64_t i = tid; i < n4; i += stride) {
+    const float4 v = w4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (int64_t i = 4 * n4 + tid; i < n; i += stride) m = fmaxf(m, fabsf(w[i]));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   __shared__ float red[4];
@@ -384,7 +393,7 @@ int launch_pair_weights(const float* w, uint16_t* wq, int taps, int n_total, int
   if (ktot % 32) return ADVOC_ERR_UNSUPPORTED;
   const int64_t n = (int64_t)taps * n_total * ktot;
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(amax_flat_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, stream, w, n, hdr);
+  hipLaunchKernelGGL(amax_flat_kernel, dim3(grid_for(n, 256 * 16)), dim3(256), 0, stream, w, n, hdr);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   int64_t blocks = (int64_t)taps * (ktot / 32) * ((n_total + 31) / 32);
   if (blocks > 4096) blocks = 4096;
