@@ -1,6 +1,7 @@
-// Patch gather-GEMM on operand images: the stride-1 gathers of the model (transposed-conv forward and conv
-// backward-data as four sub-pixel phases of 2x2 taps; the 4x4 stride-1 convolution of the discriminator's layer_4
-// in both directions) with the A operand read ONCE per workgroup instead of once per tap.
+// Patch gather-GEMM on operand images: every gather of the model on a grid of at least 16 x 16 points (transposed-conv
+// forward and conv backward-data as four sub-pixel phases of 2x2 taps; the 4x4 stride-1 convolution of the
+// discriminator's layer_4 in both directions; the 4x4 stride-2 gathers -- conv forward, transposed-conv backward-data --
+// as four parity planes of the input) with the A operand read ONCE per workgroup instead of once per tap.
 //
 // Same arithmetic and operand images as igemm_h3.hip (fp16 pairs, three MFMA products per fp32 product, replaces the
 // cuDNN / Eigen Conv2DBackpropInput / Conv2D kernels TF1 runs for models/advoc/advoc_model.py:25-69,185-199).  What
@@ -24,7 +25,8 @@
 // blocks of 2 patch rows x 16 columns a group is columns {0-3, 12-15} of one row and {4-11} of the next, i.e. 16
 // different columns, and (address bit 7, position) -- the 16-byte slot of the 256-byte bank row -- is different for
 // each of them whatever the tap offset and the halo width (a swizzle by the linear pixel index is 2-way conflicted
-// whenever the halo width is not a multiple of 16: measured 450 -> ... TFLOP/s with the DMAs ablated).
+// whenever the halo pitch is odd: 25 % of the LDS cycles of the 4x4 kernel were replays, 450 -> 510 TFLOP/s with the
+// DMAs ablated once fixed).
 #include <string>
 
 #include "common.h"
