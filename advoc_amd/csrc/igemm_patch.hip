@@ -409,58 +409,66 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       gs4 = *reinterpret_cast<const float4*>(gsc + ch);
       gh4 = *reinterpret_cast<const float4*>(gsh + ch);
     }
+    // Loads and stores retire through ONE in-order counter here, so a global load placed after a store waits for the
+    // store's round trip: the plain per-row load -> wait -> store chain costs one memory latency per 16 bytes (measured:
+    // 2/3 of the time of the 64-column backward-data launches).  Per 32-row block ALL global loads (pre-activation values,
+    // masks, the value to add to) are issued together, and those of block i + 1 go out BEFORE the stores of block i
+    // (their registers are free once block i's values are computed).  Rows that store nothing load from pixel 0.
+    int off[4];
+    float4 xp[4], old[4];
+    uchar4 mk[4];
+#define ADVOC_P3_PRELOAD(I)                                                                               \
+    _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                    \
+      const int pix = s_pix[di * PW_ + (I) * 32 + trow + 8 * ps];                                         \
+      off[ps] = pix < 0 ? -1 : pix * d_c + ch;                                                            \
+      const int lo = pix < 0 ? ch : off[ps];                                                              \
+      if (BWD) {                                                                                          \
+        if (use_grad) xp[ps] = *reinterpret_cast<const float4*>(d_xpre + lo);                             \
+        if (d_gmask) mk[ps] = *reinterpret_cast<const uchar4*>(d_gmask + lo);                             \
+        if (d_accum) old[ps] = *reinterpret_cast<const float4*>(dp + lo);                                 \
+      } else {                                                                                            \
+        if (p.y_mask) mk[ps] = *reinterpret_cast<const uchar4*>(p.y_mask + lo);                           \
+      }                                                                                                   \
+    }
+    ADVOC_P3_PRELOAD(0);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      // ALL global loads of the block (pre-activation values, masks, the value to add to) are issued before anything is
-      // used or stored: loads and stores retire through one in-order counter here, so a load placed after a store
-      // waits for the store's round trip, and the plain per-row load -> wait -> store chain costs one memory latency
-      // per 16 bytes (measured: 2/3 of the time of the 64-column backward-data launches).  Rows that store nothing
-      // load from pixel 0.
-      int off[4];
-      float4 xp[4], old[4];
-      uchar4 mk[4];
-#pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        const int pix = s_pix[di * PW_ + i * 32 + trow + 8 * ps];
-        off[ps] = pix < 0 ? -1 : pix * d_c + ch;
-        const int lo = pix < 0 ? ch : off[ps];
-        if (BWD) {
-          if (use_grad) xp[ps] = *reinterpret_cast<const float4*>(d_xpre + lo);
-          if (d_gmask) mk[ps] = *reinterpret_cast<const uchar4*>(d_gmask + lo);
-          if (d_accum) old[ps] = *reinterpret_cast<const float4*>(dp + lo);
-        } else {
-          if (p.y_mask) mk[ps] = *reinterpret_cast<const uchar4*>(p.y_mask + lo);
-        }
-      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * half_e) * LDT + l32_e] = acc[i][j][r];
       wave_lds_sync();
+      float4 v[4];
+      int so[4];
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
-        float4 v = *reinterpret_cast<const float4*>(T + (trow + 8 * ps) * LDT + 4 * tq);
-        v.x = fmaf(v.x, unscale, bias4.x); v.y = fmaf(v.y, unscale, bias4.y);
-        v.z = fmaf(v.z, unscale, bias4.z); v.w = fmaf(v.w, unscale, bias4.w);
+        v[ps] = *reinterpret_cast<const float4*>(T + (trow + 8 * ps) * LDT + 4 * tq);
+        v[ps].x = fmaf(v[ps].x, unscale, bias4.x); v[ps].y = fmaf(v[ps].y, unscale, bias4.y);
+        v[ps].z = fmaf(v[ps].z, unscale, bias4.z); v[ps].w = fmaf(v[ps].w, unscale, bias4.w);
         if (!BWD && p.y_mask) {
-          v.x *= mk[ps].x * p.y_mask_scale; v.y *= mk[ps].y * p.y_mask_scale;
-          v.z *= mk[ps].z * p.y_mask_scale; v.w *= mk[ps].w * p.y_mask_scale;
+          v[ps].x *= mk[ps].x * p.y_mask_scale; v[ps].y *= mk[ps].y * p.y_mask_scale;
+          v[ps].z *= mk[ps].z * p.y_mask_scale; v[ps].w *= mk[ps].w * p.y_mask_scale;
         }
         if (use_grad) {
           float4 x = xp[ps];
           x.x = x.x * gs4.x + gh4.x; x.y = x.y * gs4.y + gh4.y; x.z = x.z * gs4.z + gh4.z; x.w = x.w * gs4.w + gh4.w;
-          v.x *= x.x > 0.f ? 1.f : gslope; v.y *= x.y > 0.f ? 1.f : gslope;
-          v.z *= x.z > 0.f ? 1.f : gslope; v.w *= x.w > 0.f ? 1.f : gslope;
+          v[ps].x *= x.x > 0.f ? 1.f : gslope; v[ps].y *= x.y > 0.f ? 1.f : gslope;
+          v[ps].z *= x.z > 0.f ? 1.f : gslope; v[ps].w *= x.w > 0.f ? 1.f : gslope;
         }
         if (BWD && d_gmask) {
-          v.x *= mk[ps].x * d_gmask_scale; v.y *= mk[ps].y * d_gmask_scale;
-          v.z *= mk[ps].z * d_gmask_scale; v.w *= mk[ps].w * d_gmask_scale;
+          v[ps].x *= mk[ps].x * d_gmask_scale; v[ps].y *= mk[ps].y * d_gmask_scale;
+          v[ps].z *= mk[ps].z * d_gmask_scale; v[ps].w *= mk[ps].w * d_gmask_scale;
         }
         if (BWD && d_accum) {
-          v.x += old[ps].x; v.y += old[ps].y; v.z += old[ps].z; v.w += old[ps].w;
+          v[ps].x += old[ps].x; v[ps].y += old[ps].y; v[ps].z += old[ps].z; v[ps].w += old[ps].w;
         }
-        if (off[ps] >= 0) *reinterpret_cast<float4*>(dp + off[ps]) = v;
+        so[ps] = off[ps];
       }
+      if (i + 1 < MT) { ADVOC_P3_PRELOAD(i + 1); }
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps)
+        if (so[ps] >= 0) *reinterpret_cast<float4*>(dp + so[ps]) = v[ps];
       wave_lds_sync();
     }
+#undef ADVOC_P3_PRELOAD
   }
   if (BWD) break;
   __syncthreads();          // the next tile's DMAs overwrite the LDS this epilogue read
