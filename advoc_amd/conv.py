@@ -94,7 +94,7 @@ class Layer(object):
 
   def __init__(self, kind, x0, y, weight, bias=None, x1=None, in_w=None, out_w=None, stride=(2, 2),
                pad=(1, 1), in_act=ACT_NONE, drop_mask=None, drop_scale=0., in_scale=None,
-               in_shift=None, in_mask=None, in_mask_scale=0., workspace=True):
+               in_shift=None, in_mask=None, in_mask_scale=0., workspace=True, w_amax=None):
     kh, kw = int(weight.shape[0]), int(weight.shape[1])
     cin = x0.shape[3] + (x1.shape[3] if x1 is not None else 0)
     cout = y.shape[3]
@@ -103,9 +103,11 @@ class Layer(object):
       raise _lib.AdvocHipError('kernel shape {} != {}'.format(tuple(weight.shape), want))
     if bias is not None and tuple(bias.shape) != (cout,):
       raise _lib.AdvocHipError('bias shape {} != ({},)'.format(tuple(bias.shape), cout))
-    for t in (weight, bias, drop_mask, in_scale, in_shift, in_mask):
+    for t in (weight, bias, drop_mask, in_scale, in_shift, in_mask, w_amax):
       if t is not None:
         _lib.require_device(t)
+    if w_amax is not None and (w_amax.dtype != torch.int32 or w_amax.numel() != 1):
+      raise _lib.AdvocHipError('w_amax must be one int32 (float bits of max |kernel|, advoc_segmented_amax_f32)')
     if in_mask is not None and (in_mask.dtype != torch.uint8 or tuple(in_mask.shape) != tuple(x0.shape)):
       raise _lib.AdvocHipError('input mask must be uint8 with the shape of x0')
     if in_scale is not None and (tuple(in_scale.shape) != (cin,) or tuple(in_shift.shape) != (cin,)):
@@ -113,7 +115,7 @@ class Layer(object):
     if drop_mask is not None and (drop_mask.dtype != torch.uint8 or tuple(drop_mask.shape) != tuple(y.shape)):
       raise _lib.AdvocHipError('dropout mask must be uint8 with the shape of y')
     self.kind = kind
-    self.tensors = (x0, x1, y, weight, bias, drop_mask, in_scale, in_shift, in_mask)
+    self.tensors = (x0, x1, y, weight, bias, drop_mask, in_scale, in_shift, in_mask, w_amax)
     self.x0, self.x1, self.y, self.weight, self.bias = x0, x1, y, weight, bias
     s = _lib.ConvLayer()
     s.kind = kind
@@ -128,6 +130,7 @@ class Layer(object):
     s.y = _t4(y, out_w)
     s.w = _lib.ptr(weight)
     s.b = _lib.ptr(bias)
+    s.w_amax = _lib.ptr(w_amax)
     s.drop_mask = _lib.ptr(drop_mask)
     s.drop_scale = float(drop_scale)
     s.in_mask = _lib.ptr(in_mask)

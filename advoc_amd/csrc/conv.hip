@@ -327,6 +327,7 @@ extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stre
   p.a_img_out = L->x_img; p.a_hdr_out = L->x_img ? L->x_hdr : nullptr;
   p.a_img_current = (L->img_flags & ADVOC_IMG_X_CURRENT) != 0;
   p.a_img_delayed = (L->img_flags & ADVOC_IMG_X_DELAYED) != 0;
+  p.w_amax = L->w_amax;
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
 
@@ -404,6 +405,7 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
   p.a_img_current = (L->img_flags & ADVOC_IMG_DY_CURRENT) != 0;
   p.a_img_delayed = (L->img_flags & ADVOC_IMG_DY_DELAYED) != 0;
   p.a_colsum = L->dy_img ? L->db_fused : nullptr;       // the bias gradient rides in the dy image pass (igemm_h3.hip)
+  p.w_amax = L->w_amax;
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
 

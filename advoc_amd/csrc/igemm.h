@@ -53,6 +53,7 @@ struct GatherGemmParams {
   int tap[kMaxPhases][kMaxTaps];  // (dy & 0xff) | (dx & 0xff) << 8 | wtap << 16
   // ---- B operand ----
   const float* w;
+  const unsigned* w_amax;  // optional: float bits of max |w| already on the device (advoc_segmented_amax_f32)
   int n_total;
   int k_order;             // 0: channel slices inner, taps outer; 1: taps inner
   int n_valid;             // 0 = n_total; else only the first n_valid columns exist in w / are stored

@@ -594,9 +594,11 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   if (!name_only && tuning().h3_skip_prep) {
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
   } else if (!name_only) {
-    hipError_t e = hipMemsetAsync(hdr_b, 0, 8, stream);
-    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
-    int rc = launch_pair_weights(p.w, wq, taps, N, ktot, b_kn, hdr_b, stream);
+    if (!p.w_amax) {
+      hipError_t e = hipMemsetAsync(hdr_b, 0, 8, stream);
+      if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    }
+    int rc = launch_pair_weights(p.w, wq, taps, N, ktot, b_kn, hdr_b, stream, p.w_amax);
     if (rc != ADVOC_OK) return rc;
     if (!(p.a_img_out && p.a_img_current)) {
       // one scale for the whole A operand: the largest magnitude over both sources of a channel concat

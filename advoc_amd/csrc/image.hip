@@ -62,6 +62,15 @@ __device__ __forceinline__ void load8(const float* __restrict__ x, int64_t e, in
   }
 }
 
+// Largest-magnitude words are raised by ONE thread per workgroup, and only when the value it reads from memory is
+// smaller: same-address atomics retire one by one in the L2 (measured ~10 ns each, tools/micro/img_bw.hip: 4096
+// workgroups ending together = a 40 us tail on a 25 us pass).  A stale read can only be smaller than the truth (the word
+// grows monotonically), so a skipped atomic is never a lost maximum.  The launchers keep these grids at kReduceBlocks.
+__device__ __forceinline__ void raise_amax(unsigned* word, float m) {
+  const unsigned bits = __float_as_uint(m);
+  if (m > 0.f && bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, bits);
+}
+
 // amax[0] = max(amax[0], max |transformed x|) as the bit pattern of a non-negative float (orders like an unsigned)
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n8, int c,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (m > 0.f) atomicMax(amax, __float_as_uint(m));
+    raise_amax(amax, m);
   }
 }
 
@@ -107,7 +116,35 @@ __global__ __launch_bounds__(256) void amax_flat_kernel(const float* __restrict_
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (m > 0.f) atomicMax(amax, __float_as_uint(m));
+    raise_amax(amax, m);
+  }
+}
+
+// out[seg] = max |base[off[seg] .. off[seg] + size[seg])| as float bits, for many tensors of one arena in ONE launch
+// (blockIdx.y = tensor, blockIdx.x = slice of it); out zeroed by the launcher
+__global__ __launch_bounds__(256) void segmented_amax_kernel(const float* __restrict__ base, const int64_t* __restrict__ off,
+                                                             const int64_t* __restrict__ size, unsigned* __restrict__ out) {
+  const int seg = blockIdx.y;
+  const float* w = base + off[seg];
+  const int64_t n = size[seg];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float m = 0.f;
+  const int64_t n4 = (reinterpret_cast<uintptr_t>(w) & 15) == 0 ? n >> 2 : 0;
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  for (int64_t i = tid; i < n4; i += stride) {
+    const float4 v = w4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (int64_t i = 4 * n4 + tid; i < n; i += stride) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    raise_amax(out + seg, m);
   }
 }
 
@@ -216,7 +253,7 @@ __global__ __launch_bounds__(256) void pair_image_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
       vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-      if (vmax > 0.f) atomicMax(hdr, __float_as_uint(vmax));
+      raise_amax(hdr, vmax);
     }
     if (sat) atomicAdd(hdr + 3, (unsigned)sat);
   }
@@ -246,14 +283,15 @@ __global__ __launch_bounds__(256) void pair_image_kernel(const float* __restrict
 //   pairs != 0: fp16 pair,   wq[tap][n_total][ktot / 32][plane][32], scaled by the power of two from hdr[0]
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ wq,
                                                             int taps, int n_total, int n_valid, int ktot, int b_kn,
-                                                            int pairs, unsigned* __restrict__ hdr) {
+                                                            int pairs, unsigned* __restrict__ hdr,
+                                                            const unsigned* __restrict__ amax_src) {
   __shared__ float tile[32][33];
   const int tk = (ktot + 31) / 32, tn = (n_total + 31) / 32;
   const int64_t plane = (int64_t)taps * n_total * ktot;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
   float up = 1.f;
   if (pairs) {
-    up = up_scale(hdr[0]);
+    up = up_scale(amax_src ? amax_src[0] : hdr[0]);       // amax_src: the largest |w| from advoc_segmented_amax_f32
     if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = __float_as_uint(1.f / up);
   }
   for (int b = blockIdx.x; b < taps * tk * tn; b += gridDim.x) {
@@ -305,6 +343,13 @@ int grid_for(int64_t items, int per_block) {
   if (blocks > 256 * 16) blocks = 256 * 16;
   return (int)(blocks < 1 ? 1 : blocks);
 }
+// passes that end in one atomic per workgroup (raise_amax): two workgroups per CU stream at the same rate as sixteen
+// (5.2 TB/s on 1 GB, tools/micro/img_bw.hip) and leave an eighth of the atomics
+constexpr int kReduceBlocks = 512;
+int grid_for_reduce(int64_t items, int per_block) {
+  const int g = grid_for(items, per_block);
+  return g > kReduceBlocks ? kReduceBlocks : g;
+}
 
 }  // namespace
 
@@ -314,7 +359,7 @@ int launch_amax(const float* x, int64_t elems, int c, const float* scale, const 
   if (elems <= 0) return ADVOC_OK;
   if (c % 8 || elems % 8) return ADVOC_ERR_UNSUPPORTED;
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(amax_kernel, dim3(grid_for(elems / 8, 256 * 4)), dim3(256), 0, stream, x, elems / 8, c, scale,
+  hipLaunchKernelGGL(amax_kernel, dim3(grid_for_reduce(elems / 8, 256 * 4)), dim3(256), 0, stream, x, elems / 8, c, scale,
                      shift, slope_of(act), mask, mask_scale, amax);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
@@ -338,7 +383,7 @@ int launch_pair_image(const float* x, uint16_t* img, int64_t elems, int c, const
   // (256 threads per block: block size and grid stride are multiples of c / 8 whenever image_colsum_ok(c))
   auto kern = delayed ? (colsum ? pair_image_kernel<true, true> : pair_image_kernel<true, false>)
                       : (colsum ? pair_image_kernel<false, true> : pair_image_kernel<false, false>);
-  hipLaunchKernelGGL(kern, dim3(grid_for(elems / 8, 256)), dim3(256), 0, stream, x, reinterpret_cast<__half*>(img),
+  hipLaunchKernelGGL(kern, dim3(delayed ? grid_for_reduce(elems / 8, 256) : grid_for(elems / 8, 256)), dim3(256), 0, stream, x, reinterpret_cast<__half*>(img),
                      elems / 8, c, scale, shift, slope_of(act), mask, mask_scale, hdr, colsum, w_log, w_pitch);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   if (colsum) {
@@ -382,26 +427,44 @@ int launch_split_weights(const float* w, uint16_t* wq, int taps, int n_total, in
   if (blocks > 4096) blocks = 4096;
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, wq, taps, n_total,
-                     n_valid, ktot, b_kn ? 1 : 0, 0, (unsigned*)nullptr);
+                     n_valid, ktot, b_kn ? 1 : 0, 0, (unsigned*)nullptr, (const unsigned*)nullptr);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }
 
 int launch_pair_weights(const float* w, uint16_t* wq, int taps, int n_total, int ktot, bool b_kn, unsigned* hdr,
-                        hipStream_t stream) {
+                        hipStream_t stream, const unsigned* amax_src) {
   if (!w || !wq || !hdr) return ADVOC_ERR_NULL;
   if (ktot % 32) return ADVOC_ERR_UNSUPPORTED;
   const int64_t n = (int64_t)taps * n_total * ktot;
-  ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(amax_flat_kernel, dim3(grid_for(n, 256 * 16)), dim3(256), 0, stream, w, n, hdr);
-  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  if (!amax_src) {                      // (hdr[0] zeroed by the caller)
+    ADVOC_CLEAR_LAUNCH_ERROR();
+    hipLaunchKernelGGL(amax_flat_kernel, dim3(grid_for_reduce(n, 256 * 16)), dim3(256), 0, stream, w, n, hdr);
+    ADVOC_RETURN_IF_LAUNCH_FAILED();
+  }
   int64_t blocks = (int64_t)taps * (ktot / 32) * ((n_total + 31) / 32);
   if (blocks > 4096) blocks = 4096;
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, wq, taps, n_total,
-                     n_total, ktot, b_kn ? 1 : 0, 1, hdr);
+                     n_total, ktot, b_kn ? 1 : 0, 1, hdr, amax_src);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }
 
 }  // namespace advoc
+
+extern "C" int advoc_segmented_amax_f32(const float* base, const int64_t* offsets, const int64_t* sizes, int32_t count,
+                                        uint32_t* amax_out, advoc_stream_t stream) {
+  if (count < 0) return ADVOC_ERR_BAD_SHAPE;
+  if (count == 0) return ADVOC_OK;
+  if (!base || !offsets || !sizes || !amax_out) return ADVOC_ERR_NULL;
+  if (count > 65535) return ADVOC_ERR_UNSUPPORTED;
+  hipStream_t s = advoc::as_stream(stream);
+  hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(uint32_t) * (size_t)count, s);
+  if (e != hipSuccess) { advoc::note_hip_error(e); return ADVOC_ERR_HIP; }
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(advoc::segmented_amax_kernel, dim3(64, (unsigned)count), dim3(256), 0, s, base, offsets, sizes,
+                     amax_out);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}

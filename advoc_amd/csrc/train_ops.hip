@@ -161,6 +161,13 @@ unsigned grid_for(int64_t n, int per_thread = 1) {
   return (unsigned)b;
 }
 
+// the loss kernels end in one atomic per workgroup on ONE address: same-address atomics retire one by one (~10 ns each,
+// tools/micro/img_bw.hip), so their grids stay at two workgroups per CU
+unsigned grid_for_sum(int64_t n) {
+  const unsigned b = grid_for(n);
+  return b > 512 ? 512 : b;
+}
+
 }  // namespace
 
 using advoc::as_stream;
@@ -173,7 +180,7 @@ extern "C" int advoc_gan_d_loss(const float* logit_real, const float* logit_fake
   hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(float), as_stream(stream));
   if (e != hipSuccess) { advoc::note_hip_error(e); return ADVOC_ERR_HIP; }
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(d_loss_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), logit_real,
+  hipLaunchKernelGGL(d_loss_kernel, dim3(grid_for_sum(n)), dim3(256), 0, as_stream(stream), logit_real,
                      logit_fake, n, 1.f / (float)n, dlogit_real, dlogit_fake, loss_sum);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
@@ -189,12 +196,12 @@ extern "C" int advoc_gan_g_loss(const float* logit_fake, int64_t n_logits, const
   if (e != hipSuccess) { advoc::note_hip_error(e); return ADVOC_ERR_HIP; }
   if (logit_fake) {
     ADVOC_CLEAR_LAUNCH_ERROR();
-    hipLaunchKernelGGL(g_gan_kernel, dim3(grid_for(n_logits)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(g_gan_kernel, dim3(grid_for_sum(n_logits)), dim3(256), 0, as_stream(stream),
                        logit_fake, n_logits, gan_weight / (float)n_logits, dlogit_fake, loss_sums);
     ADVOC_RETURN_IF_LAUNCH_FAILED();
   }
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(l1_kernel, dim3(grid_for(n_spec)), dim3(256), 0, as_stream(stream), gen, target,
+  hipLaunchKernelGGL(l1_kernel, dim3(grid_for_sum(n_spec)), dim3(256), 0, as_stream(stream), gen, target,
                      n_spec, l1_weight / (float)n_spec, accum_dgen, dgen, loss_sums + 1);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;

@@ -62,8 +62,10 @@ constexpr int kColsumReplicas = 64;
 constexpr int64_t kColsumBytes = (int64_t)kColsumReplicas * 1024 * 4;
 // weights [tap][k][n] (b_kn) or [tap][n][k] -> wq[tap][n_total][ktot / 32][plane][32] fp16 (amax pass included;
 // hdr[0] must be zero on entry)
+// amax_src != null: the largest |w| is already known (advoc_segmented_amax_f32: one launch per arena instead of one
+// magnitude pass per weight image) -- the magnitude pass is skipped and hdr[0] is not read
 int launch_pair_weights(const float* w, uint16_t* wq, int taps, int n_total, int ktot, bool b_kn, unsigned* hdr,
-                        hipStream_t stream);
+                        hipStream_t stream, const unsigned* amax_src = nullptr);
 // ---- bf16 triple weights (register-split kernels of igemm.hip): wq[plane][tap][n_total][ktot], zeros for n >= n_valid
 int launch_split_weights(const float* w, uint16_t* wq, int taps, int n_total, int n_valid, int ktot, bool b_kn,
                          hipStream_t stream);

@@ -263,6 +263,17 @@ class Advoc(Model):
             t.fill_(1.0)
       st['g_t'] = st['d_t'] = 0
       st['sums'] = torch.zeros(4, dtype=torch.float32, device=dev)
+      # largest |w| of every kernel, one launch per arena (advoc_segmented_amax_f32) at the start of each forward pass
+      # instead of one magnitude pass per weight image (two per layer and step)
+      for net in ('g', 'd'):
+        ar = st[net + '_arena']
+        names = [k for k in ar.offsets if k.endswith('/kernel')]
+        sizes = [int(st[net + '_P'][k].numel()) for k in names]
+        st[net + '_wamax_index'] = dict((k, i) for i, k in enumerate(names))
+        st[net + '_wamax_off'] = torch.tensor([ar.offsets[k][0] for k in names], dtype=torch.int64, device=dev)
+        st[net + '_wamax_size'] = torch.tensor(sizes, dtype=torch.int64, device=dev)
+        st[net + '_wamax'] = torch.zeros(len(names), dtype=torch.int32, device=dev)
+      st['wamax_on'] = os.environ.get('ADVOC_WEIGHT_AMAX', '1') == '1'
     st['B'] = B
     if 'side_stream' not in st:
       st['side_stream'] = torch.cuda.Stream(device=dev)
@@ -357,6 +368,12 @@ class Advoc(Model):
       b = gbn.get(name_src)
       return (b['scale'], b['shift']) if b else (None, None)
 
+    def wamax(net, kernel_name):
+      if not st['wamax_on']:
+        return None
+      i = st[net + '_wamax_index'][kernel_name]
+      return st[net + '_wamax'][i:i + 1]
+
     # ---- generator layers ----
     L = collections.OrderedDict()
     x = st['x_in']
@@ -367,7 +384,7 @@ class Advoc(Model):
       pl, _ = C.same_pad(src.shape[2], 4, enc_s[i][1])
       sc, sh = aff_of('encoder_%d' % i) if i > 0 else (None, None)
       L['encoder_%d' % (i + 1)] = C.Layer(C.CONV, src, e[i], P[s + '/kernel'], P[s + '/bias'],
-                                          stride=enc_s[i], pad=(pt, pl),
+                                          w_amax=wamax('g', s + '/kernel'), stride=enc_s[i], pad=(pt, pl),
                                           in_act=C.ACT_NONE if i == 0 else C.ACT_LRELU,
                                           in_scale=sc, in_shift=sh)
     for j, (idx, c, drop) in enumerate(dec):
@@ -385,7 +402,8 @@ class Advoc(Model):
       # Without BN the producer applies its own dropout in its epilogue.  With BN dropout acts
       # AFTER the normalisation (advoc_model.py:142-149), i.e. on the consumer's loads.
       L['decoder_%d' % idx] = C.Layer(
-          C.DECONV, x0, d[idx], P[s + '/kernel'], P[s + '/bias'], x1=x1, in_w=in_w, stride=dec_s[j],
+          C.DECONV, x0, d[idx], P[s + '/kernel'], P[s + '/bias'], w_amax=wamax('g', s + '/kernel'), x1=x1, in_w=in_w,
+          stride=dec_s[j],
           pad=(1, 1), in_act=C.ACT_RELU,
           drop_mask=mk[0] if (mk and not bn_on) else None, drop_scale=1.0 / mk[1] if (mk and not bn_on) else 0.,
           in_scale=sc, in_shift=sh,
@@ -395,7 +413,8 @@ class Advoc(Model):
     last = d[dec[-1][0]] if dec else e[-1]
     sc, sh = dec_aff.get('decoder_1', (None, None))
     src_mask = masks.get(dec[-1][0]) if dec else None
-    L['decoder_1'] = C.Layer(C.DECONV, last, gen_out, P[s + '/kernel'], P[s + '/bias'], x1=e[0],
+    L['decoder_1'] = C.Layer(C.DECONV, last, gen_out, P[s + '/kernel'], P[s + '/bias'],
+                             w_amax=wamax('g', s + '/kernel'), x1=e[0],
                              in_w=e[0].shape[2], out_w=F, stride=(2, 2), pad=(1, 1), in_act=C.ACT_RELU,
                              in_scale=sc, in_shift=sh,
                              in_mask=src_mask[0] if (src_mask and bn_on) else None,
@@ -427,11 +446,11 @@ class Advoc(Model):
         s = 'discriminator/layer_%d/conv2d' % (i + 1)
         if i == 0:
           lay = C.Layer(C.CONV, st['d_cond'][lo:hi], a[0][lo:hi], DP[s + '/kernel'], DP[s + '/bias'],
-                        x1=st['d_target'][lo:hi], stride=(2, 2), pad=(1, 1), in_act=C.ACT_NONE)
+                        w_amax=wamax('d', s + '/kernel'), x1=st['d_target'][lo:hi], stride=(2, 2), pad=(1, 1), in_act=C.ACT_NONE)
         else:
           b = bns.get(i - 1)
           lay = C.Layer(C.CONV, a[i - 1][lo:hi], a[i][lo:hi], DP[s + '/kernel'], DP[s + '/bias'],
-                        stride=(strides[i],) * 2, pad=(1, 1), in_act=C.ACT_LRELU,
+                        w_amax=wamax('d', s + '/kernel'), stride=(strides[i],) * 2, pad=(1, 1), in_act=C.ACT_LRELU,
                         in_scale=b['scale'] if b else None, in_shift=b['shift'] if b else None)
         out.append(lay)
       return out, bns
@@ -561,10 +580,23 @@ class Advoc(Model):
   # ------------------------------------------------------------------------------------------
   # forward passes
   # ------------------------------------------------------------------------------------------
+  def _refresh_weight_amax(self, net):
+    """max |w| of every kernel of arena `net` ('g' / 'd') in one launch.  Run at the start of each forward pass over
+    the network, i.e. after any optimizer step, checkpoint load or in-place edit of the parameters that came before it;
+    the backward pass of the same step reads the same (unchanged) kernels."""
+    st = self._built
+    if not st['wamax_on']:
+      return
+    out = st[net + '_wamax']
+    _lib.check(_lib.load().advoc_segmented_amax_f32(
+        _lib.ptr(st[net + '_param']), _lib.ptr(st[net + '_wamax_off']), _lib.ptr(st[net + '_wamax_size']),
+        out.numel(), _lib.ptr(out), _lib.stream()), 'advoc_segmented_amax_f32')
+
   def _gen_forward(self, x):
     st = self._built
     if x.data_ptr() != st['x_in'].data_ptr():
       st['x_in'].copy_(x)
+    self._refresh_weight_amax('g')
     self._refresh_masks(self._rank * st['B'])
     gbn = st['g_bn']
     for name, lay in st['g_layers'].items():
@@ -574,6 +606,7 @@ class Advoc(Model):
     return st['gen_out']
 
   def _disc_forward(self, layers, bns):
+    self._refresh_weight_amax('d')
     for i, lay in enumerate(layers):
       lay.forward()
       if i in bns:

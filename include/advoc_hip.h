@@ -243,7 +243,17 @@ typedef struct advoc_conv_layer {
    * first if it does not accumulate, and skips advoc_conv_backward_bias.  Only where advoc_conv_bias_fusable() says
    * so and the backward-data call runs on the image kernels (advoc_conv_kernel_name); ignored otherwise. */
   float* db_fused;
+  /* optional: float bits of max |w| over the whole kernel tensor, already on the device (advoc_segmented_amax_f32 after
+   * every weight update).  The image kernels scale their weight image with it and skip their own magnitude pass over
+   * the weights (one per forward / backward-data call otherwise).  MUST be current: a stale, smaller value overflows
+   * the fp16 image. */
+  const uint32_t* w_amax;
 } advoc_conv_layer;
+
+/* amax_out[i] = float bits of max |base[offsets[i] .. offsets[i] + sizes[i])| for `count` tensors of one arena, in one
+ * launch (offsets / sizes / amax_out in device memory; amax_out is zeroed first).  Feeds advoc_conv_layer.w_amax. */
+int advoc_segmented_amax_f32(const float* base, const int64_t* offsets, const int64_t* sizes, int32_t count,
+                             uint32_t* amax_out, advoc_stream_t stream);
 
 /* 1: the layer's output-gradient image pass can carry the bias gradient (db_fused above): dy_img present and cout such
  * that a thread of the image pass keeps one group of 8 channels (32 <= cout <= 1024, 256 % (cout / 8) == 0) */

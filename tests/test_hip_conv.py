@@ -723,3 +723,75 @@ def test_bias_gradient_rides_in_the_output_gradient_image_pass(hip, case, hipenv
       assert rel(db - (5.0 if rep == 2 else 0.0), db_o) < TOL, (rep, rel(db, db_o))     # already there
     L.backward_weight(dy, dw, db, accumulate=(rep == 2))
     assert rel(db - (5.0 if rep == 2 else 0.0), db_o) < TOL, (rep, rel(db, db_o))
+
+
+@gpu
+def test_segmented_amax_of_an_arena(hip):
+  """advoc_segmented_amax_f32: max |w| of many tensors of one flat buffer in one launch, as float bits; segments that are
+  empty, all zero, one element long, not 16-byte aligned, or longer than one grid sweep."""
+  import ctypes
+  from advoc_amd import _lib
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(5)
+  flat = torch.randn(3_000_000, generator=g).to(dev)
+  segs = [(0, 16), (16, 1), (17, 4099), (4116, 0), (4120, 64), (8192, 2_500_000), (2_600_000, 4 * 4 * 256 * 64)]
+  flat[4120:4184] = 0.
+  flat[9000] = -77.5
+  off = torch.tensor([s[0] for s in segs], dtype=torch.int64, device=dev)
+  size = torch.tensor([s[1] for s in segs], dtype=torch.int64, device=dev)
+  out = torch.full((len(segs),), 123, dtype=torch.int32, device=dev)
+  _lib.check(_lib.load().advoc_segmented_amax_f32(_lib.ptr(flat), _lib.ptr(off), _lib.ptr(size), len(segs), _lib.ptr(out),
+                                                  _lib.stream()), 'advoc_segmented_amax_f32')
+  got = out.view(torch.float32).cpu()
+  for i, (o, n) in enumerate(segs):
+    want = float(flat[o:o + n].abs().max()) if n else 0.0
+    assert float(got[i]) == want, (i, float(got[i]), want)
+  assert float(got[5]) == 77.5
+
+
+@gpu
+@pytest.mark.parametrize('case', [c for c in H3 if c[0] in ('h3_enc', 'h3_dec_skip')] +
+                         [c[0] for c in PATCH if c[0][0] in ('p3_dec_skip', 'p3_enc_bwd_odd')], ids=lambda c: c[0])
+def test_weight_magnitude_from_the_arena_pass(hip, case, hipenv):
+  """advoc_conv_layer.w_amax: with the largest |w| handed in (advoc_segmented_amax_f32) the image kernels skip their own
+  magnitude pass over the kernel and give bit-identical results, forward and backward-data, also after the kernel
+  changed (refreshed w_amax).  A magnitude that only shares the power of two gives the same image as well."""
+  import ctypes
+  from advoc_amd import conv, _lib
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1)
+  c = build_case(case)
+  dev = torch.device('cuda')
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w, dy = c['w'].to(dev).clone(), c['dy'].to(dev)
+  cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+  y = torch.empty(x0.shape[0], c['oh'], c['out_w'], cout, device=dev)
+  amax = torch.zeros(1, dtype=torch.int32, device=dev)
+  off = torch.zeros(1, dtype=torch.int64, device=dev)
+  size = torch.full((1,), w.numel(), dtype=torch.int64, device=dev)
+
+  def refresh():
+    _lib.check(_lib.load().advoc_segmented_amax_f32(_lib.ptr(w), _lib.ptr(off), _lib.ptr(size), 1, _lib.ptr(amax),
+                                                    _lib.stream()), 'advoc_segmented_amax_f32')
+
+  def run(w_amax):
+    L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'],
+                   w_amax=w_amax)
+    assert 'h3' in L.kernel_name(0) and 'h3' in L.kernel_name(1)
+    y.zero_()
+    L.forward()
+    dx0 = torch.zeros_like(x0)
+    dx1 = torch.zeros_like(x1) if x1 is not None else None
+    L.backward_data(dy, dx0, dx1)
+    return y.clone(), dx0.clone()
+
+  for rep in range(2):
+    refresh()
+    assert float(amax.view(torch.float32)) == float(w.abs().max())
+    a, b = run(None), run(amax)
+    for u, v in zip(a, b):
+      assert torch.equal(u, v)
+    w.mul_(37.0)                          # "optimizer step": another power of two
+  with pytest.raises(_lib.AdvocHipError):
+    conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'],
+               w_amax=torch.zeros(2, dtype=torch.int32, device=dev))

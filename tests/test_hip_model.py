@@ -325,6 +325,51 @@ def test_side_stream_weight_gradients_equal_serial_execution(hip, monkeypatch):
 
 
 @gpu
+def test_weight_magnitudes_follow_the_parameters(hip, monkeypatch):
+  """One advoc_segmented_amax_f32 launch per arena at the start of every forward pass replaces the per-image magnitude
+  passes over the kernels (ADVOC_WEIGHT_AMAX=0 restores them): the table holds max |kernel| of the CURRENT parameters
+  after optimizer steps and after an in-place edit, and the generator output does not change."""
+  from advoc_amd.model import AdvocSmall, Modes
+  dev = torch.device('cuda')
+  x, target = batch(16, 128, 9)
+  x, target = x.to(dev), target.to(dev)
+  for on in (0, 1):
+    monkeypatch.setenv('ADVOC_WEIGHT_AMAX', str(on))
+    m = AdvocSmall(Modes.TRAIN)
+    m.subseq_len = 128
+    m.train_batch_size = 16
+    m.build(batch_size=16, seed=4)
+    st = m._built
+    assert st['wamax_on'] == bool(on)
+    assert all(bool(lay.struct.w_amax) == bool(on) for lay in st['g_layers'].values())
+    m((x, target))
+    for _ in range(3):
+      m.train_loop()
+    assert all(np.isfinite(v) for v in m.losses().values())
+  # the last forward pass over each network ran BEFORE its last Adam step: a fresh pass brings the table up to date
+  for rep in range(2):
+    calls = m._dropout_calls
+    out1 = m._gen_forward(st['x_in']).clone()
+    m._disc_forward(st['d_layers_fake'], st['d_bn_fake'])
+    for net in ('g', 'd'):
+      got = st[net + '_wamax'].view(torch.float32).cpu()
+      for k, i in st[net + '_wamax_index'].items():
+        assert float(got[i]) == float(st[net + '_P'][k].abs().max()), (rep, k)
+    saved = [(lay, lay.struct.w_amax) for lay in st['g_layers'].values()]
+    for lay, _ in saved:
+      lay.struct.w_amax = None                       # the layers take the magnitude themselves again
+    m._dropout_calls = calls                         # same dropout masks
+    out0 = m._gen_forward(st['x_in']).clone()
+    for lay, p in saved:
+      lay.struct.w_amax = p
+    # same power of two, same weight images (bit-identical per layer: test_hip_conv.py); what is left is the order of the
+    # split-K atomics of the small deep layers
+    assert rel(out1, out0) < 2e-6, (rep, rel(out1, out0))
+    for k in st['g_wamax_index']:
+      st['g_P'][k].mul_(300.0 if 'encoder_2' in k else 0.01)      # e.g. a checkpoint restore: the next pass sees it
+
+
+@gpu
 def test_training_on_split_bf16_path_tracks_fp32_path(hip, hipenv):
   """At the benchmark geometry (32 clips x 256 frames) most contractions run on the split-bf16 matrix path
   (igemm.hip / wgrad.hip); with ADVOC_IGEMM_X6=0 ADVOC_WGRAD_X6=0 the same model runs on the fp32 MFMA
