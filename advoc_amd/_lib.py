@@ -9,7 +9,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libadvoc_hip.so')
+# ADVOC_HIP_LIB: another build of the same library (A/B timing of kernel variants, tools/micro); never a fallback
+LIB_PATH = os.environ.get('ADVOC_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libadvoc_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'advoc_hip.h')
 
 _p = ctypes.c_void_p

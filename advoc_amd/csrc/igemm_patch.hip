@@ -413,22 +413,35 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     // store's round trip: the plain per-row load -> wait -> store chain costs one memory latency per 16 bytes (measured:
     // 2/3 of the time of the 64-column backward-data launches).  Per 32-row block ALL global loads (pre-activation values,
     // masks, the value to add to) are issued together, and those of block i + 1 go out BEFORE the stores of block i
-    // (their registers are free once block i's values are computed).  Rows that store nothing load from pixel 0.
-    int off[4];
-    float4 xp[4], old[4];
-    uchar4 mk[4];
+    // (their registers are free once block i's values are computed).
+    // Every access is a BUFFER instruction whose offset is out of range for the rows that store nothing (loads return
+    // zero, stores are dropped) and for the tensors this launch does not have: no branch and no exec mask around any of
+    // them, so the number of stores between a load and its use is known at compile time and the wait for block i + 1's
+    // loads leaves block i's four stores in flight (s_waitcnt vmcnt(4)) -- with `if (row valid) store` the compiler had
+    // to wait for vmcnt(0), i.e. for the round trip of every block's stores.
+    constexpr unsigned kOob = 0xffffff00u;              // >= num_records of every descriptor below
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(dp, 0, kOob, 0x00020000);
+    const bool has_mask = BWD ? d_gmask != nullptr : p.y_mask != nullptr;
+    const uint8_t* const mask_p = BWD ? d_gmask : p.y_mask;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(use_grad ? d_xpre : dp), 0, use_grad ? kOob : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(
+        has_mask ? const_cast<uint8_t*>(mask_p) : reinterpret_cast<uint8_t*>(dp), 0, has_mask ? kOob : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(dp, 0, (BWD && d_accum) ? kOob : 0u, 0x00020000);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned off[4];                                   // element offset of the row's 4 channels, kOob for rows without a pixel
+    u32x4 xp[4], old[4];
+    unsigned mk[4];
 #define ADVOC_P3_PRELOAD(I)                                                                               \
     _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                    \
       const int pix = s_pix[di * PW_ + (I) * 32 + trow + 8 * ps];                                         \
-      off[ps] = pix < 0 ? -1 : pix * d_c + ch;                                                            \
-      const int lo = pix < 0 ? ch : off[ps];                                                              \
+      off[ps] = pix < 0 ? kOob : (unsigned)(pix * d_c + ch);                                              \
+      const unsigned ob = pix < 0 ? kOob : off[ps] * 4u;                                                  \
       if (BWD) {                                                                                          \
-        if (use_grad) xp[ps] = *reinterpret_cast<const float4*>(d_xpre + lo);                             \
-        if (d_gmask) mk[ps] = *reinterpret_cast<const uchar4*>(d_gmask + lo);                             \
-        if (d_accum) old[ps] = *reinterpret_cast<const float4*>(dp + lo);                                 \
-      } else {                                                                                            \
-        if (p.y_mask) mk[ps] = *reinterpret_cast<const uchar4*>(p.y_mask + lo);                           \
+        xp[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ob, 0, 0);                                   \
+        old[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, ob, 0, 0);                                  \
       }                                                                                                   \
+      mk[ps] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, off[ps], 0, 0);                                 \
     }
     ADVOC_P3_PRELOAD(0);
 #pragma unroll
@@ -437,35 +450,38 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * half_e) * LDT + l32_e] = acc[i][j][r];
       wave_lds_sync();
       float4 v[4];
-      int so[4];
+      unsigned so[4];
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         v[ps] = *reinterpret_cast<const float4*>(T + (trow + 8 * ps) * LDT + 4 * tq);
         v[ps].x = fmaf(v[ps].x, unscale, bias4.x); v[ps].y = fmaf(v[ps].y, unscale, bias4.y);
         v[ps].z = fmaf(v[ps].z, unscale, bias4.z); v[ps].w = fmaf(v[ps].w, unscale, bias4.w);
-        if (!BWD && p.y_mask) {
-          v[ps].x *= mk[ps].x * p.y_mask_scale; v[ps].y *= mk[ps].y * p.y_mask_scale;
-          v[ps].z *= mk[ps].z * p.y_mask_scale; v[ps].w *= mk[ps].w * p.y_mask_scale;
-        }
         if (use_grad) {
-          float4 x = xp[ps];
+          float4 x = make_float4(__uint_as_float(xp[ps].x), __uint_as_float(xp[ps].y), __uint_as_float(xp[ps].z),
+                                 __uint_as_float(xp[ps].w));
           x.x = x.x * gs4.x + gh4.x; x.y = x.y * gs4.y + gh4.y; x.z = x.z * gs4.z + gh4.z; x.w = x.w * gs4.w + gh4.w;
           v[ps].x *= x.x > 0.f ? 1.f : gslope; v[ps].y *= x.y > 0.f ? 1.f : gslope;
           v[ps].z *= x.z > 0.f ? 1.f : gslope; v[ps].w *= x.w > 0.f ? 1.f : gslope;
         }
-        if (BWD && d_gmask) {
-          v[ps].x *= mk[ps].x * d_gmask_scale; v[ps].y *= mk[ps].y * d_gmask_scale;
-          v[ps].z *= mk[ps].z * d_gmask_scale; v[ps].w *= mk[ps].w * d_gmask_scale;
+        if (has_mask) {
+          const float ms = BWD ? d_gmask_scale : p.y_mask_scale;
+          v[ps].x *= (float)(mk[ps] & 0xffu) * ms; v[ps].y *= (float)((mk[ps] >> 8) & 0xffu) * ms;
+          v[ps].z *= (float)((mk[ps] >> 16) & 0xffu) * ms; v[ps].w *= (float)(mk[ps] >> 24) * ms;
         }
         if (BWD && d_accum) {
-          v[ps].x += old[ps].x; v[ps].y += old[ps].y; v[ps].z += old[ps].z; v[ps].w += old[ps].w;
+          v[ps].x += __uint_as_float(old[ps].x); v[ps].y += __uint_as_float(old[ps].y);
+          v[ps].z += __uint_as_float(old[ps].z); v[ps].w += __uint_as_float(old[ps].w);
         }
-        so[ps] = off[ps];
+        so[ps] = off[ps] == kOob ? kOob : off[ps] * 4u;
       }
       if (i + 1 < MT) { ADVOC_P3_PRELOAD(i + 1); }
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps)
-        if (so[ps] >= 0) *reinterpret_cast<float4*>(dp + so[ps]) = v[ps];
+      for (int ps = 0; ps < 4; ++ps) {
+        u32x4 sv;
+        sv.x = __float_as_uint(v[ps].x); sv.y = __float_as_uint(v[ps].y);
+        sv.z = __float_as_uint(v[ps].z); sv.w = __float_as_uint(v[ps].w);
+        __builtin_amdgcn_raw_buffer_store_b128(sv, rs_d, so[ps], 0, 0);
+      }
       wave_lds_sync();
     }
 #undef ADVOC_P3_PRELOAD

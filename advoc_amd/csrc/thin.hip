@@ -25,6 +25,10 @@ namespace advoc {
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// buffer offset that is out of range for every descriptor of the epilogues below (destinations are < 4 GB - 256 B:
+// checked by the launchers)
+constexpr unsigned kThinOob = 0xffffff00u;
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
   if (act == ADVOC_ACT_LRELU02) return fmaxf(0.2f * v, v);
@@ -52,7 +56,7 @@ constexpr int kThinPatch = kThinPatchRows * kThinPatchCols * 2;   // x up to 2 c
 // PL: patch elements per lane (ceil(pr * pc * ktot / 64)); a template parameter because the fetch
 // registers (value + mask factor + coordinates per element) decide the occupancy of the wide-N cases
 template <int KP, int NT, bool B_KN, int PL>
-__global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams p, int dy_min, int dx_min,
+__global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const GatherGemmParams p, int dy_min, int dx_min,
                                                           int pr, int pc, int tiles_x) {
   __shared__ int s_pix[4][2][32];
   __shared__ int s_delta[KP];     // LDS-patch offset of slot k' relative to the lane's column origin
@@ -102,15 +106,20 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
   }
   // patch elements this lane stages every tile: element e = lane + 64 i -> (row, col, channel)
   const int patch_elems = pr * pc * ktot;
-  int pe_row[PL], pe_col[PL], pe_ci[PL];
+  int pe[PL];                       // row | col << 3 | channel << 12, -1 past the patch (one register per element)
+  // (decoded where used, from a copy the compiler cannot see through: hoisted out of the tile loop the three fields
+  // would live in three registers per element again)
+#define PE_ROW(i) (pq_##i < 0 ? -1 : (pq_##i & 7))
+#define PE_COL(i) ((pq_##i >> 3) & 0x1ff)
+#define PE_CI(i) ((pq_##i >> 12) & 1)
+#define PE_OPEN(i) int pq_##i = pe[i]; asm volatile("" : "+v"(pq_##i));
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
     const int e = lane + 64 * i;
     const int ee = e < patch_elems ? e : 0;
-    pe_ci[i] = ee % ktot;
+    const int ci_ = ee % ktot;
     const int px = ee / ktot;
-    pe_col[i] = px % pc;
-    pe_row[i] = e < patch_elems ? px / pc : -1;
+    pe[i] = e < patch_elems ? ((px / pc) | ((px % pc) << 3) | (ci_ << 12)) : -1;
   }
   __syncthreads();
   // this lane's K slots (k' = 2 s + half): LDS offsets relative to the tile's patch, decoded once
@@ -134,12 +143,13 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
     const int img_ = rowid_ / p.gh, gy_ = rowid_ - img_ * p.gh;                                       \
     const int iy0_ = gy_ * p.sy + dy_min, ix0_ = gx0_ * p.sx + dx_min;                                \
     _Pragma("unroll") for (int i = 0; i < PL; ++i) {                                     \
-      const int iy = iy0_ + pe_row[i], ix = ix0_ + pe_col[i];                                         \
+      PE_OPEN(i)                                                                                      \
+      const int iy = iy0_ + PE_ROW(i), ix = ix0_ + PE_COL(i);                                         \
       float v = 0.f, mk = 1.f;                                                                        \
-      if (pe_row[i] >= 0 && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) {     \
-        const bool second = pe_ci[i] >= p.c0;                                                         \
-        const int off = second ? ((img_ * p.a_h + iy) * p.a1_pitch + ix) * p.c1 + (pe_ci[i] - p.c0)   \
-                               : ((img_ * p.a_h + iy) * p.a0_pitch + ix) * p.c0 + pe_ci[i];           \
+      if (PE_ROW(i) >= 0 && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) {     \
+        const bool second = PE_CI(i) >= p.c0;                                                         \
+        const int off = second ? ((img_ * p.a_h + iy) * p.a1_pitch + ix) * p.c1 + (PE_CI(i) - p.c0)   \
+                               : ((img_ * p.a_h + iy) * p.a0_pitch + ix) * p.c0 + PE_CI(i);           \
         v = (second ? p.a1 : p.a0)[off];                                                              \
         if (p.a_mask && !second) mk = p.a_mask[off] * p.a_mask_scale;                                 \
       }                                                                                               \
@@ -147,6 +157,43 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
       pm[i] = mk;                                                                                     \
     }                                                                                                 \
   }
+  // what the epilogue of one 32-channel column block loads (see there)
+  struct EpiLoads {
+    unsigned off[4];               // element offset of the row's 4 channels in its destination, kThinOob without a pixel
+    u32x4 xp[4];
+    unsigned gm[4], ym[4];
+  };
+  EpiLoads epi;
+#define ADVOC_THIN_PRELOAD(J)                                                                                     \
+  {                                                                                                               \
+    const int nt0_ = n0 + 32 * (J);                                                                               \
+    const int di_ = nt0_ >= p.n_split ? 1 : 0;                                                                    \
+    const GemmDest& d_ = p.d[di_];                                                                                \
+    const bool ok_ = nt0_ < N && d_.p != nullptr;                                                                 \
+    const int ch_ = (di_ ? nt0_ - p.n_split : nt0_) + 4 * (lane & 7);                                             \
+    const bool grad_ = ok_ && p.grad_act != ADVOC_ACT_NONE;                                                       \
+    const __amdgpu_buffer_rsrc_t rs_x_ = __builtin_amdgcn_make_buffer_rsrc(                                      \
+        const_cast<float*>(grad_ ? d_.xpre : d_.p), 0, grad_ ? kThinOob : 0u, 0x00020000);                        \
+    const __amdgpu_buffer_rsrc_t rs_g_ = __builtin_amdgcn_make_buffer_rsrc(                                      \
+        (ok_ && d_.gmask) ? const_cast<uint8_t*>(d_.gmask) : reinterpret_cast<uint8_t*>(d_.p), 0,                 \
+        (ok_ && d_.gmask) ? kThinOob : 0u, 0x00020000);                                                           \
+    const __amdgpu_buffer_rsrc_t rs_y_ = __builtin_amdgcn_make_buffer_rsrc(                                      \
+        (ok_ && p.y_mask) ? const_cast<uint8_t*>(p.y_mask) : reinterpret_cast<uint8_t*>(d_.p), 0,                 \
+        (ok_ && p.y_mask) ? kThinOob : 0u, 0x00020000);                                                           \
+    EpiLoads& e_ = epi;                                                                                  \
+    _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                            \
+      const int pix = s_pix[wave][di_][(lane >> 3) + 8 * ps];                                                     \
+      e_.off[ps] = pix < 0 ? kThinOob : (unsigned)(pix * d_.c + ch_);                                             \
+      const unsigned ob = pix < 0 ? kThinOob : e_.off[ps] * 4u;                                                   \
+      e_.xp[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_x_, ob, 0, 0);                                         \
+      e_.gm[ps] = __builtin_amdgcn_raw_buffer_load_b32(rs_g_, e_.off[ps], 0, 0);                                  \
+      e_.ym[ps] = __builtin_amdgcn_raw_buffer_load_b32(rs_y_, e_.off[ps], 0, 0);                                  \
+    }                                                                                                             \
+  }
+  // the bias was loaded before the loop: consume it once here, so that its use inside the loop is not a wait for "every
+  // memory operation in flight" (the compiler cannot tell loop iterations apart) -- that wait included the stores
+#pragma unroll
+  for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(bias[j]));
   const int tile0 = blockIdx.x * 4 + wave;
   if (tile0 < tiles) ADVOC_THIN_FETCH(tile0);
   for (int tile = tile0; tile < tiles; tile += gridDim.x * 4) {
@@ -170,11 +217,12 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
       const int iy0 = gy * p.sy + dy_min, ix0 = gx0 * p.sx + dx_min;
 #pragma unroll
       for (int i = 0; i < PL; ++i) {
-        if (pe_row[i] < 0) continue;
+        PE_OPEN(i)
+        if (PE_ROW(i) < 0) continue;
         float v = pv[i];
-        const int iy = iy0 + pe_row[i], ix = ix0 + pe_col[i];
+        const int iy = iy0 + PE_ROW(i), ix = ix0 + PE_COL(i);
         const bool inb = (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
-        if (p.in_scale) v = inb ? v * p.in_scale[pe_ci[i]] + p.in_shift[pe_ci[i]] : 0.f;
+        if (p.in_scale) v = inb ? v * p.in_scale[PE_CI(i)] + p.in_shift[PE_CI(i)] : 0.f;
         v = fmaxf(v, slope * v);
         patch[lane + 64 * i] = v * pm[i];
       }
@@ -184,6 +232,7 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
       const int next = tile + gridDim.x * 4;
       if (next < tiles) ADVOC_THIN_FETCH(next);
     }
+    ADVOC_THIN_PRELOAD(0)
     // A operand: one scalar per K slot from the patch
     float a[KP / 2];
 #pragma unroll
@@ -200,57 +249,80 @@ __global__ __launch_bounds__(256) void thin_k_gemm_kernel(const GatherGemmParams
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], s_w[2 * s + half][32 * j + l32], acc[j], 0, 0, 0);
 
     wave_lds_sync();
-    // transpose each 32x32 tile through a private LDS patch: 16-byte accesses on 128-byte rows
+    // ---- epilogue: each 32x32 tile is transposed through a private LDS patch (16-byte accesses on 128-byte rows) ----
+    // Global loads and stores retire through ONE in-order counter, so `load x; wait; store` per row pays a memory round
+    // trip per KILOBYTE (measured: decoder_1 backward-data at 1.4 TB/s).  All accesses are buffer instructions whose
+    // offset is out of range for rows without a pixel and for tensors this launch does not have (loads return zero,
+    // stores are dropped): no branch around any of them.  A column block issues all its loads first (block 0 before the
+    // MFMAs), transposes while they fly, then stores: one round trip per 32-channel block instead of one per row.
     float* T = &s_T[wave][0];
     const int trow = lane >> 3, tq = lane & 7;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int nt0 = n0 + 32 * j;
-      if (nt0 >= N) continue;
-      const int di = nt0 >= p.n_split ? 1 : 0;
-      const GemmDest& d = p.d[di];
-      if (d.p == nullptr) continue;
-      const int ch = (di ? nt0 - p.n_split : nt0) + 4 * tq;
+      if (j > 0) ADVOC_THIN_PRELOAD(j)              // (block 0's loads went out before the MFMAs)
+      EpiLoads& e = epi;
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l32] = acc[j][r] + bias[j];
       wave_lds_sync();
+      float4 v[4];
+      unsigned so[4];
+      const int di = (n0 + 32 * j) >= p.n_split ? 1 : 0;
+      const GemmDest& d = p.d[di];
+      const bool okj = n0 + 32 * j < N && d.p != nullptr;
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
-        const int row = trow + 8 * ps;
-        const int pix = s_pix[wave][di][row];
-        if (pix < 0) continue;
-        const int off = pix * d.c + ch;
-        float4 v = *reinterpret_cast<const float4*>(T + row * 36 + 4 * tq);
+        v[ps] = *reinterpret_cast<const float4*>(T + (trow + 8 * ps) * 36 + 4 * tq);
         if (p.y_mask) {
-          const uchar4 mk = *reinterpret_cast<const uchar4*>(p.y_mask + off);
-          v.x *= mk.x * p.y_mask_scale; v.y *= mk.y * p.y_mask_scale;
-          v.z *= mk.z * p.y_mask_scale; v.w *= mk.w * p.y_mask_scale;
+          const unsigned mk = e.ym[ps];
+          v[ps].x *= (float)(mk & 0xffu) * p.y_mask_scale; v[ps].y *= (float)((mk >> 8) & 0xffu) * p.y_mask_scale;
+          v[ps].z *= (float)((mk >> 16) & 0xffu) * p.y_mask_scale; v[ps].w *= (float)(mk >> 24) * p.y_mask_scale;
         }
         if (p.grad_act != ADVOC_ACT_NONE) {
-          float4 x = *reinterpret_cast<const float4*>(d.xpre + off);
+          float4 x = make_float4(__uint_as_float(e.xp[ps].x), __uint_as_float(e.xp[ps].y), __uint_as_float(e.xp[ps].z),
+                                 __uint_as_float(e.xp[ps].w));
           if (d.gscale) {
+            const int ch = (di ? n0 + 32 * j - p.n_split : n0 + 32 * j) + 4 * tq;
             const float4 gs = *reinterpret_cast<const float4*>(d.gscale + ch);
             const float4 gh = *reinterpret_cast<const float4*>(d.gshift + ch);
             x.x = x.x * gs.x + gh.x; x.y = x.y * gs.y + gh.y; x.z = x.z * gs.z + gh.z; x.w = x.w * gs.w + gh.w;
           }
-          v.x *= x.x > 0.f ? 1.f : gslope; v.y *= x.y > 0.f ? 1.f : gslope;
-          v.z *= x.z > 0.f ? 1.f : gslope; v.w *= x.w > 0.f ? 1.f : gslope;
+          v[ps].x *= x.x > 0.f ? 1.f : gslope; v[ps].y *= x.y > 0.f ? 1.f : gslope;
+          v[ps].z *= x.z > 0.f ? 1.f : gslope; v[ps].w *= x.w > 0.f ? 1.f : gslope;
         }
         if (d.gmask) {
-          const uchar4 mk = *reinterpret_cast<const uchar4*>(d.gmask + off);
-          v.x *= mk.x * d.gmask_scale; v.y *= mk.y * d.gmask_scale;
-          v.z *= mk.z * d.gmask_scale; v.w *= mk.w * d.gmask_scale;
+          const unsigned mk = e.gm[ps];
+          v[ps].x *= (float)(mk & 0xffu) * d.gmask_scale; v[ps].y *= (float)((mk >> 8) & 0xffu) * d.gmask_scale;
+          v[ps].z *= (float)((mk >> 16) & 0xffu) * d.gmask_scale; v[ps].w *= (float)(mk >> 24) * d.gmask_scale;
         }
-        if (d.accum) {
-          const float4 o = *reinterpret_cast<const float4*>(d.p + off);
-          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        so[ps] = e.off[ps] == kThinOob ? kThinOob : e.off[ps] * 4u;
+      }
+      if (okj && d.accum) {                      // (no thin layer of the models accumulates: not worth 16 registers of prefetch)
+        const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(d.p, 0, kThinOob, 0x00020000);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(rs_o, so[ps], 0, 0);
+          v[ps].x += __uint_as_float(o.x); v[ps].y += __uint_as_float(o.y);
+          v[ps].z += __uint_as_float(o.z); v[ps].w += __uint_as_float(o.w);
         }
-        *reinterpret_cast<float4*>(d.p + off) = v;
+      }
+      const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(d.p, 0, okj ? kThinOob : 0u, 0x00020000);
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        u32x4 sv;
+        sv.x = __float_as_uint(v[ps].x); sv.y = __float_as_uint(v[ps].y);
+        sv.z = __float_as_uint(v[ps].z); sv.w = __float_as_uint(v[ps].w);
+        __builtin_amdgcn_raw_buffer_store_b128(sv, rs_d, so[ps], 0, 0);
       }
       wave_lds_sync();
     }
   }
+#undef ADVOC_THIN_PRELOAD
 }
+
+#undef PE_ROW
+#undef PE_COL
+#undef PE_CI
+#undef PE_OPEN
 
 template <int KP, bool B_KN>
 int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
@@ -277,24 +349,38 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
   const int tiles_x = (p.gw + 31) / 32;
   const int64_t tiles = (int64_t)p.batch * p.gh * tiles_x;
   if (tiles > 0x7fffffffLL / 64) return ADVOC_ERR_UNSUPPORTED;
+  // the epilogue addresses its destinations with 32-bit byte offsets
+  for (int di = 0; di < 2; ++di)
+    if (p.d[di].p && (int64_t)p.batch * p.out_h * p.d[di].pitch * p.d[di].c * 4 >= (int64_t)kThinOob)
+      return ADVOC_ERR_UNSUPPORTED;
   int64_t bx = ceil_div(tiles, 4);
   const int by = (N + 32 * nt - 1) / (32 * nt);
-  // whole rounds of the chip: `resident` workgroups fit at once (occupancy query, cached)
   const int pl = (pr * pc * (p.c0 + p.c1) + 63) / 64;
-  // ~6 workgroups per CU fit (LDS): launch whole rounds of the chip, grid-stride over the tiles
-  const int resident = 6 * 256;
-  const int64_t cap = resident / (by * p.nphase) > 0 ? resident / (by * p.nphase) : 1;
-  if (bx > cap) bx = cap;
-  dim3 grid((unsigned)bx, (unsigned)by, (unsigned)p.nphase);
+  dim3 grid(1, (unsigned)by, (unsigned)p.nphase);
   ADVOC_CLEAR_LAUNCH_ERROR();
+  // the grid is ONE round of the chip (as many workgroups as are resident at once: occupancy query per instance, cached),
+  // grid-striding over the tiles: a second, partial round would leave most CUs idle behind it
 #define ADVOC_THIN_LAUNCH(NT_, PL_)                                                                   \
-  hipLaunchKernelGGL((thin_k_gemm_kernel<KP, NT_, B_KN, PL_>), grid, dim3(256), 0, stream, p, dy_min, dx_min, pr, \
-                     pc, tiles_x)
+  {                                                                                                   \
+    static int per_cu = 0;                                                                            \
+    if (per_cu == 0) {                                                                                \
+      int nb = 0;                                                                                     \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, thin_k_gemm_kernel<KP, NT_, B_KN, PL_>, 256, 0) != hipSuccess || \
+          nb < 1)                                                                                     \
+        nb = 2;                                                                                       \
+      per_cu = nb;                                                                                    \
+    }                                                                                                 \
+    const int64_t cap = (int64_t)per_cu * device_cu_count() / (by * p.nphase);                        \
+    if (bx > cap) bx = cap > 0 ? cap : 1;                                                             \
+    grid.x = (unsigned)bx;                                                                            \
+    hipLaunchKernelGGL((thin_k_gemm_kernel<KP, NT_, B_KN, PL_>), grid, dim3(256), 0, stream, p, dy_min, dx_min, pr, \
+                       pc, tiles_x);                                                                  \
+  }
 #define ADVOC_THIN_LAUNCH_PL(NT_)                                                                     \
   {                                                                                                   \
-    if (pl <= 3) ADVOC_THIN_LAUNCH(NT_, 3);                                                           \
-    else if (pl <= 5) ADVOC_THIN_LAUNCH(NT_, 5);                                                      \
-    else ADVOC_THIN_LAUNCH(NT_, 9);                                                                   \
+    if (pl <= 3) ADVOC_THIN_LAUNCH(NT_, 3)                                                            \
+    else if (pl <= 5) ADVOC_THIN_LAUNCH(NT_, 5)                                                       \
+    else ADVOC_THIN_LAUNCH(NT_, 9)                                                                    \
   }
   if (nt == 4) ADVOC_THIN_LAUNCH_PL(4)
   else if (nt == 2) ADVOC_THIN_LAUNCH_PL(2)
