@@ -172,6 +172,11 @@ class Layer(object):
     # algorithmic HBM bytes of one pass: every input element once, every output element once, weights
     self.bytes_fwd = 4.0 * (x0.shape[0] * x0.shape[1] * lw * cin + y.shape[0] * y.shape[1] * s.y.w * cout
                             + kh * kw * cin * cout)
+    # backward-data through an input activation reads the pre-activation input once more (act'(x) gates dx: the
+    # reference's ReluGrad / LeakyReluGrad op reads it too); forward and the weight gradient touch x, y / dy, w once
+    self.bytes_dir = (self.bytes_fwd,
+                      self.bytes_fwd + (4.0 * x0.shape[0] * x0.shape[1] * lw * cin if in_act != ACT_NONE else 0.0),
+                      self.bytes_fwd)
 
   def kernel_name(self, direction):
     """Kernel template instance this layer launches for direction 0 fwd / 1 bwd-data / 2 bwd-weight."""
@@ -187,7 +192,7 @@ class Layer(object):
     if prof is None:
       fn()
     else:
-      prof.timed(self.kernel_name(direction), self.flops, self.bytes_fwd, fn)
+      prof.timed(self.kernel_name(direction), self.flops, self.bytes_dir[direction], fn)
 
   def _timed_image(self, which, dy=None):
     """With a launch profiler attached, the operand-image passes of an image-based call are launched (and timed) on

@@ -463,7 +463,8 @@ extern "C" int advoc_segmented_amax_f32(const float* base, const int64_t* offset
   hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(uint32_t) * (size_t)count, s);
   if (e != hipSuccess) { advoc::note_hip_error(e); return ADVOC_ERR_HIP; }
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(advoc::segmented_amax_kernel, dim3(64, (unsigned)count), dim3(256), 0, s, base, offsets, sizes,
+  // 256 slices per tensor: the 8M-element kernels of the deep layers set the duration of the launch (64 slices: 100 us)
+  hipLaunchKernelGGL(advoc::segmented_amax_kernel, dim3(256, (unsigned)count), dim3(256), 0, s, base, offsets, sizes,
                      amax_out);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;

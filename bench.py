@@ -351,7 +351,12 @@ def roofline_from(prof, model, batch, ms_per_step, prof_steps, verbose):
     mfma = 'mfma' in k or 'gather_gemm' in k or 'wgrad_h3' in k or 'patch_gemm' in k
     entry = dict(kernel=k, launches_per_step=v['launches'] / prof_steps, share_of_conv_stack=v['ms'] / tot,
                  avg_launch_ms=v['ms'] / v['launches'])
-    if mfma and v['flops'] > 0:
+    # the roof that bounds a kernel is the one that needs MORE time for its algorithmic work: flops at the peak of the
+    # matrix pipe it runs on, or bytes at the HBM peak (the 1- and 2-channel edge layers and the 16-column first stage of
+    # the two-stage path run MFMA instructions but move ~8 flop per byte)
+    t_hbm = v['bytes'] / (HBM_PEAK_GBS * 1e9)
+    t_mfma = v['flops'] / (mfma_pipe(k)[0] * 1e12) if (mfma and v['flops'] > 0) else 0.0
+    if t_mfma >= t_hbm:
       peak = mfma_pipe(k)[0]
       entry.update(bound='mfma', achieved=v['flops'] / (v['ms'] * 1e-3) / 1e12, peak=round(peak, 1), unit='TFLOP/s')
     else:
