@@ -28,6 +28,7 @@
 // Tile mapping (XCD-aware order), split-K, the tail split and the epilogue are those of igemm.hip.
 #include <stdlib.h>
 
+#include <cstdio>
 #include <string>
 
 #include "common.h"
@@ -440,6 +441,12 @@ int launch_h(const GatherGemmParams& p, hipStream_t stream, const char** name_on
   const int64_t gx = ceil_div(M, C::BM) * (p.n_total / C::BN);
   GatherGemmParams q = p;
   dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)p.nphase);
+  static const bool log_launches = getenv("ADVOC_H3_LOG") != nullptr;     // which launch is which (tools/micro)
+  if (log_launches)
+    fprintf(stderr, "h3 launch <%d,%d,%d,%d> batch %d grid %dx%d (+%d) phases %d N %d K %d taps %d bwd %d: %u x %u x %u wgs, "
+            "tail main %d rem %d split %d\n", MT, NT, NS, WGM, p.batch, p.gh, p.gw, p.gx_off, p.nphase, p.n_total,
+            p.c0 + p.c1, p.ntaps, p.grad_act != ADVOC_ACT_NONE || p.d[1].p != nullptr, grid.x, grid.y, grid.z, tail.main,
+            tail.rem, tail.split);
   if (ksplit > 1) {
     // partial sums meet in the destination with fp32 atomics: start from zero (logical region only: columns
     // beyond out_w -- pitch padding -- stay untouched)
@@ -568,7 +575,20 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     if (ksplit < 1) ksplit = 1;
   }
   if (tail.split < 2 && ksplit == 1 && !patch_nph) tail = plan_tail(tiles, nkt);
-  const int64_t tail_bytes = (int64_t)sizeof(float) * tail.rem * tail.split * BM * BN;
+  // the per-tap launch that takes the 1..4 remainder columns of a patch launch (below): one 128 x 64 tile per workgroup
+  // and under one workgroup per CU it runs at the latency of a single K pipeline (~1 us per K tile, 60-90 us for 1-3 % of
+  // the layer's work): its tiles are cut into K slices that meet in the workspace, like the deep layers' above
+  int64_t rtiles = 0;
+  if (patch_nph && geom.rem) {
+    rtiles = ceil_div((int64_t)p.batch * p.gh * geom.rem, 128) * (N / 64) * p.nphase;
+    if (tuning().h3_rem_ws && rtiles <= 256 && tuning().igemm_splitk) {
+      int split = (int)ceil_div((int64_t)tuning().h3_rem_wgs_per_cu * device_cu_count(), rtiles);
+      if (split > nkt / tuning().h3_rem_split_div) split = nkt / tuning().h3_rem_split_div;
+      if (split > 16) split = 16;
+      if (split >= 2) { tail.main = 0; tail.rem = (int)rtiles; tail.split = split; }
+    }
+  }
+  const int64_t tail_bytes = (int64_t)sizeof(float) * tail.rem * tail.split * (patch_nph ? 128 * 64 : BM * BN);
   const int64_t need = hdr_bytes + wq_bytes + i0_bytes + i1_bytes;
   if (scratch_query) { *scratch_query = need + tail_bytes; return ADVOC_OK; }
   if (!scratch || scratch_bytes < need) return ADVOC_ERR_UNSUPPORTED;
@@ -625,14 +645,17 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     pr.gx_off = geom.px * 16;
     // few rows, the whole contraction: split K over workgroups (zero fill + atomics) only when the contraction is long
     // and the launch would leave most of the chip idle
-    const int64_t rtiles = ceil_div((int64_t)pr.batch * pr.gh * pr.gw, 128) * (N / 64) * pr.nphase;
     int rsplit = 1;
-    if (nkt >= 64 && rtiles < device_cu_count() && tuning().igemm_splitk) {
-      rsplit = (int)ceil_div((int64_t)device_cu_count(), rtiles);
-      if (rsplit > nkt / 16) rsplit = nkt / 16;
+    const Tuning& tn = tuning();
+    if (tail.split > 1 && tail_ws && tail_cnt)
+      return launch_h<2, 1, 2>(pr, stream, nullptr, tail, tail_ws, tail_cnt, 1);
+    if (nkt >= 4 * tn.h3_rem_split_div && rtiles < (int64_t)tn.h3_rem_wgs_per_cu * device_cu_count() && tn.igemm_splitk) {
+      rsplit = (int)ceil_div((int64_t)tn.h3_rem_wgs_per_cu * device_cu_count(), rtiles);
+      if (rsplit > nkt / tn.h3_rem_split_div) rsplit = nkt / tn.h3_rem_split_div;
       if (rsplit > 16) rsplit = 16;
       if (rsplit < 1) rsplit = 1;
     }
+    if (tn.h3_rem_stages == 3) return launch_h<2, 1, 3>(pr, stream, nullptr, TailPlan(), nullptr, nullptr, rsplit);
     return launch_h<2, 1, 2>(pr, stream, nullptr, TailPlan(), nullptr, nullptr, rsplit);
   }
   if (k.wgm == 4 && k.nt == 4) return launch_h<2, 4, 2, 4>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);

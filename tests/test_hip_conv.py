@@ -322,6 +322,21 @@ def test_layer_patch_kernels(hip, case, want, persist, hipenv):
 
 
 @gpu
+@pytest.mark.parametrize('mode', ['workspace', 'atomics', 'one_pass'])
+@pytest.mark.parametrize('case,want', [c for c in PATCH if c[0][0].startswith('p3_rem')], ids=lambda c: c[0] if isinstance(c, tuple) else '')
+def test_patch_remainder_columns_k_split(hip, case, want, mode, hipenv):
+  """The per-tap launch that takes the 1..4 grid columns a patch launch leaves over: K slices meeting in the workspace
+  (default), in the destination with atomics (ADVOC_H3_REM_WS=0), or no split at all -- same results."""
+  if mode == 'workspace':
+    hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1, ADVOC_H3_REM_WS=1, ADVOC_H3_REM_WGS_PER_CU=4, ADVOC_H3_REM_SPLIT_DIV=2)
+  elif mode == 'atomics':
+    hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1, ADVOC_H3_REM_WS=0, ADVOC_H3_REM_WGS_PER_CU=4, ADVOC_H3_REM_SPLIT_DIV=2)
+  else:
+    hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1, ADVOC_IGEMM_SPLITK=0)
+  test_layer_all_directions(hip, case)
+
+
+@gpu
 @pytest.mark.parametrize('variant', H3_VARIANTS, ids=['t%d_s%d' % v for v in H3_VARIANTS])
 @pytest.mark.parametrize('case', H3, ids=[c[0] for c in H3])
 def test_layer_operand_image_kernels(hip, case, variant, hipenv):

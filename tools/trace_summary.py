@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Per-kernel table from a rocprofv3 --kernel-trace --output-format csv run.
     python tools/trace_summary.py DIR/*_kernel_trace.csv [--skip-first N] > profiles/rNN_x_kernel_trace.md
---skip-first drops the first N dispatches of every kernel (warm-up iterations)."""
+--skip-first drops the first N dispatches of every kernel (warm-up iterations).
+--by-grid SUBSTR adds one row per grid size for the kernels whose name contains SUBSTR (which launches of a shared instance
+cost what)."""
 import collections
 import csv
 import os
@@ -32,6 +34,16 @@ def main():
     print('| `%s` | %d | %.3f | %.1f | %.1f | %.1f | %.1f | %s | %s | %s | %s |' % (
         name, len(d), sum(d) / 1e6, sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3, 100.0 * sum(d) / tot,
         a['vg'], a['av'], a['lds'], a['scr']))
+  if '--by-grid' in sys.argv:
+    sub = sys.argv[sys.argv.index('--by-grid') + 1]
+    rows = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+      if sub in short(r['Kernel_Name']):
+        key = (short(r['Kernel_Name']), r.get('Grid_Size') or r.get('Grid_Size_X'), r.get('Workgroup_Size') or r.get('Workgroup_Size_X'))
+        rows.setdefault(key, []).append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    print('\n| kernel | grid | workgroup | calls | avg us | total ms |\n|---|---|---|---|---|---|')
+    for (name, g, wg), d in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+      print('| `%s` | %s | %s | %d | %.1f | %.3f |' % (name, g, wg, len(d), sum(d) / len(d) / 1e3, sum(d) / 1e6))
   print('\ntotal kernel time %.3f ms over %d dispatches' % (tot / 1e6, sum(len(a['d']) for a in agg.values())))
 
 
