@@ -66,6 +66,10 @@ Tuning read_env() {
   t.h3_patch_rem = env_int("ADVOC_H3_PATCH_REM", 1);
   t.h3_patch_persist = env_int("ADVOC_H3_PATCH_PERSIST", 1);
   t.h3_patch_ablate = env_int("ADVOC_H3_PATCH_ABLATE", 0);
+  t.h3_deep_wgs_per_cu = env_int("ADVOC_H3_DEEP_WGS_PER_CU", 2);
+  t.h3_deep_split_div = env_int("ADVOC_H3_DEEP_SPLIT_DIV", 8);
+  if (t.h3_deep_wgs_per_cu < 1) t.h3_deep_wgs_per_cu = 1;
+  if (t.h3_deep_split_div < 2) t.h3_deep_split_div = 2;
   t.h3_rem_ws = env_int("ADVOC_H3_REM_WS", 1);
   t.h3_rem_stages = env_int("ADVOC_H3_REM_STAGES", 2);
   t.h3_rem_wgs_per_cu = env_int("ADVOC_H3_REM_WGS_PER_CU", 2);

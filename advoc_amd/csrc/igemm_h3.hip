@@ -562,8 +562,8 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     // WORKSPACE -- the tail-split mechanism with no whole tiles: the last slice to arrive sums the parked partial tiles
     // in slice order and runs the ordinary epilogue (no zero fill, no atomics, bias and activation gradient fused as
     // usual; <= 256 tiles: one arrival counter each)
-    int split = (int)ceil_div((int64_t)2 * device_cu_count(), tiles);
-    if (split > nkt / 8) split = nkt / 8;
+    int split = (int)ceil_div((int64_t)tuning().h3_deep_wgs_per_cu * device_cu_count(), tiles);
+    if (split > nkt / tuning().h3_deep_split_div) split = nkt / tuning().h3_deep_split_div;
     if (split > 16) split = 16;
     if (split >= 2) { tail.main = 0; tail.rem = (int)tiles; tail.split = split; }
   }
