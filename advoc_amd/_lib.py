@@ -41,7 +41,7 @@ class ConvLayer(ctypes.Structure):
       ('in_mask', _p), ('in_mask_scale', _f32),
       ('workspace', _p), ('workspace_bytes', _i64),
       ('x_img', _p), ('x_hdr', _p), ('dy_img', _p), ('dy_hdr', _p), ('img_flags', _i32),
-      ('db_fused', _p), ('w_amax', _p),
+      ('db_fused', _p), ('w_amax', _p), ('w_img', _p * 2), ('w_img_hdr', _p * 2),
   ]
 
 
@@ -72,6 +72,8 @@ PROTOTYPES = {
     'advoc_conv_image_bytes': (_i64, [_p, _i32]),
     'advoc_conv_bias_fusable': (ctypes.c_int, [_p]),
     'advoc_segmented_amax_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p]),
+    'advoc_conv_weight_image_desc': (ctypes.c_int, [_p, _i32, _p]),
+    'advoc_weight_images_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p, _p]),
     'advoc_conv_make_image': (ctypes.c_int, [_p, _i32, _p, _p]),
     'advoc_conv_forward': (ctypes.c_int, [_p, _p]),
     'advoc_conv_backward_data': (ctypes.c_int, [_p, _p, _p, _p, _i32, _i32, _p]),

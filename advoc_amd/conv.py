@@ -178,6 +178,19 @@ class Layer(object):
                       self.bytes_fwd + (4.0 * x0.shape[0] * x0.shape[1] * lw * cin if in_act != ACT_NONE else 0.0),
                       self.bytes_fwd)
 
+  def weight_image_desc(self, direction):
+    """(taps, n_total, ktot, b_kn, bytes) of the weight image the forward (0) / backward-data (1) call reads, or None when
+    that direction does not run on the image kernels (advoc_conv_weight_image_desc)."""
+    out = (ctypes.c_int64 * 5)()
+    _lib.check(_lib.load().advoc_conv_weight_image_desc(ctypes.byref(self.struct), direction, out),
+               'advoc_conv_weight_image_desc')
+    return tuple(int(v) for v in out) if out[4] > 0 else None
+
+  def set_weight_image(self, direction, img_ptr, hdr_ptr):
+    """Persistent weight image of this direction (advoc_weight_images_f32 keeps it current; None: per-call images)."""
+    self.struct.w_img[direction] = img_ptr
+    self.struct.w_img_hdr[direction] = hdr_ptr
+
   def kernel_name(self, direction):
     """Kernel template instance this layer launches for direction 0 fwd / 1 bwd-data / 2 bwd-weight."""
     if direction not in self._names:

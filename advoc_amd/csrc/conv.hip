@@ -7,6 +7,8 @@
 // :89-158 (generator), :184-202 (discriminator) and their TF gradients.
 #include "conv_internal.h"
 #include "tuning.h"
+#include <string.h>
+
 #include "x6.h"
 
 namespace advoc {
@@ -328,6 +330,7 @@ extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stre
   p.a_img_current = (L->img_flags & ADVOC_IMG_X_CURRENT) != 0;
   p.a_img_delayed = (L->img_flags & ADVOC_IMG_X_DELAYED) != 0;
   p.w_amax = L->w_amax;
+  p.w_img = L->w_img[0]; p.w_img_hdr = L->w_img_hdr[0];
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
 
@@ -406,6 +409,7 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
   p.a_img_delayed = (L->img_flags & ADVOC_IMG_DY_DELAYED) != 0;
   p.a_colsum = L->dy_img ? L->db_fused : nullptr;       // the bias gradient rides in the dy image pass (igemm_h3.hip)
   p.w_amax = L->w_amax;
+  p.w_img = L->w_img[1]; p.w_img_hdr = L->w_img_hdr[1];
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
 
@@ -475,6 +479,30 @@ extern "C" int advoc_conv_backward_bias(const advoc_conv_layer* L, const float* 
   if (!dy || !db) return ADVOC_ERR_NULL;
   return launch_bias_grad(dy, L->drop_mask, L->drop_scale, (int64_t)L->y.n * L->y.h, L->y.w,
                           L->y.w_pitch, L->y.c, db, accumulate, as_stream(stream));
+}
+
+// {taps, n_total, ktot, b_kn, bytes} of the weight image direction 0 (forward) / 1 (backward-data) of this layer reads;
+// bytes = 0 when that direction does not run on the image kernels
+extern "C" int advoc_conv_weight_image_desc(const advoc_conv_layer* L, int32_t direction, int64_t* out5_host) {
+  int rc = validate_layer(L);
+  if (rc != ADVOC_OK) return rc;
+  if (!out5_host) return ADVOC_ERR_NULL;
+  if (direction != 0 && direction != 1) return ADVOC_ERR_UNSUPPORTED;
+  for (int i = 0; i < 5; ++i) out5_host[i] = 0;
+  GatherGemmParams p;
+  bool b_kn;
+  float dummy = 0.f;
+  rc = direction == 0 ? build_forward(L, p, b_kn)
+                      : build_backward_data(L, &dummy, &dummy, L->x1.p ? &dummy : nullptr, 0, 0, p, b_kn);
+  if (rc != ADVOC_OK) return rc;
+  const char* name = nullptr;
+  rc = run_gather(p, b_kn, nullptr, &name, L->workspace, L->workspace_bytes);
+  if (rc != ADVOC_OK) return rc;
+  int taps, n_total, ktot;
+  if (!name || !strstr(name, "_h3_kernel") || !h3_weight_image_shape(p, &taps, &n_total, &ktot)) return ADVOC_OK;
+  out5_host[0] = taps; out5_host[1] = n_total; out5_host[2] = ktot; out5_host[3] = b_kn ? 1 : 0;
+  out5_host[4] = ((int64_t)4 * taps * n_total * ktot + 255) / 256 * 256;
+  return ADVOC_OK;
 }
 
 extern "C" int advoc_conv_kernel_name(const advoc_conv_layer* L, int32_t direction, char* buf_host,

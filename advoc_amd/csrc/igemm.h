@@ -54,6 +54,8 @@ struct GatherGemmParams {
   // ---- B operand ----
   const float* w;
   const unsigned* w_amax;  // optional: float bits of max |w| already on the device (advoc_segmented_amax_f32)
+  const uint16_t* w_img;   // optional: the CURRENT fp16 pair image of w for this direction (advoc_weight_images_f32) and
+  const unsigned* w_img_hdr;   // its 4-word header ([1] = 2^-s): the call builds no weight image
   int n_total;
   int k_order;             // 0: channel slices inner, taps outer; 1: taps inner
   int n_valid;             // 0 = n_total; else only the first n_valid columns exist in w / are stored
@@ -104,6 +106,8 @@ int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
 
 // ---- shared launch helpers (igemm.hip) ----
 int device_cu_count();
+// taps / columns / K of the weight image a gather launch reads (igemm_h3.hip); false: not on the image kernels
+bool h3_weight_image_shape(const GatherGemmParams& p, int* taps, int* n_total, int* ktot);
 // A launch of T equal workgroups on C compute units costs ceil(T / C) rounds when they are all resident: the last
 // T mod C tiles are cut into `split` K slices each so that the extra round is 1 / split of a tile long.
 struct TailPlan { int main = 0, rem = 0, split = 0; };

@@ -532,6 +532,14 @@ bool h3_eligible(const GatherGemmParams& p) {
   return true;
 }
 
+bool h3_weight_image_shape(const GatherGemmParams& p, int* taps, int* n_total, int* ktot) {
+  if (!h3_eligible(p)) return false;
+  *taps = weight_taps_of(p);
+  *n_total = p.n_total;
+  *ktot = p.c0 + p.c1;
+  return true;
+}
+
 // Workspace layout of one launch: [operand headers 256 B][weight image][image of source 0][image of source 1]
 // [tail partials]
 int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t stream, const char** name_only,
@@ -602,6 +610,10 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   char* img_home = p.a_img_out ? reinterpret_cast<char*>(p.a_img_out) : ws + hdr_bytes + wq_bytes;
   uint16_t* img0 = reinterpret_cast<uint16_t*>(img_home);
   uint16_t* img1 = reinterpret_cast<uint16_t*>(img_home + i0_bytes);
+  if (p.w_img && p.w_img_hdr) {          // persistent, current weight image (advoc_weight_images_f32)
+    wq = const_cast<uint16_t*>(p.w_img);
+    hdr_b = const_cast<unsigned*>(p.w_img_hdr);
+  }
   p.a_hdr = hdr_a; p.b_hdr = hdr_b;
   p.wq = wq;
   p.wq_taps = taps;
@@ -614,12 +626,15 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   if (!name_only && tuning().h3_skip_prep) {
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
   } else if (!name_only) {
-    if (!p.w_amax) {
-      hipError_t e = hipMemsetAsync(hdr_b, 0, 8, stream);
-      if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    int rc = ADVOC_OK;
+    if (!(p.w_img && p.w_img_hdr)) {
+      if (!p.w_amax) {
+        hipError_t e = hipMemsetAsync(hdr_b, 0, 8, stream);
+        if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+      }
+      rc = launch_pair_weights(p.w, wq, taps, N, ktot, b_kn, hdr_b, stream, p.w_amax);
+      if (rc != ADVOC_OK) return rc;
     }
-    int rc = launch_pair_weights(p.w, wq, taps, N, ktot, b_kn, hdr_b, stream, p.w_amax);
-    if (rc != ADVOC_OK) return rc;
     if (!(p.a_img_out && p.a_img_current)) {
       // one scale for the whole A operand: the largest magnitude over both sources of a channel concat
       const ImageSource s0 = {p.a0, e0, p.c0, p.in_scale, p.in_shift, p.in_act, p.a_mask, p.a_mask_scale};

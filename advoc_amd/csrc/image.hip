@@ -338,6 +338,59 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
+// Every weight image of a network in ONE launch (advoc_weight_images_f32): blockIdx.y = image, described by a row of 8
+// int64 in device memory {w offset from base (elements), taps, n_total, ktot, b_kn, index into the magnitude table, byte
+// offset of the image in the pool, index of its 4-word header}; same arithmetic and layout as split_weights_kernel's
+// fp16-pair form, the scale from the arena's magnitude table (advoc_segmented_amax_f32).
+__global__ __launch_bounds__(256) void weight_images_kernel(const float* __restrict__ base,
+                                                            const unsigned* __restrict__ amax,
+                                                            const int64_t* __restrict__ table,
+                                                            char* __restrict__ pool, unsigned* __restrict__ hdrs) {
+  __shared__ float tile[32][33];
+  const int64_t* row = table + 8 * (int64_t)blockIdx.y;
+  const float* w = base + row[0];
+  const int taps = (int)row[1], n_total = (int)row[2], ktot = (int)row[3], b_kn = (int)row[4];
+  uint16_t* wq = reinterpret_cast<uint16_t*>(pool + row[6]);
+  unsigned* hdr = hdrs + 4 * row[7];
+  const int tk = ktot / 32, tn = (n_total + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float up = up_scale(amax[row[5]]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = __float_as_uint(1.f / up);
+  for (int b = blockIdx.x; b < taps * tk * tn; b += gridDim.x) {
+    const int t = b / (tk * tn), r = b - t * (tk * tn);
+    const int k0 = (r / tn) * 32, n0 = (r % tn) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = ty + 8 * i;
+      float x = 0.f;
+      if (b_kn) {
+        const int k = k0 + rr, n = n0 + tx;
+        if (n < n_total) x = w[((int64_t)t * ktot + k) * n_total + n];
+        tile[rr][tx] = x;
+      } else {
+        const int n = n0 + rr, k = k0 + tx;
+        if (n < n_total) x = w[((int64_t)t * n_total + n) * ktot + k];
+        tile[tx][rr] = x;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + ty + 8 * i, k = k0 + tx;
+      if (n < n_total) {
+        const float a = tile[tx][ty + 8 * i] * up;
+        const __half a0 = __float2half_rn(a);
+        const __half a1 = __float2half_rn(a - __half2float(a0));
+        const int64_t o = ((int64_t)t * n_total + n) * ktot + k;
+        uint16_t* q = wq + (o >> 5) * 64 + (o & 31);
+        q[0] = __half_as_ushort(a0);
+        q[32] = __half_as_ushort(a1);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 int grid_for(int64_t items, int per_block) {
   int64_t blocks = ceil_div(items, per_block);
   if (blocks > 256 * 16) blocks = 256 * 16;
@@ -452,6 +505,19 @@ int launch_pair_weights(const float* w, uint16_t* wq, int taps, int n_total, int
 }
 
 }  // namespace advoc
+
+extern "C" int advoc_weight_images_f32(const float* base, const uint32_t* amax, const int64_t* table, int32_t count,
+                                       void* pool, uint32_t* hdrs, advoc_stream_t stream) {
+  if (count < 0) return ADVOC_ERR_BAD_SHAPE;
+  if (count == 0) return ADVOC_OK;
+  if (!base || !amax || !table || !pool || !hdrs) return ADVOC_ERR_NULL;
+  if (count > 65535) return ADVOC_ERR_UNSUPPORTED;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(advoc::weight_images_kernel, dim3(256, (unsigned)count), dim3(256), 0, advoc::as_stream(stream), base,
+                     amax, table, reinterpret_cast<char*>(pool), hdrs);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
 
 extern "C" int advoc_segmented_amax_f32(const float* base, const int64_t* offsets, const int64_t* sizes, int32_t count,
                                         uint32_t* amax_out, advoc_stream_t stream) {

@@ -465,6 +465,44 @@ class Advoc(Model):
     for lay in list(L.values()) + st['d_layers_fake'] + st.get('d_layers_real', []) + st.get('d_layers_2b', []):
       lay.reuse_images = True
       lay.delayed_scale = os.environ.get('ADVOC_DELAYED_SCALE', '1') == '1'
+    self._bind_weight_images(st, 'g', list(L.values()), dev)
+    self._bind_weight_images(st, 'd', st['d_layers_fake'] + st.get('d_layers_real', []) + st.get('d_layers_2b', []), dev)
+
+  def _bind_weight_images(self, st, net, layers, dev):
+    """Persistent fp16 pair images of every kernel the image kernels read (forward and backward-data layouts), rebuilt
+    by ONE advoc_weight_images_f32 launch per forward pass over the network (right after the magnitude launch) instead of
+    one small launch per layer call -- 54 per train step.  Layers that share a kernel (the discriminator's real / fake /
+    2B passes) share its images.  ADVOC_WEIGHT_IMAGES=0: per-call images."""
+    st[net + '_wimg'] = None
+    st[net + '_wdirty'] = True            # new layers, new (empty) image pool
+    if not st['wamax_on'] or os.environ.get('ADVOC_WEIGHT_IMAGES', '1') != '1':
+      return
+    names = dict((t.data_ptr(), k) for k, t in st[net + '_P'].items() if k.endswith('/kernel'))
+    slots, rows, uses = {}, [], []
+    pool_bytes = 0
+    for lay in layers:
+      name = names.get(lay.weight.data_ptr())
+      if name is None:
+        continue
+      for direction in (0, 1):
+        desc = lay.weight_image_desc(direction)
+        if desc is None:
+          continue
+        key = (name,) + desc[:4]
+        if key not in slots:
+          slots[key] = (pool_bytes, len(rows))
+          rows.append([st[net + '_arena'].offsets[name][0], desc[0], desc[1], desc[2], desc[3],
+                       st[net + '_wamax_index'][name], pool_bytes, len(rows)])
+          pool_bytes += desc[4]
+        uses.append((lay, direction) + slots[key])
+    if not rows:
+      return
+    pool = torch.empty(pool_bytes, dtype=torch.uint8, device=dev)
+    hdrs = torch.zeros(4 * len(rows), dtype=torch.int32, device=dev)
+    table = torch.tensor(rows, dtype=torch.int64, device=dev)
+    for lay, direction, off, idx in uses:
+      lay.set_weight_image(direction, pool.data_ptr() + off, hdrs.data_ptr() + 16 * idx)
+    st[net + '_wimg'] = dict(pool=pool, hdrs=hdrs, table=table, count=len(rows), uses=uses)
 
   # ------------------------------------------------------------------------------------------
   # batch-norm plumbing
@@ -527,8 +565,17 @@ class Advoc(Model):
       for k, v in self._built[net + '_P'].items():
         if k in state:
           v.copy_(state[k].to(v.device, torch.float32))
+    self.parameters_changed()
     if 'global_step' in state:
       self.step = int(state['global_step'])
+
+  def parameters_changed(self, net=None):
+    """The kernels of `net` ('g' / 'd', None = both) were written: their magnitude table and weight images are rebuilt by
+    the next forward pass over the network.  The framework's own writers (Adam, load_state_dict, the data-parallel
+    broadcast) call this; code that edits the parameter views in place must call it too."""
+    if self._built:
+      for n in (('g', 'd') if net is None else (net,)):
+        self._built[n + '_wdirty'] = True
 
   def image_saturations(self):
     """Elements that exceeded the fp16 range of a delayed-scale operand image (conv.Layer.delayed_scale) and were
@@ -581,16 +628,23 @@ class Advoc(Model):
   # forward passes
   # ------------------------------------------------------------------------------------------
   def _refresh_weight_amax(self, net):
-    """max |w| of every kernel of arena `net` ('g' / 'd') in one launch.  Run at the start of each forward pass over
-    the network, i.e. after any optimizer step, checkpoint load or in-place edit of the parameters that came before it;
-    the backward pass of the same step reads the same (unchanged) kernels."""
+    """max |w| of every kernel of arena `net` ('g' / 'd') and every weight image of the network, one launch each.  Called
+    at the start of each forward pass over the network; does its work when the parameters were written since the last
+    time (parameters_changed: Adam step, load_state_dict, broadcast) -- i.e. ONCE per optimizer step; the second generator
+    pass of a train_loop and the backward passes read the same images."""
     st = self._built
-    if not st['wamax_on']:
+    if not st['wamax_on'] or not st.get(net + '_wdirty', True):
       return
+    st[net + '_wdirty'] = False
     out = st[net + '_wamax']
     _lib.check(_lib.load().advoc_segmented_amax_f32(
         _lib.ptr(st[net + '_param']), _lib.ptr(st[net + '_wamax_off']), _lib.ptr(st[net + '_wamax_size']),
         out.numel(), _lib.ptr(out), _lib.stream()), 'advoc_segmented_amax_f32')
+    wi = st.get(net + '_wimg')
+    if wi:
+      _lib.check(_lib.load().advoc_weight_images_f32(
+          _lib.ptr(st[net + '_param']), _lib.ptr(out), _lib.ptr(wi['table']), wi['count'], _lib.ptr(wi['pool']),
+          _lib.ptr(wi['hdrs']), _lib.stream()), 'advoc_weight_images_f32')
 
   def _gen_forward(self, x):
     st = self._built
@@ -666,6 +720,7 @@ class Advoc(Model):
         _lib.ptr(st[net + '_param']), _lib.ptr(flat), _lib.ptr(st[net + '_m']), _lib.ptr(st[net + '_v']),
         flat.numel(), lr_t, self._beta1, self._beta2, self._adam_eps, 1.0 / self._world_size,
         _lib.stream()), 'advoc_adam_tf_f32')
+    st[net + '_wdirty'] = True
 
   def _load_batch(self, batch):
     st = self._built

@@ -119,6 +119,7 @@ class DataParallel(object):
     st = model._built
     for k in ('g_param', 'd_param', 'g_m', 'g_v', 'd_m', 'd_v'):
       self._collective(dist.broadcast, st[k], src=0)
+    model.parameters_changed()
 
   def barrier(self):
     if self.enabled:

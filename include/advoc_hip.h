@@ -248,12 +248,29 @@ typedef struct advoc_conv_layer {
    * the weights (one per forward / backward-data call otherwise).  MUST be current: a stale, smaller value overflows
    * the fp16 image. */
   const uint32_t* w_amax;
+  /* optional: persistent fp16 pair images of the kernel for the forward ([0]) and the backward-data ([1]) call, and their
+   * 16-byte headers, built for ALL layers of a network by ONE advoc_weight_images_f32 launch after a weight update
+   * (sizes and shapes: advoc_conv_weight_image_desc).  When non-null the call builds no weight image of its own (54
+   * small launches per AdVoc train step otherwise) and trusts the image to be CURRENT. */
+  const uint16_t* w_img[2];
+  const uint32_t* w_img_hdr[2];
 } advoc_conv_layer;
 
 /* amax_out[i] = float bits of max |base[offsets[i] .. offsets[i] + sizes[i])| for `count` tensors of one arena, in one
  * launch (offsets / sizes / amax_out in device memory; amax_out is zeroed first).  Feeds advoc_conv_layer.w_amax. */
 int advoc_segmented_amax_f32(const float* base, const int64_t* offsets, const int64_t* sizes, int32_t count,
                              uint32_t* amax_out, advoc_stream_t stream);
+
+/* out5_host = {taps, n_total, ktot, b_kn, bytes} of the weight image the forward (direction 0) / backward-data (1) call of
+ * this layer reads; bytes = 0 when that direction does not run on the image kernels (host-side, no launch). */
+int advoc_conv_weight_image_desc(const advoc_conv_layer* layer, int32_t direction, int64_t* out5_host);
+
+/* Builds `count` weight images in one launch.  table (device): 8 int64 per image {offset of the kernel tensor from `base`
+ * in elements, taps, n_total, ktot, b_kn (the first four numbers of advoc_conv_weight_image_desc), index of the tensor in
+ * `amax` (advoc_segmented_amax_f32's output, already current on `stream`), byte offset of the image in `pool` (256-byte
+ * aligned), index of its 4-word header in `hdrs`}.  Feeds advoc_conv_layer.w_img / w_img_hdr. */
+int advoc_weight_images_f32(const float* base, const uint32_t* amax, const int64_t* table, int32_t count, void* pool,
+                            uint32_t* hdrs, advoc_stream_t stream);
 
 /* 1: the layer's output-gradient image pass can carry the bias gradient (db_fused above): dy_img present and cout such
  * that a thread of the image pass keeps one group of 8 channels (32 <= cout <= 1024, 256 % (cout / 8) == 0) */

@@ -770,7 +770,7 @@ def test_segmented_amax_of_an_arena(hip):
 def test_weight_magnitude_from_the_arena_pass(hip, case, hipenv):
   """advoc_conv_layer.w_amax: with the largest |w| handed in (advoc_segmented_amax_f32) the image kernels skip their own
   magnitude pass over the kernel and give bit-identical results, forward and backward-data, also after the kernel
-  changed (refreshed w_amax).  A magnitude that only shares the power of two gives the same image as well."""
+  changed (refreshed w_amax); so do the persistent weight images of advoc_weight_images_f32 (w_img / w_img_hdr)."""
   import ctypes
   from advoc_amd import conv, _lib
   hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1)
@@ -800,12 +800,35 @@ def test_weight_magnitude_from_the_arena_pass(hip, case, hipenv):
     L.backward_data(dy, dx0, dx1)
     return y.clone(), dx0.clone()
 
+  def run_with_persistent_images():
+    """advoc_weight_images_f32: both weight images of the layer from one launch, handed in as w_img / w_img_hdr"""
+    L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'],
+                   w_amax=amax)
+    descs = [L.weight_image_desc(d) for d in (0, 1)]
+    assert all(d is not None for d in descs) and descs[0][3] != descs[1][3]        # one [tap][k][n], one [tap][n][k]
+    offs = [0, descs[0][4]]
+    pool = torch.empty(descs[0][4] + descs[1][4], dtype=torch.uint8, device=dev)
+    hdrs = torch.zeros(8, dtype=torch.int32, device=dev)
+    table = torch.tensor([[0, d[0], d[1], d[2], d[3], 0, offs[i], i] for i, d in enumerate(descs)], dtype=torch.int64,
+                         device=dev)
+    _lib.check(_lib.load().advoc_weight_images_f32(_lib.ptr(w), _lib.ptr(amax), _lib.ptr(table), 2, _lib.ptr(pool),
+                                                   _lib.ptr(hdrs), _lib.stream()), 'advoc_weight_images_f32')
+    for d in (0, 1):
+      L.set_weight_image(d, pool.data_ptr() + offs[d], hdrs.data_ptr() + 16 * d)
+    y.zero_()
+    L.forward()
+    dx0 = torch.zeros_like(x0)
+    dx1 = torch.zeros_like(x1) if x1 is not None else None
+    L.backward_data(dy, dx0, dx1)
+    return y.clone(), dx0.clone()
+
   for rep in range(2):
     refresh()
     assert float(amax.view(torch.float32)) == float(w.abs().max())
-    a, b = run(None), run(amax)
-    for u, v in zip(a, b):
+    a, b, pi = run(None), run(amax), run_with_persistent_images()
+    for u, v, z in zip(a, b, pi):
       assert torch.equal(u, v)
+      assert torch.equal(u, z)
     w.mul_(37.0)                          # "optimizer step": another power of two
   with pytest.raises(_lib.AdvocHipError):
     conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'],

@@ -356,17 +356,23 @@ def test_weight_magnitudes_follow_the_parameters(hip, monkeypatch):
       for k, i in st[net + '_wamax_index'].items():
         assert float(got[i]) == float(st[net + '_P'][k].abs().max()), (rep, k)
     saved = [(lay, lay.struct.w_amax) for lay in st['g_layers'].values()]
+    assert st['g_wimg'] and st['d_wimg'] and any(lay.struct.w_img[0] for lay, _ in saved)
     for lay, _ in saved:
-      lay.struct.w_amax = None                       # the layers take the magnitude themselves again
+      lay.struct.w_amax = None                       # the layers take the magnitude and build their weight images
+      for d in (0, 1):                               # themselves again
+        lay.set_weight_image(d, None, None)
     m._dropout_calls = calls                         # same dropout masks
     out0 = m._gen_forward(st['x_in']).clone()
     for lay, p in saved:
       lay.struct.w_amax = p
+    for lay, d, off, idx in st['g_wimg']['uses']:
+      lay.set_weight_image(d, st['g_wimg']['pool'].data_ptr() + off, st['g_wimg']['hdrs'].data_ptr() + 16 * idx)
     # same power of two, same weight images (bit-identical per layer: test_hip_conv.py); what is left is the order of the
     # split-K atomics of the small deep layers
     assert rel(out1, out0) < 2e-6, (rep, rel(out1, out0))
     for k in st['g_wamax_index']:
-      st['g_P'][k].mul_(300.0 if 'encoder_2' in k else 0.01)      # e.g. a checkpoint restore: the next pass sees it
+      st['g_P'][k].mul_(300.0 if 'encoder_2' in k else 0.01)      # an in-place edit of the views ...
+    m.parameters_changed('g')                                      # ... announced: the next pass sees it
 
 
 @gpu
