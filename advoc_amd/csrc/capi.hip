@@ -66,6 +66,8 @@ Tuning read_env() {
   t.h3_patch_rem = env_int("ADVOC_H3_PATCH_REM", 1);
   t.h3_patch_persist = env_int("ADVOC_H3_PATCH_PERSIST", 1);
   t.h3_patch_ablate = env_int("ADVOC_H3_PATCH_ABLATE", 0);
+  t.thin_wgrad_nt = env_int("ADVOC_THIN_WGRAD_NT", 4);
+  if (t.thin_wgrad_nt != 1 && t.thin_wgrad_nt != 2) t.thin_wgrad_nt = 4;
   t.h3_deep_wgs_per_cu = env_int("ADVOC_H3_DEEP_WGS_PER_CU", 2);
   t.h3_deep_split_div = env_int("ADVOC_H3_DEEP_SPLIT_DIV", 8);
   if (t.h3_deep_wgs_per_cu < 1) t.h3_deep_wgs_per_cu = 1;

@@ -20,6 +20,7 @@
 #include <string>
 
 #include "conv_internal.h"
+#include "tuning.h"
 
 namespace advoc {
 namespace {
@@ -561,18 +562,32 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
 
   // Combine the four waves of the block in LDS, then ONE atomic per output element per block:
   // thousands of waves hammering the same <= 32 x cb addresses serialise in L2 otherwise.
-  __shared__ float s_red[4][NT][16][64];
+  // (The sums meet in the Q staging area, which is dead by now, two waves at a time: a [4][NT][16][64] array of its own
+  // was 64 KB of the 104 KB of the NT = 4 instance -- ONE workgroup per CU, i.e. one wave per SIMD with nothing to run
+  // while it waits for its loads.)
+  static_assert(2 * NT * 1024 <= 4 * PT * LDQ, "the reduction fits in the staging area");
+  __syncthreads();
+  float* red = &s_q[0][0];                // [2][NT][16][64]
+  if (wave >= 2) {
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s_red[wave][j][r][lane] = acc[j][r];
+      for (int r = 0; r < 16; ++r) red[((wave - 2) * NT + j) * 1024 + r * 64 + lane] = acc[j][r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * NT + j) * 1024 + r * 64 + lane] += acc[j][r];
+  }
   __syncthreads();
   for (int idx = threadIdx.x; idx < NT * 16 * 64; idx += 256) {
     const int ln = idx & 63, r = (idx >> 6) & 15, j = idx >> 10;
     const int row = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);     // A row index (tap, a)
     const int b = b0 + 32 * j + (ln & 31);
     if (row >= rows || b >= cb) continue;
-    const float v = s_red[0][j][r][ln] + s_red[1][j][r][ln] + s_red[2][j][r][ln] + s_red[3][j][r][ln];
+    const float v = red[j * 1024 + r * 64 + ln] + red[(NT + j) * 1024 + r * 64 + ln];
     const int rt = row / ca, ra = row % ca;
     unsafeAtomicAdd(p.dw + ((int64_t)(p.tap[rt] >> 16) * ca + ra) * cb + b, v);
   }
@@ -594,7 +609,8 @@ int launch_thin_k_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
 int launch_wgrad_thin_mfma(const WgradParams& p, hipStream_t stream, const char** name_only) {
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   if (ca < 1 || ca > 2 || p.ntaps * ca > 32 || cb % 32) return ADVOC_ERR_UNSUPPORTED;
-  const int nt = cb % 128 == 0 ? 4 : (cb % 64 == 0 ? 2 : 1);
+  int nt = cb % 128 == 0 ? 4 : (cb % 64 == 0 ? 2 : 1);
+  if (nt > tuning().thin_wgrad_nt) nt = tuning().thin_wgrad_nt;
   if (name_only) {
     *name_only = nt == 4 ? "thin_wgrad_kernel<4>" : (nt == 2 ? "thin_wgrad_kernel<2>" : "thin_wgrad_kernel<1>");
     return ADVOC_OK;
@@ -616,23 +632,34 @@ int launch_wgrad_thin_mfma(const WgradParams& p, hipStream_t stream, const char*
   const int64_t tiles = (int64_t)p.batch * p.gh * tiles_x;
   if (tiles > 0x7fffffffLL / 64) return ADVOC_ERR_UNSUPPORTED;
   const int by = cb / (32 * nt);
-  // ~2048 waves over the tile axis (2 blocks of 4 waves per CU); each wave keeps one tile of loads in
-  // flight while it multiplies the previous one
-  int64_t waves = 2048 / by;
-  if (waves < 4) waves = 4;
-  int64_t chunk = ceil_div(tiles, waves);
-  if (chunk < 4) chunk = 4;
-  const int64_t bx = ceil_div(ceil_div(tiles, chunk), 4);
-  dim3 grid((unsigned)bx, (unsigned)by);
+  // one round of the chip (as many workgroups as are resident at once: occupancy query per instance, cached), the tile
+  // axis cut into one contiguous run per wave; each wave keeps one tile of loads in flight while it multiplies the
+  // previous one
+  dim3 grid(1, (unsigned)by);
+  int64_t chunk = 4;
   ADVOC_CLEAR_LAUNCH_ERROR();
 #define ADVOC_TW_LAUNCH(NT_, PL_)                                                                     \
-  hipLaunchKernelGGL((thin_wgrad_kernel<NT_, PL_>), grid, dim3(256), 0, stream, p, (int)chunk, tiles_x, dy_min, dx_min, \
-                     pr, pc)
+  {                                                                                                   \
+    static int per_cu = 0;                                                                            \
+    if (per_cu == 0) {                                                                                \
+      int nb = 0;                                                                                     \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, thin_wgrad_kernel<NT_, PL_>, 256, 0) != hipSuccess || nb < 1) \
+        nb = 1;                                                                                       \
+      per_cu = nb;                                                                                    \
+    }                                                                                                 \
+    int64_t waves = (int64_t)4 * per_cu * device_cu_count() / by;                                     \
+    if (waves < 4) waves = 4;                                                                         \
+    chunk = ceil_div(tiles, waves);                                                                   \
+    if (chunk < 4) chunk = 4;                                                                         \
+    grid.x = (unsigned)ceil_div(ceil_div(tiles, chunk), 4);                                           \
+    hipLaunchKernelGGL((thin_wgrad_kernel<NT_, PL_>), grid, dim3(256), 0, stream, p, (int)chunk, tiles_x, dy_min, dx_min, \
+                       pr, pc);                                                                       \
+  }
 #define ADVOC_TW_LAUNCH_PL(NT_)                                                                       \
   {                                                                                                   \
-    if (pl <= 2) ADVOC_TW_LAUNCH(NT_, 2);                                                             \
-    else if (pl <= 3) ADVOC_TW_LAUNCH(NT_, 3);                                                        \
-    else ADVOC_TW_LAUNCH(NT_, 5);                                                                     \
+    if (pl <= 2) ADVOC_TW_LAUNCH(NT_, 2)                                                              \
+    else if (pl <= 3) ADVOC_TW_LAUNCH(NT_, 3)                                                         \
+    else ADVOC_TW_LAUNCH(NT_, 5)                                                                      \
   }
   if (nt == 4) ADVOC_TW_LAUNCH_PL(4)
   else if (nt == 2) ADVOC_TW_LAUNCH_PL(2)
