@@ -135,6 +135,9 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
     const int gc = lpos ^ ((r >> 1) & 7);
     a_b0[g] = (((img * p.a_h + a_y[g]) * p.a0_pitch + a_x[g]) * p.c0) * 4 + gc * 16;     // bytes into the image
     a_b1[g] = (((img * p.a_h + a_y[g]) * p.a1_pitch + a_x[g]) * p.c1) * 4 + gc * 16;
+    a_b1[g] -= a_b0[g];        // kept as the DIFFERENCE: `second ? a_b1[g] : a_b0[g]` in the K loop made the compiler merge
+                               // the two arrays into one in scratch memory, indexed by `second` -- a scratch load and
+                               // an s_waitcnt vmcnt(0), i.e. a wait for every DMA in flight, per DMA slot and K tile
   }
   int b_off[CGB];
 #pragma unroll
@@ -179,7 +182,7 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
     _Pragma("unroll") for (int g = 0; g < RGA; ++g) {                                                    \
       const int iy_ = a_y[g] + dy_, ix_ = a_x[g] + dx_;                                                  \
       const bool ok_ = a_ok[g] && (unsigned)iy_ < (unsigned)p.in_h && (unsigned)ix_ < (unsigned)p.in_w;  \
-      const int voff_ = ok_ ? (second_ ? a_b1[g] : a_b0[g]) + delta_ : (int)0x80000000;                  \
+      const int voff_ = ok_ ? a_b0[g] + (second_ ? a_b1[g] : 0) + delta_ : (int)0x80000000;              \
       unsigned char* d_ = st_ + (wave * RGA + g) * 1024;                                                 \
       if (ABL != 3) {                                                                                    \
         if (second_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_void_p)(d_), 16, voff_, 0, 0, 0);    \
