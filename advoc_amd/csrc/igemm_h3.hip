@@ -160,6 +160,9 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
   int ld_tap = taps_inner ? kt_begin % p.ntaps : kt_begin / kpt;
   int ld_k0 = (taps_inner ? kt_begin / p.ntaps : kt_begin % kpt) * BK;
 
+  // the tap table of this phase, one entry per lane, read with v_readlane in the K loop: an s_load there is followed by
+  // s_waitcnt lgkmcnt(0), i.e. by the scalar memory latency once per K tile
+  const int tapv = p.tap[phase][lane < p.ntaps ? lane : 0];
   // Issues the DMAs of the next K tile of the walk into stage ST (a compile-time constant in the unrolled
   // loop below).  Tiles past kt_end wrap round to valid ones; their data is never read.
 #define ADVOC_H3_ISSUE(ST)                                                                               \
@@ -172,7 +175,7 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
       ld_k0 += BK;                                                                                       \
       if (ld_k0 == ktot) { ld_k0 = 0; if (++ld_tap == p.ntaps) ld_tap = 0; }                             \
     }                                                                                                    \
-    const int tp_ = __builtin_amdgcn_readfirstlane(p.tap[phase][ti_]);                                   \
+    const int tp_ = __builtin_amdgcn_readlane(tapv, ti_);                                                \
     const int dy_ = (int)(int8_t)(tp_ & 0xff), dx_ = (int)(int8_t)((tp_ >> 8) & 0xff);                   \
     const int wtap_ = tp_ >> 16;                                                                         \
     const bool second_ = k0_ >= p.c0;                                                                    \
