@@ -157,6 +157,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // of every step's LDS reads).  (S2: one table for all waves, entry 4 plane + t, offsets already relative to the
   // plane's halo origin)
   const int tapv_c = S2 ? g.s2_tap[ln & (kMaxTaps - 1)] : p.tap[phase][ln & (kMaxTaps - 1)];
+  // the parity planes' first rows / columns as four scalars: indexed as g.s2_a0y[parity] in the K loop they were scalar
+  // LOADS from the kernel arguments, each followed by s_waitcnt lgkmcnt(0), three times per K slice
+  const int s2y0 = g.s2_a0y[0], s2y1 = g.s2_a0y[1], s2x0 = g.s2_a0x[0], s2x1 = g.s2_a0x[1];
   const int tapv_b = S2 ? tapv_c : p.tap[b_phase][ln & (kMaxTaps - 1)];
   const int nt = tile / npatch;
   const int pid = tile - nt * npatch;
@@ -193,8 +196,8 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       const int h_ = blk_ * 8 + lr_;                                                                      \
       const int hy_ = (h_ * hmagic) >> 16;                                                                \
       const int hx_ = h_ - hy_ * hw;                                                                      \
-      const int iy_ = S2 ? 2 * (gy0 + hy_ + g.s2_a0y[ppy_]) + ppy_ : gy0 + hy_ + g.dy0;                    \
-      const int ix_ = S2 ? 2 * (gx0 + hx_ + g.s2_a0x[ppx_]) + ppx_ : gx0 + hx_ + g.dx0;                    \
+      const int iy_ = S2 ? 2 * (gy0 + hy_ + (ppy_ ? s2y1 : s2y0)) + ppy_ : gy0 + hy_ + g.dy0;              \
+      const int ix_ = S2 ? 2 * (gx0 + hx_ + (ppx_ ? s2x1 : s2x0)) + ppx_ : gx0 + hx_ + g.dx0;              \
       const bool ok_ = h_ < hpix && hx_ < C::HW && (unsigned)iy_ < (unsigned)p.in_h &&                    \
                        (unsigned)ix_ < (unsigned)p.in_w;                                                  \
       const int voff_ = ok_ ? (((img * p.a_h + iy_) * pitch_ + ix_) * c_ + kk_) * 4 +                     \
