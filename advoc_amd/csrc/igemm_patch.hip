@@ -135,8 +135,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const int t_lo = xcd < tr_ ? xcd * (tq_ + 1) : tr_ * (tq_ + 1) + (xcd - tr_) * tq_;
   const int t_hi = t_lo + tq_ + (xcd < tr_ ? 1 : 0);
 
-  // (the backward-data instances take ONE tile per workgroup: with the K loop's per-lane constants kept alive across the
-  // epilogue for a next tile, their epilogue -- accumulators + the block's prefetched operands -- spills)
+  // (the backward-data instances used to take ONE tile per workgroup: with the K loop's per-lane constants kept alive
+  // across the epilogue for a next tile, their epilogue -- accumulators + the block's prefetched operands -- spilled;
+  // since the constants are derived from an opaque copy of the lane id per tile, below, they walk tiles too: 1-2 %)
   for (int tile = t_lo + slot; tile < t_hi; tile += per_xcd) {
   // The per-lane constants of the K loop are derived from an OPAQUE copy of the lane id inside the tile loop: hoisted out
   // of it they would stay alive across the epilogue, whose accumulators + prefetched operands then spill (80-230
@@ -489,7 +490,6 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     }
 #undef ADVOC_P3_PRELOAD
   }
-  if (BWD) break;
   __syncthreads();          // the next tile's DMAs overwrite the LDS this epilogue read
   }  // tiles
 }
@@ -517,7 +517,7 @@ int launch_patch(const GatherGemmParams& p, const PatchGeom& g, hipStream_t stre
   // one per CU (160 KB of LDS each), every workgroup walks tiles -- 2-4 % faster on every layer of the model
   const int64_t tiles = (int64_t)p.batch * g.py * g.px * (p.n_total / C::BN);
   int64_t wgs = (tiles + 7) / 8 * 8;
-  if (t.h3_patch_persist && !BWD) {
+  if (t.h3_patch_persist && (!BWD || t.h3_patch_persist == 2)) {
     const int64_t cus = device_cu_count() / 8 * 8;
     if (wgs > cus && cus >= 8) wgs = cus;
   }

@@ -289,7 +289,7 @@ PATCH = [
 
 
 @gpu
-@pytest.mark.parametrize('persist', [1, 0], ids=['persistent', 'tile_per_wg'])
+@pytest.mark.parametrize('persist', [2, 1, 0], ids=['persistent', 'persistent_forward_only', 'tile_per_wg'])
 @pytest.mark.parametrize('case,want', PATCH, ids=[c[0][0] for c in PATCH])
 def test_layer_patch_kernels(hip, case, want, persist, hipenv):
   from advoc_amd import conv
