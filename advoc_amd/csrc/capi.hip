@@ -53,7 +53,7 @@ Tuning read_env() {
   t.igemm_korder = env_int("ADVOC_IGEMM_KORDER", -1);
   t.wgrad_x6 = env_int("ADVOC_WGRAD_X6", 1);
   t.wgrad_h3 = env_int("ADVOC_WGRAD_H3", 1);
-  t.wgrad_h3_min_m = env_int("ADVOC_WGRAD_H3_MIN_M", 4096);
+  t.wgrad_h3_min_m = env_int("ADVOC_WGRAD_H3_MIN_M", 128);
   t.wgrad_h3_tile = env_int("ADVOC_WGRAD_H3_TILE", 0);
   t.h3 = env_int("ADVOC_H3", 1);
   t.h3_tile = env_int("ADVOC_H3_TILE", 0);
