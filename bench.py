@@ -540,11 +540,12 @@ def main():
         'vs_baseline': None,
         'dtype': 'f32',
         'dtype_note': 'fp32 tensors and fp32 accumulation everywhere; the large conv contractions run on the 16-bit '
-                      'matrix cores with each fp32 operand written as a sum of 16-bit terms -- forward / backward-data: '
-                      'two fp16 terms of the operand scaled by one power of two per tensor, three of the four partial '
-                      'products (representation and dropped term <= 2^-22 relative); weight gradients: three bf16 '
-                      'terms, six of nine partial products -- measured against float64 at or below the error of the '
-                      'fp32 MFMA chain on the same layers (tests/test_hip_conv.py, tools/micro/h3_numerics.py)',
+                      'matrix cores with each fp32 operand written as a sum of 16-bit terms -- forward, backward-data '
+                      'and weight gradients: two fp16 terms of the operand scaled by one power of two per tensor, three '
+                      'of the four partial products (representation and dropped term <= 2^-22 relative); shapes outside '
+                      'those kernels: three bf16 terms, six of nine partial products, or the fp32 MFMA (1-2 channel edge '
+                      'layers) -- measured against float64 at or below the error of the fp32 MFMA chain on the same '
+                      'layers (tests/test_hip_conv.py, tools/micro/h3_numerics.py)',
         'data': 'synthetic',
         'config': {
             'workload': 'AdVoc-%s train_loop (1 D update + 1 G update on fresh batches), LJSpeech '
