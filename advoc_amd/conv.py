@@ -166,6 +166,12 @@ class Layer(object):
     self._names = {}
     self._db_done_for = None
     self._bias_fusable = bool(_lib.load().advoc_conv_bias_fusable(ctypes.byref(s)))
+    self._thin_bias = False
+    if kind == CONV and cin <= 2 and workspace:
+      try:
+        self._thin_bias = 'thin_wgrad_kernel' in self.kernel_name(2)
+      except _lib.AdvocHipError:
+        pass
     lw = s.x0.w
     grid = (y.shape[1] * s.y.w) if kind == CONV else (x0.shape[1] * lw)
     self.flops = 2.0 * x0.shape[0] * grid * kh * kw * cin * cout
@@ -286,17 +292,22 @@ class Layer(object):
     if self.reuse_images:
       flags = (1 if self._x_current else 0) | (2 if self._dy_current_ptr == dy.data_ptr() else 0)
     self.struct.img_flags = flags | self._delayed_bits()
+    db_done = getattr(self, '_db_done_for', None) == dy.data_ptr()
+    # 1-2 channel inputs (encoder_1, layer_1): the weight-gradient kernel reads every dy element exactly once and takes the
+    # bias gradient on the way (advoc_conv_backward_weight's db argument)
+    db_rides = db is not None and not db_done and self._thin_bias
+    if db_rides:
+      _lib.require_device(db)
     self._run(2, lambda: _lib.check(_lib.load().advoc_conv_backward_weight(
-        ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dw), None, int(accumulate), _lib.stream()),
-        'advoc_conv_backward_weight'))
+        ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db) if db_rides else None, int(accumulate),
+        _lib.stream()), 'advoc_conv_backward_weight'))
     self.struct.img_flags = 0
     if 'h3' in self.kernel_name(2):        # the image-based weight gradient has (re)built whatever was not current
       self._x_built = self._x_built or bool(self.struct.x_img)
       self._dy_built = self._dy_built or bool(self.struct.dy_img)
     self._dy_current_ptr = None          # one use per backward_data: the next step's dy lives at the same address
-    db_done = getattr(self, '_db_done_for', None) == dy.data_ptr()
     self._db_done_for = None
-    if db is not None and not db_done:
+    if db is not None and not db_done and not db_rides:
       _lib.require_device(db)
       call = lambda: _lib.check(_lib.load().advoc_conv_backward_bias(      # noqa: E731
           ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(db), int(accumulate), _lib.stream()),

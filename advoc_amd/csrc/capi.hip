@@ -66,6 +66,7 @@ Tuning read_env() {
   t.h3_patch_rem = env_int("ADVOC_H3_PATCH_REM", 1);
   t.h3_patch_persist = env_int("ADVOC_H3_PATCH_PERSIST", 2);
   t.h3_patch_ablate = env_int("ADVOC_H3_PATCH_ABLATE", 0);
+  t.thin_wgrad_bias = env_int("ADVOC_THIN_WGRAD_BIAS", 1);
   t.thin_wgrad_nt = env_int("ADVOC_THIN_WGRAD_NT", 4);
   if (t.thin_wgrad_nt != 1 && t.thin_wgrad_nt != 2) t.thin_wgrad_nt = 4;
   t.h3_deep_wgs_per_cu = env_int("ADVOC_H3_DEEP_WGS_PER_CU", 2);

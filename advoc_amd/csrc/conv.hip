@@ -372,7 +372,10 @@ extern "C" int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* L, int32_t
   if (direction == 2) {      // backward-weight: operand images of the image-based kernel
     WgradParams w;
     float dummy = 0.f;
-    if (build_backward_weight(L, &dummy, &dummy, w) != ADVOC_OK || !wgrad_h3_eligible(w)) return 0;
+    if (build_backward_weight(L, &dummy, &dummy, w) != ADVOC_OK) return 0;
+    // thin layers: the replica table of the bias sums that ride in thin_wgrad_kernel
+    if (w.P.c0 + w.P.c1 <= 2) return w.Q.p0 == &dummy && (w.Q.c0 + w.Q.c1) <= 1024 ? kColsumBytes : 0;
+    if (!wgrad_h3_eligible(w)) return 0;
     int64_t a, b, c, d;
     return 256 + wgrad_h3_operand_bytes(w.P, w.batch, &a, &b) + wgrad_h3_operand_bytes(w.Q, w.batch, &c, &d);
   }
@@ -429,8 +432,27 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
   const int ca = p.P.c0 + p.P.c1;
   if (ca <= 2) {
     const int cb = p.Q.c0 + p.Q.c1;
-    rc = (cb % 32 == 0 && p.ntaps * ca <= 32) ? launch_wgrad_thin_mfma(p, as_stream(stream)) : ADVOC_ERR_UNSUPPORTED;
-    if (rc == ADVOC_ERR_UNSUPPORTED) rc = launch_wgrad_thin(p, as_stream(stream));   // odd channel counts / wide tap spans
+    // the bias gradient rides in the weight-gradient kernel when its wide operand IS the output gradient (encoder_1,
+    // layer_1): that kernel reads every dy element exactly once anyway
+    const bool thin_mfma = cb % 32 == 0 && p.ntaps * ca <= 32;
+    bool db_fused = false;
+    if (thin_mfma && db && p.Q.p0 == dy && !p.Q.p1 && cb <= 1024 && L->workspace && L->workspace_bytes >= kColsumBytes &&
+        tuning().thin_wgrad_bias) {
+      if (!accumulate) {
+        hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)cb, as_stream(stream));
+        if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+      }
+      p.qsum_out = db;
+      p.qsum_table = L->workspace;
+      db_fused = true;
+    }
+    rc = thin_mfma ? launch_wgrad_thin_mfma(p, as_stream(stream)) : ADVOC_ERR_UNSUPPORTED;
+    if (rc == ADVOC_ERR_UNSUPPORTED) {                 // odd channel counts / wide tap spans
+      p.qsum_out = p.qsum_table = nullptr;
+      db_fused = false;
+      rc = launch_wgrad_thin(p, as_stream(stream));
+    }
+    if (db_fused) db = nullptr;
   } else {
     rc = ADVOC_ERR_UNSUPPORTED;
     if (wgrad_h3_eligible(p)) {

@@ -52,6 +52,10 @@ struct WgradParams {
   int tap[kMaxTaps];   // (dy & 0xff) | (dx & 0xff) << 8 | wtap << 16
   float* dw;           // accumulated with atomics; zero-filled by the launcher unless `accumulate`
   int accumulate;
+  // thin_wgrad only (Q = the output gradient): the per-channel sums of the transformed Q values -- the layer's bias
+  // gradient -- are taken on the way: added to qsum_table[kColsumReplicas][cb] (zeroed scratch), folded into qsum_out
+  float* qsum_out;
+  float* qsum_table;
 };
 
 int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream,

@@ -418,6 +418,13 @@ int launch_amax(const float* x, int64_t elems, int c, const float* scale, const 
   return ADVOC_OK;
 }
 
+int launch_colsum_reduce(const float* table, float* out, int c, hipStream_t stream) {
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, table, out, c);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
 bool image_colsum_ok(int c) { return c >= 32 && c <= 1024 && 256 % (c / 8) == 0 && c % 8 == 0; }
 
 int launch_pair_image(const float* x, uint16_t* img, int64_t elems, int c, const float* scale, const float* shift,

@@ -21,6 +21,7 @@
 
 #include "conv_internal.h"
 #include "tuning.h"
+#include "x6.h"
 
 namespace advoc {
 namespace {
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
       v.z *= mk.z * p.Q.mask_scale; v.w *= mk.w * p.Q.mask_scale;                                     \
     }                                                                                                 \
     if (q_on[i]) *reinterpret_cast<float4*>(Qs + qk[i] * LDQ + (qch[i] - b0)) = v;                    \
+    if (p.qsum_table && live_) { qs[i].x += v.x; qs[i].y += v.y; qs[i].z += v.z; qs[i].w += v.w; }      \
   }                                                                                                   \
   _Pragma("unroll") for (int i = 0; i < PL; ++i) {                                                    \
     if (pe_row[i] < 0) continue;                                                                      \
@@ -541,6 +543,11 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // per-channel sums of the parked Q values (the bias gradient when Q is the output gradient): every Q element passes
+  // through exactly one PARK of the launch
+  float4 qs[QL];
+#pragma unroll
+  for (int i = 0; i < QL; ++i) qs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   if (t_begin < t_end) ADVOC_TW_FETCH(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
@@ -591,6 +598,24 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
     const int rt = row / ca, ra = row % ca;
     unsafeAtomicAdd(p.dw + ((int64_t)(p.tap[rt] >> 16) * ca + ra) * cb + b, v);
   }
+  if (p.qsum_table) {
+    // lanes -> LDS (one slot per channel of the column block), then ONE global atomic per channel and workgroup into the
+    // replica this workgroup belongs to (same-address atomics from every workgroup would queue up in the L2)
+    __syncthreads();
+    float* s_sum = &s_patch[0][0];
+    for (int t = threadIdx.x; t < 32 * NT; t += 256) s_sum[t] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < QL; ++i) {
+      if (!q_on[i]) continue;
+      float* d = s_sum + (qch[i] - b0);
+      atomicAdd(d, qs[i].x); atomicAdd(d + 1, qs[i].y); atomicAdd(d + 2, qs[i].z); atomicAdd(d + 3, qs[i].w);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 32 * NT; t += 256)
+      if (b0 + t < cb)
+        unsafeAtomicAdd(p.qsum_table + (size_t)(blockIdx.x & (kColsumReplicas - 1)) * cb + b0 + t, s_sum[t]);
+  }
 }
 
 }  // namespace
@@ -617,6 +642,10 @@ int launch_wgrad_thin_mfma(const WgradParams& p, hipStream_t stream, const char*
   }
   if (!p.accumulate) {
     hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
+    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+  }
+  if (p.qsum_table) {
+    hipError_t e = hipMemsetAsync(p.qsum_table, 0, sizeof(float) * kColsumReplicas * (size_t)cb, stream);
     if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
   }
   int dy_min = 127, dy_max = -128, dx_min = 127, dx_max = -128;
@@ -667,6 +696,7 @@ int launch_wgrad_thin_mfma(const WgradParams& p, hipStream_t stream, const char*
 #undef ADVOC_TW_LAUNCH_PL
 #undef ADVOC_TW_LAUNCH
   ADVOC_RETURN_IF_LAUNCH_FAILED();
+  if (p.qsum_table && p.qsum_out) return launch_colsum_reduce(p.qsum_table, p.qsum_out, cb, stream);
   return ADVOC_OK;
 }
 

@@ -58,6 +58,8 @@ int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* i
                        hipStream_t stream, float* colsum0 = nullptr, int w_log = 0, int w_pitch = 0,
                        float* colsum_table = nullptr);
 bool image_colsum_ok(int c);
+// out[ch] += sum over the kColsumReplicas copies of table[r][ch] (the fold of every replica table of this library)
+int launch_colsum_reduce(const float* table, float* out, int c, hipStream_t stream);
 constexpr int kColsumReplicas = 64;
 constexpr int64_t kColsumBytes = (int64_t)kColsumReplicas * 1024 * 4;
 // weights [tap][k][n] (b_kn) or [tap][n][k] -> wq[tap][n_total][ktot / 32][plane][32] fp16 (amax pass included;

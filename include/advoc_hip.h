@@ -322,7 +322,10 @@ int advoc_conv_kernel_name(const advoc_conv_layer* layer, int32_t direction, cha
 
 /* Gradient w.r.t. kernel and bias: dw has the layout of layer->w, db is [cout] (NULL = skip).
  * accumulate == 0 overwrites dw / db, != 0 adds to them (a variable shared by two passes, e.g. the
- * discriminator on real and on fake inputs).  Replaces Conv2DBackpropFilter / BiasAddGrad. */
+ * discriminator on real and on fake inputs).  Replaces Conv2DBackpropFilter / BiasAddGrad.
+ * db: for layers with 1-2 input channels (encoder_1, discriminator layer_1) and a workspace the per-channel sums are
+ * taken inside the weight-gradient kernel, which reads every dy element exactly once anyway; elsewhere a separate pass
+ * over dy (or pass NULL and use advoc_conv_layer.db_fused / advoc_conv_backward_bias). */
 int advoc_conv_backward_weight(const advoc_conv_layer* layer, const float* dy, float* dw, float* db,
                                int32_t accumulate, advoc_stream_t stream);
 
