@@ -354,6 +354,192 @@ def write_checkpoint(prefix, tensors):
     f.write(bytes(data))
 
 
+# ---------------------------------------------------------------------------------------------
+# MetaGraphDef (``*.meta``): the graph a checkpoint belongs to
+# ---------------------------------------------------------------------------------------------
+def _signed64(v):
+  return v - (1 << 64) if v >= 1 << 63 else v
+
+
+def _packed_varints(buf):
+  out, pos = [], 0
+  while pos < len(buf):
+    v, pos = _get_varint(buf, pos)
+    out.append(_signed64(v))
+  return out
+
+
+def _repeated_ints(msg, field):
+  """repeated int64 / int32 / bool field: packed (one bytes blob) or one varint per element."""
+  out = []
+  for v in msg.get(field, []):
+    out += _packed_varints(v) if isinstance(v, bytes) else [_signed64(v)]
+  return out
+
+
+def _repeated_floats(msg, field):
+  out = []
+  for v in msg.get(field, []):
+    if isinstance(v, bytes):
+      out += list(struct.unpack('<%df' % (len(v) // 4), v))
+    else:
+      out.append(struct.unpack('<f', struct.pack('<I', v))[0])
+  return out
+
+
+def _parse_tensor(buf):
+  """TensorProto (tensorflow/core/framework/tensor.proto) -> numpy array (strings: list of bytes)."""
+  m = _parse_proto(buf)
+  dt = m.get(1, [0])[0]
+  shape = _parse_shape(m[2][0]) if 2 in m else ()
+  count = int(np.prod(shape)) if shape else 1
+  if dt == 7:                                            # DT_STRING
+    vals = [bytes(v) for v in m.get(8, [])]
+    return vals if shape else (vals[0] if vals else b'')
+  if dt not in _DT_TO_NP:
+    raise NotImplementedError('TensorProto dtype {}'.format(dt))
+  npdt = np.dtype(_DT_TO_NP[dt])
+  if 4 in m and len(m[4][0]):                            # tensor_content: raw little-endian bytes
+    arr = np.frombuffer(m[4][0], dtype=npdt.newbyteorder('<')).astype(npdt)
+  else:
+    if dt == 1:
+      vals = _repeated_floats(m, 5)                      # float_val
+    elif dt == 2:
+      vals = []
+      for v in m.get(6, []):                             # double_val
+        vals += list(struct.unpack('<%dd' % (len(v) // 8), v)) if isinstance(v, bytes) \
+            else [struct.unpack('<d', struct.pack('<Q', v))[0]]
+    elif dt == 9:
+      vals = _repeated_ints(m, 10)                       # int64_val
+    elif dt == 10:
+      vals = [bool(v) for v in _repeated_ints(m, 11)]    # bool_val
+    else:
+      vals = _repeated_ints(m, 7)                        # int_val (int32, uint8, int16, int8, ...)
+    arr = np.asarray(vals, dtype=npdt)
+    if arr.size == 1 and count > 1:                      # a single value stands for a constant-filled tensor
+      arr = np.full(count, arr[0], dtype=npdt)
+    elif arr.size == 0:
+      arr = np.zeros(count, dtype=npdt)
+  if arr.size != count:
+    raise ValueError('TensorProto holds {} values for shape {}'.format(arr.size, shape))
+  return arr.reshape(shape)
+
+
+def _parse_attr(buf):
+  """AttrValue (attr_value.proto) -> python value."""
+  m = _parse_proto(buf)
+  if 2 in m:
+    return m[2][0].decode('utf-8', 'replace')
+  if 3 in m:
+    return _signed64(m[3][0])
+  if 4 in m:
+    return struct.unpack('<f', struct.pack('<I', m[4][0]))[0]
+  if 5 in m:
+    return bool(m[5][0])
+  if 6 in m:
+    return ('dtype', m[6][0])
+  if 7 in m:
+    sm = _parse_proto(m[7][0])
+    return ('shape', None if sm.get(3, [0])[0] else list(_parse_shape(m[7][0])))
+  if 8 in m:
+    return _parse_tensor(m[8][0])
+  if 1 in m:
+    lv = _parse_proto(m[1][0])
+    if 2 in lv:
+      return [v.decode('utf-8', 'replace') for v in lv[2]]
+    if 3 in lv:
+      return _repeated_ints(lv, 3)
+    if 4 in lv:
+      return _repeated_floats(lv, 4)
+    if 5 in lv:
+      return [bool(v) for v in _repeated_ints(lv, 5)]
+    if 6 in lv:
+      return [('dtype', v) for v in _repeated_ints(lv, 6)]
+    if 7 in lv:
+      return [('shape', list(_parse_shape(v))) for v in lv[7]]
+    return []
+  return None
+
+
+def read_meta_graph(path):
+  """Reads a TensorFlow MetaGraphDef (what ``tf.train.export_meta_graph`` writes and the reference's scripts import:
+  scripts/spectrogram_advoc.py:55-64, scripts/generate_spectrogram.py, models/melspecgan/infer.py) without TensorFlow.
+
+  Returns dict(nodes=OrderedDict name -> dict(op, inputs, attrs), collections={name: [str]}, saver=dict(...),
+  tf_version=str).  Used to check that a model built here has the variables / hyper-parameters of the graph a published
+  checkpoint was saved from (variables(), check_model_against_meta_graph)."""
+  import collections as _c
+  with open(path, 'rb') as f:
+    data = f.read()
+  mg = _parse_proto(data)
+  if 2 not in mg:
+    raise ValueError('{!r}: no GraphDef inside (not a MetaGraphDef)'.format(path))
+  info = _parse_proto(mg[1][0]) if 1 in mg else {}
+  gd = _parse_proto(mg[2][0])
+  nodes = _c.OrderedDict()
+  for nb in gd.get(1, []):
+    n = _parse_proto(nb)
+    attrs = {}
+    for ab in n.get(5, []):
+      kv = _parse_proto(ab)
+      attrs[kv[1][0].decode()] = _parse_attr(kv[2][0]) if 2 in kv else None
+    nodes[n[1][0].decode()] = dict(op=n[2][0].decode(), inputs=[i.decode() for i in n.get(3, [])], attrs=attrs)
+  colls = {}
+  for cb in mg.get(4, []):
+    kv = _parse_proto(cb)
+    key = kv[1][0].decode()
+    val = _parse_proto(kv[2][0]) if 2 in kv else {}
+    items = []
+    if 1 in val:                                          # NodeList
+      items = [v.decode() for v in _parse_proto(val[1][0]).get(1, [])]
+    elif 2 in val:                                        # BytesList: serialized VariableDef {1: variable_name, ...}
+      for b in _parse_proto(val[2][0]).get(1, []):
+        try:
+          items.append(_parse_proto(b)[1][0].decode())
+        except Exception:                                 # not a VariableDef: keep the raw length
+          items.append('<%d bytes>' % len(b))
+    colls[key] = items
+  saver = {}
+  if 3 in mg:
+    sd = _parse_proto(mg[3][0])
+    saver = dict(filename_tensor_name=sd.get(1, [b''])[0].decode(), save_tensor_name=sd.get(2, [b''])[0].decode(),
+                 restore_op_name=sd.get(3, [b''])[0].decode(), max_to_keep=sd.get(4, [0])[0],
+                 version=sd.get(7, [0])[0])
+  return dict(nodes=nodes, collections=colls, saver=saver,
+              tf_version=info.get(5, [b''])[0].decode() if 5 in info else '')
+
+
+def meta_graph_variables(meta):
+  """OrderedDict variable name -> (numpy dtype, shape) of the VariableV2 / VarHandleOp nodes of read_meta_graph()'s
+  result, in graph (creation) order."""
+  import collections as _c
+  out = _c.OrderedDict()
+  for name, n in meta['nodes'].items():
+    if n['op'] in ('VariableV2', 'Variable', 'VarHandleOp'):
+      dt = n['attrs'].get('dtype')
+      shp = n['attrs'].get('shape')
+      out[name] = (np.dtype(_DT_TO_NP[dt[1]]) if dt and dt[1] in _DT_TO_NP else None,
+                   tuple(shp[1]) if shp and shp[1] is not None else None)
+  return out
+
+
+def check_model_against_meta_graph(specs, meta, scope=None):
+  """`specs`: [(variable name, shape)] of a model built here.  Raises ValueError naming the first variable of the meta
+  graph (under `scope`) that the model lacks or shapes differently, and the first model variable the graph lacks."""
+  gv = meta_graph_variables(meta)
+  if scope:
+    gv = dict((k, v) for k, v in gv.items() if k.startswith(scope))
+  mine = dict((k, tuple(s)) for k, s in specs)
+  for k, (_, shape) in gv.items():
+    if k not in mine:
+      raise ValueError('meta graph variable {!r} {} has no counterpart in the model'.format(k, shape))
+    if shape is not None and mine[k] != shape:
+      raise ValueError('variable {!r}: model shape {} != meta graph shape {}'.format(k, mine[k], shape))
+  for k in mine:
+    if k not in gv:
+      raise ValueError('model variable {!r} is not in the meta graph'.format(k))
+
+
 def load_into_model(prefix, model, generator_only=False):
   """Copies every variable of `model.state_dict()` found in the TF checkpoint into the model
   (names and layouts are TF's own, so no transposition).  Returns (loaded names, missing names, step)."""

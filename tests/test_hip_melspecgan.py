@@ -1,5 +1,6 @@
-"""MelspecGAN generator inference on MI355X vs the torch-CPU oracle (PARITY UNPINNED: the reference
-has no test or golden tensor for this network; see oracle/melspecgan_torch.py)."""
+"""MelspecGAN generator inference on MI355X vs the torch-CPU oracle and vs the TensorFlow-written inference graph of the
+reference (models/melspecgan/infer.meta decoded into tests/golden/melspecgan_graph.json; the graph's STRUCTURE is pinned by
+it, its trained weights are not reachable)."""
 import os
 import subprocess
 import sys
@@ -80,6 +81,27 @@ def test_generator_matches_oracle(hip, dim, batchnorm):
     G(z, training=True)
   with pytest.raises(ValueError):
     G(torch.zeros(3, 99))
+
+
+@gpu
+def test_generator_matches_the_tensorflow_graph(hip):
+  """The HIP generator (dim 64, batch norm: the configuration the reference exported) against the TF-written graph
+  evaluated op by op in float64 (tests/tf_graph_interp.py) -- no oracle transcription in between."""
+  import json
+  import tf_graph_interp as interp
+  from advoc_amd.melspecgan import MelspecGANGenerator
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'melspecgan_graph.json')) as f:
+    graph = json.load(f)
+  P = M.init_params(dim=64, seed=11)
+  G = MelspecGANGenerator(dim=64, batchnorm=True)
+  G.load_state_dict(P)
+  z = torch.randn(4, 100, generator=torch.Generator().manual_seed(5))
+  want = interp.run(graph, 'G_z', {'z': z.double()}, {k: v.double() for k, v in P.items()})
+  got = G(z, denorm=True)
+  assert tuple(got.shape) == tuple(want.shape) == (4, 64, 80, 1)
+  assert rel(got, want) < 1e-4, rel(got, want)
+  pre = interp.run(graph, 'G/Tanh', {'z': z.double()}, {k: v.double() for k, v in P.items()})
+  assert rel(G(z, denorm=False), pre) < 1e-4
 
 
 @gpu
