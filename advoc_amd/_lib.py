@@ -42,7 +42,10 @@ class ConvLayer(ctypes.Structure):
       ('workspace', _p), ('workspace_bytes', _i64),
       ('x_img', _p), ('x_hdr', _p), ('dy_img', _p), ('dy_hdr', _p), ('img_flags', _i32),
       ('db_fused', _p), ('w_amax', _p), ('w_img', _p * 2), ('w_img_hdr', _p * 2),
+      ('wgrad_table', _p),
   ]
+
+WGRAD_TABLE_BYTES = 262144      # ADVOC_WGRAD_TABLE_BYTES
 
 
 # name -> (restype, argtypes).  Must list every symbol include/advoc_hip.h declares

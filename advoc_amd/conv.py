@@ -81,7 +81,8 @@ class Layer(object):
   reuse_images = False
   # True: consecutive calls on this layer see data of the same scale (the train step): after the first (exact, two-pass)
   # image of a buffer, later images are built in ONE pass with the scale taken from the previous image's largest
-  # magnitude (ADVOC_IMG_*_DELAYED, 2^6 of head room; csrc/image.hip).  False (default): always the exact two-pass form.
+  # magnitude (ADVOC_IMG_*_DELAYED, 2^6 of head room; a tensor that leaves it, or shrinks by more than 2^6, is re-imaged
+  # exactly on the device in the same call; csrc/image.hip).  False (default): always the exact two-pass form.
   delayed_scale = False
 
   @staticmethod
@@ -157,17 +158,27 @@ class Layer(object):
         nbytes = _lib.load().advoc_conv_image_bytes(ctypes.byref(s), which)
         if nbytes > 0:
           img = torch.empty(nbytes // 2, dtype=torch.int16, device=x0.device)
-          hdr = torch.zeros(4, dtype=torch.int32, device=x0.device)
+          hdr = torch.zeros(8, dtype=torch.int32, device=x0.device)
           setattr(s, img_field, img.data_ptr())
           setattr(s, hdr_field, hdr.data_ptr())
           self._img += [img, hdr]
       self.tensors = self.tensors + tuple(self._img)
     s.img_flags = 0
+    # headers of dy_img per caller ROLE (set_dy_role): one layer object can see output gradients of different losses in
+    # one train step (the discriminator's fake pass: D-loss gradients in the D step, G-loss gradients in the G step);
+    # each role keeps its own magnitude history so that delayed scaling compares like with like
+    self._dy_roles = {}
+    self._dy_role = None
     self._names = {}
     self._db_done_for = None
     self._bias_fusable = bool(_lib.load().advoc_conv_bias_fusable(ctypes.byref(s)))
     self._thin_bias = False
     if kind == CONV and cin <= 2 and workspace:
+      # the replica table of the bias sums that ride in the thin weight-gradient kernel: owned by the layer, because
+      # weight gradients run on a side stream next to other layers' users of the shared workspace (advoc_amd.model)
+      table = torch.empty(_lib.WGRAD_TABLE_BYTES // 4, dtype=torch.float32, device=x0.device)
+      s.wgrad_table = table.data_ptr()
+      self.tensors = self.tensors + (table,)
       try:
         self._thin_bias = 'thin_wgrad_kernel' in self.kernel_name(2)
       except _lib.AdvocHipError:
@@ -235,6 +246,33 @@ class Layer(object):
     else:
       self._dy_built = True
     return 1 if which == 0 else 2
+
+  def set_dy_role(self, role):
+    """Selects the magnitude history (header) the next backward_data / backward_weight calls use for the image of dy.
+    The image buffer itself is shared; only the 32-byte header (and its 'an image was built before' flag) is per role."""
+    if not self.struct.dy_img or role == self._dy_role:
+      return
+    if self._dy_role is None:                       # the header allocated with the buffer becomes the first role's
+      self._dy_roles[role] = [self._img[-1], self._dy_built] if role not in self._dy_roles else self._dy_roles[role]
+    else:
+      self._dy_roles[self._dy_role][1] = self._dy_built
+      if role not in self._dy_roles:
+        hdr = torch.zeros(8, dtype=torch.int32, device=self.x0.device)
+        self._dy_roles[role] = [hdr, False]
+        self.tensors = self.tensors + (hdr,)
+    self._dy_role = role
+    hdr, built = self._dy_roles[role]
+    self.struct.dy_hdr = hdr.data_ptr()
+    self._dy_built = built
+    self._dy_current_ptr = None
+
+  def image_headers(self):
+    """Every operand-image header of this layer (torch int32[8] each)."""
+    out = list(self._img[1::2])
+    for hdr, _ in self._dy_roles.values():
+      if all(hdr.data_ptr() != h.data_ptr() for h in out):
+        out.append(hdr)
+    return out
 
   def _delayed_bits(self):
     if not self.delayed_scale:

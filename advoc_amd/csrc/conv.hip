@@ -13,6 +13,8 @@
 
 namespace advoc {
 
+static_assert(kColsumBytes == ADVOC_WGRAD_TABLE_BYTES, "advoc_conv_layer.wgrad_table size");
+
 static inline int pack_tap(int dy, int dx, int wtap) {
   return (dy & 0xff) | ((dx & 0xff) << 8) | (wtap << 16);
 }
@@ -373,8 +375,7 @@ extern "C" int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* L, int32_t
     WgradParams w;
     float dummy = 0.f;
     if (build_backward_weight(L, &dummy, &dummy, w) != ADVOC_OK) return 0;
-    // thin layers: the replica table of the bias sums that ride in thin_wgrad_kernel
-    if (w.P.c0 + w.P.c1 <= 2) return w.Q.p0 == &dummy && (w.Q.c0 + w.Q.c1) <= 1024 ? kColsumBytes : 0;
+    if (w.P.c0 + w.P.c1 <= 2) return 0;      // thin layers: no shared scratch (the bias table is advoc_conv_layer.wgrad_table)
     if (!wgrad_h3_eligible(w)) return 0;
     int64_t a, b, c, d;
     return 256 + wgrad_h3_operand_bytes(w.P, w.batch, &a, &b) + wgrad_h3_operand_bytes(w.Q, w.batch, &c, &d);
@@ -436,14 +437,13 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
     // layer_1): that kernel reads every dy element exactly once anyway
     const bool thin_mfma = cb % 32 == 0 && p.ntaps * ca <= 32;
     bool db_fused = false;
-    if (thin_mfma && db && p.Q.p0 == dy && !p.Q.p1 && cb <= 1024 && L->workspace && L->workspace_bytes >= kColsumBytes &&
-        tuning().thin_wgrad_bias) {
+    if (thin_mfma && db && p.Q.p0 == dy && !p.Q.p1 && cb <= 1024 && L->wgrad_table && tuning().thin_wgrad_bias) {
       if (!accumulate) {
         hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)cb, as_stream(stream));
         if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
       }
       p.qsum_out = db;
-      p.qsum_table = L->workspace;
+      p.qsum_table = L->wgrad_table;      // the layer's own: this call may run beside workspace users on another stream
       db_fused = true;
     }
     rc = thin_mfma ? launch_wgrad_thin_mfma(p, as_stream(stream)) : ADVOC_ERR_UNSUPPORTED;

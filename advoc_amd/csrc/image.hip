@@ -160,7 +160,8 @@ __device__ __forceinline__ float up_scale(unsigned amax_bits) {
 // Delayed scaling (DELAYED): the scale comes from the largest magnitude of the PREVIOUS image written to this buffer
 // (hdr[2]), placed at [2^9, 2^10) -- 2^6 of head room before fp16 overflows, and still 22 significant bits for every
 // element within 2^12 of the largest -- while this pass records its own largest magnitude in hdr[0] for the next one:
-// one pass over the tensor instead of two.  Values beyond the head room saturate at +-65504 and are counted in hdr[3].
+// one pass over the tensor instead of two.  Values beyond the head room are counted in hdr[3] (and written saturated at
+// +-65504): refit_image_kernel, always launched behind the pass, then rebuilds the image with the exact scale.
 __device__ __forceinline__ float up_scale_delayed(unsigned prev_bits) {
   const int e = (int)((prev_bits >> 23) & 0xffu);
   if (e == 0 || e == 255) return 1.f;
@@ -169,10 +170,26 @@ __device__ __forceinline__ float up_scale_delayed(unsigned prev_bits) {
   return __uint_as_float((unsigned)(s + 127) << 23);
 }
 
-// hdr[0] <- 0, hdr[2] <- old hdr[0]: the image about to be written becomes "current", the last one "previous"
+// hdr[0] <- 0, hdr[2] <- old hdr[0]: the image about to be written becomes "current", the last one "previous";
+// hdr[4] <- hdr[3]: the out-of-range count before this pass (refit_image_kernel compares the two)
 __global__ void rotate_hdr_kernel(unsigned* __restrict__ hdr) {
   hdr[2] = hdr[0];
   hdr[0] = 0u;
+  hdr[4] = hdr[3];
+}
+
+// Does the one-pass (delayed-scale) image just written under this header have to be rebuilt with its own scale?
+//   * a value left the fp16 range under the previous image's scale (hdr[3] moved during the pass), or
+//   * the tensor shrank by more than 2^6 (the small elements would keep absolute, not relative, precision), or
+//   * there was no usable previous magnitude (all-zero / non-finite previous image) and this one is not all zero.
+// Inside [2^-6, 2^6] of the previous magnitude the one-pass image keeps >= 22 significant bits for every element within
+// 2^-9 of the largest and an absolute error <= 2^-28 of the largest below that.
+__device__ __forceinline__ bool image_needs_refit(const unsigned* __restrict__ hdr) {
+  const unsigned cur = hdr[0], prev = hdr[2];
+  const int ec = (int)((cur >> 23) & 0xffu), ep = (int)((prev >> 23) & 0xffu);
+  if (hdr[3] != hdr[4]) return true;
+  if (ep == 0 || ep == 255) return ec != 0;
+  return ec + 6 < ep;
 }
 
 // out[ch] += sum over the replicas of table[r][ch]
@@ -274,6 +291,49 @@ __global__ __launch_bounds__(256) void pair_image_kernel(const float* __restrict
       for (int j = 0; j < 8; ++j)
         unsafeAtomicAdd(colsum + (size_t)(blockIdx.x & (kColsumReplicas - 1)) * c + threadIdx.x * 8 + j, t[j]);
     }
+  }
+}
+
+// Always launched behind a delayed-scale image pass; exits at once unless image_needs_refit().  Then it rebuilds the
+// image (both sources of the operand: blockIdx.y) with the EXACT scale of the magnitude the pass has just recorded in
+// hdr[0] -- the two-pass form, its first pass already done -- so that no consumer ever reads a clamped or underflowed
+// operand: the step that sees a tensor jump is as exact as any other, without a host round trip.  hdr[5] counts the
+// refits (summaries).  The bias-gradient sums of the pass are taken from the fp32 values and need no repair.
+struct RefitSource {
+  const float* x;
+  __half* img;
+  int64_t n8;
+  int c;
+  const float* scale;
+  const float* shift;
+  float slope;
+  const uint8_t* mask;
+  float mask_scale;
+};
+__global__ __launch_bounds__(256) void refit_image_kernel(RefitSource s0, RefitSource s1, unsigned* __restrict__ hdr) {
+  if (!image_needs_refit(hdr)) return;
+  const RefitSource& s = blockIdx.y == 0 ? s0 : s1;
+  const float up = up_scale(hdr[0]);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    hdr[1] = __float_as_uint(1.f / up);
+    atomicAdd(hdr + 5, 1u);
+  }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < s.n8; i += stride) {
+    const int64_t e = i * 8;
+    float v[8];
+    load8(s.x, e, s.c, s.scale, s.shift, s.slope, s.mask, s.mask_scale, v);
+    __half2 h0[4], h1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = v[2 * j] * up, b = v[2 * j + 1] * up;
+      const __half a0 = __float2half_rn(a), b0 = __float2half_rn(b);
+      h0[j] = __halves2half2(a0, b0);
+      h1[j] = __halves2half2(__float2half_rn(a - __half2float(a0)), __float2half_rn(b - __half2float(b0)));
+    }
+    __half* o = s.img + (e >> 5) * 64 + ((e >> 3) & 3) * 8;
+    *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(h0);
+    *reinterpret_cast<uint4*>(o + 32) = *reinterpret_cast<const uint4*>(h1);
   }
 }
 
@@ -478,6 +538,15 @@ int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* i
   if (rc == ADVOC_OK && s1.elems)
     rc = launch_pair_image(s1.x, img1, s1.elems, s1.c, s1.scale, s1.shift, s1.act, s1.mask, s1.mask_scale, hdr, delayed,
                            stream, nullptr, 0, 0, nullptr);
+  if (rc == ADVOC_OK && delayed && s0.elems > 0) {
+    const RefitSource r0 = {s0.x, reinterpret_cast<__half*>(img), s0.elems / 8, s0.c, s0.scale, s0.shift, slope_of(s0.act),
+                            s0.mask, s0.mask_scale};
+    const RefitSource r1 = {s1.x, reinterpret_cast<__half*>(img1), s1.elems / 8, s1.c, s1.scale, s1.shift, slope_of(s1.act),
+                            s1.mask, s1.mask_scale};
+    ADVOC_CLEAR_LAUNCH_ERROR();
+    hipLaunchKernelGGL(refit_image_kernel, dim3(256, s1.elems ? 2 : 1), dim3(256), 0, stream, r0, r1, hdr);
+    ADVOC_RETURN_IF_LAUNCH_FAILED();
+  }
   return rc;
 }
 

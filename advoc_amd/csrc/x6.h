@@ -36,11 +36,14 @@ int launch_pair_image(const float* x, uint16_t* img, int64_t elems, int c, const
                       int act, const uint8_t* mask, float mask_scale, unsigned* hdr, bool delayed, hipStream_t stream,
                       float* colsum = nullptr, int w_log = 0, int w_pitch = 0, float* colsum_table = nullptr);
 // One GEMM operand = one or two channel-concatenated sources under ONE scale.  make_operand_image writes the image
-// (source 1 behind source 0 at its 256-byte-rounded size) and the 16-byte header {[0] largest magnitude of this image,
-// [1] 2^-s, [2] largest magnitude of the previous image in this buffer, [3] saturated values}.  delayed == false: the
-// exact two-pass form (magnitude pass, then image pass, largest magnitude at [2^13, 2^14)).  delayed == true (the
-// header must hold a previous image's magnitude): ONE pass, scale from the previous image's magnitude placed at
-// [2^9, 2^10), this image's magnitude recorded for the next call (image.hip).
+// (source 1 behind source 0 at its 256-byte-rounded size) and the 32-byte header {[0] largest magnitude of this image,
+// [1] 2^-s, [2] largest magnitude of the previous image in this buffer, [3] values that left the one-pass head room
+// (cumulative), [4] word 3 before the last pass, [5] exact refits taken (cumulative), [6..7] reserved}.  delayed ==
+// false: the exact two-pass form (magnitude pass, then image pass, largest magnitude at [2^13, 2^14)).  delayed == true:
+// ONE pass, scale from the previous image's magnitude placed at [2^9, 2^10), this image's magnitude recorded for the
+// next call, followed by refit_image_kernel, which rebuilds the image with the exact scale whenever a value left the
+// head room, the tensor shrank by more than 2^6 or the header held no usable magnitude -- on the device, in the same
+// stream, so the consumer never sees a clamped operand (image.hip).
 struct ImageSource {
   const float* x;
   int64_t elems;

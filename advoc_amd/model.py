@@ -577,19 +577,28 @@ class Advoc(Model):
       for n in (('g', 'd') if net is None else (net,)):
         self._built[n + '_wdirty'] = True
 
-  def image_saturations(self):
-    """Elements that exceeded the fp16 range of a delayed-scale operand image (conv.Layer.delayed_scale) and were
-    clamped, summed over all layers since the buffers were allocated.  0 in a healthy run: a non-zero value means a
-    tensor grew more than 64 x from one step to the next.  Synchronises; call it at summary time, not per step."""
+  def _image_header_sum(self, word):
     st = self._built
     if not st:
       return 0
     layers = list(st.get('g_layers', {}).values()) + st.get('d_layers_fake', []) + st.get('d_layers_real', []) \
         + st.get('d_layers_2b', [])
-    hdrs = [h for lay in layers for h in lay._img[1::2]]
+    hdrs = [h for lay in layers for h in lay.image_headers()]
     if not hdrs:
       return 0
-    return int(torch.stack([h[3].to(torch.int64) for h in hdrs]).sum().item())
+    return int(torch.stack([h[word].to(torch.int64) for h in hdrs]).sum().item())
+
+  def image_saturations(self):
+    """Elements that left the fp16 head room of a one-pass (delayed-scale) operand image, summed over all layers since
+    the buffers were allocated: a tensor grew more than 64 x from one step to the next.  Every such image was rebuilt
+    with its exact scale before anything read it (image_refits), so this is a statistic, not an error.  Synchronises;
+    call it at summary time, not per step."""
+    return self._image_header_sum(3)
+
+  def image_refits(self):
+    """Operand images that the device re-built with the exact scale because the tensor left the [2^-6, 2^6] window of
+    its previous magnitude (csrc/image.hip: refit_image_kernel).  Costs one extra pass over that tensor each."""
+    return self._image_header_sum(5)
 
   def optimizer_state(self):
     st = self._built
@@ -788,6 +797,7 @@ class Advoc(Model):
     for k, (layers, bns, lo, hi) in enumerate(passes):
       acc = True
       for i in range(4, -1, -1):
+        layers[i].set_dy_role('d')
         s = 'discriminator/layer_%d/conv2d' % (i + 1)
         g = st['g_d_act'][i][lo:hi]
         if i in bns:
@@ -797,6 +807,13 @@ class Advoc(Model):
           layers[i].backward_data(g, st['g_d_act'][i - 1][lo:hi], db=DG[s + '/bias'], db_accumulate=acc)
         with self._wgrad_ctx():
           layers[i].backward_weight(g, DG[s + '/kernel'], DG[s + '/bias'], accumulate=acc)
+      if len(passes) > 1:
+        # batch norm (two passes): the next pass starts only when this pass's weight gradients are done.  Measured (r3,
+        # tools/micro/side_race_bisect.py): with the tail of pass 0's weight gradients (the long thin-layer kernel) still
+        # running next to the first backward-data launches of pass 1, a few thousand elements of a backward-data output
+        # came out wrong in ~1 of 3 runs (gradients off by 1e-3) although no buffer is shared between the two; the cause
+        # was not found (agent-scope fences in the workspace K-split did not change it), so the overlap is not allowed.
+        self._join_wgrad()
     self._join_wgrad()
     self._adam('d')
     st['last_counts_d'] = n
@@ -864,6 +881,8 @@ class Advoc(Model):
         gen.numel(), float(self.gan_weight), float(self.l1_weight), _lib.ptr(glog) if use_gan else None,
         _lib.ptr(g_out), 0, _lib.ptr(st['sums'][1:3]), _lib.stream()), 'advoc_gan_g_loss')
     if use_gan:
+      for lay in Lf:
+        lay.set_dy_role('g')      # G-loss gradients: their own magnitude history (the D step's are ~sigma(D(fake)) x smaller)
       for i in range(4, 0, -1):
         if i in bnf:   # through the discriminator's batch norm; its parameter gradients are not used here
           self._bn_backward(bnf[i], st['g_d_act'][i][B:], discard_param_grads=True)

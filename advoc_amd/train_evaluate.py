@@ -221,10 +221,10 @@ def train(fps, args):
     now = time.time()
     if dp.rank == 0 and now - last_summary >= args.train_summary_every_nsecs:
       rec = dict(step=_step, time=now, **model.losses())
-      sat = model.image_saturations()
-      if sat:
-        rec['operand_image_saturations'] = sat
-        print('WARNING: {} operand-image elements left the fp16 head room (set ADVOC_DELAYED_SCALE=0)'.format(sat))
+      refits = model.image_refits()
+      if refits:       # tensors that jumped out of the one-pass scale window were re-imaged exactly (no clamped step)
+        rec['operand_image_refits'] = refits
+        rec['operand_image_saturations'] = model.image_saturations()
       log.write(json.dumps(rec) + '\n')
       log.flush()
       events.add_scalars(model.losses(), _step, wall_time=now)      # tags as advoc_model.py:272-275

@@ -231,7 +231,9 @@ typedef struct advoc_conv_layer {
    * reads them instead of making its own: img_flags bit 0 = x_img is current (the inputs have not changed since the
    * call that filled it), bit 1 = dy_img is current (filled by a call with the same dy).  A forward / backward-data call
    * that finds its bit set skips its image passes too (advoc_conv_make_image fills a buffer on its own).  Sizes:
-   * advoc_conv_image_bytes(); headers 16 bytes each.  Without the buffers the images live in `workspace` per call. */
+   * advoc_conv_image_bytes(); headers 32 bytes each (8 words, zeroed by the caller once: {largest magnitude, 2^-s,
+   * previous magnitude, values outside the one-pass head room, [3] before the last pass, exact refits, reserved x2}).
+   * Without the buffers the images live in `workspace` per call. */
   uint16_t* x_img;
   uint32_t* x_hdr;
   uint16_t* dy_img;
@@ -254,7 +256,14 @@ typedef struct advoc_conv_layer {
    * small launches per AdVoc train step otherwise) and trusts the image to be CURRENT. */
   const uint16_t* w_img[2];
   const uint32_t* w_img_hdr[2];
+  /* optional: ADVOC_WGRAD_TABLE_BYTES of device scratch OWNED BY THIS LAYER for the backward-weight call of a layer with
+   * <= 2 input channels: when non-null and `db` is passed, the bias gradient rides in the weight-gradient kernel (which
+   * reads every dy element exactly once) through a replica table kept here.  It is deliberately not part of
+   * `workspace`: weight gradients may run on a stream of their own next to backward-data calls of other layers that
+   * use the shared workspace. */
+  float* wgrad_table;
 } advoc_conv_layer;
+#define ADVOC_WGRAD_TABLE_BYTES 262144
 
 /* amax_out[i] = float bits of max |base[offsets[i] .. offsets[i] + sizes[i])| for `count` tensors of one arena, in one
  * launch (offsets / sizes / amax_out in device memory; amax_out is zeroed first).  Feeds advoc_conv_layer.w_amax. */
@@ -280,8 +289,10 @@ int advoc_conv_bias_fusable(const advoc_conv_layer* layer);
 #define ADVOC_IMG_DY_CURRENT 2
 /* the header of the buffer holds the largest magnitude of an image written to it before (an earlier call on data of the
  * same scale, e.g. the previous train step): the image may be built in ONE pass with the scale derived from that
- * magnitude (2^6 of head room; beyond it values saturate and are counted in header word 3) instead of a magnitude pass
- * followed by the image pass.  Never set on the first call for a buffer. */
+ * magnitude (2^6 of head room) instead of a magnitude pass followed by the image pass.  When a value leaves the head
+ * room (counted in header word 3), the tensor has shrunk by more than 2^6 or the header holds no usable magnitude, the
+ * call rebuilds the image with the exact scale on the device (always-launched refit kernel, counted in header word 5):
+ * the result never depends on a clamped operand. */
 #define ADVOC_IMG_X_DELAYED 4
 #define ADVOC_IMG_DY_DELAYED 8
 

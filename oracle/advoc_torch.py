@@ -302,6 +302,27 @@ def grads(P, x, target, cfg, masks, which):
   return collections.OrderedDict(zip(keys, g)), {k: v.detach() for k, v in L.items()}
 
 
+def grads_in_chunks(P, x, target, cfg, masks, which, chunk):
+  """grads() evaluated `chunk` clips at a time (bounded memory at BASELINE batch sizes).  Valid WITHOUT batch norm only:
+  every loss of advoc_model.py:238-245 is a mean over the batch of per-clip terms, so the batch gradient is the
+  clip-count-weighted mean of the chunk gradients and the losses are the weighted means of the chunk losses."""
+  assert not cfg.use_batchnorm
+  B = x.shape[0]
+  total, info = None, {}
+  for lo in range(0, B, chunk):
+    hi = min(B, lo + chunk)
+    wgt = (hi - lo) / float(B)
+    g, L = grads(P, x[lo:hi], target[lo:hi], cfg, {k: v[lo:hi] for k, v in masks.items()}, which)
+    if total is None:
+      total = collections.OrderedDict((k, v * wgt) for k, v in g.items())
+    else:
+      for k, v in g.items():
+        total[k] += v * wgt
+    for k in ('d_loss', 'g_gan', 'g_l1', 'g_loss'):
+      info[k] = info.get(k, 0.0) + float(L[k]) * wgt
+  return total, info
+
+
 # ----------------------------------------------------------------------------
 # TF AdamOptimizer(0.0002, 0.5) (advoc_model.py:250-257)
 # ----------------------------------------------------------------------------

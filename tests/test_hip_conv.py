@@ -667,35 +667,84 @@ def test_delayed_scale_images_match_the_exact_two_pass_form(hip, hipenv):
 
 
 @gpu
-def test_delayed_scale_counts_what_leaves_the_head_room(hip, hipenv):
-  """A tensor that grows 1000 x between two steps exceeds the one-pass image's head room (>= 64 x): the elements are
-  clamped to the fp16 range and COUNTED in header word 3 (model.image_saturations() reports the sum); the step after
-  that is exact again because the header now carries the new magnitude."""
+@pytest.mark.parametrize('jump', [1000.0, 200.0, 1e-4, 0.0])
+def test_delayed_scale_never_applies_a_clamped_or_underflowed_image(hip, hipenv, jump):
+  """A tensor that grows 100-1000 x between two steps leaves the one-pass image's head room (2^6); one that shrinks 1e4 x
+  (or becomes all zero, then comes back) would lose precision.  The pass counts / detects it and refit_image_kernel
+  rebuilds the image with the exact scale IN THE SAME CALL: forward, backward-data and the weight gradient of the jump
+  step equal the exact two-pass results, header word 5 counts the refit, and the next step is one-pass again."""
   from advoc_amd import conv
   hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_WGRAD_H3_MIN_M=1)
   dev = torch.device('cuda')
   g = torch.Generator().manual_seed(22)
   x = torch.randn(2, 16, 33, 128, generator=g).to(dev)
   w = (torch.randn(4, 4, 128, 256, generator=g) * 0.05).to(dev)
+  dy = torch.randn(2, 8, 17, 256, generator=g).to(dev)
 
   def make(delayed):
     y = torch.empty(2, 8, 17, 256, device=dev)
-    L = conv.Layer(conv.CONV, x.clone(), y, w, None, stride=(2, 2), pad=(1, 1))
+    L = conv.Layer(conv.CONV, x.clone(), y, w, None, stride=(2, 2), pad=(1, 1), in_act=conv.ACT_LRELU)
     L.delayed_scale, L.reuse_images = delayed, True
     return L
+
+  def step(L, scale):
+    L.x0.copy_(x * scale)
+    L.forward()
+    dx = torch.zeros_like(x)
+    L.backward_data(dy * scale, dx)
+    dw = torch.zeros_like(w)
+    L.backward_weight(dy * scale, dw)
+    return L.y.clone(), dx, dw
   exact, delayed = make(False), make(True)
   for L in (exact, delayed):
-    L.forward()                                   # first image: exact for both
-  for L in (exact, delayed):
-    L.x0.copy_(x * 1000.0)
-    L.forward()
-  sat = int(delayed._img[1].cpu()[3])
-  assert sat > 0                                  # clamped and counted ...
-  assert rel(delayed.y, exact.y) > 1e-4           # ... and visibly so
-  for L in (exact, delayed):
-    L.forward()                                   # header now holds the new magnitude
-  assert int(delayed._img[1].cpu()[3]) == sat
-  assert rel(delayed.y, exact.y) < 2e-6
+    step(L, 1.0)                                    # first image: exact for both
+  ref = step(exact, jump if jump else 0.0)
+  got = step(delayed, jump if jump else 0.0)
+  hx, hdy = delayed._img[1].cpu(), delayed._img[3].cpu()
+  assert int(hx[5]) == 1 and int(hdy[5]) == 1       # both operand images were refitted, once
+  if jump > 64:
+    assert int(hx[3]) > 0 and int(hdy[3]) > 0       # values left the head room during the one-pass image ...
+  for a, b in zip(got, ref):                        # ... and nothing read the clamped image
+    if jump:
+      assert rel(a, b) < 2e-6, (jump, rel(a, b))
+    else:
+      assert float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0
+  # next step at the new scale: one pass, no refit (from all-zero: no usable magnitude -> exact refit once more)
+  ref = step(exact, jump if jump else 3.0)
+  got = step(delayed, jump if jump else 3.0)
+  hx, hdy = delayed._img[1].cpu(), delayed._img[3].cpu()
+  assert int(hx[5]) == (1 if jump else 2) and int(hdy[5]) == (1 if jump else 2)
+  for a, b in zip(got, ref):
+    assert rel(a, b) < 2e-6, (jump, rel(a, b))
+
+
+@gpu
+def test_output_gradient_roles_keep_separate_magnitude_histories(hip, hipenv):
+  """Layer.set_dy_role: one layer object that sees gradients of two losses per step (the discriminator's fake pass with
+  batch norm: D-loss gradients in the D step, ~1000 x larger G-loss gradients in the G step) keeps one header per role,
+  so neither sequence ever leaves its own one-pass window (no refits after the first image of each role)."""
+  from advoc_amd import conv
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_WGRAD_H3_MIN_M=1)
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(23)
+  x = torch.randn(2, 16, 33, 128, generator=g).to(dev)
+  w = (torch.randn(4, 4, 128, 256, generator=g) * 0.05).to(dev)
+  dy = torch.randn(2, 8, 17, 256, generator=g).to(dev)
+  y = torch.empty(2, 8, 17, 256, device=dev)
+  L = conv.Layer(conv.CONV, x, y, w, None, stride=(2, 2), pad=(1, 1), in_act=conv.ACT_LRELU)
+  L.delayed_scale, L.reuse_images = True, True
+  E = conv.Layer(conv.CONV, x, torch.empty_like(y), w, None, stride=(2, 2), pad=(1, 1), in_act=conv.ACT_LRELU)
+  for it in range(3):
+    for role, scale in (('d', 1e-3), ('g', 1.0)):
+      L.set_dy_role(role)
+      dx, dxe = torch.zeros_like(x), torch.zeros_like(x)
+      L.backward_data(dy * scale, dx)
+      E.backward_data(dy * scale, dxe)
+      assert rel(dx, dxe) < 2e-6
+  hdrs = L.image_headers()
+  assert len(hdrs) == 3                              # x, dy role 'd', dy role 'g'
+  assert sum(int(h.cpu()[5]) for h in hdrs) == 0     # never out of window
+  assert all(int(h.cpu()[2]) != 0 for h in hdrs[1:])   # both roles ran the one-pass form
 
 
 @gpu

@@ -285,10 +285,13 @@ def test_short_training_run_reduces_l1(hip):
 
 
 @gpu
-def test_side_stream_weight_gradients_equal_serial_execution(hip, monkeypatch):
+@pytest.mark.parametrize('bn', [False, True])
+def test_side_stream_weight_gradients_equal_serial_execution(hip, monkeypatch, bn):
   """Weight / bias gradients run on a side stream by default (model._wgrad_ctx); ADVOC_WGRAD_STREAM=0 keeps
   the step on one stream.  Same gradients (up to the order of the weight-gradient atomics), same losses
-  after a few steps -- a missing stream dependency would show as stale or torn gradients."""
+  after a few steps -- a missing stream dependency would show as stale or torn gradients.  bn=True: the D step makes two
+  passes, so the layer_1 weight gradient of pass 0 (side stream, bias sums in the layer's own table) overlaps the
+  backward-data calls of pass 1 (main stream, shared workspace)."""
   from advoc_amd.model import AdvocSmall, Modes
   dev = torch.device('cuda')
   x, target = batch(16, 128, 9)
@@ -299,6 +302,7 @@ def test_side_stream_weight_gradients_equal_serial_execution(hip, monkeypatch):
     m = AdvocSmall(Modes.TRAIN)
     m.subseq_len = 128
     m.train_batch_size = 16
+    m.use_batchnorm = bn
     m.build(batch_size=16, seed=4)
     assert m._built['side_on'] == side
     m((x, target))
@@ -314,12 +318,14 @@ def test_side_stream_weight_gradients_equal_serial_execution(hip, monkeypatch):
     g1, l1 = run(True)
     g0, l0 = run(False)
     for k in g0:
-      if k.startswith('discriminator'):          # taken at identical weights
+      if k.startswith('discriminator') and (not bn or k.endswith('layer_1/conv2d/bias') or k.endswith('layer_1/conv2d/kernel')
+                                            or k.endswith('layer_5/conv2d/bias')):          # taken at identical weights
         # The real and the fake half of the 2B batch pull these gradients in opposite directions and nearly cancel at
         # initialisation, which amplifies the order of the fp32 atomics (the only thing that differs between the two
         # schedules) ~100x: measured 2e-7 .. 9e-6 between two runs of the SAME schedule (tools/micro/side_race.py);
         # a missing dependency shows as >= 1e-2.
-        assert rel(g1[k], g0[k]) < 5e-5, (trial, k, rel(g1[k], g0[k]))
+        # (bn=True: the biases in front of a batch norm have exactly-zero gradients, pure round-off on both sides)
+        assert rel(g1[k], g0[k]) < 5e-5, (trial, bn, k, rel(g1[k], g0[k]))
     for key in ('gen_loss_L1', 'disc_loss', 'gen_loss_GAN'):
       assert abs(l1[key] - l0[key]) <= 0.02 * abs(l0[key]) + 1e-3, (trial, key, l1[key], l0[key])
 

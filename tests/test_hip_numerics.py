@@ -1,0 +1,128 @@
+"""The fp16-pair operand-image arithmetic (csrc/image.hip) on data that is NOT friendly: every contraction
+of the train step is fp32-exact-class only if one power-of-two scale per tensor is enough, so the image kernels are driven
+here with (a) log-normal activations (sigma = 3: magnitudes spread over > 2^17), (b) a real |STFT| of speech
+(tests/golden/mono.wav through the HIP extractor -- 6 decades between the loudest bin and the noise floor, the actual
+input statistics of the model, models/advoc/train_evaluate.py:55-56), (c) output gradients of 1e-6 with sparse 1e3 x
+outliers (late-training GAN gradients), in all three directions (forward, backward-data, weight gradient), with the exact
+two-pass images and with the one-pass (delayed-scale) images of a second step, against float64 on the CPU.
+Bar: rel-L2 2e-5 (the bar of tests/test_hip_conv.py; the fp32 MFMA chain measures 4e-7 .. 1e-6 on the same data).
+Promoted from tools/micro/h3_numerics.py."""
+import os
+
+import pytest
+import torch
+
+from oracle import advoc_torch as A
+
+gpu = pytest.mark.gpu
+BAR = 2e-5
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name, kind, (B, H, W), c0, c1, cout, stride, act, kernels expected (fwd, bwd-data, wgrad)
+CASES = [
+    ('enc4_like_s2', 0, (8, 32, 64), 128, 0, 256, (2, 2), 1),
+    ('layer4_like_s1', 0, (8, 32, 32), 128, 0, 256, (1, 1), 1),
+    ('dec4_like_skip', 1, (8, 16, 33), 256, 256, 128, (2, 2), 2),
+    ('enc2_like_64ch', 0, (4, 64, 64), 64, 0, 128, (2, 2), 1),
+]
+
+
+def rel(a, b):
+  a, b = a.detach().double().cpu(), b.detach().double().cpu()
+  return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def speech_magnitudes():
+  """|STFT| (1024 / 256) of the reference's own test clip through the HIP extractor: [T, 513] float32 on the CPU."""
+  from advoc_amd import audioio, spectral
+  fs, wav = audioio.decode_audio(os.path.join(HERE, 'golden', 'mono.wav'), fastwav=True)
+  return spectral.stft_magnitude(wav[None], 1024, 256)[0, :, :, 0].cpu()
+
+
+def activations(kind, shape, gen):
+  """[n, h, w, c] float32 with the requested statistics."""
+  n, h, w, c = shape
+  if kind == 'lognormal':
+    return torch.randn(shape, generator=gen) * torch.exp(3.0 * torch.randn(shape, generator=gen))
+  S = speech_magnitudes()                                     # [T, 513]: channel = time shift, column = frequency bin
+  T = S.shape[0]
+  idx_t = (torch.arange(h)[:, None, None] * 3 + torch.arange(c)[None, None, :] + torch.arange(n)[:, None, None, None] * 37) % T
+  idx_f = (torch.arange(w) * (512 // max(w - 1, 1)))[None, None, :, None].expand(n, h, w, c)
+  x = S[idx_t.expand(n, h, w, c), idx_f]
+  sign = torch.where(torch.rand(shape, generator=gen) < 0.5, -1.0, 1.0)     # pre-activations carry signs
+  return x * sign
+
+
+def gradients(shape, gen):
+  g = torch.randn(shape, generator=gen) * 1e-6
+  spikes = torch.rand(shape, generator=gen) < 1e-3
+  return torch.where(spikes, g * 1e3, g)
+
+
+def float64_layer(kind, x0, x1, W, w, stride, act, dy):
+  parts = [x0[:, :, :W]] + ([x1] if x1 is not None else [])
+  xin = torch.cat(parts, dim=3).double().requires_grad_(True)
+  a = A.lrelu(xin) if act == 1 else torch.relu(xin)
+  w64 = w.double().requires_grad_(True)
+  if kind == 0:
+    y = A.discrim_conv(a, w64, None, stride)                  # pad 1, k 4 (models/advoc/advoc_model.py:25-32)
+  else:
+    y = A.gen_deconv(a, w64, None, strides=stride)
+  ga, gw = torch.autograd.grad(y, [a, w64], dy.double())
+  return y.detach(), ga, gw
+
+
+@gpu
+@pytest.mark.parametrize('delayed', [False, True], ids=['exact_images', 'one_pass_images'])
+@pytest.mark.parametrize('patch', [True, False], ids=['patch_kernels', 'per_tap_tiles'])
+@pytest.mark.parametrize('data', ['lognormal', 'speech'])
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_image_kernels_on_wide_dynamic_range(hip, hipenv, case, data, patch, delayed):
+  from advoc_amd import conv
+  name, kind, (B, H, W), c0, c1, cout, stride, act = case
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_WGRAD_H3_MIN_M=1, ADVOC_H3_PATCH_MIN_WGS=1, ADVOC_H3_PATCH=1 if patch else 0)
+  gen = torch.Generator().manual_seed(len(name) + (1 if data == 'speech' else 0))
+  trim = 1 if c1 else 0
+  x0 = activations(data, (B, H, W + trim, c0), gen)
+  x1 = activations(data, (B, H, W, c1), gen) if c1 else None
+  w = torch.randn((4, 4, c0 + c1, cout) if kind == 0 else (4, 4, cout, c0 + c1), generator=gen) * 0.02
+  if kind == 0:
+    oh, ow = (H + 2 - 4) // stride[0] + 1, (W + 2 - 4) // stride[1] + 1
+  else:
+    oh, ow = 2 * H, 2 * W
+  dy = gradients((B, oh, ow, cout), gen)
+  y64, ga64, gw64 = float64_layer(kind, x0, x1, W, w, stride, act, dy)
+
+  dev = torch.device('cuda')
+  y = torch.empty(B, oh, ow, cout, device=dev)
+  L = conv.Layer(kind, x0.to(dev), y, w.to(dev), None, x1=x1.to(dev) if c1 else None, in_w=W, stride=stride, pad=(1, 1), in_act=act)
+  L.reuse_images, L.delayed_scale = True, delayed
+  names = [L.kernel_name(d) for d in range(3)]
+  assert all('h3' in n for n in names), names                 # the operand-image kernels are what runs
+  assert any('patch' in n for n in names[:2]) == patch, names
+  # backward-data is compared WITHOUT the activation gate (d / d act(x)): the gate is exact arithmetic
+  steps = 2 if delayed else 1
+  for it in range(steps):
+    if it == 1:       # a second step on data of the same scale but different values: the one-pass images
+      gen2 = torch.Generator().manual_seed(99)
+      x0 = x0 * (0.5 + torch.rand(x0.shape, generator=gen2))
+      dy = dy * (0.5 + torch.rand(dy.shape, generator=gen2))
+      L.x0.copy_(x0.to(dev))
+      y64, ga64, gw64 = float64_layer(kind, x0, x1, W, w, stride, act, dy)
+    L.struct.in_act = act
+    L.forward()
+    dx0 = torch.zeros(B, H, W + trim, c0, device=dev)
+    dx1 = torch.zeros(B, H, W, c1, device=dev) if c1 else None
+    L.struct.in_act = 0
+    L.backward_data(dy.to(dev), dx0, dx1)
+    L.struct.in_act = act
+    dw = torch.zeros_like(L.weight)
+    L.backward_weight(dy.to(dev), dw)
+  gx = torch.cat([dx0[:, :, :W]] + ([dx1] if c1 else []), dim=3)
+  errs = (rel(y, y64), rel(gx, ga64), rel(dw, gw64))
+  print('%s %s %s: fwd %.2e bwd-data %.2e wgrad %.2e  %s' % (name, data, 'one-pass' if delayed else 'exact', *errs, names))
+  assert max(errs) < BAR, (errs, names)
+  if delayed:
+    hx, hdy = L._img[1].cpu(), L._img[3].cpu()
+    assert int(hx[2]) != 0 and int(hdy[2]) != 0               # the second step really took the one-pass form
+    assert int(hx[5]) == 0 and int(hdy[5]) == 0               # ... and stayed inside its window (no refit)
