@@ -309,14 +309,16 @@ class Layer(object):
       if not db_accumulate:
         db.zero_()
       self.struct.db_fused = _lib.ptr(db)
-    self.struct.img_flags = self._timed_image(1, dy) | self._delayed_bits()
-    self._run(1, lambda: _lib.check(_lib.load().advoc_conv_backward_data(
-        ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dx0), _lib.ptr(dx1), int(accum0),
-        int(accum1), _lib.stream()), 'advoc_conv_backward_data'))
-    self.struct.img_flags = 0
-    if fuse_db:
+    try:
+      self.struct.img_flags = self._timed_image(1, dy) | self._delayed_bits()
+      self._run(1, lambda: _lib.check(_lib.load().advoc_conv_backward_data(
+          ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dx0), _lib.ptr(dx1), int(accum0),
+          int(accum1), _lib.stream()), 'advoc_conv_backward_data'))
+    finally:                     # a failed call must not leave a stale bias pointer / flags behind
+      self.struct.img_flags = 0
       self.struct.db_fused = None
-      self._db_done_for = dy.data_ptr()
+    if fuse_db:
+      self._db_done_for = (dy.data_ptr(), db.data_ptr())
     if self.struct.dy_img and 'h3' in self.kernel_name(1):
       self._dy_built = True
     self._dy_current_ptr = dy.data_ptr() if (self.struct.dy_img and 'h3' in self.kernel_name(1)) else None
@@ -330,16 +332,20 @@ class Layer(object):
     if self.reuse_images:
       flags = (1 if self._x_current else 0) | (2 if self._dy_current_ptr == dy.data_ptr() else 0)
     self.struct.img_flags = flags | self._delayed_bits()
-    db_done = getattr(self, '_db_done_for', None) == dy.data_ptr()
+    # (the bias gradient counts as done only for the SAME dy and the SAME db buffer the backward_data call summed into)
+    db_done = db is not None and self._db_done_for == (dy.data_ptr(), db.data_ptr())
     # 1-2 channel inputs (encoder_1, layer_1): the weight-gradient kernel reads every dy element exactly once and takes the
     # bias gradient on the way (advoc_conv_backward_weight's db argument)
     db_rides = db is not None and not db_done and self._thin_bias
     if db_rides:
       _lib.require_device(db)
-    self._run(2, lambda: _lib.check(_lib.load().advoc_conv_backward_weight(
-        ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db) if db_rides else None, int(accumulate),
-        _lib.stream()), 'advoc_conv_backward_weight'))
-    self.struct.img_flags = 0
+    try:
+      self._run(2, lambda: _lib.check(_lib.load().advoc_conv_backward_weight(
+          ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db) if db_rides else None, int(accumulate),
+          _lib.stream()), 'advoc_conv_backward_weight'))
+    finally:
+      self.struct.img_flags = 0
+    self._x_current = False                # one use per forward: the caller may rewrite the inputs before the next call
     if 'h3' in self.kernel_name(2):        # the image-based weight gradient has (re)built whatever was not current
       self._x_built = self._x_built or bool(self.struct.x_img)
       self._dy_built = self._dy_built or bool(self.struct.dy_img)

@@ -58,14 +58,22 @@ Tuning read_env() {
   t.h3 = env_int("ADVOC_H3", 1);
   t.h3_tile = env_int("ADVOC_H3_TILE", 0);
   t.h3_stages = env_int("ADVOC_H3_STAGES", 0);
+#ifdef ADVOC_DIAG      // switches that make results WRONG (timing experiments, tools/micro): only in `make DIAG=1` builds
   t.h3_skip_prep = env_int("ADVOC_H3_SKIP_PREP", 0);
+#else
+  t.h3_skip_prep = 0;
+#endif
   t.h3_min_tiles = env_int("ADVOC_H3_MIN_TILES", 4);
   t.h3_patch = env_int("ADVOC_H3_PATCH", 1);
   t.h3_patch_min_wgs = env_int("ADVOC_H3_PATCH_MIN_WGS", 256);
   t.h3_patch_s2 = env_int("ADVOC_H3_PATCH_S2", 1);
   t.h3_patch_rem = env_int("ADVOC_H3_PATCH_REM", 1);
   t.h3_patch_persist = env_int("ADVOC_H3_PATCH_PERSIST", 2);
+#ifdef ADVOC_DIAG
   t.h3_patch_ablate = env_int("ADVOC_H3_PATCH_ABLATE", 0);
+#else
+  t.h3_patch_ablate = 0;
+#endif
   t.thin_wgrad_bias = env_int("ADVOC_THIN_WGRAD_BIAS", 1);
   t.thin_wgrad_nt = env_int("ADVOC_THIN_WGRAD_NT", 4);
   if (t.thin_wgrad_nt != 1 && t.thin_wgrad_nt != 2) t.thin_wgrad_nt = 4;

@@ -66,7 +66,7 @@ def vocode_batch(model, specs, spectral_util=None, phase_estimation='gl60', chun
   if phase_estimation == 'lws':
     return gen, spectral.lws_batch(gen.abs().contiguous(), SpectralUtil.NFFT, SpectralUtil.NHOP)
   if phase_estimation[:2] != 'gl':
-    raise ValueError()
+    raise ValueError("phase_estimation {!r}: expected 'lws', 'gl<iterations>' (e.g. 'gl60') or None".format(phase_estimation))
   if unit_phase is None:
     unit_phase = torch.rand(gen.shape, device=gen.device)
   wav = spectral.griffin_lim_batch(gen.abs(), SpectralUtil.NFFT, SpectralUtil.NHOP, int(phase_estimation[2:]),

@@ -934,6 +934,27 @@ class Advoc(Model):
     self.step += 1
     st['last_counts_g'] = (logits.numel(), gen.numel())
 
+  def G_train_op(self, batch=None):
+    """The reference's `G_train_op` (advoc_model.py:254-255: Adam minimize of gen_loss_total over G_vars, increments the
+    global step) as a callable: one generator update on `batch`, or on the next batch of the feed given to __call__
+    (what `sess.run(model.G_train_op)` does with the iterator-backed inputs)."""
+    if batch is None:
+      if self._feed is None:
+        raise RuntimeError('call model(feed) first')
+      batch = self._feed()
+    self.build(batch_size=batch[0].shape[0])
+    self.g_step(batch)
+    return self.step
+
+  def D_train_op(self, batch=None):
+    """The reference's `D_train_op` (advoc_model.py:256-257): one discriminator update, see G_train_op."""
+    if batch is None:
+      if self._feed is None:
+        raise RuntimeError('call model(feed) first')
+      batch = self._feed()
+    self.build(batch_size=batch[0].shape[0])
+    self.d_step(batch)
+
   def train_loop(self, sess=None):
     """D update on one batch, G update on the NEXT batch; returns the global step
     (reference advoc_model.py:285-289; `sess` is accepted and ignored)."""

@@ -70,6 +70,12 @@ def _prune(train_dir, pattern, keep):
     return int(m.group(1)) if m else -1
   fps = sorted(glob.glob(os.path.join(train_dir, pattern)), key=step_of)
   for fp in fps[:-keep] if keep > 0 else []:
+    # the TensorFlow bundle of the same step (ADVOC_EXPORT_TF_CKPT=1) goes with its .pt: max_to_keep bounds disk use
+    for twin in glob.glob(fp[:-3] + '.index') + glob.glob(fp[:-3] + '.data-*'):
+      try:
+        os.remove(twin)
+      except OSError:
+        pass
     try:
       os.remove(fp)
     except OSError:

@@ -34,6 +34,7 @@ def test_bench_line_single_gpu_small_and_quick(hip):
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
     assert key in r, key
   assert r['n_gpus'] == 1 and r['steps'] == 3 and r['warmup'] == 1 and r['higher_is_better'] is True
+  assert r['dist'] is None
   assert r['unit'] == 'mel-frames/s' and r['vs_baseline'] is None and r['data'] == 'synthetic'
   assert abs(r['value'] - 8 * 256 * 3 / (r['ms_per_step'] * 3e-3)) < 1e-6 * r['value']
   assert 'workload' in r['config'] and 'model' not in r['config']
@@ -51,3 +52,8 @@ def test_plain_python_bench_gpus_2_spawns_its_own_ranks(hip):
   assert r['scaling'] == 'weak' and r['cpu_baseline'] is None
   assert abs(r['value'] - 8 * 256 * 2 / (r['ms_per_step'] * 2e-3)) < 1e-6 * r['value']
   assert abs(r['per_gpu_value'] * 2 - r['value']) < 1e-6 * r['value']
+  # what the collectives ran on: so that a SCALE record shows the transport saw N ranks
+  d = r['dist']
+  assert d['backend'] == 'gloo' and d['world_size'] == 2 and sorted(x['rank'] for x in d['ranks']) == [0, 1]
+  assert all(x['device'] == 'cuda:0' and x['name'] for x in d['ranks'])
+  assert d['g_arena_bytes'] > 0 and d['g_arena_allreduce_ms'] > 0

@@ -164,6 +164,18 @@ def test_tf_format_export_next_to_native_checkpoints(hip, tmp_path, monkeypatch)
       assert torch.equal(a[k].cpu(), b[k].cpu()), k
 
 
+def test_prune_removes_the_tensorflow_twins_of_a_pruned_checkpoint(tmp_path):
+  """max_to_keep bounds disk use also with ADVOC_EXPORT_TF_CKPT=1: the .index / .data-* bundle of a pruned step goes
+  with its .pt."""
+  from advoc_amd import train_evaluate as TE
+  for step in (3, 10, 20, 100):
+    for ext in ('.pt', '.index', '.data-00000-of-00001'):
+      (tmp_path / ('model.ckpt-%d%s' % (step, ext))).write_bytes(b'x')
+  TE._prune(str(tmp_path), 'model.ckpt-*.pt', 2)
+  left = sorted(os.listdir(tmp_path))
+  assert left == sorted('model.ckpt-%d%s' % (s_, e) for s_ in (20, 100) for e in ('.pt', '.index', '.data-00000-of-00001'))
+
+
 def test_event_file_image_and_audio_summaries(tmp_path):
   """tf.summary.image / tf.summary.audio values (advoc_model.py:268-281): tags, PNG and WAV payloads decode back."""
   import io
