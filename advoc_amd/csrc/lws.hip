@@ -196,6 +196,202 @@ __global__ __launch_bounds__(256) void lws_batch_kernel(const float2* __restrict
   out[i] = with_phase_of(a, z, cur);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The reference's geometry (nfft 1024, hop 256: Q = 4, L = 5, P = 4, 513 bins) on kernels built for it (r3).  The r2
+// kernels above spent their time in the tap loop: two LDS reads per tap (data + weight), a three-way branch for the
+// conjugate-symmetric bins beyond the one-sided spectrum, and two workgroup barriers per Jacobi step -- ~10 us per step,
+// 3 072 dependent steps per clip, one CU per clip: 35 of the 48 ms of a 64-clip batch.  Here
+//   * a thread keeps the 63 complex weights of ITS bin in registers for the whole launch (the frame rotation depends on
+//     (f + p) mod 4 only, i.e. on the thread);
+//   * rows carry their L - 1 mirrored bins on both sides (written conjugated by the threads that own the source bins), so
+//     a tap is one unconditional 8-byte LDS read at row[m + 4];
+//   * the frame being refined is double-buffered (read one copy, write the other): one barrier per step;
+//   * the 100 batch sweeps run on LDS tiles of 16 frames + 3 halo frames either side of one clip instead of 63 global
+//     (L1 / L2) loads per bin.
+// Both are bound by LDS bandwidth now (63 x 8 B per bin and step).
+constexpr int kFH = 4;                     // mirrored bins either side of a row (L - 1)
+constexpr int kFBins = 513;
+constexpr int kFRow = kFBins + 2 * kFH;    // float2 per LDS row
+constexpr int kFQ = 4, kFL = 5, kFKW = 9, kFP = 4;
+constexpr int kSweepFrames = 8;            // frames per tile of the batch sweep
+
+// The weight of tap (q, p) at bin m = f + p is alpha_q(p) (-i)^(q m): the frame rotation exp(-2 pi i m q nhop / nfft) is a
+// power of -i for hop = nfft / 4.  alpha_q(p) = W[q][p][0] is the same for every thread (scalar loads, no vector
+// registers -- 63 complex weights per thread spilled 750 bytes of scratch per lane); the rotation is applied to sums:
+//   sum_p alpha_q(p) (-i)^(q (f + p)) x[f + p] = (-i)^(q f) * sum_c (-i)^(q c) * [ sum_{p = c mod 4} alpha_q(p) x[f + p] ]
+// -- compile-time quarter turns on the four class sums, one per-thread unit factor rot[q] = (-i)^(q f) per row.
+template <int QI, bool SKIP_CENTRE>      // QI = q + Q - 1
+__device__ __forceinline__ void row_taps(const float2* __restrict__ row, int f, const float2* __restrict__ W, float2 rot,
+                                         float2& z) {
+  float2 cs[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+#pragma unroll
+  for (int p = -(kFL - 1); p <= kFL - 1; ++p) {
+    if (SKIP_CENTRE && p == 0) continue;
+    const float2 al = W[(QI * kFKW + p + kFL - 1) * kFP];        // uniform address: scalar load
+    const float2 x = row[f + p];
+    float2& c = cs[p & 3];
+    c.x = fmaf(al.x, x.x, c.x); c.x = fmaf(-al.y, x.y, c.x);
+    c.y = fmaf(al.x, x.y, c.y); c.y = fmaf(al.y, x.x, c.y);
+  }
+  // t = sum_c (-i)^(q c) cs[c], q = QI - (Q - 1):  (-i)^k v = v, (v.y, -v.x), (-v.x, -v.y), (-v.y, v.x) for k = 0..3
+  constexpr int q = QI - (kFQ - 1);
+  float2 t = cs[0];
+#pragma unroll
+  for (int c = 1; c < 4; ++c) {
+    const int k = ((q * c) % 4 + 4) % 4;
+    const float2 v = cs[c];
+    if (k == 0) { t.x += v.x; t.y += v.y; }
+    else if (k == 1) { t.x += v.y; t.y -= v.x; }
+    else if (k == 2) { t.x -= v.x; t.y -= v.y; }
+    else { t.x -= v.y; t.y += v.x; }
+  }
+  z.x = fmaf(rot.x, t.x, z.x); z.x = fmaf(-rot.y, t.y, z.x);
+  z.y = fmaf(rot.x, t.y, z.y); z.y = fmaf(rot.y, t.x, z.y);
+}
+
+// rot[q + Q - 1] = (-i)^(q f)
+__device__ __forceinline__ void bin_rotations(int f, float2 (&rot)[2 * kFQ - 1]) {
+#pragma unroll
+  for (int qi = 0; qi < 2 * kFQ - 1; ++qi) {
+    const int k = ((qi - (kFQ - 1)) * (f & 3)) & 3;
+    rot[qi] = make_float2(k == 0 ? 1.f : (k == 2 ? -1.f : 0.f), k == 1 ? -1.f : (k == 3 ? 1.f : 0.f));
+  }
+}
+
+template <int QI>
+__device__ __forceinline__ void row_dispatch(const float2* __restrict__ ring_row, const float2* __restrict__ cur, int f,
+                                             const float2* __restrict__ W, const float2 (&rot)[2 * kFQ - 1], float2& z) {
+  if (QI == kFQ - 1) row_taps<QI, true>(cur, f, W, rot[QI], z);
+  else row_taps<QI, false>(ring_row, f, W, rot[QI], z);
+}
+
+// row[f] = v plus the mirrored copies that other bins read beyond the one-sided spectrum: bin m < 0 is conj(bin -m),
+// bin m >= 513 is conj(bin 1024 - m)
+__device__ __forceinline__ void store_bin(float2* __restrict__ row, int f, float2 v) {
+  row[f] = v;
+  const float2 cv = make_float2(v.x, -v.y);
+  if (f >= 1 && f <= kFH) row[-f] = cv;
+  if (f >= kFBins - 1 - kFH && f <= kFBins - 2) row[2 * (kFBins - 1) - f] = cv;
+}
+
+__global__ __launch_bounds__(576) void lws_causal_fast_kernel(const CausalParams c, const float2* __restrict__ W) {
+  extern __shared__ __attribute__((aligned(16))) float2 lws_smem[];
+  float2* ring = lws_smem + kFH;                       // [kRing] rows of kFRow, pointing at bin 0
+  float2* alt = lws_smem + kRing * kFRow + kFH;        // second copy of the frame being worked on
+  const int clip = blockIdx.x;
+  const int f = threadIdx.x < kFBins ? threadIdx.x : kFBins - 1;     // (idle lanes shadow the last bin, never store)
+  const bool live = threadIdx.x < kFBins;
+  float2 rot[2 * kFQ - 1];
+  bin_rotations(f, rot);
+  float2* spec = c.spec + (int64_t)clip * c.T * kFBins;
+  const float* mag = c.mag + (int64_t)clip * c.T * kFBins;
+  const float ref = c.mean_mag[clip];
+  for (int i = threadIdx.x; i < (kRing + 1) * kFRow; i += blockDim.x) lws_smem[i] = make_float2(0.f, 0.f);
+  __syncthreads();
+  int last_init = -1;
+
+  // frames t + q, q in [q_lo, q_hi] that exist and hold data; the frame itself (q = 0) is read from `cur`
+  auto local_sum = [&](int t, int q_lo, int q_hi, const float2* cur) -> float2 {
+    float2 z = make_float2(0.f, 0.f);
+#define ADVOC_LWS_ROW(QI)                                                                                   \
+    {                                                                                                       \
+      const int q_ = (QI) - (kFQ - 1), tq_ = t + q_;                                                        \
+      if (!(q_ < q_lo || q_ > q_hi || tq_ < 0 || tq_ >= c.T || tq_ > last_init))      /* uniform */          \
+        row_dispatch<QI>(ring + (tq_ & (kRing - 1)) * kFRow, cur, f, W, rot, z);                            \
+    }
+    ADVOC_LWS_ROW(0) ADVOC_LWS_ROW(1) ADVOC_LWS_ROW(2) ADVOC_LWS_ROW(3) ADVOC_LWS_ROW(4) ADVOC_LWS_ROW(5) ADVOC_LWS_ROW(6)
+#undef ADVOC_LWS_ROW
+    return z;
+  };
+
+  // `steps` Jacobi steps on frame t, alternating between its ring row and `alt`; the result ends in the ring row
+  auto refine = [&](int t, int steps, int q_lo, int q_hi, bool nofuture) {
+    float2* home = ring + (t & (kRing - 1)) * kFRow;
+    const float a = mag[(int64_t)t * kFBins + f];
+    float2* src = home;
+    float2* dst = alt;
+    for (int i = 0; i < steps; ++i) {
+      float thr;
+      if (nofuture) thr = c.nf_thr[i] > 0.f ? c.nf_thr[i] * ref : -1.f;
+      else thr = steps > 1 ? c.on_alpha * __expf(-c.on_beta * (float)i) * ref : 0.f;
+      const float2 old = src[f];
+      float2 nv = old;
+      if (a > thr) nv = with_phase_of(a, local_sum(t, q_lo, q_hi, src), nofuture ? make_float2(a, 0.f) : old);
+      if (live) store_bin(dst, f, nv);
+      __syncthreads();
+      float2* tmp = src; src = dst; dst = tmp;
+    }
+    if (src != home) {                 // odd number of steps: bring the result home
+      if (live) store_bin(home, f, src[f]);
+      __syncthreads();
+    }
+  };
+
+  auto init_frame = [&](int t) {
+    float2* home = ring + (t & (kRing - 1)) * kFRow;
+    if (live) store_bin(home, f, c.use_init ? spec[(int64_t)t * kFBins + f] : make_float2(0.f, 0.f));
+    last_init = t;
+    __syncthreads();
+    if (!c.use_init) refine(t, c.nf_steps, -(kFQ - 1), 0, true);
+  };
+
+  const int la = c.look_ahead;
+  for (int t0 = 0; t0 <= la && t0 < c.T; ++t0) init_frame(t0);
+  for (int t = 0; t < c.T; ++t) {
+    const int ta = t + la;
+    if (ta < c.T && ta > la) init_frame(ta);
+    refine(t, c.online_iterations, -(kFQ - 1), kFQ - 1, false);
+    if (live) spec[(int64_t)t * kFBins + f] = ring[(t & (kRing - 1)) * kFRow + f];
+  }
+}
+
+// One batch sweep on LDS tiles: a workgroup = kSweepFrames frames of one clip (+ Q - 1 frames either side), a thread =
+// one bin walking the tile's frames with its weights in registers.
+__global__ __launch_bounds__(576) void lws_sweep_fast_kernel(const float2* __restrict__ in, float2* __restrict__ out,
+                                                             const float* __restrict__ mag,
+                                                             const float* __restrict__ mean_mag, int T, float thr_mult,
+                                                             const float2* __restrict__ W, int tiles_per_clip) {
+  extern __shared__ __attribute__((aligned(16))) float2 lws_smem[];
+  constexpr int kRows = kSweepFrames + 2 * (kFQ - 1);
+  float2* rows = lws_smem + kFH;
+  const int clip = blockIdx.x / tiles_per_clip;
+  const int t0 = (blockIdx.x - clip * tiles_per_clip) * kSweepFrames;
+  const int f = threadIdx.x < kFBins ? threadIdx.x : kFBins - 1;
+  const bool live = threadIdx.x < kFBins;
+  const float2* src = in + (int64_t)clip * T * kFBins;
+#pragma unroll 2
+  for (int r = 0; r < kRows; ++r) {
+    const int t = t0 - (kFQ - 1) + r;
+    float2 v = make_float2(0.f, 0.f);
+    if (t >= 0 && t < T) v = src[(int64_t)t * kFBins + f];
+    if (live) store_bin(rows + r * kFRow, f, v);
+  }
+  float2 rot[2 * kFQ - 1];
+  bin_rotations(f, rot);
+  const float thr = thr_mult * mean_mag[clip];
+  __syncthreads();
+  const int nt = T - t0 < kSweepFrames ? T - t0 : kSweepFrames;
+  for (int tt = 0; tt < nt; ++tt) {
+    const int64_t i = ((int64_t)clip * T + t0 + tt) * kFBins + f;
+    const float a = mag[i];
+    const float2* centre = rows + (tt + kFQ - 1) * kFRow;
+    float2 v = centre[f];
+    if (a > thr) {
+      float2 z = make_float2(0.f, 0.f);
+      row_dispatch<0>(centre - 3 * kFRow, centre, f, W, rot, z);
+      row_dispatch<1>(centre - 2 * kFRow, centre, f, W, rot, z);
+      row_dispatch<2>(centre - 1 * kFRow, centre, f, W, rot, z);
+      row_dispatch<3>(centre, centre, f, W, rot, z);
+      row_dispatch<4>(centre + 1 * kFRow, centre, f, W, rot, z);
+      row_dispatch<5>(centre + 2 * kFRow, centre, f, W, rot, z);
+      row_dispatch<6>(centre + 3 * kFRow, centre, f, W, rot, z);
+      v = with_phase_of(a, z, v);
+    }
+    if (live) out[i] = v;
+  }
+}
+
 // mean_mag[clip] = mean of mag[clip][:][:]
 __global__ __launch_bounds__(256) void lws_mean_kernel(const float* __restrict__ mag, int64_t per_clip, float* __restrict__ mean_mag) {
   const float* src = mag + (int64_t)blockIdx.x * per_clip;
@@ -248,7 +444,11 @@ extern "C" int advoc_lws_causal_c64(float* spec, const float* mag, const float* 
   LwsTables tb = {reinterpret_cast<const float2*>(weights), Q, L, period, nfft, bins};
   const size_t lds = sizeof(float2) * ((size_t)kRing * bins + (size_t)(2 * Q - 1) * (2 * L - 1) * period);
   ADVOC_CLEAR_LAUNCH_ERROR();
-  if (Q == 4 && L == 5 && period == 4)
+  if (Q == kFQ && L == kFL && period == kFP && bins == kFBins && nofuture_steps <= kMaxNf) {
+    constexpr size_t lds_fast = sizeof(float2) * (size_t)(kRing + 1) * kFRow;
+    hipLaunchKernelGGL(lws_causal_fast_kernel, dim3((unsigned)clips), dim3(576), lds_fast, advoc::as_stream(stream), c,
+                       reinterpret_cast<const float2*>(weights));
+  } else if (Q == 4 && L == 5 && period == 4)
     hipLaunchKernelGGL((lws_causal_kernel<4, 5, 4>), dim3((unsigned)clips), dim3(576), lds, advoc::as_stream(stream), c, tb);
   else
     hipLaunchKernelGGL((lws_causal_kernel<0, 0, 0>), dim3((unsigned)clips), dim3(576), lds, advoc::as_stream(stream), c, tb);
@@ -272,7 +472,18 @@ extern "C" int advoc_lws_batch_c64(const float* spec_in, float* spec_out, const 
   if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
   LwsTables tb = {reinterpret_cast<const float2*>(weights), Q, L, period, nfft, bins};
   ADVOC_CLEAR_LAUNCH_ERROR();
-  if (Q == 4 && L == 5 && period == 4)
+  if (Q == kFQ && L == kFL && period == kFP && bins == kFBins) {
+    const int64_t tiles_per_clip = advoc::ceil_div(nframes, kSweepFrames);
+    if (clips * tiles_per_clip > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+    constexpr size_t lds_sweep = sizeof(float2) * (size_t)(kSweepFrames + 2 * (kFQ - 1)) * kFRow;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lws_sweep_fast_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep);
+    if (attr != hipSuccess) { advoc::note_hip_error(attr); return ADVOC_ERR_HIP; }
+    hipLaunchKernelGGL(lws_sweep_fast_kernel, dim3((unsigned)(clips * tiles_per_clip)), dim3(576), lds_sweep,
+                       advoc::as_stream(stream), reinterpret_cast<const float2*>(spec_in),
+                       reinterpret_cast<float2*>(spec_out), mag, mean_mag, (int)nframes, threshold,
+                       reinterpret_cast<const float2*>(weights), (int)tiles_per_clip);
+  } else if (Q == 4 && L == 5 && period == 4)
     hipLaunchKernelGGL((lws_batch_kernel<4, 5, 4>), dim3((unsigned)blocks), dim3(256), 0, advoc::as_stream(stream),
                        reinterpret_cast<const float2*>(spec_in), reinterpret_cast<float2*>(spec_out), mag, mean_mag,
                        (int)nframes, threshold, tb, total);

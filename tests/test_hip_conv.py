@@ -783,7 +783,7 @@ def test_bias_gradient_rides_in_the_output_gradient_image_pass(hip, case, hipenv
     dw = torch.zeros_like(w)
     L.backward_data(dy, dx0, dx1, db=db, db_accumulate=(rep == 2))
     if L._bias_fusable:
-      assert L._db_done_for == dy.data_ptr()
+      assert L._db_done_for == (dy.data_ptr(), db.data_ptr())
       assert rel(db - (5.0 if rep == 2 else 0.0), db_o) < TOL, (rep, rel(db, db_o))     # already there
     L.backward_weight(dy, dw, db, accumulate=(rep == 2))
     assert rel(db - (5.0 if rep == 2 else 0.0), db_o) < TOL, (rep, rel(db, db_o))
