@@ -221,33 +221,41 @@ constexpr int kSweepFrames = 8;            // frames per tile of the batch sweep
 // registers -- 63 complex weights per thread spilled 750 bytes of scratch per lane); the rotation is applied to sums:
 //   sum_p alpha_q(p) (-i)^(q (f + p)) x[f + p] = (-i)^(q f) * sum_c (-i)^(q c) * [ sum_{p = c mod 4} alpha_q(p) x[f + p] ]
 // -- compile-time quarter turns on the four class sums, one per-thread unit factor rot[q] = (-i)^(q f) per row.
+typedef float f2v __attribute__((ext_vector_type(2)));
+// c += al * x (complex) as TWO packed instructions: v_pk_fma_f32 takes the scalar weight, the half swap and the sign flip
+// as operand modifiers
+__device__ __forceinline__ void cmac(f2v& c, float2 al, f2v x) {
+  c = __builtin_elementwise_fma((f2v){al.x, al.x}, x, c);
+  c = __builtin_elementwise_fma((f2v){-al.y, al.y}, __builtin_shufflevector(x, x, 1, 0), c);
+}
+// t += (-i)^k v, k compile time
+template <int K>
+__device__ __forceinline__ void add_rot(f2v& t, f2v v) {
+  if (K == 0) t += v;
+  else if (K == 1) t += (f2v){v.y, -v.x};
+  else if (K == 2) t -= v;
+  else t += (f2v){-v.y, v.x};
+}
+constexpr int mod4(int v) { return ((v % 4) + 4) % 4; }
+
 template <int QI, bool SKIP_CENTRE>      // QI = q + Q - 1
 __device__ __forceinline__ void row_taps(const float2* __restrict__ row, int f, const float2* __restrict__ W, float2 rot,
                                          float2& z) {
-  float2 cs[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+  const f2v* r = reinterpret_cast<const f2v*>(row);
+  f2v cs[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
   for (int p = -(kFL - 1); p <= kFL - 1; ++p) {
     if (SKIP_CENTRE && p == 0) continue;
-    const float2 al = W[(QI * kFKW + p + kFL - 1) * kFP];        // uniform address: scalar load
-    const float2 x = row[f + p];
-    float2& c = cs[p & 3];
-    c.x = fmaf(al.x, x.x, c.x); c.x = fmaf(-al.y, x.y, c.x);
-    c.y = fmaf(al.x, x.y, c.y); c.y = fmaf(al.y, x.x, c.y);
+    cmac(cs[p & 3], W[(QI * kFKW + p + kFL - 1) * kFP], r[f + p]);        // W: uniform address, scalar load
   }
-  // t = sum_c (-i)^(q c) cs[c], q = QI - (Q - 1):  (-i)^k v = v, (v.y, -v.x), (-v.x, -v.y), (-v.y, v.x) for k = 0..3
   constexpr int q = QI - (kFQ - 1);
-  float2 t = cs[0];
-#pragma unroll
-  for (int c = 1; c < 4; ++c) {
-    const int k = ((q * c) % 4 + 4) % 4;
-    const float2 v = cs[c];
-    if (k == 0) { t.x += v.x; t.y += v.y; }
-    else if (k == 1) { t.x += v.y; t.y -= v.x; }
-    else if (k == 2) { t.x -= v.x; t.y -= v.y; }
-    else { t.x -= v.y; t.y += v.x; }
-  }
-  z.x = fmaf(rot.x, t.x, z.x); z.x = fmaf(-rot.y, t.y, z.x);
-  z.y = fmaf(rot.x, t.y, z.y); z.y = fmaf(rot.y, t.x, z.y);
+  f2v t = cs[0];
+  add_rot<mod4(q * 1)>(t, cs[1]);
+  add_rot<mod4(q * 2)>(t, cs[2]);
+  add_rot<mod4(q * 3)>(t, cs[3]);
+  f2v zz = {z.x, z.y};
+  cmac(zz, rot, t);
+  z = make_float2(zz.x, zz.y);
 }
 
 // rot[q + Q - 1] = (-i)^(q f)
@@ -351,11 +359,15 @@ __global__ __launch_bounds__(576) void lws_causal_fast_kernel(const CausalParams
 __global__ __launch_bounds__(576) void lws_sweep_fast_kernel(const float2* __restrict__ in, float2* __restrict__ out,
                                                              const float* __restrict__ mag,
                                                              const float* __restrict__ mean_mag, int T, float thr_mult,
-                                                             const float2* __restrict__ W, int tiles_per_clip) {
+                                                             const float2* __restrict__ W, int tiles_per_clip,
+                                                             const float* __restrict__ tile_max) {
   extern __shared__ __attribute__((aligned(16))) float2 lws_smem[];
   constexpr int kRows = kSweepFrames + 2 * (kFQ - 1);
   float2* rows = lws_smem + kFH;
   const int clip = blockIdx.x / tiles_per_clip;
+  // sparse mode (advoc_lws_batch_sweeps_c64): no bin of this tile is above the threshold -> nothing to do, `out` already
+  // holds these bins (both buffers start equal and a bin below a non-increasing threshold has never been touched)
+  if (tile_max && !(tile_max[blockIdx.x] > thr_mult * mean_mag[clip])) return;
   const int t0 = (blockIdx.x - clip * tiles_per_clip) * kSweepFrames;
   const int f = threadIdx.x < kFBins ? threadIdx.x : kFBins - 1;
   const bool live = threadIdx.x < kFBins;
@@ -390,6 +402,23 @@ __global__ __launch_bounds__(576) void lws_sweep_fast_kernel(const float2* __res
     }
     if (live) out[i] = v;
   }
+}
+
+// tile_max[clip * tiles_per_clip + tile] = largest magnitude of the tile's frames
+__global__ __launch_bounds__(256) void lws_tile_max_kernel(const float* __restrict__ mag, int T, int tiles_per_clip,
+                                                           float* __restrict__ tile_max) {
+  const int clip = blockIdx.x / tiles_per_clip;
+  const int t0 = (blockIdx.x - clip * tiles_per_clip) * kSweepFrames;
+  const int nt = T - t0 < kSweepFrames ? T - t0 : kSweepFrames;
+  const float* src = mag + ((int64_t)clip * T + t0) * kFBins;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nt * kFBins; i += 256) m = fmaxf(m, src[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_max[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // mean_mag[clip] = mean of mag[clip][:][:]
@@ -482,7 +511,7 @@ extern "C" int advoc_lws_batch_c64(const float* spec_in, float* spec_out, const 
     hipLaunchKernelGGL(lws_sweep_fast_kernel, dim3((unsigned)(clips * tiles_per_clip)), dim3(576), lds_sweep,
                        advoc::as_stream(stream), reinterpret_cast<const float2*>(spec_in),
                        reinterpret_cast<float2*>(spec_out), mag, mean_mag, (int)nframes, threshold,
-                       reinterpret_cast<const float2*>(weights), (int)tiles_per_clip);
+                       reinterpret_cast<const float2*>(weights), (int)tiles_per_clip, (const float*)nullptr);
   } else if (Q == 4 && L == 5 && period == 4)
     hipLaunchKernelGGL((lws_batch_kernel<4, 5, 4>), dim3((unsigned)blocks), dim3(256), 0, advoc::as_stream(stream),
                        reinterpret_cast<const float2*>(spec_in), reinterpret_cast<float2*>(spec_out), mag, mean_mag,
@@ -492,5 +521,65 @@ extern "C" int advoc_lws_batch_c64(const float* spec_in, float* spec_out, const 
                        reinterpret_cast<const float2*>(spec_in), reinterpret_cast<float2*>(spec_out), mag, mean_mag,
                        (int)nframes, threshold, tb, total);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+// All batch sweeps of run_lws in one call: spec_a holds the result of the time-ordered pass and receives the final
+// spectrogram, spec_b is a work buffer of the same size, tile_work >= clips * ceil(nframes / 8) floats.  With
+// non-increasing thresholds (the reference's schedule alpha * exp(-beta * i^gamma)) on the reference geometry the sweeps
+// are SPARSE: both buffers start equal, a tile none of whose bins exceeds the sweep's threshold is skipped outright (its
+// bins have never changed), so the early sweeps -- thresholds far above most of a speech spectrogram -- cost what their
+// active tiles cost instead of a full pass over memory.  Otherwise: one dense advoc_lws_batch_c64 sweep per threshold.
+extern "C" int advoc_lws_batch_sweeps_c64(float* spec_a, float* spec_b, const float* mag, const float* mean_mag,
+                                          int64_t clips, int64_t nframes, int32_t nfft, int32_t nhop, const float* weights,
+                                          int32_t period, int32_t L, const float* thresholds_host, int32_t n_sweeps,
+                                          float* tile_work, advoc_stream_t stream) {
+  if (clips < 0 || nframes < 0 || n_sweeps < 0 || nfft < 4 || nhop < 1 || nhop > nfft) return ADVOC_ERR_BAD_SHAPE;
+  if (clips == 0 || nframes == 0 || n_sweeps == 0) return ADVOC_OK;
+  if (!spec_a || !spec_b || !mag || !mean_mag || !weights || !thresholds_host) return ADVOC_ERR_NULL;
+  if (spec_a == spec_b) return ADVOC_ERR_UNSUPPORTED;
+  const int bins = nfft / 2 + 1;
+  const int Q = (nfft + nhop - 1) / nhop;
+  hipStream_t st = advoc::as_stream(stream);
+  bool sparse = Q == kFQ && L == kFL && period == kFP && bins == kFBins && tile_work != nullptr;
+  for (int i = 1; i < n_sweeps && sparse; ++i) sparse = thresholds_host[i] <= thresholds_host[i - 1];
+  const size_t bytes = sizeof(float2) * (size_t)clips * (size_t)nframes * (size_t)bins;
+  float* cur = spec_a;
+  float* nxt = spec_b;
+  if (!sparse) {
+    for (int i = 0; i < n_sweeps; ++i) {
+      const int rc = advoc_lws_batch_c64(cur, nxt, mag, mean_mag, clips, nframes, nfft, nhop, weights, period, L,
+                                         thresholds_host[i], stream);
+      if (rc != ADVOC_OK) return rc;
+      float* t = cur; cur = nxt; nxt = t;
+    }
+  } else {
+    if (nframes > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+    const int64_t tiles_per_clip = advoc::ceil_div(nframes, kSweepFrames);
+    if (clips * tiles_per_clip > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+    hipError_t e = hipMemcpyAsync(spec_b, spec_a, bytes, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { advoc::note_hip_error(e); return ADVOC_ERR_HIP; }
+    ADVOC_CLEAR_LAUNCH_ERROR();
+    hipLaunchKernelGGL(lws_tile_max_kernel, dim3((unsigned)(clips * tiles_per_clip)), dim3(256), 0, st, mag, (int)nframes,
+                       (int)tiles_per_clip, tile_work);
+    ADVOC_RETURN_IF_LAUNCH_FAILED();
+    constexpr size_t lds_sweep = sizeof(float2) * (size_t)(kSweepFrames + 2 * (kFQ - 1)) * kFRow;
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lws_sweep_fast_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep);
+    if (attr != hipSuccess) { advoc::note_hip_error(attr); return ADVOC_ERR_HIP; }
+    for (int i = 0; i < n_sweeps; ++i) {
+      ADVOC_CLEAR_LAUNCH_ERROR();
+      hipLaunchKernelGGL(lws_sweep_fast_kernel, dim3((unsigned)(clips * tiles_per_clip)), dim3(576), lds_sweep, st,
+                         reinterpret_cast<const float2*>(cur), reinterpret_cast<float2*>(nxt), mag, mean_mag, (int)nframes,
+                         thresholds_host[i], reinterpret_cast<const float2*>(weights), (int)tiles_per_clip,
+                         (const float*)tile_work);
+      ADVOC_RETURN_IF_LAUNCH_FAILED();
+      float* t = cur; cur = nxt; nxt = t;
+    }
+  }
+  if (cur != spec_a) {          // odd number of sweeps: the newest iterate is in spec_b
+    hipError_t e = hipMemcpyAsync(spec_a, cur, bytes, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { advoc::note_hip_error(e); return ADVOC_ERR_HIP; }
+  }
   return ADVOC_OK;
 }

@@ -595,12 +595,17 @@ def lws_spectrogram_batch(spec, nfft, nhop, L=LWS_L, look_ahead=LWS_LOOK_AHEAD,
       _lib.ptr(cur), _lib.ptr(mag), _lib.ptr(mean_mag), clips, T, nfft, nhop, _lib.ptr(W), P, L, look_ahead,
       thr, len(nofuture_thresholds), int(online[0]), float(online[1]), float(online[2]), int(use_init), _lib.stream()),
       'advoc_lws_causal_c64')
-  nxt = torch.empty_like(cur)
-  for i in range(int(batch[0])):
-    t = float(batch[1]) * math.exp(-float(batch[2]) * float(i) ** float(batch[3]))
-    _lib.check(lib.advoc_lws_batch_c64(_lib.ptr(cur), _lib.ptr(nxt), _lib.ptr(mag), _lib.ptr(mean_mag), clips, T, nfft,
-                                       nhop, _lib.ptr(W), P, L, t, _lib.stream()), 'advoc_lws_batch_c64')
-    cur, nxt = nxt, cur
+  n_sweeps = int(batch[0])
+  if n_sweeps > 0:
+    # all sweeps in one C call: sparse on the reference's (non-increasing) threshold schedule -- tiles with no bin above
+    # the sweep's threshold are skipped (csrc/lws.hip)
+    nxt = torch.empty_like(cur)
+    ts = (ctypes.c_float * n_sweeps)(*[float(batch[1]) * math.exp(-float(batch[2]) * float(i) ** float(batch[3]))
+                                        for i in range(n_sweeps)])
+    tile_work = torch.empty(clips * ((T + 7) // 8), dtype=torch.float32, device=dev)
+    _lib.check(lib.advoc_lws_batch_sweeps_c64(_lib.ptr(cur), _lib.ptr(nxt), _lib.ptr(mag), _lib.ptr(mean_mag), clips, T,
+                                              nfft, nhop, _lib.ptr(W), P, L, ts, n_sweeps, _lib.ptr(tile_work),
+                                              _lib.stream()), 'advoc_lws_batch_sweeps_c64')
   return torch.view_as_complex(cur)
 
 

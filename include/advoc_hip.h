@@ -120,6 +120,14 @@ int advoc_lws_causal_c64(float* spec, const float* mag, const float* mean_mag, i
 int advoc_lws_batch_c64(const float* spec_in, float* spec_out, const float* mag, const float* mean_mag, int64_t clips,
                         int64_t nframes, int32_t nfft, int32_t nhop, const float* weights, int32_t period,
                         int32_t L, float threshold, advoc_stream_t stream);
+/* All batch sweeps of run_lws in one call (thresholds_host[n_sweeps], multiples of mean_mag): spec_a = output of the
+ * time-ordered pass on entry, the final spectrogram on return; spec_b = work buffer of the same size; tile_work = clips *
+ * ceil(nframes / 8) floats of scratch (may be NULL: dense sweeps).  Non-increasing thresholds on the reference geometry
+ * (nfft 1024, hop 256, L 5) run SPARSE: tiles of 8 frames none of whose bins exceeds the sweep's threshold are skipped. */
+int advoc_lws_batch_sweeps_c64(float* spec_a, float* spec_b, const float* mag, const float* mean_mag, int64_t clips,
+                               int64_t nframes, int32_t nfft, int32_t nhop, const float* weights, int32_t period,
+                               int32_t L, const float* thresholds_host, int32_t n_sweeps, float* tile_work,
+                               advoc_stream_t stream);
 
 /* Host helper: fills tw_host[2 * nfft] with the double-precision-evaluated twiddle table the
  * STFT kernels expect (upload it once; it is read-only). */

@@ -76,6 +76,44 @@ def test_kernels_match_the_cpu_restatement(hip, complex_input):
 
 
 @gpu
+@pytest.mark.parametrize('n_sweeps', [7, 30])
+def test_sparse_sweeps_equal_dense_sweeps(hip, n_sweeps):
+  """advoc_lws_batch_sweeps_c64 skips the 8-frame tiles none of whose bins exceeds a sweep's threshold (speech: most of
+  the spectrogram during the early, high-threshold sweeps); the result is bit-identical to one dense
+  advoc_lws_batch_c64 sweep per threshold, for odd and even sweep counts, and the dense fall-back (increasing
+  thresholds) goes through the same entry point."""
+  import ctypes
+  import math
+  from advoc_amd import _lib, spectral
+  lib = _lib.load()
+  x = _mono22()[:40000]
+  A = torch.from_numpy(np.abs(spectral.stft(x, 1024, 256, pad_end=False))[:, :, 0].astype(np.float32)).cuda()
+  mag = torch.stack([A, A.flip(0) * 0.3, torch.rand_like(A)]).contiguous()        # speech, quiet speech, noise
+  clips, T, bins = mag.shape
+  start = spectral.lws_spectrogram_batch(mag, 1024, 256, batch=(0, 1.0, 0.0, 1.0))
+  W, P = spectral._lws_tables(1024, 256, 5)
+  mean_mag = mag.mean(dim=(1, 2)).contiguous()
+  for sched in ('decreasing', 'increasing'):
+    ts = [30.0 * math.exp(-0.25 * i) for i in range(n_sweeps)]
+    if sched == 'increasing':
+      ts = ts[::-1]
+    cur = torch.view_as_real(start).contiguous().clone()
+    nxt = torch.empty_like(cur)
+    for t in ts:
+      _lib.check(lib.advoc_lws_batch_c64(_lib.ptr(cur), _lib.ptr(nxt), _lib.ptr(mag), _lib.ptr(mean_mag), clips, T, 1024,
+                                         256, _lib.ptr(W), P, 5, t, _lib.stream()))
+      cur, nxt = nxt, cur
+    a = torch.view_as_real(start).contiguous().clone()
+    b = torch.full_like(a, float('nan'))
+    work = torch.empty(clips * ((T + 7) // 8), dtype=torch.float32, device='cuda')
+    _lib.check(lib.advoc_lws_batch_sweeps_c64(_lib.ptr(a), _lib.ptr(b), _lib.ptr(mag), _lib.ptr(mean_mag), clips, T, 1024,
+                                              256, _lib.ptr(W), P, 5, (ctypes.c_float * n_sweeps)(*ts), n_sweeps,
+                                              _lib.ptr(work), _lib.stream()))
+    assert torch.equal(a, cur), sched
+    assert not torch.equal(a, torch.view_as_real(start))          # the sweeps did something
+
+
+@gpu
 def test_true_spectrogram_stays_put_like_the_reference_known_answer(hip):
   """tests/test_spectral.py:184-208 hands run_lws the COMPLEX stft of mono.wav (22 kHz): mean |x_lws - x| =
   0.0004236908353.  The input here comes from a different resampler, so the number is reproduced in order of
