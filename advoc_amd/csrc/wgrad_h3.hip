@@ -310,7 +310,8 @@ int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned*
   const int64_t resident = (big ? 1 : 2) * (int64_t)device_cu_count();
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
   int64_t ksplit = ceil_div(resident, tiles);
-  if (M / ksplit >= 4096) ksplit = ceil_div(2 * resident, tiles);
+  if (tuning().wgrad_h3_rounds > 0) ksplit = ceil_div(tuning().wgrad_h3_rounds * resident, tiles);
+  else if (M / ksplit >= 4096) ksplit = ceil_div(2 * resident, tiles);
   const int64_t max_split = ceil_div(M, 8 * WK);
   if (ksplit > max_split) ksplit = max_split;
   if (ksplit < 1) ksplit = 1;

@@ -23,6 +23,10 @@ Pinning status ("Oracle"):
                     against closed-form micro cases (tests/test_oracle_conv.py).
   * loader_np    -- PARITY UNPINNED (no reference test); restates
                     advoc/loader.py:133-186 and tf.contrib.signal.frame.
-  * melspecgan_torch -- PARITY UNPINNED (no reference test, golden tensor or reachable
-                    checkpoint); restates the MelspecGAN generator's inference graph.
+  * melspecgan_torch -- STRUCTURE PINNED (r3): equals, to float64 round-off, the TensorFlow-written inference graph the
+                    reference holds (models/melspecgan/infer.meta, decoded into tests/golden/melspecgan_graph.json and
+                    evaluated op by op by tests/tf_graph_interp.py; variable table, BN epsilon / mode, transposed-conv
+                    strides / padding / output shapes, output mapping).  Trained weights are not reachable: no numeric
+                    golden output exists.  The same file pins TF's Conv2DBackpropInput SAME rule, which
+                    advoc_torch.gen_deconv shares.
 """

@@ -1,7 +1,10 @@
 """torch-CPU restatement of the MelspecGAN generator's INFERENCE graph.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED: the reference holds no test, golden
-tensor or reachable checkpoint for this network; TF semantics are transcribed op by op.
+TEST INFRASTRUCTURE (see oracle/__init__.py).  STRUCTURE PINNED (r3) by the one TensorFlow-written artefact the
+reference holds, models/melspecgan/infer.meta: tests/test_melspecgan_graph.py evaluates that graph op by op
+(tests/tf_graph_interp.py, Conv2DBackpropInput literally as the autograd gradient of a SAME conv) and requires
+`generator` below to equal it to float64 round-off, and the variable table / hyper-parameters to match.  No trained
+weights or golden tensors are reachable, so there is no numeric known answer.
 
 Restated (paths relative to /root/reference):
   models/melspecgan/conv2d.py:4-14     dense_layer            x @ W + b, W [in, out]

@@ -112,3 +112,20 @@ def test_adam_is_tensorflows_formulation():
 def test_dropout_is_inverted_dropout():
   x = torch.tensor([2.0, 4.0, 6.0])
   assert torch.equal(A.dropout(x, torch.tensor([1.0, 0.0, 1.0]), 0.5), torch.tensor([4.0, 0.0, 12.0]))
+
+
+def test_gen_deconv_is_tensorflow_conv2d_backprop_input():
+  """tf.layers.conv2d_transpose(k=4, strides, 'same') runs TF's Conv2DBackpropInput.  tests/tf_graph_interp.py implements
+  that op from its definition (the autograd gradient of a SAME-padded strided conv) and is validated on the
+  TensorFlow-written MelspecGAN graph (tests/test_melspecgan_graph.py); the AdVoc oracle's transposed conv
+  (models/advoc/advoc_model.py:53-69) must be the same function, for both stride settings the model uses."""
+  import tf_graph_interp as interp
+  g = torch.Generator().manual_seed(0)
+  for strides, (h, w) in (((2, 2), (5, 9)), ((1, 2), (1, 5)), ((2, 2), (1, 3))):
+    x = torch.randn(2, h, w, 6, generator=g, dtype=torch.float64)
+    kern = torch.randn(4, 4, 3, 6, generator=g, dtype=torch.float64)          # [kh, kw, out, in]
+    got = A.gen_deconv(x, kern, torch.zeros(3, dtype=torch.float64), strides=strides)
+    want = interp.conv2d_backprop_input([2, strides[0] * h, strides[1] * w, 3], kern, x, [1, strides[0], strides[1], 1],
+                                        'SAME', 'NHWC')
+    assert tuple(got.shape) == tuple(want.shape)
+    assert float((got - want).abs().max()) < 1e-12

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-OUT=gpurun_out/prof_r02; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/prof_r03; mkdir -p $OUT
 CMD="env ADVOC_WGRAD_STREAM=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-only --prof-steps 0"
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1; echo trace rc=$?
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1; echo fetch rc=$?
@@ -12,4 +12,3 @@ python tools/sq_summary.py $S > $OUT/pmc_mfma.md
 head -20 $OUT/kernel_trace.md; head -12 $OUT/pmc_hbm.md; head -12 $OUT/pmc_mfma.md
 # keep only the summaries (raw csv is large)
 rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/sq
-python tools/micro/h3_numerics.py 2>&1 | grep -v amdgpu | tee $OUT/h3_numerics.txt
