@@ -428,10 +428,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
         for (int r = 0; r < 16; ++r)
           __hip_atomic_store(part + (((wave * MT + i) * NT + j) * 16 + r) * 64 + lane, acc[i][j][r],
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // RELEASE at agent scope: the partial tile must be visible to a workgroup on ANOTHER XCD (its own L2) before the
-    // arrival counter moves.  A bare s_waitcnt only says this XCD's L2 has taken the stores; under heavy traffic from a
-    // kernel on another stream the counter overtook them (side stream + batch norm: gradients off by 1e-3, r3).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // (r3: an agent-scope RELEASE fence here -- buffer_wbl2, a write-back of this XCD's whole L2 -- was tried while chasing
+    // a side-stream race and cost +46 % on this kernel (58 -> 85 us average, +1 ms per step) without changing the race:
+    // the partial tiles are written with agent-scope stores that bypass the non-coherent L2 path already.)
     __builtin_amdgcn_s_waitcnt(0);        // this thread's partial has reached the coherent level ...
     __syncthreads();
     int* s_flag = reinterpret_cast<int*>(smem);
@@ -441,7 +440,6 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmPar
     const int arrived = *s_flag;
     __syncthreads();                      // smem is reused below
     if (arrived != ks_cnt - 1) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // (pairs with the release above: nothing stale from this XCD's L2)
     if (tid == 0)                         // ready for the next launch
       __hip_atomic_store(p.tail_cnt + tail_tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float* all = p.tail_ws + (size_t)tail_tile * ks_cnt * TILE;

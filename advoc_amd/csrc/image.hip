@@ -185,9 +185,11 @@ __global__ void rotate_hdr_kernel(unsigned* __restrict__ hdr) {
 // Inside [2^-6, 2^6] of the previous magnitude the one-pass image keeps >= 22 significant bits for every element within
 // 2^-9 of the largest and an absolute error <= 2^-28 of the largest below that.
 __device__ __forceinline__ bool image_needs_refit(const unsigned* __restrict__ hdr) {
-  const unsigned cur = hdr[0], prev = hdr[2];
+  const unsigned cur = __hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned prev = __hip_atomic_load(hdr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int ec = (int)((cur >> 23) & 0xffu), ep = (int)((prev >> 23) & 0xffu);
-  if (hdr[3] != hdr[4]) return true;
+  if (__hip_atomic_load(hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+      __hip_atomic_load(hdr + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
   if (ep == 0 || ep == 255) return ec != 0;
   return ec + 6 < ep;
 }
@@ -310,10 +312,28 @@ struct RefitSource {
   const uint8_t* mask;
   float mask_scale;
 };
+// The LAST workgroup to finish also rotates the header for the next pass (hdr[2] <- hdr[0], hdr[0] <- 0, hdr[4] <- hdr[3];
+// arrival counter in hdr[6]): every workgroup has read what it needs by then, and the one-thread rotate_hdr_kernel
+// launch in front of every one-pass image (44 per train step, ~5 us each) is gone.
+__device__ __forceinline__ void refit_done(unsigned* __restrict__ hdr) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned total = gridDim.x * gridDim.y;
+    if (atomicAdd(hdr + 6, 1u) == total - 1) {
+      hdr[6] = 0u;
+      hdr[2] = hdr[0];
+      hdr[4] = hdr[3];
+      __hip_atomic_store(hdr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 __global__ __launch_bounds__(256) void refit_image_kernel(RefitSource s0, RefitSource s1, unsigned* __restrict__ hdr) {
-  if (!image_needs_refit(hdr)) return;
+  // (volatile reads: the decision must come from memory before this workgroup is counted as done)
+  const bool needs = image_needs_refit(hdr);
+  const unsigned cur_bits = __hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!needs) { refit_done(hdr); return; }
   const RefitSource& s = blockIdx.y == 0 ? s0 : s1;
-  const float up = up_scale(hdr[0]);
+  const float up = up_scale(cur_bits);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     hdr[1] = __float_as_uint(1.f / up);
     atomicAdd(hdr + 5, 1u);
@@ -335,6 +355,7 @@ __global__ __launch_bounds__(256) void refit_image_kernel(RefitSource s0, RefitS
     *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(h0);
     *reinterpret_cast<uint4*>(o + 32) = *reinterpret_cast<const uint4*>(h1);
   }
+  refit_done(hdr);
 }
 
 // One workgroup = one 32 (k) x 32 (n) tile of one tap, through LDS so that both the fp32 reads (along n for the
@@ -521,11 +542,7 @@ int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* i
   const int64_t b0 = (4 * s0.elems + 255) / 256 * 256;
   uint16_t* img1 = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(img) + b0);
   int rc = ADVOC_OK;
-  if (delayed) {
-    ADVOC_CLEAR_LAUNCH_ERROR();
-    hipLaunchKernelGGL(rotate_hdr_kernel, dim3(1), dim3(1), 0, stream, hdr);
-    ADVOC_RETURN_IF_LAUNCH_FAILED();
-  } else {
+  if (!delayed) {      // (delayed: the header was rotated at the end of the previous call on this buffer)
     hipError_t e = hipMemsetAsync(hdr, 0, 8, stream);
     if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
     rc = launch_amax(s0.x, s0.elems, s0.c, s0.scale, s0.shift, s0.act, s0.mask, s0.mask_scale, hdr, stream);
@@ -544,7 +561,13 @@ int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* i
     const RefitSource r1 = {s1.x, reinterpret_cast<__half*>(img1), s1.elems / 8, s1.c, s1.scale, s1.shift, slope_of(s1.act),
                             s1.mask, s1.mask_scale};
     ADVOC_CLEAR_LAUNCH_ERROR();
-    hipLaunchKernelGGL(refit_image_kernel, dim3(256, s1.elems ? 2 : 1), dim3(256), 0, stream, r0, r1, hdr);
+    // (64 workgroups per source: the common case is "nothing to do", and their arrival atomics are serial)
+    hipLaunchKernelGGL(refit_image_kernel, dim3(64, s1.elems ? 2 : 1), dim3(256), 0, stream, r0, r1, hdr);
+    ADVOC_RETURN_IF_LAUNCH_FAILED();
+  } else if (rc == ADVOC_OK && s0.elems > 0) {
+    // exact image: leave the header rotated, ready for a one-pass image next time
+    ADVOC_CLEAR_LAUNCH_ERROR();
+    hipLaunchKernelGGL(rotate_hdr_kernel, dim3(1), dim3(1), 0, stream, hdr);
     ADVOC_RETURN_IF_LAUNCH_FAILED();
   }
   return rc;

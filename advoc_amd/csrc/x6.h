@@ -36,9 +36,12 @@ int launch_pair_image(const float* x, uint16_t* img, int64_t elems, int c, const
                       int act, const uint8_t* mask, float mask_scale, unsigned* hdr, bool delayed, hipStream_t stream,
                       float* colsum = nullptr, int w_log = 0, int w_pitch = 0, float* colsum_table = nullptr);
 // One GEMM operand = one or two channel-concatenated sources under ONE scale.  make_operand_image writes the image
-// (source 1 behind source 0 at its 256-byte-rounded size) and the 32-byte header {[0] largest magnitude of this image,
-// [1] 2^-s, [2] largest magnitude of the previous image in this buffer, [3] values that left the one-pass head room
-// (cumulative), [4] word 3 before the last pass, [5] exact refits taken (cumulative), [6..7] reserved}.  delayed ==
+// (source 1 behind source 0 at its 256-byte-rounded size) and the 32-byte header {[0] magnitude accumulator of the pass in
+// flight (0 between calls), [1] 2^-s of the image in the buffer, [2] largest magnitude of that image (the scale source
+// of the next one-pass image), [3] values that left the one-pass head room (cumulative), [4] word 3 before the last
+// pass, [5] exact refits taken (cumulative), [6] arrival counter of the refit kernel, [7] reserved}; every call leaves
+// the header "rotated" ([2] <- [0], [0] <- 0, [4] <- [3]: by the last workgroup of the refit kernel, or by a one-thread
+// kernel behind an exact image).  delayed ==
 // false: the exact two-pass form (magnitude pass, then image pass, largest magnitude at [2^13, 2^14)).  delayed == true:
 // ONE pass, scale from the previous image's magnitude placed at [2^9, 2^10), this image's magnitude recorded for the
 // next call, followed by refit_image_kernel, which rebuilds the image with the exact scale whenever a value left the

@@ -812,7 +812,7 @@ class Advoc(Model):
         # tools/micro/side_race_bisect.py): with the tail of pass 0's weight gradients (the long thin-layer kernel) still
         # running next to the first backward-data launches of pass 1, a few thousand elements of a backward-data output
         # came out wrong in ~1 of 3 runs (gradients off by 1e-3) although no buffer is shared between the two; the cause
-        # was not found (agent-scope fences in the workspace K-split did not change it), so the overlap is not allowed.
+        # was not found (agent-scope fences in the workspace K-split did not change it and were removed again), so the overlap is not allowed.
         self._join_wgrad()
     self._join_wgrad()
     self._adam('d')

@@ -239,8 +239,9 @@ typedef struct advoc_conv_layer {
    * reads them instead of making its own: img_flags bit 0 = x_img is current (the inputs have not changed since the
    * call that filled it), bit 1 = dy_img is current (filled by a call with the same dy).  A forward / backward-data call
    * that finds its bit set skips its image passes too (advoc_conv_make_image fills a buffer on its own).  Sizes:
-   * advoc_conv_image_bytes(); headers 32 bytes each (8 words, zeroed by the caller once: {largest magnitude, 2^-s,
-   * previous magnitude, values outside the one-pass head room, [3] before the last pass, exact refits, reserved x2}).
+   * advoc_conv_image_bytes(); headers 32 bytes each (8 words, zeroed by the caller once: {magnitude accumulator (0 between
+   * calls), 2^-s, largest magnitude of the image in the buffer, values outside the one-pass head room, [3] before the last
+   * pass, exact refits, arrival counter, reserved}).
    * Without the buffers the images live in `workspace` per call. */
   uint16_t* x_img;
   uint32_t* x_hdr;
