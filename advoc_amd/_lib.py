@@ -70,6 +70,7 @@ PROTOTYPES = {
     'advoc_lws_batch_sweeps_c64': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _p, _i32, _p, _p]),
     'advoc_matmul_nt_f32': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
     'advoc_mel_pinv_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    'advoc_stft_mel_pinv_f32': (ctypes.c_int, [_p, _i64, _i64, _p, _p, _i32, _i32, _i64, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     'advoc_tanh_affine_f32': (ctypes.c_int, [_p, _p, _i64, _f32, _f32, _p]),
     'advoc_mel_dbnorm_f32': (ctypes.c_int, [_p, _i64, _f32, _f32, _f32, _p]),
     'advoc_conv_workspace_bytes': (_i64, [_p, _i32]),

@@ -329,6 +329,53 @@ def pack_filterbank(meltrans_np, invmeltrans_np, device):
   return (torch.from_numpy(runs).to(device), torch.from_numpy(wp).to(device), torch.from_numpy(inv_t).to(device))
 
 
+def pack_inverse_pairs(invmeltrans_np, device):
+  """The pseudo-inverse [bins, n_mels] pre-split for the f16 matrix cores of advoc_stft_mel_pinv_f32: every row n under
+  its own power of two 2^s(n) (largest |P[n, :]| in [2^13, 2^14)) as fp16 pairs h0 + h1 (round to nearest), laid out
+  [bins / 32][n_mels / 16][plane][lane = 32 half + l32][8] in MFMA operand order, plus unscale[n] = 2^-s(n).  Same
+  arithmetic as the per-launch split of mel_pinv_kernel (csrc/melpinv.hip), done once on the host."""
+  P = np.asarray(invmeltrans_np, dtype=np.float32)
+  bins, n_mels = P.shape
+  nb, steps = (bins + 31) // 32, n_mels // 16
+  Pp = np.zeros((nb * 32, n_mels), dtype=np.float32)
+  Pp[:bins] = P
+  amax = np.abs(Pp).max(axis=1)
+  _, ex = np.frexp(amax)                                # amax = m 2^ex, m in [0.5, 1): biased exponent - 127 = ex - 1
+  sh = np.clip(14 - ex, -120, 120).astype(np.float64)
+  up = np.where(amax > 0, np.exp2(sh), 1.0).astype(np.float32)
+  a = (Pp * up[:, None]).astype(np.float32)             # exact: a power of two
+  h0 = a.astype(np.float16)
+  h1 = (a - h0.astype(np.float32)).astype(np.float16)
+  out = np.zeros((nb, steps, 2, 64, 8), dtype=np.float16)
+  for pl, h in ((0, h0), (1, h1)):
+    # h[n = 32 nb + l32, k = 16 st + 8 half + i] -> [nb, st, half, l32, i]
+    v = h.reshape(nb, 32, steps, 2, 8).transpose(0, 2, 3, 1, 4)
+    out[:, :, pl] = v.reshape(nb, steps, 64, 8)
+  return (torch.from_numpy(out.view(np.int16)).to(device).contiguous(), torch.from_numpy((1.0 / up).astype(np.float32)).to(device))
+
+
+def stft_mel_inverse(wav2d, nfft, nhop, nframes, packed, pairs):
+  """wav2d [clips, n] (device f32) -> (|STFT| [clips, T, bins], mel [clips, T, n_mels], inv [clips, T, bins]) in ONE
+  launch (advoc_stft_mel_pinv_f32, csrc/extract.hip); None when the shapes are outside the fused kernel."""
+  runs, wp, inv_t = packed
+  tab, unscale = pairs
+  clips, n = wav2d.shape
+  n_mels, bins = inv_t.shape
+  mag = torch.empty((clips, nframes, bins), dtype=torch.float32, device=wav2d.device)
+  mel = torch.empty((clips, nframes, n_mels), dtype=torch.float32, device=wav2d.device)
+  inv = torch.empty((clips, nframes, bins), dtype=torch.float32, device=wav2d.device)
+  if nfft != 1024:
+    return None
+  rc = _lib.load().advoc_stft_mel_pinv_f32(
+      _lib.ptr(wav2d), clips, n, _lib.ptr(_device_window(nfft, nhop)), _lib.ptr(_device_twiddle(nfft)), nfft, nhop, nframes,
+      _lib.ptr(wp), _lib.ptr(runs), int(wp.numel()), bins, n_mels, _lib.ptr(tab), _lib.ptr(unscale), _lib.ptr(mag),
+      _lib.ptr(mel), _lib.ptr(inv), _lib.stream())
+  if rc == _lib.ERR_UNSUPPORTED:
+    return None
+  _lib.check(rc, 'advoc_stft_mel_pinv_f32')
+  return mag, mel, inv
+
+
 def band_runs(meltrans_np):
   """[n_mels, 2] int32: first bin and one past the last bin with a non-zero weight in each filterbank row."""
   out = np.zeros((meltrans_np.shape[0], 2), dtype=np.int32)

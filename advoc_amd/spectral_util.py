@@ -19,6 +19,7 @@ class SpectralUtil(object):
   FMAX = 7600.
   NMELS = 80
   fs = 22050
+  FUSED_MAX_FRAMES = 65536      # largest call extract_training_triple hands to the one-launch extractor
 
   def __init__(self, n_mels=80, fs=22050):
     self.NMELS = n_mels
@@ -35,6 +36,8 @@ class SpectralUtil(object):
     if key not in self._dev:
       if name == 'packed':
         self._dev[key] = spectral.pack_filterbank(self.meltrans_np, self.invmeltrans_np, dev)
+      elif name == 'pairs':
+        self._dev[key] = spectral.pack_inverse_pairs(self.invmeltrans_np, dev)
       else:
         src = self.meltrans_np if name == 'mel' else self.invmeltrans_np
         self._dev[key] = torch.from_numpy(src.astype(np.float32)).to(dev).contiguous()
@@ -52,6 +55,16 @@ class SpectralUtil(object):
     """What the train step consumes per batch (models/advoc/train_evaluate.py:55-56 on top of
     advoc/loader.py:116-128): waveforms [b, n, 1, 1] in HBM -> (|STFT| [b, T, 513, 1], linear mel [b, T, n_mels, 1],
     pseudo-inverted magnitudes [b, T, 513, 1]), T = 1 + (n - nfft) // nhop frames (whole frames only)."""
+    wav = spectral._to_device_f32(wav)
+    b, n, nfeats, ch = wav.shape
+    T = 1 + (n - self.NFFT) // self.NHOP if n >= self.NFFT else 0
+    if nfeats == 1 and ch == 1 and self.NMELS == 80 and self.NFFT == 1024 and 0 < b * T <= self.FUSED_MAX_FRAMES and \
+        wav.dtype == torch.float32:
+      # ONE launch: STFT, mel and pseudo-inverse without re-reading the magnitudes (csrc/extract.hip) -- faster than the
+      # two launches up to ~64 k frames per call (the training feed is 2 x 64 clips x 256 frames = 32 k), slower above
+      out = spectral.stft_mel_inverse(wav.reshape(b, n).contiguous(), self.NFFT, self.NHOP, T, self._const('packed'), self._const('pairs'))
+      if out is not None:
+        return out[0].unsqueeze(-1), out[1].unsqueeze(-1), out[2].unsqueeze(-1)
     mag = spectral.stft_magnitude(wav, self.NFFT, self.NHOP, pad_end=False)
     # both projections in one pass over the magnitudes (csrc/melpinv.hip)
     mel, inv = spectral.mel_and_inverse(mag[:, :, :, 0], self.meltrans, self.invmeltrans, packed=self._const('packed'))

@@ -198,22 +198,31 @@ def extractor_leg(torch, spectral, su, wav, launches=30):
                                                      1024, 256, CLIP_FRAMES, _lib.ptr(out), _lib.stream()), 'stft')
     return event_timed(torch, call, launches), clips * (CLIP_SAMPLES * 4 + CLIP_FRAMES * 513 * 4)
 
-  def run_triple(clips):
-    # the two launches of SpectralUtil.extract_training_triple through the C ABI with preallocated outputs, like run_stft
-    # (the Python wrapper's per-call allocations are part of the train step's time, not of the kernels')
+  def run_triple(clips, fused):
+    # waveform -> (|X|, mel, pinv(mel)) through the C ABI with preallocated outputs, like run_stft (the Python wrapper's
+    # per-call allocations are part of the train step's time, not of the kernels'): the ONE launch of
+    # SpectralUtil.extract_training_triple (csrc/extract.hip), or the two launches it replaced (stft + mel_pinv)
     x = clips_of(clips)
     mag = torch.empty(clips, CLIP_FRAMES, 513, dtype=torch.float32, device=x.device)
     mel = torch.empty(clips, CLIP_FRAMES, 80, dtype=torch.float32, device=x.device)
     inv = torch.empty(clips, CLIP_FRAMES, 513, dtype=torch.float32, device=x.device)
     runs, wp, inv_t = su._const('packed')
+    tab, unscale = su._const('pairs')
 
-    def call():
+    def call_fused():
+      _lib.check(lib.advoc_stft_mel_pinv_f32(_lib.ptr(x), clips, x.shape[1], _lib.ptr(win), _lib.ptr(tw), 1024, 256,
+                                             CLIP_FRAMES, _lib.ptr(wp), _lib.ptr(runs), int(wp.numel()), 513, 80,
+                                             _lib.ptr(tab), _lib.ptr(unscale), _lib.ptr(mag), _lib.ptr(mel), _lib.ptr(inv),
+                                             _lib.stream()), 'stft_mel_pinv')
+
+    def call_two():
       _lib.check(lib.advoc_stft_mag_f32(_lib.ptr(x), clips, x.shape[1], _lib.ptr(win), _lib.ptr(tw), 1024, 256,
                                         CLIP_FRAMES, _lib.ptr(mag), _lib.stream()), 'stft')
       _lib.check(lib.advoc_mel_pinv_f32(_lib.ptr(mag), _lib.ptr(wp), _lib.ptr(runs), _lib.ptr(inv_t), _lib.ptr(mel),
                                         _lib.ptr(inv), clips * CLIP_FRAMES, 513, 80, int(wp.numel()), _lib.stream()),
                  'mel_pinv')
-    return event_timed(torch, call, launches), clips * (CLIP_SAMPLES * 4 + CLIP_FRAMES * (80 + 2 * 513) * 4)
+    return (event_timed(torch, call_fused if fused else call_two, launches),
+            clips * (CLIP_SAMPLES * 4 + CLIP_FRAMES * (80 + 2 * 513) * 4))
 
   nb = 2 * wav.shape[0]
   ms_l, bytes_l = run_stft(512)
@@ -225,15 +234,20 @@ def extractor_leg(torch, spectral, su, wav, launches=30):
              at_train_feed=dict(clips_per_launch=nb, avg_launch_ms=ms_b, achieved=bytes_b / (ms_b * 1e-3) / 1e9,
                                 frac=bytes_b / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 frames_per_s=nb * CLIP_FRAMES / (ms_b * 1e-3)))
-  if hasattr(su, 'extract_training_triple'):
-    ms_t, bytes_t = run_triple(512)
-    ms_tb, bytes_tb = run_triple(nb)
-    out['triple'] = dict(what='waveform -> |X|, mel, pinv(mel) (1 397 760 B per clip): stft1024_kernel + mel_pinv_kernel', clips_per_launch=512,
-                         avg_ms=ms_t, achieved=bytes_t / (ms_t * 1e-3) / 1e9,
-                         frac=bytes_t / (ms_t * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         at_train_feed=dict(clips_per_launch=nb, avg_ms=ms_tb,
-                                            achieved=bytes_tb / (ms_tb * 1e-3) / 1e9,
-                                            frac=bytes_tb / (ms_tb * 1e-3) / 1e9 / HBM_PEAK_GBS))
+  fused_max = getattr(su, 'FUSED_MAX_FRAMES', 0)
+  res = {}
+  for tag, clips in (('bulk', 512), ('feed', nb)):
+    ms_f, by = run_triple(clips, True)
+    ms_2, _ = run_triple(clips, False)
+    uses_fused = clips * CLIP_FRAMES <= fused_max            # what SpectralUtil.extract_training_triple launches at this size
+    ms = ms_f if uses_fused else ms_2
+    res[tag] = dict(clips_per_launch=clips, avg_ms=ms, achieved=by / (ms * 1e-3) / 1e9, frac=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    path='one launch (stft_mel_pinv_kernel)' if uses_fused else 'two launches (stft1024_kernel + mel_pinv_kernel)',
+                    one_launch_ms=ms_f, two_launches_ms=ms_2)
+  out['triple'] = dict(what='waveform -> |X|, mel, pinv(mel) (1 397 760 B per clip) as SpectralUtil.extract_training_triple '
+                            'launches it: ONE launch (csrc/extract.hip) up to %d frames per call, two above' % fused_max,
+                       **res['bulk'])
+  out['triple']['at_train_feed'] = res['feed']
   return out
 
 

@@ -162,6 +162,19 @@ int advoc_matmul_nt_f32(const float* x, const float* w, float* out, int64_t rows
 int advoc_mel_pinv_f32(const float* mag, const float* mel_wp, const int32_t* band_lo_hi, const float* inv_wt,
                        float* mel_out, float* inv_out, int64_t rows, int32_t bins, int32_t n_mels,
                        int32_t packed_weights, advoc_stream_t stream);
+/* The feature extractor of a training batch in ONE launch (advoc/loader.py:116-128 + models/advoc/spectral_util.py:29-43
+ * as models/advoc/train_evaluate.py:55-56 chains them): wav [batch][nsamps] -> mag [batch][nframes][513] = |STFT| (as
+ * advoc_stft_mag_f32), mel [batch][nframes][80] = mag W^T, inv [batch][nframes][513] = mel P^T (as advoc_mel_pinv_f32),
+ * the magnitudes never re-read from HBM.  mel_wp / band_lo_hi / packed_weights as advoc_mel_pinv_f32.  pinv_pairs: the
+ * pseudo-inverse pre-split for the f16 matrix cores, [17][5][2][64] blocks of 16 bytes (256-byte aligned): entry
+ * [nb][st][plane][lane = 32 half + l32] = the 8 fp16 values `plane` (0: rounded, 1: remainder) of
+ * P[n = 32 nb + l32][k = 16 st + 8 half + 0..7] * 2^s(n), zeros for n >= 513; pinv_unscale[544] = 2^-s(n), s(n) placing
+ * the largest |P[n][:]| in [2^13, 2^14) (advoc_amd.spectral.pack_inverse_pairs builds both).  nfft 1024, 80 mel bands
+ * only: ADVOC_ERR_UNSUPPORTED otherwise (callers fall back to the two launches). */
+int advoc_stft_mel_pinv_f32(const float* wav, int64_t batch, int64_t nsamps, const float* window, const float* twiddle,
+                            int32_t nfft, int32_t nhop, int64_t nframes, const float* mel_wp, const int32_t* band_lo_hi,
+                            int32_t packed_weights, int32_t bins, int32_t n_mels, const void* pinv_pairs,
+                            const float* pinv_unscale, float* mag, float* mel, float* inv, advoc_stream_t stream);
 
 /* y[i] = tanh(x[i]) * scale + shift (x == y allowed).  Replaces tf.nn.tanh + feats_denorm at the end of
  * the MelspecGAN generator, models/melspecgan/conv2d.py:139 and util.py:11-12 (scale = shift = 0.5). */

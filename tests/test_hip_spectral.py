@@ -321,3 +321,79 @@ def test_fused_mel_and_pseudo_inverse_matches_the_two_projections(hip):
   assert mag.shape == (3, 10, 513, 1) and mel.shape == (3, 10, 80, 1) and inv.shape == (3, 10, 513, 1)
   ref = su.mel_linear_to_mag_spec(su.mag_to_mel_linear_spec(mag))
   assert float((inv - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+def test_inverse_pair_table_reproduces_the_pseudo_inverse():
+  """spectral.pack_inverse_pairs (host): h0 + h1 under the row's power of two equals the float32 pseudo-inverse to 2^-22 of
+  the row's largest entry, in the MFMA operand order csrc/extract.hip reads (no GPU needed: pure numpy)."""
+  from advoc_amd import spectral
+  from oracle import spectral_np as S
+  P = S.create_inverse_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80).astype(np.float32)     # [513, 80]
+
+  tab, unscale = spectral.pack_inverse_pairs(P, 'cpu')
+  tab = tab.numpy().view(np.float16).astype(np.float64)          # [17, 5, 2, 64, 8]
+  unscale = unscale.numpy().astype(np.float64)
+  assert tab.shape == (17, 5, 2, 64, 8) and unscale.shape == (544,)
+  rec = np.zeros((544, 80))
+  for nb in range(17):
+    for st in range(5):
+      for half in range(2):
+        for l32 in range(32):
+          n, k0 = 32 * nb + l32, 16 * st + 8 * half
+          rec[n, k0:k0 + 8] = (tab[nb, st, 0, 32 * half + l32] + tab[nb, st, 1, 32 * half + l32]) * unscale[n]
+  assert np.abs(rec[513:]).max() == 0.0
+  rowmax = np.abs(P).max(axis=1).astype(np.float64)
+  err = np.abs(rec[:513] - P.astype(np.float64)).max(axis=1) / np.maximum(rowmax, 1e-300)
+  assert err[rowmax > 0].max() < 2.0 ** -21 and np.abs(rec[:513][rowmax == 0]).max(initial=0.0) == 0.0
+  big = np.abs(tab[:, :, 0]).max()
+  assert 2 ** 13 <= big < 2 ** 14                                # rows sit under [2^13, 2^14): no fp16 overflow
+
+
+@gpu
+@pytest.mark.parametrize('minw', ['4', '2'], ids=['two_wgs_per_cu', 'one_wg_per_cu'])
+def test_fused_extractor_matches_the_two_launch_path_and_the_oracle(hip, monkeypatch, minw):
+  """advoc_stft_mel_pinv_f32 (csrc/extract.hip): waveform -> (|STFT|, mel, pinv(mel)) in ONE launch.  Magnitudes are
+  bit-identical to advoc_stft_mag_f32 (same arithmetic), mel / inverse agree with advoc_mel_pinv_f32 and with the float64
+  oracle; frame counts that are not multiples of the 16-frame tile, a single frame, zero padding past the end of the
+  clip (advoc/spectral.py:60-83 pad_end), and the whole-frames-only rule of the training feed."""
+  import subprocess
+  import sys
+  from advoc_amd import _lib, spectral
+  from advoc_amd.spectral_util import SpectralUtil
+  from oracle import spectral_np as S
+  if minw != '4':          # the launch form is chosen once per process: run the non-default one in its own
+    code = ('import os, sys; os.environ["ADVOC_EXTRACT_WAVES"] = "2"; sys.path.insert(0, %r); import pytest; '
+            'sys.exit(pytest.main(["-q", "-m", "gpu", "-x", %r + "::test_fused_extractor_matches_the_two_launch_path_and_the_oracle[two_wgs_per_cu]"]))'
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    return
+  su = SpectralUtil()
+  W = S.create_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80)
+  P = S.create_inverse_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80)
+  g = torch.Generator().manual_seed(3)
+  for clips, n, T in ((3, 1024 + 256 * 36, 37), (2, 1024, 1), (5, 1024 + 256 * 15, 16), (2, 5000, 20), (64, 66304, 256)):
+    wav = ((torch.rand(clips, n, generator=g) - 0.5) * torch.logspace(-3, 0, clips)[:, None]).cuda()
+    out = spectral.stft_mel_inverse(wav, 1024, 256, T, su._const('packed'), su._const('pairs'))
+    assert out is not None
+    mag, mel, inv = out
+    mag2 = spectral._run_stft(wav, 1024, 256, T, complex_out=False)
+    assert float((mag - mag2).abs().max()) <= 1e-6 * float(mag2.abs().max()), (clips, n, T)      # same arithmetic, the compiler's own contractions
+    mel2, inv2 = spectral.mel_and_inverse(mag2, su.meltrans, su.invmeltrans, packed=su._const('packed'))
+    assert float((mel - mel2).abs().max()) <= 2e-6 * float(mel2.abs().max())
+    assert float((inv - inv2).abs().max()) <= 5e-6 * float(inv2.abs().max())
+    if clips <= 5:
+      mag64 = S.stft_mag_f64(wav.cpu().numpy()[:, :, None, None], 1024, 256)[:, :T, :, 0] if n >= 1024 + 256 * (T - 1) else None
+      if mag64 is not None:
+        mel64 = mag64 @ W.T
+        inv64 = mel64 @ P.T
+        assert np.abs(mel.cpu().numpy() - mel64).max() < 1e-5 * np.abs(mel64).max()
+        err_rows = np.abs(inv.cpu().numpy() - inv64).max(axis=2) / np.maximum(np.abs(inv64).max(axis=2), 1e-30)
+        assert err_rows.max() < 2e-5, err_rows.max()
+  # the training feed goes through it
+  wav = (torch.rand(3, 1024 + 256 * 9 + 100, 1, 1) - 0.5).cuda()
+  mag, mel, inv = su.extract_training_triple(wav)
+  assert mag.shape == (3, 10, 513, 1) and mel.shape == (3, 10, 80, 1) and inv.shape == (3, 10, 513, 1)
+  assert float((mag - spectral.stft_magnitude(wav, 1024, 256, pad_end=False)).abs().max()) <= 1e-6 * float(mag.abs().max())
+  ref = su.mel_linear_to_mag_spec(su.mag_to_mel_linear_spec(mag))
+  assert float((inv - ref).abs().max()) < 2e-5 * float(ref.abs().max())
