@@ -58,7 +58,6 @@ Tuning read_env() {
   t.wgrad_h3_rounds = env_int("ADVOC_WGRAD_H3_ROUNDS", 0);
   t.h3 = env_int("ADVOC_H3", 1);
   t.h3_tile = env_int("ADVOC_H3_TILE", 0);
-  t.h3_stages = env_int("ADVOC_H3_STAGES", 0);
 #ifdef ADVOC_DIAG      // switches that make results WRONG (timing experiments, tools/micro): only in `make DIAG=1` builds
   t.h3_skip_prep = env_int("ADVOC_H3_SKIP_PREP", 0);
 #else
@@ -83,7 +82,6 @@ Tuning read_env() {
   if (t.h3_deep_wgs_per_cu < 1) t.h3_deep_wgs_per_cu = 1;
   if (t.h3_deep_split_div < 2) t.h3_deep_split_div = 2;
   t.h3_rem_ws = env_int("ADVOC_H3_REM_WS", 1);
-  t.h3_rem_stages = env_int("ADVOC_H3_REM_STAGES", 2);
   t.h3_rem_wgs_per_cu = env_int("ADVOC_H3_REM_WGS_PER_CU", 2);
   t.h3_rem_split_div = env_int("ADVOC_H3_REM_SPLIT_DIV", 8);
   if (t.h3_rem_wgs_per_cu < 1) t.h3_rem_wgs_per_cu = 1;

@@ -490,10 +490,9 @@ Pick pick_tile(const GatherGemmParams& p) {
   const int N = p.n_total;
   Pick k = {2, 2, 2, 2};
   if (N % 128 != 0 || t.h3_tile == 4) k = {2, 1, 2, 2};      // 64-column tiles (48 KiB: three workgroups per CU)
-  else if (t.h3_tile == 2 && N % 256 == 0) k = {2, 4, 2, 2};
-  else if (t.h3_tile == 3) k = {4, 2, 2, 2};
   else if (t.h3_tile == 5 && N % 256 == 0) k = {2, 4, 2, 4};  // 256 x 256, 8 waves
-  else if (t.h3_tile == 6) k = {2, 2, 2, 4};                  // 256 x 128, 8 waves
+  // (r3: the 128 x 256 / 256 x 128 four-wave tiles, 256 x 128 on eight waves and the three-stage forms -- measured and
+  // rejected in r2, DESIGN.md section 7b -- are no longer compiled in: ADVOC_H3_TILE takes 1 | 4 | 5)
   else if (t.h3_tile == 0 && N % 256 == 0) {
     // 256 x 256 on 8 waves (one workgroup per CU) streams half the bytes per flop of 128 x 128 and measured 1.2-1.35x
     // faster on every launch with >= 2 such tiles per CU (381 vs 284 TFLOP/s on D layer_4); below that the launch would
@@ -509,8 +508,6 @@ Pick pick_tile(const GatherGemmParams& p) {
     const int64_t t128 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * (N / 128) * p.nphase;
     if (t128 < 2 * device_cu_count()) k = {2, 1, 2, 2};
   }
-  if (t.h3_stages == 2 || t.h3_stages == 3) k.ns = t.h3_stages;
-  if (k.ns == 3 && k.mt * k.nt > 4) k.ns = 2;       // 3 x 48 KiB + would not leave room: 128x256 runs two stages
   return k;
 }
 
@@ -679,17 +676,11 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
       if (rsplit > 16) rsplit = 16;
       if (rsplit < 1) rsplit = 1;
     }
-    if (tn.h3_rem_stages == 3) return launch_h<2, 1, 3>(pr, stream, nullptr, TailPlan(), nullptr, nullptr, rsplit);
     return launch_h<2, 1, 2>(pr, stream, nullptr, TailPlan(), nullptr, nullptr, rsplit);
   }
   if (k.wgm == 4 && k.nt == 4) return launch_h<2, 4, 2, 4>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
-  if (k.wgm == 4) return launch_h<2, 2, 2, 4>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
-  if (k.mt == 2 && k.nt == 1 && k.ns == 3) return launch_h<2, 1, 3>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
-  if (k.mt == 2 && k.nt == 1) return launch_h<2, 1, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
-  if (k.mt == 2 && k.nt == 2 && k.ns == 3) return launch_h<2, 2, 3>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
-  if (k.mt == 2 && k.nt == 2) return launch_h<2, 2, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
-  if (k.mt == 2 && k.nt == 4) return launch_h<2, 4, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
-  return launch_h<4, 2, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
+  if (k.nt == 1) return launch_h<2, 1, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
+  return launch_h<2, 2, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
 }
 
 }  // namespace advoc

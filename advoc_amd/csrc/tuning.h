@@ -20,8 +20,7 @@ struct Tuning {
   int wgrad_h3_tile;    // ADVOC_WGRAD_H3_TILE  1: 128 x 128, 2: 256 x 256 forced (where the shape allows)
   int wgrad_h3_rounds;  // ADVOC_WGRAD_H3_ROUNDS  > 0: K chunks per tile = this many rounds of the chip (default: 1, or 2 from 4096 grid points per chunk)
   int h3;               // ADVOC_H3             0: no operand-image kernels (register-split path instead)
-  int h3_tile;          // ADVOC_H3_TILE        1: 128x128, 2: 128x256, 3: 256x128, 4: 128x64 forced
-  int h3_stages;        // ADVOC_H3_STAGES      2 | 3 LDS stages forced
+  int h3_tile;          // ADVOC_H3_TILE        1: 128x128, 4: 128x64, 5: 256x256 (8 waves) forced
   int h3_skip_prep;     // ADVOC_H3_SKIP_PREP   1: (micro-benchmarks only; -DADVOC_DIAG builds only) reuse the images already in the workspace
   int h3_min_tiles;     // ADVOC_H3_MIN_TILES   smallest launch (128-row x 128-column tiles) that takes the image path (4: with the
                         //                      workspace K split the image kernels beat the r1 ones down to the 1 x 3-point layers)
@@ -36,7 +35,6 @@ struct Tuning {
   int h3_deep_wgs_per_cu;  // ADVOC_H3_DEEP_WGS_PER_CU  workgroups per CU the workspace K split of the deep layers aims at
   int h3_deep_split_div;   // ADVOC_H3_DEEP_SPLIT_DIV   K tiles per slice, at least
   int h3_rem_ws;        // ADVOC_H3_REM_WS      1: the K slices of the remainder launch meet in the workspace (no zero fill, no atomics)
-  int h3_rem_stages;    // ADVOC_H3_REM_STAGES  2 | 3 LDS stages of the per-tap launch that takes the 1..4 remainder columns
   int h3_rem_wgs_per_cu;   // ADVOC_H3_REM_WGS_PER_CU  workgroups per CU the K split of that launch aims at
   int h3_rem_split_div; // ADVOC_H3_REM_SPLIT_DIV  K tiles per slice, at least
   int h3_patch_ablate;  // ADVOC_H3_PATCH_ABLATE  (-DADVOC_DIAG builds only) timing experiments: bits 1 no DMA, 2 no MFMA, 4 no barrier (results are garbage)
