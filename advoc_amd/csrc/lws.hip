@@ -214,7 +214,10 @@ constexpr int kFH = 4;                     // mirrored bins either side of a row
 constexpr int kFBins = 513;
 constexpr int kFRow = kFBins + 2 * kFH;    // float2 per LDS row
 constexpr int kFQ = 4, kFL = 5, kFKW = 9, kFP = 4;
-constexpr int kSweepFrames = 8;            // frames per tile of the batch sweep
+#ifndef ADVOC_LWS_SWEEP_FRAMES
+#define ADVOC_LWS_SWEEP_FRAMES 8
+#endif
+constexpr int kSweepFrames = ADVOC_LWS_SWEEP_FRAMES;            // frames per tile of the batch sweep
 
 // The weight of tap (q, p) at bin m = f + p is alpha_q(p) (-i)^(q m): the frame rotation exp(-2 pi i m q nhop / nfft) is a
 // power of -i for hop = nfft / 4.  alpha_q(p) = W[q][p][0] is the same for every thread (scalar loads, no vector

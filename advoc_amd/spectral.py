@@ -649,7 +649,7 @@ def lws_spectrogram_batch(spec, nfft, nhop, L=LWS_L, look_ahead=LWS_LOOK_AHEAD,
     nxt = torch.empty_like(cur)
     ts = (ctypes.c_float * n_sweeps)(*[float(batch[1]) * math.exp(-float(batch[2]) * float(i) ** float(batch[3]))
                                         for i in range(n_sweeps)])
-    tile_work = torch.empty(clips * ((T + 7) // 8), dtype=torch.float32, device=dev)
+    tile_work = torch.empty(clips * ((T + 3) // 4), dtype=torch.float32, device=dev)      # >= clips * ceil(T / 8)
     _lib.check(lib.advoc_lws_batch_sweeps_c64(_lib.ptr(cur), _lib.ptr(nxt), _lib.ptr(mag), _lib.ptr(mean_mag), clips, T,
                                               nfft, nhop, _lib.ptr(W), P, L, ts, n_sweeps, _lib.ptr(tile_work),
                                               _lib.stream()), 'advoc_lws_batch_sweeps_c64')
