@@ -28,6 +28,11 @@ class Tensor4(ctypes.Structure):
   _fields_ = [('p', _p), ('n', _i32), ('h', _i32), ('w', _i32), ('c', _i32), ('w_pitch', _i32)]
 
 
+class ImageOut(ctypes.Structure):
+  """advoc_conv_layer.y_img[k] (include/advoc_hip.h)."""
+  _fields_ = [('img', _p), ('hdr', _p), ('act', _i32), ('reserved', _i32)]
+
+
 class ConvLayer(ctypes.Structure):
   """struct advoc_conv_layer (include/advoc_hip.h)."""
   _fields_ = [
@@ -43,6 +48,7 @@ class ConvLayer(ctypes.Structure):
       ('x_img', _p), ('x_hdr', _p), ('dy_img', _p), ('dy_hdr', _p), ('img_flags', _i32),
       ('db_fused', _p), ('w_amax', _p), ('w_img', _p * 2), ('w_img_hdr', _p * 2),
       ('wgrad_table', _p),
+      ('y_img', ImageOut * 2),
   ]
 
 WGRAD_TABLE_BYTES = 262144      # ADVOC_WGRAD_TABLE_BYTES
@@ -76,6 +82,7 @@ PROTOTYPES = {
     'advoc_conv_workspace_bytes': (_i64, [_p, _i32]),
     'advoc_conv_image_bytes': (_i64, [_p, _i32]),
     'advoc_conv_bias_fusable': (ctypes.c_int, [_p]),
+    'advoc_conv_emits_images': (ctypes.c_int, [_p]),
     'advoc_segmented_amax_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p]),
     'advoc_conv_weight_image_desc': (ctypes.c_int, [_p, _i32, _p]),
     'advoc_weight_images_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p, _p]),

@@ -8,6 +8,7 @@ float32 NHWC torch tensors resident in HBM; this module only fills
 happens in Python/torch.
 """
 import ctypes
+import os
 
 import torch
 
@@ -84,6 +85,10 @@ class Layer(object):
   # magnitude (ADVOC_IMG_*_DELAYED, 2^6 of head room; a tensor that leaves it, or shrinks by more than 2^6, is re-imaged
   # exactly on the device in the same call; csrc/image.hip).  False (default): always the exact two-pass form.
   delayed_scale = False
+  # True (ADVOC_EMIT_IMAGES=0 turns it off): a layer whose consumers were registered with add_image_consumer writes THEIR
+  # operand images from its own forward epilogue (advoc_conv_layer.y_img, csrc/image_emit.h) once the consumer's header
+  # holds a previous magnitude -- the consumer's image pass (a read and a write of the whole tensor) disappears
+  emit_images = os.environ.get('ADVOC_EMIT_IMAGES', '1') == '1'
 
   @staticmethod
   def _workspace_for(device, nbytes):
@@ -170,6 +175,9 @@ class Layer(object):
     self._dy_roles = {}
     self._dy_role = None
     self._names = {}
+    self._consumers = []           # [(consumer layer, source index)] whose x_img this layer's forward can write
+    self._emits = None             # advoc_conv_emits_images(), asked once
+    self._x_emitted = set()        # sources of x_img written by their producers since the last forward
     self._db_done_for = None
     self._bias_fusable = bool(_lib.load().advoc_conv_bias_fusable(ctypes.byref(s)))
     self._thin_bias = False
@@ -274,16 +282,64 @@ class Layer(object):
         out.append(hdr)
     return out
 
+  def add_image_consumer(self, consumer, source):
+    """`consumer` (a Layer) reads this layer's output y as its input `source` (0: x0, 1: x1): from the second step on this
+    layer's forward writes the consumer's operand image itself."""
+    want = consumer.x0 if source == 0 else consumer.x1
+    if want is None or want.data_ptr() != self.y.data_ptr() or tuple(want.shape) != tuple(self.y.shape):
+      raise _lib.AdvocHipError('the consumer\'s input {} is not this layer\'s output'.format(source))
+    if len(self._consumers) >= 2:
+      raise _lib.AdvocHipError('at most two image consumers per layer')
+    self._consumers.append((consumer, source))
+
+  def _emit_targets(self):
+    """[(slot, consumer, source)] this forward call writes images for."""
+    if not (Layer.emit_images and self.delayed_scale and self._consumers and Layer.profiler is None):
+      return []
+    if self._emits is None:
+      self._emits = bool(_lib.load().advoc_conv_emits_images(ctypes.byref(self.struct)))
+    if not self._emits:
+      return []
+    out = []
+    for k, (c, src) in enumerate(self._consumers):
+      cs = c.struct
+      if not (c.delayed_scale and c._x_built and cs.x_img and 'h3' in c.kernel_name(0)):
+        continue
+      if cs.in_scale or cs.in_mask:          # batch-norm affine / input dropout: not known when the producer runs
+        continue
+      out.append((k, c, src))
+    return out
+
   def _delayed_bits(self):
     if not self.delayed_scale:
       return 0
     return (4 if self._x_built else 0) | (8 if self._dy_built else 0)
 
   def forward(self):
-    self.struct.img_flags = self._timed_image(0) | self._delayed_bits()
-    self._run(0, lambda: _lib.check(
-        _lib.load().advoc_conv_forward(ctypes.byref(self.struct), _lib.stream()), 'advoc_conv_forward'))
-    self.struct.img_flags = 0
+    nsrc = 2 if self.x1 is not None else 1
+    if len(self._x_emitted) == nsrc and self.struct.x_img:
+      flags = 1 | 16                       # ADVOC_IMG_X_CURRENT | ADVOC_IMG_X_EMITTED: refit check instead of an image pass
+    else:
+      flags = self._timed_image(0)
+    self._x_emitted = set()
+    targets = self._emit_targets()
+    for k in (0, 1):
+      self.struct.y_img[k].img = None
+    for k, c, src in targets:
+      off = 0 if src == 0 else (4 * c.x0.numel() + 255) // 256 * 256
+      self.struct.y_img[k].img = c.struct.x_img + off
+      self.struct.y_img[k].hdr = c.struct.x_hdr
+      self.struct.y_img[k].act = c.struct.in_act
+    self.struct.img_flags = flags | self._delayed_bits()
+    try:
+      self._run(0, lambda: _lib.check(
+          _lib.load().advoc_conv_forward(ctypes.byref(self.struct), _lib.stream()), 'advoc_conv_forward'))
+    finally:
+      self.struct.img_flags = 0
+      for k in (0, 1):
+        self.struct.y_img[k].img = None
+    for k, c, src in targets:
+      c._x_emitted.add(src)
     if self.struct.x_img and 'h3' in self.kernel_name(0):
       self._x_built = True
     # the image-based forward kernel has just left the input image in x_img

@@ -331,9 +331,42 @@ extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stre
   p.a_img_out = L->x_img; p.a_hdr_out = L->x_img ? L->x_hdr : nullptr;
   p.a_img_current = (L->img_flags & ADVOC_IMG_X_CURRENT) != 0;
   p.a_img_delayed = (L->img_flags & ADVOC_IMG_X_DELAYED) != 0;
+  p.a_img_emitted = (L->img_flags & ADVOC_IMG_X_EMITTED) != 0;
+  for (int k = 0; k < 2; ++k) {
+    if (!L->y_img[k].img) continue;
+    if (!L->y_img[k].hdr || L->y_img[k].act < ADVOC_ACT_NONE || L->y_img[k].act > ADVOC_ACT_RELU) return ADVOC_ERR_NULL;
+    p.oimg[k].img = L->y_img[k].img;
+    p.oimg[k].hdr = L->y_img[k].hdr;
+    p.oimg[k].slope = L->y_img[k].act == ADVOC_ACT_LRELU02 ? 0.2f : (L->y_img[k].act == ADVOC_ACT_RELU ? 0.f : 1.f);
+  }
   p.w_amax = L->w_amax;
   p.w_img = L->w_img[0]; p.w_img_hdr = L->w_img_hdr[0];
+  int emits = 0;
+  if (p.oimg[0].img || p.oimg[1].img) {
+    // (a launch outside the image kernels would silently ignore y_img and leave the consumers with stale images)
+    GatherGemmParams q = p;
+    const char* nm = nullptr;
+    q.emit_report = &emits;
+    rc = run_gather(q, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes);
+    if (rc != ADVOC_OK) return rc;
+    if (!emits) return ADVOC_ERR_UNSUPPORTED;
+  }
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
+}
+
+extern "C" int advoc_conv_emits_images(const advoc_conv_layer* L) {
+  if (validate_layer(L) != ADVOC_OK) return 0;
+  GatherGemmParams p;
+  bool b_kn;
+  if (build_forward(L, p, b_kn) != ADVOC_OK) return 0;
+  p.w_amax = L->w_amax;
+  p.w_img = L->w_img[0]; p.w_img_hdr = L->w_img_hdr[0];
+  p.a_img_out = L->x_img; p.a_hdr_out = L->x_img ? L->x_hdr : nullptr;
+  int emits = 0;
+  const char* nm = nullptr;
+  p.emit_report = &emits;
+  if (run_gather(p, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes) != ADVOC_OK) return 0;
+  return emits;
 }
 
 extern "C" int advoc_conv_bias_fusable(const advoc_conv_layer* L) {

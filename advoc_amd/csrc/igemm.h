@@ -17,6 +17,15 @@ namespace advoc {
 constexpr int kMaxPhases = 4;
 constexpr int kMaxTaps = 16;
 
+// where one consumer wants the image of a forward launch's output d[0] (image_emit.h): the start of the tensor's region in
+// the consumer's operand image, the operand's rotated 8-word header ([2] = previous magnitude, [0] = accumulator, [3] =
+// out-of-window count) and the slope of the consumer's activation (1 none, 0.2 leaky ReLU, 0 ReLU); img == null: none
+struct ImgOut {
+  uint16_t* img;
+  unsigned* hdr;
+  float slope;
+};
+
 struct GemmDest {
   float* p;           // destination tensor (NHWC, `c` channels, rows `pitch` pixels apart)
   const float* xpre;  // same geometry: pre-activation forward value, for act'(x) gating (or null)
@@ -86,6 +95,12 @@ struct GatherGemmParams {
   unsigned* a_hdr_out;
   int a_img_current;       // != 0: a_img_out / a_hdr_out already hold this operand's image (skip the image passes)
   int a_img_delayed;       // != 0: a_hdr_out holds the magnitude of a previous image of this operand: one-pass image
+  int a_img_emitted;       // != 0 (with a_img_current): the image was written by the producers' epilogues under the delayed
+                           // scale (image_emit.h): run the refit check (and the header rotation) before reading it
+  // forward launches: up to two consumers' images of the OUTPUT d[0], written by the epilogue (image_emit.h); honoured by
+  // the image kernels' non-atomic epilogues only (launch_gather_gemm_h3 reports through emit_report what it will do)
+  ImgOut oimg[2];
+  int* emit_report;        // host pointer, name_only launches: set to 1 when this launch would write oimg
   float* a_colsum;         // != null: the image pass of source 0 adds its per-channel sums over the logical pixels here (the
                            // bias gradient, when A is an output gradient); only honoured where image_colsum_ok(c0)
   // ---- tail split (filled in by the launcher, see launch_cfg) ----

@@ -34,6 +34,7 @@
 #include "common.h"
 #include "igemm.h"
 #include "tuning.h"
+#include "image_emit.h"
 #include "x6.h"
 
 namespace advoc {
@@ -341,6 +342,15 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
   constexpr int LDT = 36;
   float* T = smem + wave * (32 * LDT);
   const int trow = lane >> 3, tq = lane & 7;
+  // consumers' operand images of the output (image_emit.h): one-pass scale from the consumer header's previous magnitude
+  const bool emit0 = p.oimg[0].img != nullptr && !atomic_split, emit1 = p.oimg[1].img != nullptr && !atomic_split;
+  const float eup0 = emit0 ? emit_up_scale(p.oimg[0].hdr[2]) : 1.f, eup1 = emit1 ? emit_up_scale(p.oimg[1].hdr[2]) : 1.f;
+  float evmax0 = 0.f, evmax1 = 0.f;
+  int esat0 = 0, esat1 = 0;
+  if (tid == 0) {      // (every workgroup that reaches an epilogue: the same value)
+    if (emit0) p.oimg[0].hdr[1] = __float_as_uint(1.f / eup0);
+    if (emit1) p.oimg[1].hdr[1] = __float_as_uint(1.f / eup1);
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int nt0 = n0 + (wn * NT + j) * 32;
@@ -410,10 +420,16 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
           v.x += old[ps].x; v.y += old[ps].y; v.z += old[ps].z; v.w += old[ps].w;
         }
         *reinterpret_cast<float4*>(dst) = v;
+        if (di == 0) {
+          if (emit0) emit4(p.oimg[0], eup0, v, (unsigned)off[ps], evmax0, esat0);
+          if (emit1) emit4(p.oimg[1], eup1, v, (unsigned)off[ps], evmax1, esat1);
+        }
       }
       wave_lds_sync();
     }
   }
+  if (emit0) emit_finish(p.oimg[0], evmax0, esat0);
+  if (emit1) emit_finish(p.oimg[1], evmax1, esat1);
 }
 
 template <int MT, int NT, int NS, int WGM>
@@ -606,6 +622,11 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   const int64_t need = hdr_bytes + wq_bytes + i0_bytes + i1_bytes;
   if (scratch_query) { *scratch_query = need + tail_bytes; return ADVOC_OK; }
   if (!scratch || scratch_bytes < need) return ADVOC_ERR_UNSUPPORTED;
+  // consumers' images from this launch's epilogue (image_emit.h): every epilogue must see the final value, so no K
+  // split that meets in the destination with atomics (the workspace splits are fine: their last slice runs the epilogue)
+  const bool want_emit = p.oimg[0].img != nullptr || p.oimg[1].img != nullptr;
+  if (want_emit) ksplit = 1;
+  if (p.emit_report) *p.emit_report = 1;
   p.k_order = tuning().igemm_korder >= 0 ? tuning().igemm_korder : 1;
   char* ws = reinterpret_cast<char*>(scratch);
   unsigned* hdr_b = reinterpret_cast<unsigned*>(ws) + 2;
@@ -641,6 +662,15 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
       rc = launch_pair_weights(p.w, wq, taps, N, ktot, b_kn, hdr_b, stream, p.w_amax);
       if (rc != ADVOC_OK) return rc;
     }
+    if (p.a_img_out && p.a_img_current && p.a_img_emitted) {
+      // the producers' epilogues wrote this image under the one-pass scale: the refit check (exact re-image from the fp32
+      // tensors when a value left the window) and the header rotation, as behind a one-pass image built here
+      const ImageSource s0 = {p.a0, e0, p.c0, p.in_scale, p.in_shift, p.in_act, p.a_mask, p.a_mask_scale};
+      const ImageSource s1 = {p.a1, e1, p.c1, p.in_scale ? p.in_scale + p.c0 : nullptr,
+                              p.in_shift ? p.in_shift + p.c0 : nullptr, p.in_act, nullptr, 0.f};
+      rc = launch_image_refit(s0, s1, img0, hdr_a, stream);
+      if (rc != ADVOC_OK) return rc;
+    }
     if (!(p.a_img_out && p.a_img_current)) {
       // one scale for the whole A operand: the largest magnitude over both sources of a channel concat
       const ImageSource s0 = {p.a0, e0, p.c0, p.in_scale, p.in_shift, p.in_act, p.a_mask, p.a_mask_scale};
@@ -670,7 +700,7 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     const Tuning& tn = tuning();
     if (tail.split > 1 && tail_ws && tail_cnt)
       return launch_h<2, 1, 2>(pr, stream, nullptr, tail, tail_ws, tail_cnt, 1);
-    if (nkt >= 4 * tn.h3_rem_split_div && rtiles < (int64_t)tn.h3_rem_wgs_per_cu * device_cu_count() && tn.igemm_splitk) {
+    if (!want_emit && nkt >= 4 * tn.h3_rem_split_div && rtiles < (int64_t)tn.h3_rem_wgs_per_cu * device_cu_count() && tn.igemm_splitk) {
       rsplit = (int)ceil_div((int64_t)tn.h3_rem_wgs_per_cu * device_cu_count(), rtiles);
       if (rsplit > nkt / tn.h3_rem_split_div) rsplit = nkt / tn.h3_rem_split_div;
       if (rsplit > 16) rsplit = 16;

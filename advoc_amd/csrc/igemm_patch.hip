@@ -32,6 +32,7 @@
 #include "common.h"
 #include "igemm.h"
 #include "tuning.h"
+#include "image_emit.h"
 
 namespace advoc {
 namespace {
@@ -391,6 +392,15 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   float* T = smem + wave * (32 * LDT);
   const int trow = le >> 3, tq = le & 7;
   const bool use_grad = BWD && p.grad_act != ADVOC_ACT_NONE;
+  // forward: consumers' operand images of the output (image_emit.h), one-pass scale from the consumer header
+  const bool emit0 = !BWD && p.oimg[0].img != nullptr, emit1 = !BWD && p.oimg[1].img != nullptr;
+  const float eup0 = emit0 ? emit_up_scale(p.oimg[0].hdr[2]) : 1.f, eup1 = emit1 ? emit_up_scale(p.oimg[1].hdr[2]) : 1.f;
+  float evmax0 = 0.f, evmax1 = 0.f;
+  int esat0 = 0, esat1 = 0;
+  if (!BWD && tid == 0) {
+    if (emit0) p.oimg[0].hdr[1] = __float_as_uint(1.f / eup0);
+    if (emit1) p.oimg[1].hdr[1] = __float_as_uint(1.f / eup1);
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     // destination of this column block (channels [0, n_split) -> d[0], the rest -> d[1]) and its per-channel vectors
@@ -432,6 +442,10 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(
         has_mask ? const_cast<uint8_t*>(mask_p) : reinterpret_cast<uint8_t*>(dp), 0, has_mask ? kOob : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(dp, 0, (BWD && d_accum) ? kOob : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_e0 = __builtin_amdgcn_make_buffer_rsrc(
+        emit0 ? reinterpret_cast<void*>(p.oimg[0].img) : reinterpret_cast<void*>(dp), 0, emit0 ? kOob : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_e1 = __builtin_amdgcn_make_buffer_rsrc(
+        emit1 ? reinterpret_cast<void*>(p.oimg[1].img) : reinterpret_cast<void*>(dp), 0, emit1 ? kOob : 0u, 0x00020000);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     unsigned off[4];                                   // element offset of the row's 4 channels, kOob for rows without a pixel
     u32x4 xp[4], old[4];
@@ -486,10 +500,20 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
         sv.z = __float_as_uint(v[ps].z); sv.w = __float_as_uint(v[ps].w);
         __builtin_amdgcn_raw_buffer_store_b128(sv, rs_d, so[ps], 0, 0);
       }
+      if (!BWD) {            // (compile-time; unconditional buffer stores: see emit4_buffer)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const bool ok = so[ps] != kOob && di == 0;
+          emit4_buffer(rs_e0, p.oimg[0].slope, eup0, v[ps], ok ? so[ps] : kOob, ok && emit0, evmax0, esat0);
+          emit4_buffer(rs_e1, p.oimg[1].slope, eup1, v[ps], ok ? so[ps] : kOob, ok && emit1, evmax1, esat1);
+        }
+      }
       wave_lds_sync();
     }
 #undef ADVOC_P3_PRELOAD
   }
+  if (emit0) emit_finish(p.oimg[0], evmax0, esat0);
+  if (emit1) emit_finish(p.oimg[1], evmax1, esat1);
   __syncthreads();          // the next tile's DMAs overwrite the LDS this epilogue read
   }  // tiles
 }

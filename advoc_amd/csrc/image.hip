@@ -535,6 +535,23 @@ int launch_pair_image(const float* x, uint16_t* img, int64_t elems, int c, const
   return ADVOC_OK;
 }
 
+// The always-launched check behind a one-pass image (built by pair_image_kernel<true> here, or by the producers'
+// epilogues, image_emit.h): exact re-image when needed, header rotation by the last workgroup.
+int launch_image_refit(const ImageSource& s0, const ImageSource& s1, uint16_t* img, unsigned* hdr, hipStream_t stream) {
+  if (!img || !hdr || s0.elems <= 0) return ADVOC_OK;
+  const int64_t b0 = (4 * s0.elems + 255) / 256 * 256;
+  uint16_t* img1 = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(img) + b0);
+  const RefitSource r0 = {s0.x, reinterpret_cast<__half*>(img), s0.elems / 8, s0.c, s0.scale, s0.shift, slope_of(s0.act),
+                          s0.mask, s0.mask_scale};
+  const RefitSource r1 = {s1.x, reinterpret_cast<__half*>(img1), s1.elems / 8, s1.c, s1.scale, s1.shift, slope_of(s1.act),
+                          s1.mask, s1.mask_scale};
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  // (64 workgroups per source: the common case is "nothing to do", and their arrival atomics are serial)
+  hipLaunchKernelGGL(refit_image_kernel, dim3(64, s1.elems ? 2 : 1), dim3(256), 0, stream, r0, r1, hdr);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
 // One GEMM operand (one or two channel-concatenated sources, ONE scale) -> image at `img` (source 1 behind source 0 at
 // its 256-byte-rounded size) and header `hdr` (16 bytes, caller-owned, persistent across calls for delayed scaling).
 int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* img, unsigned* hdr, bool delayed,
@@ -556,14 +573,7 @@ int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* i
     rc = launch_pair_image(s1.x, img1, s1.elems, s1.c, s1.scale, s1.shift, s1.act, s1.mask, s1.mask_scale, hdr, delayed,
                            stream, nullptr, 0, 0, nullptr);
   if (rc == ADVOC_OK && delayed && s0.elems > 0) {
-    const RefitSource r0 = {s0.x, reinterpret_cast<__half*>(img), s0.elems / 8, s0.c, s0.scale, s0.shift, slope_of(s0.act),
-                            s0.mask, s0.mask_scale};
-    const RefitSource r1 = {s1.x, reinterpret_cast<__half*>(img1), s1.elems / 8, s1.c, s1.scale, s1.shift, slope_of(s1.act),
-                            s1.mask, s1.mask_scale};
-    ADVOC_CLEAR_LAUNCH_ERROR();
-    // (64 workgroups per source: the common case is "nothing to do", and their arrival atomics are serial)
-    hipLaunchKernelGGL(refit_image_kernel, dim3(64, s1.elems ? 2 : 1), dim3(256), 0, stream, r0, r1, hdr);
-    ADVOC_RETURN_IF_LAUNCH_FAILED();
+    rc = launch_image_refit(s0, s1, img, hdr, stream);
   } else if (rc == ADVOC_OK && s0.elems > 0) {
     // exact image: leave the header rotated, ready for a one-pass image next time
     ADVOC_CLEAR_LAUNCH_ERROR();

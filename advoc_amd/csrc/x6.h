@@ -63,6 +63,7 @@ struct ImageSource {
 int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* img, unsigned* hdr, bool delayed,
                        hipStream_t stream, float* colsum0 = nullptr, int w_log = 0, int w_pitch = 0,
                        float* colsum_table = nullptr);
+int launch_image_refit(const ImageSource& s0, const ImageSource& s1, uint16_t* img, unsigned* hdr, hipStream_t stream);
 bool image_colsum_ok(int c);
 // out[ch] += sum over the kColsumReplicas copies of table[r][ch] (the fold of every replica table of this library)
 int launch_colsum_reduce(const float* table, float* out, int c, hipStream_t stream);

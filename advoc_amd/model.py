@@ -420,6 +420,18 @@ class Advoc(Model):
                              in_mask=src_mask[0] if (src_mask and bn_on) else None,
                              in_mask_scale=1.0 / src_mask[1] if (src_mask and bn_on) else 0.)
     st['g_layers'] = L
+    if not bn_on:
+      # who reads whose output: from the second step on a producer's forward epilogue writes its consumers' operand
+      # images (conv.Layer.add_image_consumer; csrc/image_emit.h) -- encoder_i feeds encoder_{i+1} (leaky ReLU) and, as
+      # the second concat source, a decoder (ReLU); a decoder feeds the next decoder's first source
+      for i in range(1, len(enc_c)):
+        L['encoder_%d' % i].add_image_consumer(L['encoder_%d' % (i + 1)], 0)
+      for j, (idx, c, drop) in enumerate(dec):
+        if j == 0:
+          L['encoder_%d' % len(enc_c)].add_image_consumer(L['decoder_%d' % idx], 0)
+        else:
+          L['decoder_%d' % dec[j - 1][0]].add_image_consumer(L['decoder_%d' % idx], 0)
+          L['encoder_%d' % idx].add_image_consumer(L['decoder_%d' % idx], 1)
 
     # ---- discriminator buffers + layers ----
     # BN off: the D step runs [real ; fake] as ONE 2B batch; BN on: two B passes (each pass has its
@@ -453,6 +465,9 @@ class Advoc(Model):
                         w_amax=wamax('d', s + '/kernel'), stride=(strides[i],) * 2, pad=(1, 1), in_act=C.ACT_LRELU,
                         in_scale=b['scale'] if b else None, in_shift=b['shift'] if b else None)
         out.append(lay)
+      if not bn_on:
+        for i in range(4):
+          out[i].add_image_consumer(out[i + 1], 0)
       return out, bns
     st['d_layers_fake'], st['d_bn_fake'] = d_layers(B, 2 * B)
     if bn_on:

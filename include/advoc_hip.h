@@ -284,6 +284,15 @@ typedef struct advoc_conv_layer {
    * `workspace`: weight gradients may run on a stream of their own next to backward-data calls of other layers that
    * use the shared workspace. */
   float* wgrad_table;
+  /* optional (forward calls): up to two CONSUMERS' operand images of this layer's output y, written by the forward
+   * kernel's epilogue next to y itself (fp32 y is still written) -- the image the consuming layer's next forward call
+   * would otherwise build with a pass over y: `img` = start of y's region in the consumer's x_img (source 0: x_img; source
+   * 1: x_img + the 256-byte-rounded size of source 0's image), `hdr` = the consumer's x_hdr, `act` = the consumer's in_act.
+   * Only under the one-pass (delayed) scale: the consumer's header must hold a previous image's magnitude, and the
+   * consumer's next forward call must be made with ADVOC_IMG_X_CURRENT | ADVOC_IMG_X_EMITTED (it then runs the refit
+   * check instead of an image pass).  Honoured by the image kernels only: advoc_conv_emits_images() says whether this
+   * layer's forward call will write them; img == NULL: none. */
+  struct { uint16_t* img; uint32_t* hdr; int32_t act; int32_t reserved; } y_img[2];
 } advoc_conv_layer;
 #define ADVOC_WGRAD_TABLE_BYTES 262144
 
@@ -306,6 +315,9 @@ int advoc_weight_images_f32(const float* base, const uint32_t* amax, const int64
 /* 1: the layer's output-gradient image pass can carry the bias gradient (db_fused above): dy_img present and cout such
  * that a thread of the image pass keeps one group of 8 channels (32 <= cout <= 1024, 256 % (cout / 8) == 0) */
 int advoc_conv_bias_fusable(const advoc_conv_layer* layer);
+/* 1: a forward call on this layer writes the consumers' images of advoc_conv_layer.y_img (it runs on the image kernels
+ * and has the workspace they need); 0: y_img is ignored and the consumers must build their images themselves */
+int advoc_conv_emits_images(const advoc_conv_layer* layer);
 
 #define ADVOC_IMG_X_CURRENT 1
 #define ADVOC_IMG_DY_CURRENT 2
@@ -317,6 +329,9 @@ int advoc_conv_bias_fusable(const advoc_conv_layer* layer);
  * the result never depends on a clamped operand. */
 #define ADVOC_IMG_X_DELAYED 4
 #define ADVOC_IMG_DY_DELAYED 8
+/* with ADVOC_IMG_X_CURRENT: x_img was written by the producers of the inputs (advoc_conv_layer.y_img of their layers)
+ * under the one-pass scale since the last forward call: this call runs the refit check / header rotation first */
+#define ADVOC_IMG_X_EMITTED 16
 
 /* Bytes of the persistent operand image `which` (0: inputs, 1: output gradient) the layer can use; 0 when the layer's
  * shapes are outside the image-based kernels. */

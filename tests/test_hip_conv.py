@@ -719,6 +719,72 @@ def test_delayed_scale_never_applies_a_clamped_or_underflowed_image(hip, hipenv,
 
 
 @gpu
+@pytest.mark.parametrize('patch', [1, 0], ids=['patch_kernels', 'per_tap_tiles'])
+def test_producer_written_operand_images_equal_the_image_pass(hip, hipenv, patch):
+  """Layer.add_image_consumer (csrc/image_emit.h): from the second step on the PRODUCER's forward epilogue writes its
+  consumers' operand images (consumer activation applied, consumer's one-pass scale) and the consumer runs the refit
+  check instead of an image pass.  The images are value-identical to the ones the consumer builds itself, for one producer
+  feeding two consumers with different activations (leaky ReLU / ReLU as the second concat source under a shared
+  scale), with dropout on a producer's output; a 1000 x jump is refitted exactly."""
+  from advoc_amd import conv
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1, ADVOC_WGRAD_H3_MIN_M=1, ADVOC_H3_PATCH=patch)
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(31)
+  xin1 = torch.randn(2, 66, 66, 64, generator=g).to(dev)
+  xin2 = torch.randn(2, 16, 17, 64, generator=g).to(dev)
+  w1 = (torch.randn(4, 4, 64, 128, generator=g) * 0.05).to(dev)
+  w2 = (torch.randn(4, 4, 128, 64, generator=g) * 0.05).to(dev)
+  wc1 = (torch.randn(4, 4, 128, 256, generator=g) * 0.05).to(dev)
+  wc2 = (torch.randn(4, 4, 64, 256, generator=g) * 0.05).to(dev)
+  b1 = (torch.randn(128, generator=g) * 0.1).to(dev)
+  mask = (torch.rand(2, 32, 34, 128, generator=g) >= 0.5).to(torch.uint8).to(dev)
+
+  def make(register):
+    y1 = torch.empty(2, 32, 33, 128, device=dev)        # 33 columns: 16 n + 1, patches + a remainder-column launch
+    y2 = torch.empty(2, 32, 34, 128, device=dev)        # one more physical column than the consumer reads (trim)
+    P1 = conv.Layer(conv.CONV, xin1.clone(), y1, w1, b1, stride=(2, 2), pad=(1, 1), in_act=conv.ACT_LRELU)
+    P2 = conv.Layer(conv.DECONV, xin2.clone(), y2, w2, None, stride=(2, 2), pad=(1, 1), in_act=conv.ACT_RELU,
+                    drop_mask=mask, drop_scale=2.0)
+    C1 = conv.Layer(conv.CONV, y1, torch.empty(2, 16, 17, 256, device=dev), wc1, None, stride=(2, 2), pad=(1, 1),
+                    in_act=conv.ACT_LRELU)
+    C2 = conv.Layer(conv.DECONV, y2, torch.empty(2, 64, 66, 64, device=dev), wc2, None, x1=y1, in_w=33, stride=(2, 2),
+                    pad=(1, 1), in_act=conv.ACT_RELU)
+    for L in (P1, P2, C1, C2):
+      L.delayed_scale, L.reuse_images = True, True
+      assert 'h3' in L.kernel_name(0), L.kernel_name(0)
+    assert any('patch' in L.kernel_name(0) for L in (P1, P2)) == bool(patch), (P1.kernel_name(0), P2.kernel_name(0))
+    if register:
+      P1.add_image_consumer(C1, 0)
+      P1.add_image_consumer(C2, 1)
+      P2.add_image_consumer(C2, 0)
+    return P1, P2, C1, C2
+  A = make(True)
+  R = make(False)
+  assert conv.Layer.emit_images and A[0]._emit_targets() == []          # first step: the consumers have no history yet
+  for step, scale in enumerate((1.0, 0.8, 1.3, 1000.0, 1000.0)):
+    for P1, P2, C1, C2 in (A, R):
+      P1.x0.copy_(xin1 * scale)
+      P2.x0.copy_(xin2 * scale)
+      for L in (P1, P2, C1, C2):
+        L.forward()
+    if step >= 1:
+      assert len(A[0]._emit_targets()) == 2 and len(A[1]._emit_targets()) == 1
+    for Ca, Cr in ((A[2], R[2]), (A[3], R[3])):
+      # the operand image, value for value (as fp16: the two code paths may differ in the SIGN of a zero -- relu(-x) -- only)
+      assert torch.equal(Ca._img[0].view(torch.float16), Cr._img[0].view(torch.float16)), step
+      ha, hr = Ca._img[1].cpu(), Cr._img[1].cpu()
+      assert int(ha[1]) == int(hr[1]) and int(ha[2]) == int(hr[2]) and int(ha[5]) == int(hr[5]), (step, ha, hr)
+      assert torch.equal(Ca.y, Cr.y), step
+  assert int(A[2]._img[1].cpu()[5]) == 1 and int(A[3]._img[1].cpu()[5]) == 1     # the 1000 x jump: one exact refit each
+  # and the weight gradient of a consumer reads the producer-written image like any other
+  dy = torch.randn(2, 16, 17, 256, generator=g).to(dev)
+  dwa, dwr = torch.zeros_like(wc1), torch.zeros_like(wc1)
+  A[2].backward_weight(dy, dwa)
+  R[2].backward_weight(dy, dwr)
+  assert rel(dwa, dwr) < 1e-6
+
+
+@gpu
 def test_output_gradient_roles_keep_separate_magnitude_histories(hip, hipenv):
   """Layer.set_dy_role: one layer object that sees gradients of two losses per step (the discriminator's fake pass with
   batch norm: D-loss gradients in the D step, ~1000 x larger G-loss gradients in the G step) keeps one header per role,
