@@ -20,6 +20,7 @@
 #include <string>
 
 #include "conv_internal.h"
+#include "image_emit.h"
 #include "tuning.h"
 #include "x6.h"
 
@@ -197,6 +198,20 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
 #pragma unroll
   for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(bias[j]));
   const int tile0 = blockIdx.x * 4 + wave;
+  // forward launches: the consumers' operand images of the output (image_emit.h)
+  const ImgOut o0 = p.oimg[0], o1 = p.oimg[1];
+  const bool emit0 = o0.img != nullptr, emit1 = o1.img != nullptr;
+  const float eup0 = emit0 ? emit_up_scale(o0.hdr[2]) : 1.f, eup1 = emit1 ? emit_up_scale(o1.hdr[2]) : 1.f;
+  float evmax0 = 0.f, evmax1 = 0.f;
+  int esat0 = 0, esat1 = 0;
+  if (threadIdx.x == 0) {
+    if (emit0) o0.hdr[1] = __float_as_uint(1.f / eup0);
+    if (emit1) o1.hdr[1] = __float_as_uint(1.f / eup1);
+  }
+  const __amdgpu_buffer_rsrc_t rs_e0 = __builtin_amdgcn_make_buffer_rsrc(
+      emit0 ? reinterpret_cast<void*>(o0.img) : reinterpret_cast<void*>(p.d[0].p), 0, emit0 ? kThinOob : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_e1 = __builtin_amdgcn_make_buffer_rsrc(
+      emit1 ? reinterpret_cast<void*>(o1.img) : reinterpret_cast<void*>(p.d[0].p), 0, emit1 ? kThinOob : 0u, 0x00020000);
   if (tile0 < tiles) ADVOC_THIN_FETCH(tile0);
   for (int tile = tile0; tile < tiles; tile += gridDim.x * 4) {
     const int rowid = tile / tiles_x;
@@ -315,10 +330,20 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
         sv.z = __float_as_uint(v[ps].z); sv.w = __float_as_uint(v[ps].w);
         __builtin_amdgcn_raw_buffer_store_b128(sv, rs_d, so[ps], 0, 0);
       }
+      // consumers' operand images of the output (forward launches; image_emit.h): unconditional buffer stores, dropped by
+      // the range check for rows without a pixel and when there is no such consumer
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const bool ok = okj && di == 0 && so[ps] != kThinOob;
+        emit4_buffer(rs_e0, o0.slope, eup0, v[ps], ok ? so[ps] : kThinOob, ok && emit0, evmax0, esat0);
+        emit4_buffer(rs_e1, o1.slope, eup1, v[ps], ok ? so[ps] : kThinOob, ok && emit1, evmax1, esat1);
+      }
       wave_lds_sync();
     }
   }
 #undef ADVOC_THIN_PRELOAD
+  if (emit0) emit_finish(o0, evmax0, esat0);
+  if (emit1) emit_finish(o1, evmax1, esat1);
 }
 
 #undef PE_ROW
@@ -330,15 +355,6 @@ template <int KP, bool B_KN>
 int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** name_only) {
   const int N = p.n_total;
   const int nt = N % 128 == 0 ? 4 : (N % 64 == 0 ? 2 : 1);
-  if (name_only) {
-    static std::string names[3];
-    const int i = nt == 4 ? 2 : (nt == 2 ? 1 : 0);
-    if (names[i].empty())
-      names[i] = std::string("thin_k_gemm_kernel<") + std::to_string(KP) + ", " + std::to_string(nt) + ", " +
-                 (B_KN ? "true" : "false") + ">";
-    *name_only = names[i].c_str();
-    return ADVOC_OK;
-  }
   int dy_min = 127, dy_max = -128, dx_min = 127, dx_max = -128;
   for (int ph = 0; ph < p.nphase; ++ph)
     for (int t = 0; t < p.ntaps; ++t) {
@@ -355,6 +371,16 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
   for (int di = 0; di < 2; ++di)
     if (p.d[di].p && (int64_t)p.batch * p.out_h * p.d[di].pitch * p.d[di].c * 4 >= (int64_t)kThinOob)
       return ADVOC_ERR_UNSUPPORTED;
+  if (name_only) {
+    static std::string names[3];
+    const int i = nt == 4 ? 2 : (nt == 2 ? 1 : 0);
+    if (names[i].empty())
+      names[i] = std::string("thin_k_gemm_kernel<") + std::to_string(KP) + ", " + std::to_string(nt) + ", " +
+                 (B_KN ? "true" : "false") + ">";
+    *name_only = names[i].c_str();
+    if (p.emit_report) *p.emit_report = 1;      // the epilogue writes GatherGemmParams.oimg (image_emit.h)
+    return ADVOC_OK;
+  }
   int64_t bx = ceil_div(tiles, 4);
   const int by = (N + 32 * nt - 1) / (32 * nt);
   const int pl = (pr * pc * (p.c0 + p.c1) + 63) / 64;

@@ -785,6 +785,47 @@ def test_producer_written_operand_images_equal_the_image_pass(hip, hipenv, patch
 
 
 @gpu
+@pytest.mark.parametrize('cin,cout', [(1, 64), (2, 64), (2, 128), (1, 32)])
+def test_thin_producers_write_operand_images(hip, hipenv, cin, cout):
+  """The thin forward kernel (csrc/thin.hip: encoder_1 and the discriminator's layer_1, 1-2 input channels) writes its
+  consumer's operand image from its epilogue as the image kernels do: value-identical to the consumer's own image pass,
+  ragged widths included, and a 1000 x jump is refitted exactly."""
+  from advoc_amd import conv
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1)
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(37)
+  xin = torch.randn(2, 66, 70, cin, generator=g).to(dev)
+  w = (torch.randn(4, 4, cin, cout, generator=g) * 0.2).to(dev)
+  b = (torch.randn(cout, generator=g) * 0.1).to(dev)
+  wc = (torch.randn(4, 4, cout, 128, generator=g) * 0.05).to(dev)
+
+  def make(register):
+    y = torch.empty(2, 33, 35, cout, device=dev)
+    P = conv.Layer(conv.CONV, xin.clone(), y, w, b, stride=(2, 2), pad=(1, 1))
+    C = conv.Layer(conv.CONV, y, torch.empty(2, 16, 17, 128, device=dev), wc, None, stride=(2, 2), pad=(1, 1),
+                   in_act=conv.ACT_LRELU)
+    for L in (P, C):
+      L.delayed_scale, L.reuse_images = True, True
+    assert 'thin_k' in P.kernel_name(0) and 'h3' in C.kernel_name(0), (P.kernel_name(0), C.kernel_name(0))
+    if register:
+      P.add_image_consumer(C, 0)
+    return P, C
+  A, R = make(True), make(False)
+  for step, scale in enumerate((1.0, 0.7, 1.2, 1000.0, 1000.0)):
+    for P, C in (A, R):
+      P.x0.copy_(xin * scale)
+      P.forward()
+      C.forward()
+    if step >= 1:
+      assert len(A[0]._emit_targets()) == 1
+    assert torch.equal(A[1]._img[0].view(torch.float16), R[1]._img[0].view(torch.float16)), step
+    ha, hr = A[1]._img[1].cpu(), R[1]._img[1].cpu()
+    assert int(ha[1]) == int(hr[1]) and int(ha[2]) == int(hr[2]) and int(ha[5]) == int(hr[5]), (step, ha, hr)
+    assert torch.equal(A[1].y, R[1].y), step
+  assert int(A[1]._img[1].cpu()[5]) == 1
+
+
+@gpu
 def test_output_gradient_roles_keep_separate_magnitude_histories(hip, hipenv):
   """Layer.set_dy_role: one layer object that sees gradients of two losses per step (the discriminator's fake pass with
   batch norm: D-loss gradients in the D step, ~1000 x larger G-loss gradients in the G step) keeps one header per role,
