@@ -294,7 +294,7 @@ class Layer(object):
 
   def _emit_targets(self):
     """[(slot, consumer, source)] this forward call writes images for."""
-    if not (Layer.emit_images and self.delayed_scale and self._consumers and Layer.profiler is None):
+    if not (Layer.emit_images and self.delayed_scale and self._consumers):
       return []
     if self._emits is None:
       self._emits = bool(_lib.load().advoc_conv_emits_images(ctypes.byref(self.struct)))

@@ -58,6 +58,21 @@ struct WgradImages {
   const unsigned* p_hdr; const unsigned* q_hdr;   // {amax bits, 2^-s}
 };
 
+// One LDS-DMA instruction (16 bytes per lane: lane l's bytes land at lds_base + 16 l), written as inline assembly on
+// purpose.  Through the builtin the compiler knows the instruction writes LDS, cannot tell the two stages apart, and
+// therefore puts `s_waitcnt vmcnt(0)` in front of the first ds_read that follows -- the reads of the CURRENT stage waited
+// for the NEXT stage's loads, every K tile, so nothing was ever in flight under the MFMAs.  The hand-placed
+// `s_waitcnt vmcnt(0)` in front of each barrier is the only wait these loads need.
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4s dma_rsrc(const void* base, unsigned bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  return (u32x4s){(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void dma16(u32x4s rsrc, unsigned lds_base, int voffset) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voffset), "s"(rsrc)
+               : "memory", "m0");
+}
+
 template <int WGM, int NT>
 __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradImages& im, int tiles_n, int tiles,
                                               int chunk) {
@@ -100,10 +115,9 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   const bool q_second = q_live && q_ch >= p.Q.c0;
   const int q_c = q_second ? p.Q.c1 : p.Q.c0, q_pitch = q_second ? p.Q.pitch1 : p.Q.pitch0;
   const int q_choff = (q_second ? q_ch - p.Q.c0 : (q_live ? q_ch : 0)) * 4;
-  const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t*>(p_second ? im.p1 : im.p0), 0, p_second ? im.p1_bytes : im.p0_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t*>(q_second ? im.q1 : im.q0), 0, q_second ? im.q1_bytes : im.q0_bytes, 0x00020000);
+  const u32x4s rs_p = dma_rsrc(p_second ? im.p1 : im.p0, (unsigned)(p_second ? im.p1_bytes : im.p0_bytes));
+  const u32x4s rs_q = dma_rsrc(q_second ? im.q1 : im.q0, (unsigned)(q_second ? im.q1_bytes : im.q0_bytes));
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_p)wsm;
   // chunk position q of pixel row r holds chunk q ^ (4 if r & 2): the two planes swapped on rows 2, 3 (mod 4)
   const int lchunk16 = (lpos ^ (((lpix >> 1) & 1) << 2)) * 16;
 
@@ -117,27 +131,43 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
     gi[s] = (int)(t / (unsigned)p.gh);
     gy[s] = (int)(t - (unsigned)gi[s] * (unsigned)p.gh);
   }
-  const int step_q = WK / p.gw, step_r = WK - step_q * p.gw;       // 32 grid points = step_q rows + step_r points
+  // One K tile = 32 grid points = step_q grid rows + step_r points; step_q rows = step_i images + step_qr rows.
+  const int step_q = WK / p.gw, step_r = WK - step_q * p.gw;
+  const int step_i = step_q / p.gh, step_qr = step_q - step_i * p.gh;
   int g_lane = g_begin + lpix;                                       // grid index of slot 0
 
-#define ADVOC_WH3_ISSUE(ST)                                                                              \
+  // The DMA of a K tile is split in two: its 8 buffer offsets (ADDR: plain VALU work without a branch, computed one tile
+  // ahead so that it sits in the same basic block as the previous tile's MFMAs and issues in their shadow -- with the
+  // offsets computed between the barrier and the loads, both waves of a SIMD did ~250 instructions of address arithmetic
+  // at the same time while the matrix pipe idled) and the 8 loads themselves (FIRE, right behind the barrier).
+  int pvn[4], qvn[4];
+#define ADVOC_WH3_ADDR()                                                                                 \
   {                                                                                                      \
-    unsigned char* st_ = wsm + (ST) * STAGE;                                                             \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                      \
       const bool in_ = g_lane + 8 * s < g_end;                                                           \
       const int py_ = gy[s] * p.sy + dy, px_ = gx[s] * p.sx + dx;                                        \
       const bool pok_ = in_ && p_live && (unsigned)py_ < (unsigned)p.P.h && (unsigned)px_ < (unsigned)p.P.w; \
-      const int pv_ = pok_ ? ((gi[s] * p.P.h + py_) * p_pitch + px_) * p_c * 4 + p_choff + lchunk16 : (int)0x80000000; \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (lds_void_p)(st_ + wave * BLK + s * 1024), 16, pv_, 0, 0, 0);   \
+      pvn[s] = pok_ ? ((gi[s] * p.P.h + py_) * p_pitch + px_) * p_c * 4 + p_choff + lchunk16 : (int)0x80000000; \
       const bool qok_ = in_ && q_live;                                                                   \
-      const int qv_ = qok_ ? ((gi[s] * p.Q.h + gy[s]) * q_pitch + gx[s]) * q_c * 4 + q_choff + lchunk16 : (int)0x80000000; \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_p)(st_ + (C::PB + wave) * BLK + s * 1024), 16, qv_, 0, 0, 0); \
-      /* advance the slot by one K tile */                                                               \
-      gx[s] += step_r; gy[s] += step_q;                                                                  \
-      if (gx[s] >= p.gw) { gx[s] -= p.gw; gy[s] += 1; }                                                  \
-      while (gy[s] >= p.gh) { gy[s] -= p.gh; gi[s] += 1; }                                               \
+      qvn[s] = qok_ ? ((gi[s] * p.Q.h + gy[s]) * q_pitch + gx[s]) * q_c * 4 + q_choff + lchunk16 : (int)0x80000000; \
+      /* advance the slot by one K tile: at most one wrap per axis (step_r < gw, step_qr < gh) */      \
+      gx[s] += step_r;                                                                                   \
+      const int cx_ = gx[s] >= p.gw ? 1 : 0;                                                             \
+      gx[s] -= cx_ ? p.gw : 0;                                                                           \
+      gy[s] += step_qr + cx_;                                                                            \
+      const int cy_ = gy[s] >= p.gh ? 1 : 0;                                                             \
+      gy[s] -= cy_ ? p.gh : 0;                                                                           \
+      gi[s] += step_i + cy_;                                                                             \
     }                                                                                                    \
     g_lane += WK;                                                                                        \
+  }
+#define ADVOC_WH3_FIRE(ST)                                                                               \
+  {                                                                                                      \
+    const unsigned st_ = lds0 + (ST) * STAGE;                                                            \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                      \
+      dma16(rs_p, st_ + wave * BLK + s * 1024, pvn[s]);                                                  \
+      dma16(rs_q, st_ + (C::PB + wave) * BLK + s * 1024, qvn[s]);                                        \
+    }                                                                                                    \
   }
 
   floatx16 acc[MT][NT];
@@ -187,18 +217,24 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
     }                                                                                                    \
   }
 
-  // ---- K loop: two LDS stages, one barrier per K tile (igemm_h3.hip) ----
-  ADVOC_WH3_ISSUE(0);
+  // ---- K loop: two LDS stages, one barrier per K tile (igemm_h3.hip).  Tiles past the chunk's end arrive as zeros
+  // (offsets out of range), so the second half of the last pair is computed unconditionally: no branch between the address
+  // arithmetic and the MFMAs that hide it ----
+  ADVOC_WH3_ADDR();
+  ADVOC_WH3_FIRE(0);
+  ADVOC_WH3_ADDR();
   for (int kt = 0; kt < nkt; kt += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      ADVOC_WH3_ISSUE(u ^ 1);
-      if (kt + u < nkt) ADVOC_WH3_COMPUTE(u);
+      ADVOC_WH3_FIRE(u ^ 1);
+      ADVOC_WH3_ADDR();
+      ADVOC_WH3_COMPUTE(u);
     }
   }
-#undef ADVOC_WH3_ISSUE
+#undef ADVOC_WH3_ADDR
+#undef ADVOC_WH3_FIRE
 #undef ADVOC_WH3_COMPUTE
 #undef ADVOC_WH3_FRAG
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
