@@ -35,6 +35,7 @@
 #include "igemm.h"
 #include "tuning.h"
 #include "image_emit.h"
+#include "lds_dma.h"
 #include "x6.h"
 
 namespace advoc {
@@ -148,12 +149,11 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
     b_off[g] = ((n0 + n) * ktot) * 4 + gc * 16;
   }
   // buffer descriptors over the whole images; the weight-slab / K-slice offsets go into soffset
-  const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t*>(p.a0_img), 0, p.a0_img_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t*>(p.a1_img ? p.a1_img : p.a0_img), 0, p.a1_img_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t*>(p.wq), 0, p.wq_taps * p.n_total * ktot * 4, 0x00020000);
+  // (lds_dma.h: why the DMAs are inline assembly)
+  const u32x4s rs_a0 = dma_rsrc(p.a0_img, (unsigned)p.a0_img_bytes);
+  const u32x4s rs_a1 = dma_rsrc(p.a1_img ? p.a1_img : p.a0_img, (unsigned)p.a1_img_bytes);
+  const u32x4s rs_b = dma_rsrc(p.wq, (unsigned)(p.wq_taps * p.n_total * ktot * 4));
+  const unsigned lds0 = lds_address(smem_b);
 
   const int kt_begin = (int)((int64_t)nkt * ks_idx / ks_cnt);
   const int kt_end = (int)((int64_t)nkt * (ks_idx + 1) / ks_cnt);
@@ -182,21 +182,17 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
     const bool second_ = k0_ >= p.c0;                                                                    \
     const int delta_ = second_ ? ((dy_ * p.a1_pitch + dx_) * p.c1 + (k0_ - p.c0)) * 4                    \
                                : ((dy_ * p.a0_pitch + dx_) * p.c0 + k0_) * 4;                            \
-    unsigned char* st_ = smem_b + (ST) * C::STAGE;                                                       \
+    const unsigned st_ = lds0 + (ST) * C::STAGE;                                                         \
+    const u32x4s rs_a_ = second_ ? rs_a1 : rs_a0;                                                        \
     _Pragma("unroll") for (int g = 0; g < RGA; ++g) {                                                    \
       const int iy_ = a_y[g] + dy_, ix_ = a_x[g] + dx_;                                                  \
       const bool ok_ = a_ok[g] && (unsigned)iy_ < (unsigned)p.in_h && (unsigned)ix_ < (unsigned)p.in_w;  \
       const int voff_ = ok_ ? a_b0[g] + (second_ ? a_b1[g] : 0) + delta_ : (int)0x80000000;              \
-      unsigned char* d_ = st_ + (wave * RGA + g) * 1024;                                                 \
-      if (ABL != 3) {                                                                                    \
-        if (second_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_void_p)(d_), 16, voff_, 0, 0, 0);    \
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (lds_void_p)(d_), 16, voff_, 0, 0, 0);      \
-      }                                                                                                  \
+      if (ABL != 3) dma16(rs_a_, st_ + (wave * RGA + g) * 1024, voff_);                                  \
     }                                                                                                    \
     const int wslab_ = (wtap_ * p.n_total * ktot + k0_) * 4;                                             \
     _Pragma("unroll") for (int g = 0; g < CGB; ++g) {                                                    \
-      unsigned char* d_ = st_ + C::A_TILE + (wave * CGB + g) * 1024;                                     \
-      if (ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_p)(d_), 16, b_off[g], wslab_, 0, 0); \
+      if (ABL != 3) dma16(rs_b, st_ + C::A_TILE + (wave * CGB + g) * 1024, b_off[g], wslab_);            \
     }                                                                                                    \
   }
 

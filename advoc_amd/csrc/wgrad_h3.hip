@@ -23,6 +23,7 @@
 #include <string>
 
 #include "conv_internal.h"
+#include "lds_dma.h"
 #include "tuning.h"
 #include "x6.h"
 
@@ -37,6 +38,7 @@ typedef __attribute__((address_space(3))) void* lds_void_p;
 
 constexpr int WK = 32;              // grid points per K tile
 constexpr int BLK = WK * 128;       // bytes of one 32-channel block of a K tile
+constexpr int SL = WK / 8;          // 8-pixel DMA slots per block
 
 // WGM x 2 wavefronts, each MT x NT blocks of 32 x 32: 128 x 128 on 4 waves (two workgroups per CU) or 256 x 256 on 8
 // (one per CU, 128 KiB of LDS; half the L2 -> LDS bytes per flop -- the 128 x 128 tile runs at the DMA rate, like the
@@ -57,21 +59,6 @@ struct WgradImages {
   int p0_bytes, p1_bytes, q0_bytes, q1_bytes;
   const unsigned* p_hdr; const unsigned* q_hdr;   // {amax bits, 2^-s}
 };
-
-// One LDS-DMA instruction (16 bytes per lane: lane l's bytes land at lds_base + 16 l), written as inline assembly on
-// purpose.  Through the builtin the compiler knows the instruction writes LDS, cannot tell the two stages apart, and
-// therefore puts `s_waitcnt vmcnt(0)` in front of the first ds_read that follows -- the reads of the CURRENT stage waited
-// for the NEXT stage's loads, every K tile, so nothing was ever in flight under the MFMAs.  The hand-placed
-// `s_waitcnt vmcnt(0)` in front of each barrier is the only wait these loads need.
-typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4s dma_rsrc(const void* base, unsigned bytes) {
-  const uint64_t a = reinterpret_cast<uint64_t>(base);
-  return (u32x4s){(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
-}
-__device__ __forceinline__ void dma16(u32x4s rsrc, unsigned lds_base, int voffset) {
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voffset), "s"(rsrc)
-               : "memory", "m0");
-}
 
 template <int WGM, int NT>
 __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradImages& im, int tiles_n, int tiles,
@@ -117,54 +104,65 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   const int q_choff = (q_second ? q_ch - p.Q.c0 : (q_live ? q_ch : 0)) * 4;
   const u32x4s rs_p = dma_rsrc(p_second ? im.p1 : im.p0, (unsigned)(p_second ? im.p1_bytes : im.p0_bytes));
   const u32x4s rs_q = dma_rsrc(q_second ? im.q1 : im.q0, (unsigned)(q_second ? im.q1_bytes : im.q0_bytes));
-  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_p)wsm;
+  const unsigned lds0 = lds_address(wsm);        // (lds_dma.h: why the DMAs below are inline assembly)
   // chunk position q of pixel row r holds chunk q ^ (4 if r & 2): the two planes swapped on rows 2, 3 (mod 4)
   const int lchunk16 = (lpos ^ (((lpix >> 1) & 1) << 2)) * 16;
 
-  // grid point of each of this lane's 4 pixel slots (pixel lpix + 8 s of the K tile), tracked incrementally
-  int gy[4], gx[4], gi[4];
+  // Each lane DMAs SL pixels per K tile (pixel lpix + 8 s).  Per slot it keeps the grid column / row (for the tap's bounds
+  // check and the wraps) and the two byte offsets themselves, all advanced by ADDITION from one K tile to the next: the
+  // offsets are linear in (image, row, column), so a step of WK grid points adds one wave-uniform constant plus one more
+  // per wrap of the column / row counter.  (Recomputing ((image * h + y) * pitch + x) * c per slot and tile cost six
+  // quarter-rate integer multiplies; the address arithmetic of the two waves of a SIMD then outlasted their MFMAs.)
+  int gy[SL], gx[SL], po[SL], qo[SL];
+  const int pc4 = p_c * 4, qc4 = q_c * 4;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < SL; ++s) {
     const unsigned g = (unsigned)(g_begin + lpix + 8 * s);
     const unsigned t = g / (unsigned)p.gw;
     gx[s] = (int)(g - t * (unsigned)p.gw);
-    gi[s] = (int)(t / (unsigned)p.gh);
-    gy[s] = (int)(t - (unsigned)gi[s] * (unsigned)p.gh);
+    const int gi = (int)(t / (unsigned)p.gh);
+    gy[s] = (int)(t - (unsigned)gi * (unsigned)p.gh);
+    po[s] = ((gi * p.P.h + gy[s] * p.sy + dy) * p_pitch + gx[s] * p.sx + dx) * pc4 + p_choff + lchunk16;
+    qo[s] = ((gi * p.Q.h + gy[s]) * q_pitch + gx[s]) * qc4 + q_choff + lchunk16;
   }
-  // One K tile = 32 grid points = step_q grid rows + step_r points; step_q rows = step_i images + step_qr rows.
+  // One K tile = WK grid points = step_q grid rows + step_r points; step_q rows = step_i images + step_qr rows.
   const int step_q = WK / p.gw, step_r = WK - step_q * p.gw;
   const int step_i = step_q / p.gh, step_qr = step_q - step_i * p.gh;
-  int g_lane = g_begin + lpix;                                       // grid index of slot 0
+  const int p_row = p.sy * p_pitch * pc4, q_row = q_pitch * qc4;            // bytes per grid row
+  const int p_step = step_r * p.sx * pc4 + step_qr * p_row + step_i * p.P.h * p_pitch * pc4;
+  const int q_step = step_r * qc4 + step_qr * q_row + step_i * p.Q.h * q_pitch * qc4;
+  const int p_wrapx = p_row - p.gw * p.sx * pc4, q_wrapx = q_row - p.gw * qc4;                  // column wrap: next row
+  const int p_wrapy = p.P.h * p_pitch * pc4 - p.gh * p_row, q_wrapy = p.Q.h * q_pitch * qc4 - p.gh * q_row;   // next image
+  int g_left = g_end - (g_begin + lpix);                             // slot s is inside the chunk while 8 s < g_left
 
-  // The DMA of a K tile is split in two: its 8 buffer offsets (ADDR: plain VALU work without a branch, computed one tile
-  // ahead so that it sits in the same basic block as the previous tile's MFMAs and issues in their shadow -- with the
-  // offsets computed between the barrier and the loads, both waves of a SIMD did ~250 instructions of address arithmetic
-  // at the same time while the matrix pipe idled) and the 8 loads themselves (FIRE, right behind the barrier).
-  int pvn[4], qvn[4];
+  // The DMA of a K tile is split in two: its 2 SL buffer offsets (ADDR: plain VALU work without a branch, computed one
+  // tile ahead so that it sits in the same basic block as the previous tile's MFMAs and issues in their shadow) and the
+  // loads themselves (FIRE, right behind the barrier).
+  int pvn[SL], qvn[SL];
 #define ADVOC_WH3_ADDR()                                                                                 \
   {                                                                                                      \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                      \
-      const bool in_ = g_lane + 8 * s < g_end;                                                           \
-      const int py_ = gy[s] * p.sy + dy, px_ = gx[s] * p.sx + dx;                                        \
+    _Pragma("unroll") for (int s = 0; s < SL; ++s) {                                                     \
+      const bool in_ = 8 * s < g_left;                                                                   \
+      const int py_ = __mul24(gy[s], p.sy) + dy, px_ = __mul24(gx[s], p.sx) + dx;                        \
       const bool pok_ = in_ && p_live && (unsigned)py_ < (unsigned)p.P.h && (unsigned)px_ < (unsigned)p.P.w; \
-      pvn[s] = pok_ ? ((gi[s] * p.P.h + py_) * p_pitch + px_) * p_c * 4 + p_choff + lchunk16 : (int)0x80000000; \
-      const bool qok_ = in_ && q_live;                                                                   \
-      qvn[s] = qok_ ? ((gi[s] * p.Q.h + gy[s]) * q_pitch + gx[s]) * q_c * 4 + q_choff + lchunk16 : (int)0x80000000; \
+      pvn[s] = pok_ ? po[s] : (int)0x80000000;                                                           \
+      qvn[s] = (in_ && q_live) ? qo[s] : (int)0x80000000;                                                \
       /* advance the slot by one K tile: at most one wrap per axis (step_r < gw, step_qr < gh) */      \
       gx[s] += step_r;                                                                                   \
-      const int cx_ = gx[s] >= p.gw ? 1 : 0;                                                             \
+      const bool cx_ = gx[s] >= p.gw;                                                                    \
       gx[s] -= cx_ ? p.gw : 0;                                                                           \
-      gy[s] += step_qr + cx_;                                                                            \
-      const int cy_ = gy[s] >= p.gh ? 1 : 0;                                                             \
+      gy[s] += step_qr + (cx_ ? 1 : 0);                                                                  \
+      const bool cy_ = gy[s] >= p.gh;                                                                    \
       gy[s] -= cy_ ? p.gh : 0;                                                                           \
-      gi[s] += step_i + cy_;                                                                             \
+      po[s] += p_step + (cx_ ? p_wrapx : 0) + (cy_ ? p_wrapy : 0);                                       \
+      qo[s] += q_step + (cx_ ? q_wrapx : 0) + (cy_ ? q_wrapy : 0);                                       \
     }                                                                                                    \
-    g_lane += WK;                                                                                        \
+    g_left -= WK;                                                                                       \
   }
 #define ADVOC_WH3_FIRE(ST)                                                                               \
   {                                                                                                      \
     const unsigned st_ = lds0 + (ST) * STAGE;                                                            \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                      \
+    _Pragma("unroll") for (int s = 0; s < SL; ++s) {                                                     \
       dma16(rs_p, st_ + wave * BLK + s * 1024, pvn[s]);                                                  \
       dma16(rs_q, st_ + (C::PB + wave) * BLK + s * 1024, qvn[s]);                                        \
     }                                                                                                    \
@@ -188,11 +186,28 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
 #define ADVOC_WH3_FRAG(BASE, PLOFF, KS, H) \
   __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)((BASE) + (PLOFF) + ((KS) * 16 + (H) * 4) * 128))
 
+// The three products of one 32 x 32 block, then one DMA instruction of the NEXT tile: the 2 SL loads of a tile go out
+// one per block instead of as a burst behind the barrier (8 waves x 8 loads at once back up in the address path, and an
+// in-order wave cannot issue its MFMAs from behind a stalled load).
+#define WH3_MFMAS \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                 \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bq[j][1], acc[i][j], 0, 0, 0);    \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bq[j][0], acc[i][j], 0, 0, 0);    \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bq[j][0], acc[i][j], 0, 0, 0);    \
+          const int d_ = (ks * MT + i) * NT + j;                                                         \
+          if (d_ < 2 * SL) {                                                                             \
+            if (d_ & 1) dma16(rs_q, nst_ + (C::PB + wave) * BLK + (d_ >> 1) * 1024, qvn[d_ >> 1]);       \
+            else dma16(rs_p, nst_ + wave * BLK + (d_ >> 1) * 1024, pvn[d_ >> 1]);                        \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+          }                                                                                              \
+        }
 #define ADVOC_WH3_COMPUTE(ST)                                                                            \
   {                                                                                                      \
+    const unsigned nst_ = lds0 + ((ST) ^ 1) * STAGE;               /* the stage filled under this tile's MFMAs */ \
     const unsigned char* Pb = wsm + (ST) * STAGE;                                                        \
     const unsigned char* Qb = Pb + C::PB * BLK;                                                          \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < WK / 16; ++ks) {                                               \
       f16x8 af[MT][2], bq[NT][2];                                                                        \
       _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                   \
         const unsigned char* b_ = Pb + (wm * MT + i) * BLK;                                              \
@@ -208,12 +223,7 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
         bq[j][0] = __builtin_bit_cast(f16x8, __builtin_shufflevector(b00, b01, 0, 1, 2, 3, 4, 5, 6, 7));                            \
         bq[j][1] = __builtin_bit_cast(f16x8, __builtin_shufflevector(b10, b11, 0, 1, 2, 3, 4, 5, 6, 7));                            \
       }                                                                                                  \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                     \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                 \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bq[j][1], acc[i][j], 0, 0, 0);    \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bq[j][0], acc[i][j], 0, 0, 0);    \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bq[j][0], acc[i][j], 0, 0, 0);    \
-        }                                                                                                \
+      WH3_MFMAS                                                                                          \
     }                                                                                                    \
   }
 
@@ -228,9 +238,8 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
     for (int u = 0; u < 2; ++u) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      ADVOC_WH3_FIRE(u ^ 1);
+      ADVOC_WH3_COMPUTE(u);          // (fires the next tile's loads between its MFMAs)
       ADVOC_WH3_ADDR();
-      ADVOC_WH3_COMPUTE(u);
     }
   }
 #undef ADVOC_WH3_ADDR
