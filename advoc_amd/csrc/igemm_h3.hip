@@ -342,7 +342,6 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
   const bool emit0 = p.oimg[0].img != nullptr && !atomic_split, emit1 = p.oimg[1].img != nullptr && !atomic_split;
   const float eup0 = emit0 ? emit_up_scale(p.oimg[0].hdr[2]) : 1.f, eup1 = emit1 ? emit_up_scale(p.oimg[1].hdr[2]) : 1.f;
   float evmax0 = 0.f, evmax1 = 0.f;
-  int esat0 = 0, esat1 = 0;
   if (tid == 0) {      // (every workgroup that reaches an epilogue: the same value)
     if (emit0) p.oimg[0].hdr[1] = __float_as_uint(1.f / eup0);
     if (emit1) p.oimg[1].hdr[1] = __float_as_uint(1.f / eup1);
@@ -417,15 +416,15 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
         }
         *reinterpret_cast<float4*>(dst) = v;
         if (di == 0) {
-          if (emit0) emit4(p.oimg[0], eup0, v, (unsigned)off[ps], evmax0, esat0);
-          if (emit1) emit4(p.oimg[1], eup1, v, (unsigned)off[ps], evmax1, esat1);
+          if (emit0) emit4(p.oimg[0], eup0, v, (unsigned)off[ps], evmax0);
+          if (emit1) emit4(p.oimg[1], eup1, v, (unsigned)off[ps], evmax1);
         }
       }
       wave_lds_sync();
     }
   }
-  if (emit0) emit_finish(p.oimg[0], evmax0, esat0);
-  if (emit1) emit_finish(p.oimg[1], evmax1, esat1);
+  if (emit0) emit_finish(p.oimg[0], eup0, evmax0);
+  if (emit1) emit_finish(p.oimg[1], eup1, evmax1);
 }
 
 template <int MT, int NT, int NS, int WGM>

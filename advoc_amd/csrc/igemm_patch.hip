@@ -396,7 +396,6 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const bool emit0 = !BWD && p.oimg[0].img != nullptr, emit1 = !BWD && p.oimg[1].img != nullptr;
   const float eup0 = emit0 ? emit_up_scale(p.oimg[0].hdr[2]) : 1.f, eup1 = emit1 ? emit_up_scale(p.oimg[1].hdr[2]) : 1.f;
   float evmax0 = 0.f, evmax1 = 0.f;
-  int esat0 = 0, esat1 = 0;
   if (!BWD && tid == 0) {
     if (emit0) p.oimg[0].hdr[1] = __float_as_uint(1.f / eup0);
     if (emit1) p.oimg[1].hdr[1] = __float_as_uint(1.f / eup1);
@@ -504,16 +503,16 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const bool ok = so[ps] != kOob && di == 0;
-          emit4_buffer(rs_e0, p.oimg[0].slope, eup0, v[ps], ok ? so[ps] : kOob, ok && emit0, evmax0, esat0);
-          emit4_buffer(rs_e1, p.oimg[1].slope, eup1, v[ps], ok ? so[ps] : kOob, ok && emit1, evmax1, esat1);
+          emit4_buffer(rs_e0, p.oimg[0].slope, eup0, v[ps], ok ? so[ps] : kOob, ok && emit0, evmax0);
+          emit4_buffer(rs_e1, p.oimg[1].slope, eup1, v[ps], ok ? so[ps] : kOob, ok && emit1, evmax1);
         }
       }
       wave_lds_sync();
     }
 #undef ADVOC_P3_PRELOAD
   }
-  if (emit0) emit_finish(p.oimg[0], evmax0, esat0);
-  if (emit1) emit_finish(p.oimg[1], evmax1, esat1);
+  if (emit0) emit_finish(p.oimg[0], eup0, evmax0);
+  if (emit1) emit_finish(p.oimg[1], eup1, evmax1);
   __syncthreads();          // the next tile's DMAs overwrite the LDS this epilogue read
   }  // tiles
 }

@@ -21,22 +21,43 @@ __device__ __forceinline__ float emit_up_scale(unsigned prev_bits) {
   return __uint_as_float((unsigned)(s + 127) << 23);
 }
 
-// the 4 channels e .. e + 3 (e % 4 == 0) of one pixel, e = linear NHWC element index of the tensor
-__device__ __forceinline__ void emit4(const ImgOut& o, float up, float4 v, unsigned e, float& vmax, int& sat) {
-  float t[4] = {v.x, v.y, v.z, v.w};
-  __half h0[4], h1[4];
+typedef float emit_f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 emit_h2 __attribute__((ext_vector_type(2)));
+
+// Activation, scale and fp16 pair split of 4 values, two at a time on the packed fp32 / packed-convert instructions
+// (v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f32: ~7 VALU operations per value where the scalar form took 16 -- the
+// emitting epilogues of the 64-channel layers had become a third slower than the plain ones).  `up` = the consumer's
+// scale, or 0 for a row that must not count; vmaxs accumulates max |activation * up| BEFORE the clamp, so
+// emit_finish can tell both the magnitude (vmaxs / up, exact: a power of two) and whether anything left the fp16 window.
+// Value for value what pair_image_kernel<true> (image.hip) computes: RN(a), RN(a - RN(a)), clamp to +-65504.
+__device__ __forceinline__ void emit_split4(float slope, float up, float4 v, float& vmaxs, uint2& h0, uint2& h1) {
+  const emit_f2 t[2] = {{v.x, v.y}, {v.z, v.w}};
+  unsigned lo[2], hi[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    t[j] = fmaxf(t[j], o.slope * t[j]);
-    vmax = fmaxf(vmax, fabsf(t[j]));
-    float a = t[j] * up;
-    if (fabsf(a) > 65504.f) { a = copysignf(65504.f, a); ++sat; }      // (refit_image_kernel repairs the image)
-    h0[j] = __float2half_rn(a);
-    h1[j] = __float2half_rn(a - __half2float(h0[j]));
+  for (int k = 0; k < 2; ++k) {
+    const emit_f2 st = t[k] * slope;
+    // leaky / plain ReLU / identity (0 <= slope <= 1): the larger of t and slope t, as a median with +inf
+    emit_f2 a = {__builtin_amdgcn_fmed3f(t[k].x, st.x, __builtin_inff()), __builtin_amdgcn_fmed3f(t[k].y, st.y, __builtin_inff())};
+    a = a * up;
+    vmaxs = fmaxf(vmaxs, fmaxf(fabsf(a.x), fabsf(a.y)));
+    const emit_f2 c = {__builtin_amdgcn_fmed3f(a.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(a.y, -65504.f, 65504.f)};
+    const emit_h2 p0 = __builtin_convertvector(c, emit_h2);
+    const emit_f2 r = c - __builtin_convertvector(p0, emit_f2);
+    const emit_h2 p1 = __builtin_convertvector(r, emit_h2);
+    lo[k] = __builtin_bit_cast(unsigned, p0);
+    hi[k] = __builtin_bit_cast(unsigned, p1);
   }
+  h0 = make_uint2(lo[0], lo[1]);
+  h1 = make_uint2(hi[0], hi[1]);
+}
+
+// the 4 channels e .. e + 3 (e % 4 == 0) of one pixel, e = linear NHWC element index of the tensor
+__device__ __forceinline__ void emit4(const ImgOut& o, float up, float4 v, unsigned e, float& vmaxs) {
+  uint2 h0, h1;
+  emit_split4(o.slope, up, v, vmaxs, h0, h1);
   uint16_t* dst = o.img + (size_t)(e >> 5) * 64 + (e & 31);
-  *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(h0);
-  *reinterpret_cast<uint2*>(dst + 32) = *reinterpret_cast<const uint2*>(h1);
+  *reinterpret_cast<uint2*>(dst) = h0;
+  *reinterpret_cast<uint2*>(dst + 32) = h1;
 }
 
 // The same through a buffer descriptor, for epilogues that must not branch around their stores (igemm_patch.hip: the
@@ -44,31 +65,22 @@ __device__ __forceinline__ void emit4(const ImgOut& o, float up, float4 v, unsig
 // fp32 tensor, or an out-of-range value for rows without a pixel -- the descriptor's range check drops those stores (and
 // every store when the launch has no such consumer: num_records 0) and `valid` keeps them out of the statistics.
 __device__ __forceinline__ void emit4_buffer(__amdgpu_buffer_rsrc_t rs, float slope, float up, float4 v, unsigned byte_off,
-                                             bool valid, float& vmax, int& sat) {
-  float t[4] = {v.x, v.y, v.z, v.w};
-  __half h0[4], h1[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    t[j] = fmaxf(t[j], slope * t[j]);
-    vmax = fmaxf(vmax, valid ? fabsf(t[j]) : 0.f);
-    float a = t[j] * up;
-    const bool over = fabsf(a) > 65504.f;
-    a = over ? copysignf(65504.f, a) : a;
-    sat += (over && valid) ? 1 : 0;
-    h0[j] = __float2half_rn(a);
-    h1[j] = __float2half_rn(a - __half2float(h0[j]));
-  }
+                                             bool valid, float& vmaxs) {
+  uint2 h0, h1;
+  emit_split4(slope, valid ? up : 0.f, v, vmaxs, h0, h1);
   // element e = byte_off / 4 -> halves (e >> 5) * 64 + (e & 31) -> bytes: ((e >> 5) * 64 + (e & 31)) * 2
   const unsigned e = byte_off >> 2;
   const unsigned ib = byte_off >= 0xffffff00u ? 0xffffff00u : (((e >> 5) << 6) + (e & 31)) * 2u;
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  const uint2 p0 = *reinterpret_cast<const uint2*>(h0), p1 = *reinterpret_cast<const uint2*>(h1);
-  __builtin_amdgcn_raw_buffer_store_b64((u32x2){p0.x, p0.y}, rs, ib, 0, 0);
-  __builtin_amdgcn_raw_buffer_store_b64((u32x2){p1.x, p1.y}, rs, ib, 64, 0);
+  __builtin_amdgcn_raw_buffer_store_b64((u32x2){h0.x, h0.y}, rs, ib, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b64((u32x2){h1.x, h1.y}, rs, ib, 64, 0);
 }
 
-// once per wave, after its last emit4: the largest magnitude it saw and its out-of-window count into the header
-__device__ __forceinline__ void emit_finish(const ImgOut& o, float vmax, int sat) {
+// once per wave, after its last emit4: the largest magnitude it saw and its out-of-window count into the header (the
+// count is in LANES that saw a value beyond the window, not in values: refit_image_kernel only asks whether it moved)
+__device__ __forceinline__ void emit_finish(const ImgOut& o, float up, float vmaxs) {
+  int sat = vmaxs > 65504.f ? 1 : 0;
+  float vmax = vmaxs / up;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));

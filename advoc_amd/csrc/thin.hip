@@ -203,7 +203,6 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
   const bool emit0 = o0.img != nullptr, emit1 = o1.img != nullptr;
   const float eup0 = emit0 ? emit_up_scale(o0.hdr[2]) : 1.f, eup1 = emit1 ? emit_up_scale(o1.hdr[2]) : 1.f;
   float evmax0 = 0.f, evmax1 = 0.f;
-  int esat0 = 0, esat1 = 0;
   if (threadIdx.x == 0) {
     if (emit0) o0.hdr[1] = __float_as_uint(1.f / eup0);
     if (emit1) o1.hdr[1] = __float_as_uint(1.f / eup1);
@@ -335,15 +334,15 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         const bool ok = okj && di == 0 && so[ps] != kThinOob;
-        emit4_buffer(rs_e0, o0.slope, eup0, v[ps], ok ? so[ps] : kThinOob, ok && emit0, evmax0, esat0);
-        emit4_buffer(rs_e1, o1.slope, eup1, v[ps], ok ? so[ps] : kThinOob, ok && emit1, evmax1, esat1);
+        emit4_buffer(rs_e0, o0.slope, eup0, v[ps], ok ? so[ps] : kThinOob, ok && emit0, evmax0);
+        emit4_buffer(rs_e1, o1.slope, eup1, v[ps], ok ? so[ps] : kThinOob, ok && emit1, evmax1);
       }
       wave_lds_sync();
     }
   }
 #undef ADVOC_THIN_PRELOAD
-  if (emit0) emit_finish(o0, evmax0, esat0);
-  if (emit1) emit_finish(o1, evmax1, esat1);
+  if (emit0) emit_finish(o0, eup0, evmax0);
+  if (emit1) emit_finish(o1, eup1, evmax1);
 }
 
 #undef PE_ROW
