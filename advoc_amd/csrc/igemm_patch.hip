@@ -125,7 +125,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 
   const float gslope = act_slope_p(p.grad_act);
   const int src_c0 = p.c0, src_c1 = p.c1, src_p0 = p.a0_pitch, src_p1 = p.a1_pitch;
-  const int abl = g.ablate;       // timing experiments only (ADVOC_H3_PATCH_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier
+  const int abl = g.ablate;       // timing experiments only (ADVOC_H3_PATCH_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier, 8 no halo DMA, 16 no B DMA
 
   // ---- persistent workgroups: the launch holds one workgroup per CU; XCD x walks its own contiguous range of tiles
   // (column tile slowest, so the workgroups an XCD runs together stream the same weights), and the stores of one
@@ -206,7 +206,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
                                   ((lpos ^ ((hx_ >> 1) & 7)) * 16)                                        \
                             : (int)0x80000000;                                                            \
       unsigned char* d_ = smem_b + (HB) * C::HALO_BYTES + blk_ * 1024;                                    \
-      if (blk_ >= C::HALO_BLOCKS || (abl & 1)) continue;                                                  \
+      if (blk_ >= C::HALO_BLOCKS || (abl & 9)) continue;                                                  \
       if (second_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_void_p)(d_), 16, voff_, 0, 0, 0); \
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (lds_void_p)(d_), 16, voff_, 0, 0, 0);         \
     }                                                                                                     \
@@ -219,7 +219,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     const int wslab_ = (wtap_ * p.n_total * ktot + (S2 ? (SL) >> 2 : (SL)) * 32) * 4;                     \
     _Pragma("unroll") for (int k = 0; k < C::BPW; ++k) {                                                  \
       unsigned char* d_ = smem_b + C::OFF_B + (ST) * C::B_STAGE + (wave * C::BPW + k) * 1024;             \
-      if (!(abl & 1))                                                                                     \
+      if (!(abl & 17))                                                                                    \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_p)(d_), 16, b_off[k & 1],                \
                                                  wslab_ + k * 8 * ktot * 4, 0, 0);                        \
     }                                                                                                     \
