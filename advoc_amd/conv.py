@@ -225,12 +225,12 @@ class Layer(object):
       self._names[direction] = buf.value.decode()
     return self._names[direction]
 
-  def _run(self, direction, fn):
+  def _run(self, direction, fn, extra_bytes=0.0):
     prof = Layer.profiler
     if prof is None:
       fn()
     else:
-      prof.timed(self.kernel_name(direction), self.flops, self.bytes_dir[direction], fn)
+      prof.timed(self.kernel_name(direction), self.flops, self.bytes_dir[direction] + extra_bytes, fn)
 
   def _timed_image(self, which, dy=None):
     """With a launch profiler attached, the operand-image passes of an image-based call are launched (and timed) on
@@ -332,8 +332,10 @@ class Layer(object):
       self.struct.y_img[k].act = c.struct.in_act
     self.struct.img_flags = flags | self._delayed_bits()
     try:
+      # (the consumers' operand images this launch writes: 2 fp16 terms = 4 bytes per element and consumer)
       self._run(0, lambda: _lib.check(
-          _lib.load().advoc_conv_forward(ctypes.byref(self.struct), _lib.stream()), 'advoc_conv_forward'))
+          _lib.load().advoc_conv_forward(ctypes.byref(self.struct), _lib.stream()), 'advoc_conv_forward'),
+                extra_bytes=4.0 * self.y.numel() * len(targets))
     finally:
       self.struct.img_flags = 0
       for k in (0, 1):
