@@ -49,6 +49,7 @@ class ConvLayer(ctypes.Structure):
       ('db_fused', _p), ('w_amax', _p), ('w_img', _p * 2), ('w_img_hdr', _p * 2),
       ('wgrad_table', _p),
       ('y_img', ImageOut * 2),
+      ('wgrad_ws', _p), ('wgrad_ws_bytes', _i64),
   ]
 
 WGRAD_TABLE_BYTES = 262144      # ADVOC_WGRAD_TABLE_BYTES
@@ -80,6 +81,7 @@ PROTOTYPES = {
     'advoc_tanh_affine_f32': (ctypes.c_int, [_p, _p, _i64, _f32, _f32, _p]),
     'advoc_mel_dbnorm_f32': (ctypes.c_int, [_p, _i64, _f32, _f32, _f32, _p]),
     'advoc_conv_workspace_bytes': (_i64, [_p, _i32]),
+    'advoc_conv_wgrad_ws_bytes': (_i64, [_p]),
     'advoc_conv_image_bytes': (_i64, [_p, _i32]),
     'advoc_conv_bias_fusable': (ctypes.c_int, [_p]),
     'advoc_conv_emits_images': (ctypes.c_int, [_p]),

@@ -75,6 +75,7 @@ class Layer(object):
 
   profiler = None   # set to a LaunchProfiler to time every launch
   _workspaces = {}
+  _wgrad_scratches = {}
   # True: the caller guarantees that between a forward() and the backward_weight() that follows it the layer's inputs
   # are unchanged, and that backward_data(dy) / backward_weight(dy) of one step see the same dy contents (the train
   # step of advoc_amd.model does): the operand images forward / backward_data leave behind are then read again by
@@ -96,6 +97,17 @@ class Layer(object):
     if ws is None or ws.numel() * 4 < nbytes:
       ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
       Layer._workspaces[device] = ws
+    return ws
+
+  @staticmethod
+  def _wgrad_scratch_for(device, nbytes):
+    """Scratch for the K slices of the image weight gradient (advoc_conv_layer.wgrad_ws): one buffer per device, shared by
+    all layers and grown on demand -- their backward_weight calls must therefore be ordered on ONE stream (the model runs
+    every weight gradient on its side stream, or everything on one)."""
+    ws = Layer._wgrad_scratches.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+      ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+      Layer._wgrad_scratches[device] = ws
     return ws
 
   def __init__(self, kind, x0, y, weight, bias=None, x1=None, in_w=None, out_w=None, stride=(2, 2),
@@ -168,6 +180,12 @@ class Layer(object):
           setattr(s, hdr_field, hdr.data_ptr())
           self._img += [img, hdr]
       self.tensors = self.tensors + tuple(self._img)
+      need = _lib.load().advoc_conv_wgrad_ws_bytes(ctypes.byref(s))
+      if need > 0:
+        wws = Layer._wgrad_scratch_for(x0.device, need)
+        s.wgrad_ws = wws.data_ptr()
+        s.wgrad_ws_bytes = wws.numel() * 4
+        self.tensors = self.tensors + (wws,)
     s.img_flags = 0
     # headers of dy_img per caller ROLE (set_dy_role): one layer object can see output gradients of different losses in
     # one train step (the discriminator's fake pass: D-loss gradients in the D step, G-loss gradients in the G step);

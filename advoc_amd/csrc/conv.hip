@@ -450,6 +450,14 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
 
+extern "C" int64_t advoc_conv_wgrad_ws_bytes(const advoc_conv_layer* L) {
+  if (validate_layer(L) != ADVOC_OK) return 0;
+  WgradParams p;
+  float dummy = 0.f;
+  if (build_backward_weight(L, &dummy, &dummy, p) != ADVOC_OK) return 0;
+  return wgrad_h3_partial_bytes(p);
+}
+
 extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float* dy, float* dw,
                                           float* db, int32_t accumulate, advoc_stream_t stream) {
   int rc = validate_layer(L);
@@ -463,6 +471,8 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
       !fits_int32(L->y.n, L->y.h, L->y.w_pitch, L->y.c))
     return ADVOC_ERR_UNSUPPORTED;
   p.accumulate = accumulate;
+  p.part_ws = L->wgrad_ws;
+  p.part_ws_bytes = L->wgrad_ws ? L->wgrad_ws_bytes : 0;
   const int ca = p.P.c0 + p.P.c1;
   if (ca <= 2) {
     const int cb = p.Q.c0 + p.Q.c1;

@@ -56,6 +56,10 @@ struct WgradParams {
   // gradient -- are taken on the way: added to qsum_table[kColsumReplicas][cb] (zeroed scratch), folded into qsum_out
   float* qsum_out;
   float* qsum_table;
+  // wgrad_h3 only: scratch for the K slices' partial tiles (advoc_conv_layer.wgrad_ws); when it holds them all the slices
+  // are stored plainly and summed IN SLICE ORDER by a second launch -- no zero fill, no atomics, a deterministic sum
+  float* part_ws;
+  int64_t part_ws_bytes;
 };
 
 int launch_wgrad_mfma(const WgradParams& p, hipStream_t stream,
@@ -71,6 +75,7 @@ int wgrad_h3_make_image(const Operand& o, int batch, uint16_t* img, unsigned* hd
                         float* colsum0 = nullptr, float* colsum_table = nullptr);
 int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned* p_hdr, const uint16_t* q_img,
                     const unsigned* q_hdr, hipStream_t stream, const char** name_only = nullptr);
+int64_t wgrad_h3_partial_bytes(const WgradParams& p);      // what part_ws must hold for the atomics-free path (0: n/a)
 
 int launch_wgrad_thin_mfma(const WgradParams& p, hipStream_t stream,
                            const char** name_only = nullptr);   // P <= 2 channels, Q % 32, on MFMA

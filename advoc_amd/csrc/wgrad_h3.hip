@@ -249,6 +249,17 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   const float unscale = __uint_as_float(im.p_hdr[1]) * __uint_as_float(im.q_hdr[1]);
+  if (p.part_ws) {
+    // the K slice's partial tile in register order, 256 contiguous bytes per store: wgrad_reduce_kernel sums the slices
+    float* part = p.part_ws + (size_t)vblock * (C::ROWS * C::COLS) + (size_t)wave * (MT * NT * 1024) + lane;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[((i * NT + j) * 16 + r) * 64] = acc[i][j][r] * unscale;
+    return;
+  }
   const int half = lane >> 5, l32 = lane & 31;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -267,6 +278,32 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
       }
     }
   }
+}
+
+// dw <- (dw +) sum over the K slices z, IN ORDER, of the partial tiles the kernels above parked (slice z of tile t at
+// block z * tiles + t, values in register order: [wave][i][j][r][lane]).  One thread per tile element.
+template <int WGM, int NT>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p, int tiles_n, int tiles, int ksplit) {
+  using C = WCfg<WGM, NT>;
+  constexpr int TILE = C::ROWS * C::COLS;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int tile_id = (int)(gid / TILE);
+  const int e = (int)(gid - (int64_t)tile_id * TILE);
+  if (tile_id >= tiles) return;
+  const float* src = p.part_ws + (size_t)tile_id * TILE + e;
+  float sum = 0.f;
+  for (int z = 0; z < ksplit; ++z) sum += src[(size_t)z * tiles * TILE];
+  const int lane = e & 63, r = (e >> 6) & 15, blk = e >> 10;          // blk = (wave * MT + i) * NT + j
+  const int j = blk % NT, wi = blk / NT, i = wi % C::MT, wave = wi / C::MT;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
+  const int r0 = (tile_id / tiles_n) * C::ROWS + (wm * C::MT + i) * 32;
+  const int b = (tile_id % tiles_n) * C::COLS + (wn * NT + j) * 32 + (lane & 31);
+  if (r0 >= p.ntaps * ca || b >= cb) return;
+  const int t_ = r0 / ca;                                              // a 32-row block never straddles a tap (ca % 32 == 0)
+  const int a = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  float* out = p.dw + ((int64_t)(p.tap[t_] >> 16) * ca + (r0 - t_ * ca) + a) * cb + b;
+  *out = p.accumulate ? *out + sum : sum;
 }
 
 __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, const WgradImages im, int tiles_n,
@@ -326,28 +363,12 @@ int wgrad_h3_make_image(const Operand& o, int batch, uint16_t* img, unsigned* hd
 
 // p_img / q_img: images of P and Q (source 1 follows source 0 at the 256-byte-rounded size of source 0), hdr: their
 // {amax, 2^-s} words; the caller has filled them (wgrad_h3_make_image or an earlier forward / backward-data launch).
-int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned* p_hdr, const uint16_t* q_img,
-                    const unsigned* q_hdr, hipStream_t stream, const char** name_only) {
-  if (!wgrad_h3_eligible(p)) return ADVOC_ERR_UNSUPPORTED;
+namespace {
+// tile edge, tiles, K slices and grid points per slice of a launch
+struct WgradPlan { int edge, tiles_n; int64_t tiles, ksplit, chunk; };
+bool wgrad_h3_plan(const WgradParams& p, WgradPlan& pl) {
   const bool big = wgrad_big_tile(p);
-  if (name_only) { *name_only = big ? "wgrad_h3_256_kernel" : "wgrad_h3_kernel"; return ADVOC_OK; }
-  if (!p_img || !q_img || !p_hdr || !q_hdr) return ADVOC_ERR_NULL;
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
-  if (!p.accumulate) {
-    hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
-    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
-  }
-  int64_t pb0, pb1, qb0, qb1;
-  wgrad_h3_operand_bytes(p.P, p.batch, &pb0, &pb1);
-  wgrad_h3_operand_bytes(p.Q, p.batch, &qb0, &qb1);
-  WgradImages im = {};
-  im.p0 = p_img; im.p1 = p.P.c1 ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(p_img) + pb0) : nullptr;
-  im.q0 = q_img; im.q1 = p.Q.c1 ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(q_img) + qb0) : nullptr;
-  im.p0_bytes = (int)((int64_t)4 * p.batch * p.P.h * p.P.pitch0 * p.P.c0);
-  im.p1_bytes = (int)((int64_t)4 * p.batch * p.P.h * p.P.pitch1 * p.P.c1);
-  im.q0_bytes = (int)((int64_t)4 * p.batch * p.Q.h * p.Q.pitch0 * p.Q.c0);
-  im.q1_bytes = (int)((int64_t)4 * p.batch * p.Q.h * p.Q.pitch1 * p.Q.c1);
-  im.p_hdr = p_hdr; im.q_hdr = q_hdr;
   const int edge = big ? 256 : 128;
   const int tiles_m = (p.ntaps * ca + edge - 1) / edge, tiles_n = (cb + edge - 1) / edge;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
@@ -362,7 +383,40 @@ int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned*
   if (ksplit < 1) ksplit = 1;
   int64_t chunk = ceil_div(ceil_div(M, ksplit), WK) * WK;
   ksplit = ceil_div(M, chunk);
-  if (chunk > 0x3fffffffLL || tiles * ksplit > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
+  if (chunk > 0x3fffffffLL || tiles * ksplit > 0x7fffffffLL) return false;
+  pl = {edge, tiles_n, tiles, ksplit, chunk};
+  return true;
+}
+}  // namespace
+
+int64_t wgrad_h3_partial_bytes(const WgradParams& p) {
+  WgradPlan pl;
+  if (!wgrad_h3_eligible(p) || !wgrad_h3_plan(p, pl)) return 0;
+  return pl.tiles * pl.ksplit * (int64_t)pl.edge * pl.edge * 4;
+}
+
+int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned* p_hdr, const uint16_t* q_img,
+                    const unsigned* q_hdr, hipStream_t stream, const char** name_only) {
+  if (!wgrad_h3_eligible(p)) return ADVOC_ERR_UNSUPPORTED;
+  const bool big = wgrad_big_tile(p);
+  if (name_only) { *name_only = big ? "wgrad_h3_256_kernel" : "wgrad_h3_kernel"; return ADVOC_OK; }
+  if (!p_img || !q_img || !p_hdr || !q_hdr) return ADVOC_ERR_NULL;
+  const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
+  int64_t pb0, pb1, qb0, qb1;
+  wgrad_h3_operand_bytes(p.P, p.batch, &pb0, &pb1);
+  wgrad_h3_operand_bytes(p.Q, p.batch, &qb0, &qb1);
+  WgradImages im = {};
+  im.p0 = p_img; im.p1 = p.P.c1 ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(p_img) + pb0) : nullptr;
+  im.q0 = q_img; im.q1 = p.Q.c1 ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(q_img) + qb0) : nullptr;
+  im.p0_bytes = (int)((int64_t)4 * p.batch * p.P.h * p.P.pitch0 * p.P.c0);
+  im.p1_bytes = (int)((int64_t)4 * p.batch * p.P.h * p.P.pitch1 * p.P.c1);
+  im.q0_bytes = (int)((int64_t)4 * p.batch * p.Q.h * p.Q.pitch0 * p.Q.c0);
+  im.q1_bytes = (int)((int64_t)4 * p.batch * p.Q.h * p.Q.pitch1 * p.Q.c1);
+  im.p_hdr = p_hdr; im.q_hdr = q_hdr;
+  WgradPlan pl;
+  if (!wgrad_h3_plan(p, pl)) return ADVOC_ERR_UNSUPPORTED;
+  const int edge = pl.edge, tiles_n = pl.tiles_n;
+  const int64_t tiles = pl.tiles, ksplit = pl.ksplit, chunk = pl.chunk;
   constexpr int lds128 = 2 * WCfg<2, 2>::STAGE, lds256 = 2 * WCfg<4, 4>::STAGE;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
@@ -370,14 +424,36 @@ int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned*
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
   if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }
   if (attr2 != hipSuccess) { note_hip_error(attr2); return ADVOC_ERR_HIP; }
+  // K slices through scratch and an ordered sum when the caller's scratch holds them; fp32 atomics into the zeroed dw else
+  WgradParams pp = p;
+  const int64_t part_bytes = tiles * ksplit * (int64_t)edge * edge * 4;
+  // (the 128 x 128 launches are small and run two workgroups per CU: twice the partial tiles and a second launch cost them
+  // +9 %, the 256 x 256 ones gain 3 %: ADVOC_WGRAD_H3_ORDERED=2 orders both, 0 neither)
+  const bool ordered = p.part_ws && p.part_ws_bytes >= part_bytes &&
+                       (tuning().wgrad_h3_ordered >= 2 || (tuning().wgrad_h3_ordered == 1 && big));
+  if (!ordered) {
+    pp.part_ws = nullptr;
+    if (!p.accumulate) {
+      hipError_t e = hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.ntaps * ca * cb, stream);
+      if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    }
+  }
   ADVOC_CLEAR_LAUNCH_ERROR();
   if (big)
-    hipLaunchKernelGGL(wgrad_h3_256_kernel, dim3((unsigned)(tiles * ksplit)), dim3(512), lds256, stream, p,
+    hipLaunchKernelGGL(wgrad_h3_256_kernel, dim3((unsigned)(tiles * ksplit)), dim3(512), lds256, stream, pp,
                        im, tiles_n, (int)tiles, (int)chunk);
   else
-    hipLaunchKernelGGL(wgrad_h3_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), lds128, stream, p, im,
+    hipLaunchKernelGGL(wgrad_h3_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), lds128, stream, pp, im,
                        tiles_n, (int)tiles, (int)chunk);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
+  if (ordered) {
+    const unsigned nb = (unsigned)(tiles * edge * edge / 256);
+    if (big)
+      hipLaunchKernelGGL((wgrad_reduce_kernel<4, 4>), dim3(nb), dim3(256), 0, stream, pp, tiles_n, (int)tiles, (int)ksplit);
+    else
+      hipLaunchKernelGGL((wgrad_reduce_kernel<2, 2>), dim3(nb), dim3(256), 0, stream, pp, tiles_n, (int)tiles, (int)ksplit);
+    ADVOC_RETURN_IF_LAUNCH_FAILED();
+  }
   return ADVOC_OK;
 }
 

@@ -293,6 +293,13 @@ typedef struct advoc_conv_layer {
    * check instead of an image pass).  Honoured by the image kernels only: advoc_conv_emits_images() says whether this
    * layer's forward call will write them; img == NULL: none. */
   struct { uint16_t* img; uint32_t* hdr; int32_t act; int32_t reserved; } y_img[2];
+  /* optional (backward-weight calls of the image kernels): device scratch for the partial tiles of the K slices the
+   * pixel grid is cut into, advoc_conv_wgrad_ws_bytes() of it.  With it the slices are stored plainly and summed in
+   * slice order by a second launch -- no zero fill of dw, no fp32 atomics (a quarter of the kernel's time on the large
+   * layers), and a sum that does not depend on the order workgroups finish in.  May be SHARED by all layers whose
+   * backward-weight calls run on one stream; like wgrad_table it is not part of `workspace`.  NULL: atomics. */
+  float* wgrad_ws;
+  int64_t wgrad_ws_bytes;
 } advoc_conv_layer;
 #define ADVOC_WGRAD_TABLE_BYTES 262144
 
@@ -342,6 +349,8 @@ int advoc_conv_make_image(const advoc_conv_layer* layer, int32_t which, const fl
 
 /* Scratch the layer can use for `direction` (0 forward, 1 backward-data, 2 backward-weight); 0 when it needs none. */
 int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* layer, int32_t direction);
+/* bytes of advoc_conv_layer.wgrad_ws this layer's backward-weight call can use (0: it would not use any) */
+int64_t advoc_conv_wgrad_ws_bytes(const advoc_conv_layer* layer);
 
 /* Forward.  Replaces TF Conv2D / Conv2DBackpropInput(+BiasAdd, activations, concat, dropout)
  * built at advoc_model.py:89-158 (generator) and :184-202 (discriminator). */

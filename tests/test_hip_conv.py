@@ -2,6 +2,8 @@
 (oracle/advoc_torch.py), layer shapes mirroring each layer type of AdVoc / AdVoc-small at
 reduced size, including the odd widths (SAME pad (1,2)), the skip concat, the [:, :, :-1, :]
 trims, dropout masks and the thin edge layers.  Tolerance: fp32 summation-order noise."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -411,6 +413,42 @@ def test_layer_operand_image_weight_gradient_256_tile(hip, case, hipenv):
   L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
   assert L.kernel_name(2) == 'wgrad_h3_256_kernel', L.kernel_name(2)
   test_layer_all_directions(hip, case)
+
+
+@gpu
+@pytest.mark.parametrize('tile', [1, 2])
+def test_weight_gradient_k_slices_summed_in_order(hip, hipenv, tile):
+  """advoc_conv_layer.wgrad_ws: the K slices of the image weight gradient are parked and summed in slice order by a
+  second launch instead of meeting in fp32 atomics -- the same numbers (up to the order of fp32 additions), bit for bit
+  the same from call to call (the atomic sum is not), and `accumulate` adds to what dw held.  Both tile sizes."""
+  from advoc_amd import conv
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(43)
+  x = torch.randn(4, 32, 66, 128, generator=g).to(dev)
+  w = (torch.randn(4, 4, 128, 256, generator=g) * 0.05).to(dev)
+  dy = torch.randn(4, 16, 33, 256, generator=g).to(dev)
+  y = torch.empty(4, 16, 33, 256, device=dev)
+
+  def run(ordered, accumulate=False, base=None):
+    hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_WGRAD_H3_MIN_M=1, ADVOC_WGRAD_H3_TILE=tile, ADVOC_WGRAD_H3_ORDERED=ordered)
+    L = conv.Layer(conv.CONV, x, y, w, None, stride=(2, 2), pad=(1, 1), in_act=conv.ACT_LRELU)
+    assert L.kernel_name(2) == ('wgrad_h3_256_kernel' if tile == 2 else 'wgrad_h3_kernel')
+    assert L.struct.wgrad_ws and L.struct.wgrad_ws_bytes >= hip.advoc_conv_wgrad_ws_bytes(ctypes.byref(L.struct)) > 0
+    dw = torch.full_like(w, float('nan')) if base is None else base.clone()
+    L.backward_weight(dy, dw, accumulate=accumulate)
+    torch.cuda.synchronize()
+    return dw
+  atomic = run(0)
+  a, b = run(2), run(2)
+  assert torch.equal(a, b)                                   # ordered: reproducible (and the NaN fill was overwritten)
+  assert rel(a, atomic) < 1e-6
+  base = torch.randn(w.shape, generator=g).to(dev)
+  acc = run(2, accumulate=True, base=base)
+  assert rel(acc, base + a) < 1e-6
+  # the default orders the 256 x 256 tile only
+  d1, d2 = run(1), run(1)
+  if tile == 2:
+    assert torch.equal(d1, d2) and torch.equal(d1, a)
 
 
 @gpu
