@@ -80,7 +80,9 @@ struct PCfg {
   static constexpr int HALO_BYTES = HALO_BLOCKS * 1024;
   static constexpr int B_STAGE = BROWS * 128;
   static constexpr int OFF_B = 2 * HALO_BYTES;
-  static constexpr int LDS_BYTES = OFF_B + 2 * B_STAGE;     // 146 | 160 | 142 | 110 KiB
+  // NPH = 3 (24 MFMAs per wave and tap, half the other instances'): FOUR tap buffers, two taps per rendezvous
+  static constexpr int NBUF = NPH == 3 ? 4 : 2;
+  static constexpr int LDS_BYTES = OFF_B + NBUF * B_STAGE;  // 146 | 160 | 142 | 142 KiB
   static constexpr int PTS_W = 32 * MT;                    // grid points per wave
   static constexpr int EPI_BYTES = WAVES * (32 * 36 * 4 + 2 * PTS_W * 4);
   static_assert(WAVES * NST * HPS >= HALO_BLOCKS, "every halo block has a DMA slot");
@@ -275,6 +277,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 #pragma unroll
   for (int t = 0; t < NST; ++t) ADVOC_P3_HALO(0, t, 0);
   ADVOC_P3_B(0, 0, 0);
+  if (C::NBUF == 4) ADVOC_P3_B(0, 1, 1);
 
   // ---- K loop: one barrier per step.  Wait for the own DMAs of this step's B tile (and, at a slice boundary, of the
   // halo), barrier (everyone's data landed, everyone finished the step before), issue the next step's B tile into the
@@ -284,6 +287,43 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // step are fetched under the MFMAs of the second (a0 is carried across the barrier) and only the B fragments wait
   // for the barrier. ----
   f16x8 a0[MT][2], a1[MT][2], b0[NT][2], b1[NT][2];
+  if constexpr (C::NBUF == 4) {
+    // Two taps per rendezvous (NST = 4: taps 0, 1 in buffers 0, 1, taps 2, 3 in buffers 2, 3): the pair that is not being
+    // read is filled, with the halo pieces of both its steps, behind the first MFMA group of the pair that is.
+    static_assert(C::NBUF != 4 || (NST == 4 && !C::CARRY && !C::DOUBLE_B), "two tap pairs per K slice");
+#define ADVOC_P3_TAP(T, BUF, ISSUE)                                                                       \
+  ADVOC_P3_LOAD_A(a0, hb, T, 0);                                                                          \
+  ADVOC_P3_LOAD_B(b0, BUF, 0);                                                                            \
+  ADVOC_P3_LOAD_A(a1, hb, T, 1);                                                                          \
+  ADVOC_P3_MFMA(a0, b0);                                                                                  \
+  ISSUE;                                                                                                  \
+  ADVOC_P3_LOAD_B(b0, BUF, 1);                                                                            \
+  ADVOC_P3_MFMA(a1, b0);
+    for (int s = 0; s < nslices; ++s) {
+      const int hb = s & 1;
+      const bool more = s + 1 < nslices;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!(abl & 4)) __builtin_amdgcn_s_barrier();
+      ADVOC_P3_TAP(0, 0, {
+        ADVOC_P3_B(s, 2, 2);
+        ADVOC_P3_B(s, 3, 3);
+        if (more) { ADVOC_P3_HALO(s + 1, 0, hb ^ 1); ADVOC_P3_HALO(s + 1, 1, hb ^ 1); }
+      })
+      ADVOC_P3_TAP(1, 1, {})
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!(abl & 4)) __builtin_amdgcn_s_barrier();
+      ADVOC_P3_TAP(2, 2, {
+        if (more) {
+          ADVOC_P3_B(s + 1, 0, 0);
+          ADVOC_P3_B(s + 1, 1, 1);
+          ADVOC_P3_HALO(s + 1, 2, hb ^ 1);
+          ADVOC_P3_HALO(s + 1, 3, hb ^ 1);
+        }
+      })
+      ADVOC_P3_TAP(3, 3, {})
+    }
+#undef ADVOC_P3_TAP
+  } else
   for (int s = 0; s < nslices; ++s) {
     const int hb = s & 1;
     const bool more = s + 1 < nslices;

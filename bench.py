@@ -423,6 +423,8 @@ def roofline_from(prof, model, batch, ms_per_step, prof_steps, verbose):
                   launches=r['launches'], avg_launch_ms=r['ms'] / r['launches'],
                   share_of_step=r['ms'] / prof_steps / ms_per_step, instrumented_steps=prof_steps,
                   measured='HIP events per launch on %d serial steps right after the timed region' % prof_steps,
+                  launch_covers=('wgrad_h3_256_kernel + the wgrad_reduce_kernel that sums its K slices in order (one C call; '
+                                 'rocprofv3 lists the two separately)') if name == 'wgrad_h3_256_kernel' else name,
                   kernels=kernels[:24])
   if top['bound'] == 'mfma':
     roofline.update(pipe=mfma_pipe(name)[1],
