@@ -357,8 +357,19 @@ __global__ __launch_bounds__(576) void lws_causal_fast_kernel(const CausalParams
   }
 }
 
-// One batch sweep on LDS tiles: a workgroup = kSweepFrames frames of one clip (+ Q - 1 frames either side), a thread =
-// one bin walking the tile's frames with its weights in registers.
+// One batch sweep on LDS tiles: a workgroup = kSweepFrames frames of one clip (+ Q - 1 frames either side).
+//
+// A thread owns ONE bin and ALL the tile's frames: the value at (row R, bin f + p) is read from LDS once and feeds every
+// frame tt = R - (Q - 1) - q it is a tap (q, p) of -- 14 x 9 = 126 reads for 8 x 63 = 504 complex MACs where one frame at
+// a time re-read every value up to seven times (the sweeps were bound by exactly those reads).  For the weights to stay
+// scalar the rotation R_q(f + p) must not depend on the lane: a WAVE holds bins of one residue class cl = f mod 4 (f = 4 j
+// + cl, j = the lane's index), so W[q][p][(cl + p) mod 4] is one scalar load per (q, p), and rows are stored as four
+// PLANES by bin mod 4 -- bin m at plane m & 3, index (m + 4) >> 2 -- so that the lanes of a wave read consecutive words
+// (bins 4 apart in an interleaved row would hit 4 of the 32 banks).  Eight accumulators per thread, no per-thread weights.
+constexpr int kPlane = 132;                     // float2 per plane: bins -4 .. 516 -> indices 0 .. 130
+constexpr int kPRow = 4 * kPlane;               // float2 per planar row
+__device__ __forceinline__ int planar(int m) { return (m & 3) * kPlane + ((m + 4) >> 2); }
+
 __global__ __launch_bounds__(576) void lws_sweep_fast_kernel(const float2* __restrict__ in, float2* __restrict__ out,
                                                              const float* __restrict__ mag,
                                                              const float* __restrict__ mean_mag, int T, float thr_mult,
@@ -366,43 +377,83 @@ __global__ __launch_bounds__(576) void lws_sweep_fast_kernel(const float2* __res
                                                              const float* __restrict__ tile_max) {
   extern __shared__ __attribute__((aligned(16))) float2 lws_smem[];
   constexpr int kRows = kSweepFrames + 2 * (kFQ - 1);
-  float2* rows = lws_smem + kFH;
+  float2* rows = lws_smem;
   const int clip = blockIdx.x / tiles_per_clip;
   // sparse mode (advoc_lws_batch_sweeps_c64): no bin of this tile is above the threshold -> nothing to do, `out` already
   // holds these bins (both buffers start equal and a bin below a non-increasing threshold has never been touched)
   if (tile_max && !(tile_max[blockIdx.x] > thr_mult * mean_mag[clip])) return;
   const int t0 = (blockIdx.x - clip * tiles_per_clip) * kSweepFrames;
-  const int f = threadIdx.x < kFBins ? threadIdx.x : kFBins - 1;
-  const bool live = threadIdx.x < kFBins;
   const float2* src = in + (int64_t)clip * T * kFBins;
-#pragma unroll 2
-  for (int r = 0; r < kRows; ++r) {
-    const int t = t0 - (kFQ - 1) + r;
-    float2 v = make_float2(0.f, 0.f);
-    if (t >= 0 && t < T) v = src[(int64_t)t * kFBins + f];
-    if (live) store_bin(rows + r * kFRow, f, v);
-  }
-  float2 rot[2 * kFQ - 1];
-  bin_rotations(f, rot);
-  const float thr = thr_mult * mean_mag[clip];
-  __syncthreads();
-  const int nt = T - t0 < kSweepFrames ? T - t0 : kSweepFrames;
-  for (int tt = 0; tt < nt; ++tt) {
-    const int64_t i = ((int64_t)clip * T + t0 + tt) * kFBins + f;
-    const float a = mag[i];
-    const float2* centre = rows + (tt + kFQ - 1) * kFRow;
-    float2 v = centre[f];
-    if (a > thr) {
-      float2 z = make_float2(0.f, 0.f);
-      row_dispatch<0>(centre - 3 * kFRow, centre, f, W, rot, z);
-      row_dispatch<1>(centre - 2 * kFRow, centre, f, W, rot, z);
-      row_dispatch<2>(centre - 1 * kFRow, centre, f, W, rot, z);
-      row_dispatch<3>(centre, centre, f, W, rot, z);
-      row_dispatch<4>(centre + 1 * kFRow, centre, f, W, rot, z);
-      row_dispatch<5>(centre + 2 * kFRow, centre, f, W, rot, z);
-      row_dispatch<6>(centre + 3 * kFRow, centre, f, W, rot, z);
-      v = with_phase_of(a, z, v);
+  // ---- the tile's rows, coalesced (thread = bin), into the planar layout with the mirrored bins either side ----
+  {
+    const int b = threadIdx.x;
+    if (b < kFBins) {
+      float2 vr[kRows];                                    // every row's load in flight before the first LDS write
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) {
+        const int t = t0 - (kFQ - 1) + r;
+        vr[r] = make_float2(0.f, 0.f);
+        if (t >= 0 && t < T) vr[r] = src[(int64_t)t * kFBins + b];
+      }
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) {
+        const float2 v = vr[r];
+        float2* row = rows + r * kPRow;
+        row[planar(b)] = v;
+        const float2 cv = make_float2(v.x, -v.y);          // bin m < 0 is conj(bin -m), bin m >= 513 is conj(bin 1024 - m)
+        if (b >= 1 && b <= kFH) row[planar(-b)] = cv;
+        if (b >= kFBins - 1 - kFH && b <= kFBins - 2) row[planar(2 * (kFBins - 1) - b)] = cv;
+      }
     }
+  }
+  // ---- wave -> residue class, lane -> index within it: waves 0-2 class 0 (129 bins), 3-4 / 5-6 / 7-8 classes 1 / 2 / 3 ----
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cl = wave < 3 ? 0 : 1 + ((wave - 3) >> 1);
+  const int jn = cl == 0 ? 129 : 128;
+  const int jraw = (wave < 3 ? wave : ((wave - 3) & 1)) * 64 + (threadIdx.x & 63);
+  const bool live = jraw < jn;
+  const int j = live ? jraw : jn - 1;                     // (idle lanes shadow the class's last bin, never store)
+  const int f = 4 * j + cl;
+  const float thr = thr_mult * mean_mag[clip];
+  const int nt = T - t0 < kSweepFrames ? T - t0 : kSweepFrames;
+  // the tile's magnitudes at this bin; a wave none of whose bins is above the threshold in any frame skips the taps
+  float a[kSweepFrames];
+  bool any = false;
+#pragma unroll
+  for (int tt = 0; tt < kSweepFrames; ++tt) {
+    a[tt] = tt < nt ? mag[((int64_t)clip * T + t0 + tt) * kFBins + f] : 0.f;
+    any = any || a[tt] > thr;
+  }
+  const bool wave_active = __ballot(any && live) != 0;
+  __syncthreads();
+  f2v z[kSweepFrames];
+#pragma unroll
+  for (int tt = 0; tt < kSweepFrames; ++tt) z[tt] = (f2v){0.f, 0.f};
+#pragma unroll 1                                          // (unrolled, the scheduler hoists all 126 reads and spills)
+  for (int p = wave_active ? -(kFL - 1) : kFL; p <= kFL - 1; ++p) {
+    const int cp = cl + p;                                // uniform
+    const int off = (cp & 3) * kPlane + ((cp + 4) >> 2) + j;
+    float2 w[2 * kFQ - 1];
+#pragma unroll
+    for (int qi = 0; qi < 2 * kFQ - 1; ++qi) w[qi] = W[(qi * kFKW + p + kFL - 1) * kFP + (cp & 3)];      // scalar loads
+    if (p == 0) w[kFQ - 1] = make_float2(0.f, 0.f);       // the bin itself is not a tap
+#pragma unroll
+    for (int R = 0; R < kRows; ++R) {
+      const f2v x = *reinterpret_cast<const f2v*>(rows + R * kPRow + off);
+#pragma unroll
+      for (int qi = 0; qi < 2 * kFQ - 1; ++qi) {
+        const int tt = R - qi;                            // row R = frame tt + (Q - 1) + q, q = qi - (Q - 1)
+        if (tt < 0 || tt >= kSweepFrames) continue;
+        cmac(z[tt], w[qi], x);
+      }
+    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < kSweepFrames; ++tt) {
+    if (tt >= nt) break;
+    const int64_t i = ((int64_t)clip * T + t0 + tt) * kFBins + f;
+    float2 v = rows[(tt + kFQ - 1) * kPRow + planar(f)];
+    if (a[tt] > thr) v = with_phase_of(a[tt], make_float2(z[tt].x, z[tt].y), v);
     if (live) out[i] = v;
   }
 }
@@ -507,7 +558,7 @@ extern "C" int advoc_lws_batch_c64(const float* spec_in, float* spec_out, const 
   if (Q == kFQ && L == kFL && period == kFP && bins == kFBins) {
     const int64_t tiles_per_clip = advoc::ceil_div(nframes, kSweepFrames);
     if (clips * tiles_per_clip > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
-    constexpr size_t lds_sweep = sizeof(float2) * (size_t)(kSweepFrames + 2 * (kFQ - 1)) * kFRow;
+    constexpr size_t lds_sweep = sizeof(float2) * (size_t)(kSweepFrames + 2 * (kFQ - 1)) * kPRow;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lws_sweep_fast_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep);
     if (attr != hipSuccess) { advoc::note_hip_error(attr); return ADVOC_ERR_HIP; }
@@ -566,7 +617,7 @@ extern "C" int advoc_lws_batch_sweeps_c64(float* spec_a, float* spec_b, const fl
     hipLaunchKernelGGL(lws_tile_max_kernel, dim3((unsigned)(clips * tiles_per_clip)), dim3(256), 0, st, mag, (int)nframes,
                        (int)tiles_per_clip, tile_work);
     ADVOC_RETURN_IF_LAUNCH_FAILED();
-    constexpr size_t lds_sweep = sizeof(float2) * (size_t)(kSweepFrames + 2 * (kFQ - 1)) * kFRow;
+    constexpr size_t lds_sweep = sizeof(float2) * (size_t)(kSweepFrames + 2 * (kFQ - 1)) * kPRow;
     const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lws_sweep_fast_kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep);
     if (attr != hipSuccess) { advoc::note_hip_error(attr); return ADVOC_ERR_HIP; }
