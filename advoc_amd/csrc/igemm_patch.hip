@@ -92,7 +92,9 @@ struct PCfg {
 // BWD = 0: forward epilogue (bias, dropout mask on the result, one destination); BWD = 1: backward-data epilogue
 // (activation gradient at the pre-activation value, the consumer's BN affine / dropout mask, accumulate, two
 // destinations)
-template <int NPH, int W, int BWD>
+// NE: consumers whose operand images the (forward) epilogue writes, in oimg[0 .. NE): a compile-time count, so that a
+// launch pays for the image arithmetic of the consumers it has and no more
+template <int NPH, int W, int BWD, int NE>
 __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, const PatchGeom& g) {
   using C = PCfg<NPH, W>;
   constexpr int NST = C::NST, BN = C::BN, HPS = C::HPS, MT = C::MT, NT = C::NT;
@@ -433,7 +435,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const int trow = le >> 3, tq = le & 7;
   const bool use_grad = BWD && p.grad_act != ADVOC_ACT_NONE;
   // forward: consumers' operand images of the output (image_emit.h), one-pass scale from the consumer header
-  const bool emit0 = !BWD && p.oimg[0].img != nullptr, emit1 = !BWD && p.oimg[1].img != nullptr;
+  constexpr bool emit0 = !BWD && NE >= 1, emit1 = !BWD && NE >= 2;
   const float eup0 = emit0 ? emit_up_scale(p.oimg[0].hdr[2]) : 1.f, eup1 = emit1 ? emit_up_scale(p.oimg[1].hdr[2]) : 1.f;
   float evmax0 = 0.f, evmax1 = 0.f;
   if (!BWD && tid == 0) {
@@ -543,8 +545,8 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const bool ok = so[ps] != kOob && di == 0;
-          emit4_buffer(rs_e0, p.oimg[0].slope, eup0, v[ps], ok ? so[ps] : kOob, ok && emit0, evmax0);
-          emit4_buffer(rs_e1, p.oimg[1].slope, eup1, v[ps], ok ? so[ps] : kOob, ok && emit1, evmax1);
+          if (emit0) emit4_buffer(rs_e0, p.oimg[0].slope, eup0, v[ps], ok ? so[ps] : kOob, ok, evmax0);
+          if (emit1) emit4_buffer(rs_e1, p.oimg[1].slope, eup1, v[ps], ok ? so[ps] : kOob, ok, evmax1);
         }
       }
       wave_lds_sync();
@@ -557,14 +559,22 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   }  // tiles
 }
 
-template <int NPH, int BWD>
+template <int NPH, int BWD, int NE>
 __global__ __launch_bounds__(512, 1) void patch_gemm_h3_kernel(const GatherGemmParams p, const PatchGeom g) {
-  patch_gemm_h3_body<NPH, 8, BWD>(p, g);
+  patch_gemm_h3_body<NPH, 8, BWD, NE>(p, g);
 }
 
-template <int NPH, int BWD>
-int launch_patch(const GatherGemmParams& p, const PatchGeom& g, hipStream_t stream, const char** name_only) {
+template <int NPH, int BWD, int NE = 0>
+int launch_patch(const GatherGemmParams& p_in, const PatchGeom& g, hipStream_t stream, const char** name_only) {
   using C = PCfg<NPH, 8>;
+  if (!BWD && NE == 0 && !name_only && (p_in.oimg[0].img || p_in.oimg[1].img)) {
+    // forward launch with image consumers: the instance compiled for their number, consumers packed into oimg[0 .. n)
+    GatherGemmParams q = p_in;
+    if (!q.oimg[0].img) { q.oimg[0] = q.oimg[1]; q.oimg[1] = ImgOut{}; }
+    if (q.oimg[1].img) return launch_patch<NPH, BWD, BWD ? 0 : 2>(q, g, stream, name_only);
+    return launch_patch<NPH, BWD, BWD ? 0 : 1>(q, g, stream, name_only);
+  }
+  const GatherGemmParams& p = p_in;
   const Tuning& t = tuning();
   if (name_only) {
     static const std::string name = std::string("patch_gemm_h3_kernel<") + std::to_string(NPH) + ", " +
@@ -572,7 +582,7 @@ int launch_patch(const GatherGemmParams& p, const PatchGeom& g, hipStream_t stre
     *name_only = name.c_str();
     return ADVOC_OK;
   }
-  auto kern = patch_gemm_h3_kernel<NPH, BWD>;
+  auto kern = patch_gemm_h3_kernel<NPH, BWD, NE>;
   const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
   if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }
