@@ -16,6 +16,11 @@ constexpr float kEps = 1e-12f;  // EPS, advoc_model.py:8
 
 __device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
 
+// the discriminator's output activation on its own (advoc_model.py:201; the train step fuses it into the loss kernels)
+__global__ __launch_bounds__(256) void sigmoid_kernel(const float* __restrict__ z, float* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = sigmoidf(z[i]);
+}
+
 // block-level sum of `v` added atomically into *dst (one atomic per block)
 __device__ __forceinline__ void block_atomic_sum(float v, float* dst, float* red) {
   v = wave_sum(v);
@@ -219,6 +224,16 @@ extern "C" int advoc_adam_tf_f32(float* param, const float* grad, float* m, floa
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), param,
                      grad, m, v, count, lr_t, beta1, beta2, epsilon, grad_scale);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+extern "C" int advoc_sigmoid_f32(const float* logits, float* prob, int64_t count, advoc_stream_t stream) {
+  if (!logits || !prob) return ADVOC_ERR_NULL;
+  if (count < 0) return ADVOC_ERR_BAD_SHAPE;
+  if (count == 0) return ADVOC_OK;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(grid_for(count, 1)), dim3(256), 0, as_stream(stream), logits, prob, count);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }

@@ -709,7 +709,11 @@ class Advoc(Model):
     st['d_cond'][B:].copy_(cond)
     st['d_target'][B:].copy_(tgt)
     self._disc_forward(st['d_layers_fake'], st['d_bn_fake'])
-    return torch.sigmoid(st['d_act'][4][B:])
+    logits = st['d_act'][4][B:]
+    prob = torch.empty_like(logits)
+    _lib.check(_lib.load().advoc_sigmoid_f32(_lib.ptr(logits), _lib.ptr(prob), logits.numel(), _lib.stream()),
+               'advoc_sigmoid_f32')
+    return prob
 
   # ------------------------------------------------------------------------------------------
   # train step

@@ -451,6 +451,10 @@ int advoc_adam_tf_f32(float* param, const float* grad, float* m, float* v, int64
 /* tf.nn.dropout keep mask (advoc_model.py:144-149): mask[i] = floor(keep_prob + u_i) in {0,1},
  * u_i = Philox-4x32-10(seed, offset + i) -- a pure function of (seed, offset + i), so a global
  * batch sharded over GPUs draws the same mask as the unsharded batch.  offset % 4 == 0. */
+/* prob[i] = 1 / (1 + exp(-logits[i])): the discriminator's output activation (models/advoc/advoc_model.py:201) for
+ * Advoc.build_discriminator; the train step never materialises it (fused into the loss kernels above) */
+int advoc_sigmoid_f32(const float* logits, float* prob, int64_t count, advoc_stream_t stream);
+
 int advoc_dropout_mask_u8(uint8_t* mask, int64_t count, uint64_t seed, uint64_t offset, float keep_prob,
                           advoc_stream_t stream);
 
