@@ -19,7 +19,7 @@ struct Tuning {
   int wgrad_h3_min_m;   // ADVOC_WGRAD_H3_MIN_M smallest pixel grid (batch x gh x gw) that takes the image-based weight gradient
   int wgrad_h3_tile;    // ADVOC_WGRAD_H3_TILE  1: 128 x 128, 2: 256 x 256 forced (where the shape allows)
   int wgrad_h3_ordered; // ADVOC_WGRAD_H3_ORDERED 0: K slices of the image weight gradient always meet in fp32 atomics; 1: the 256 x 256 tile's through wgrad_ws when the layer has it; 2: the 128 x 128 tile's too
-  int wgrad_h3_rounds;  // ADVOC_WGRAD_H3_ROUNDS  > 0: K chunks per tile = this many rounds of the chip (default: 1, or 2 from 4096 grid points per chunk)
+  int wgrad_h3_rounds;  // ADVOC_WGRAD_H3_ROUNDS  > 0: K chunks per tile = this many rounds of the chip (default: 1)
   int h3;               // ADVOC_H3             0: no operand-image kernels (register-split path instead)
   int h3_tile;          // ADVOC_H3_TILE        1: 128x128, 4: 128x64, 5: 256x256 (8 waves) forced
   int h3_skip_prep;     // ADVOC_H3_SKIP_PREP   1: (micro-benchmarks only; -DADVOC_DIAG builds only) reuse the images already in the workspace

@@ -375,9 +375,11 @@ bool wgrad_h3_plan(const WgradParams& p, WgradPlan& pl) {
   // 64 KiB of LDS: two workgroups per CU; 128 KiB: one
   const int64_t resident = (big ? 1 : 2) * (int64_t)device_cu_count();
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
+  // one round of the chip (ADVOC_WGRAD_H3_ROUNDS=n: n rounds).  Two rounds for chunks of >= 4096 grid points was the rule
+  // while the slices met in atomics (no difference then: 45.56 vs 45.60 ms per step); with the slices parked and summed by
+  // a second launch every extra slice is 256 KB more to write and read back: one round is -0.65 ms per step (42.1 -> 41.45)
   int64_t ksplit = ceil_div(resident, tiles);
   if (tuning().wgrad_h3_rounds > 0) ksplit = ceil_div(tuning().wgrad_h3_rounds * resident, tiles);
-  else if (M / ksplit >= 4096) ksplit = ceil_div(2 * resident, tiles);
   const int64_t max_split = ceil_div(M, 8 * WK);
   if (ksplit > max_split) ksplit = max_split;
   if (ksplit < 1) ksplit = 1;
