@@ -29,6 +29,27 @@ def test_header_and_binding_agree(lib):
   assert sorted(_lib.PROTOTYPES) == syms, 'PROTOTYPES in _lib.py must list every header symbol'
 
 
+def test_layer_struct_layout_matches_the_header(tmp_path):
+  """The ctypes mirror of struct advoc_conv_layer (advoc_amd/_lib.py:ConvLayer) against the header compiled as C: total
+  size and the offset of every member the binding names -- a member added to one side only would otherwise show up as
+  wrong numbers on the GPU, not as an error."""
+  import ctypes
+  fields = [f[0] for f in _lib.ConvLayer._fields_]
+  src = ['#include <stdio.h>', '#include <stddef.h>', '#include "advoc_hip.h"', 'int main(void) {',
+         '  printf("sizeof %zu\\n", sizeof(advoc_conv_layer));']
+  src += ['  printf("%s %%zu\\n", offsetof(advoc_conv_layer, %s));' % (f, f) for f in fields]
+  src += ['  printf("image_out %zu\\n", sizeof(((advoc_conv_layer*)0)->y_img[0]));', '  return 0;', '}']
+  c = tmp_path / 'layout.c'
+  c.write_text('\n'.join(src))
+  exe = tmp_path / 'layout'
+  subprocess.run(['gcc', '-std=c99', '-I', os.path.dirname(_lib.HEADER_PATH), str(c), '-o', str(exe)], check=True)
+  out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+  assert int(out['sizeof']) == ctypes.sizeof(_lib.ConvLayer)
+  assert int(out['image_out']) == ctypes.sizeof(_lib.ImageOut)
+  for f in fields:
+    assert int(out[f]) == getattr(_lib.ConvLayer, f).offset, f
+
+
 def test_every_header_symbol_is_exported(lib):
   out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
   exported = set(l.split()[-1] for l in out.splitlines() if ' T ' in l)
