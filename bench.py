@@ -637,6 +637,9 @@ def main():
         'per_gpu_value': value / dp.world_size,
         'target_frames_per_s_per_gpu': 50000,
         'losses': losses,
+        'delayed_scaling': {'exact_refits': int(model.image_refits()), 'values_out_of_window': int(model.image_saturations()),
+                            'note': 'operand images re-built on the device with the exact scale since the model was built '
+                                    '(warm-up + timed + instrumented steps); nothing clamped is ever consumed'},
         'roofline': roofline,
         'extractor': extractor,
         'inference': inference,
