@@ -575,6 +575,8 @@ def main():
   if prof is not None and dp.rank == 0:
     roofline = roofline_from(prof, args.model, B, ms_per_step, prof_steps, bool(os.environ.get('ADVOC_BENCH_VERBOSE')))
   losses = model.losses() if dp.rank == 0 else None
+  delayed = ({'exact_refits': int(model.image_refits()), 'values_out_of_window': int(model.image_saturations())}
+             if dp.rank == 0 else None)
   dist_info = dist_report(torch, dp, model)
 
   extractor = inference = small = loader_res = None
@@ -637,7 +639,7 @@ def main():
         'per_gpu_value': value / dp.world_size,
         'target_frames_per_s_per_gpu': 50000,
         'losses': losses,
-        'delayed_scaling': {'exact_refits': int(model.image_refits()), 'values_out_of_window': int(model.image_saturations()),
+        'delayed_scaling': {**delayed,
                             'note': 'operand images re-built on the device with the exact scale since the model was built '
                                     '(warm-up + timed + instrumented steps); nothing clamped is ever consumed'},
         'roofline': roofline,
