@@ -482,15 +482,24 @@ __global__ __launch_bounds__(256) void lws_tile_max_kernel(const float* __restri
   if (threadIdx.x == 0) tile_max[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// mean_mag[clip] = mean of mag[clip][:][:]
-__global__ __launch_bounds__(256) void lws_mean_kernel(const float* __restrict__ mag, int64_t per_clip, float* __restrict__ mean_mag) {
+// mean_mag[clip] = mean of mag[clip][:][:] (double accumulation; 1024 threads per clip, 16-byte loads where the clip's
+// slice allows: 256 threads with scalar loads took 176 us per call, 2 % of a 64-clip LWS batch)
+__global__ __launch_bounds__(1024) void lws_mean_kernel(const float* __restrict__ mag, int64_t per_clip, float* __restrict__ mean_mag) {
   const float* src = mag + (int64_t)blockIdx.x * per_clip;
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < per_clip; i += blockDim.x) s += (double)src[i];
-  __shared__ double red[256];
+  if (per_clip % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    for (int64_t i = threadIdx.x; i < per_clip / 4; i += blockDim.x) {
+      const float4 v = src4[i];
+      s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < per_clip; i += blockDim.x) s += (double)src[i];
+  }
+  __shared__ double red[1024];
   red[threadIdx.x] = s;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = 512; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
     __syncthreads();
   }
@@ -506,7 +515,7 @@ extern "C" int advoc_lws_mean_mag_f32(const float* mag, int64_t clips, int64_t p
   if (!mag || !mean_mag) return ADVOC_ERR_NULL;
   if (clips > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
   ADVOC_CLEAR_LAUNCH_ERROR();
-  hipLaunchKernelGGL(lws_mean_kernel, dim3((unsigned)clips), dim3(256), 0, advoc::as_stream(stream), mag, per_clip, mean_mag);
+  hipLaunchKernelGGL(lws_mean_kernel, dim3((unsigned)clips), dim3(1024), 0, advoc::as_stream(stream), mag, per_clip, mean_mag);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }

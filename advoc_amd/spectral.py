@@ -624,7 +624,12 @@ def lws_spectrogram_batch(spec, nfft, nhop, L=LWS_L, look_ahead=LWS_LOOK_AHEAD,
   lib = _lib.load()
   _lib.require_device(spec)
   use_init = spec.is_complex()
-  mag = (spec.abs() if use_init else spec.abs()).to(torch.float32).contiguous()
+  if use_init:
+    c = torch.view_as_real(spec.to(torch.complex64)).contiguous()
+    mag = torch.empty(c.shape[:-1], dtype=torch.float32, device=c.device)
+    _lib.check(lib.advoc_cabs_f32(_lib.ptr(c), _lib.ptr(mag), mag.numel(), _lib.stream()), 'advoc_cabs_f32')
+  else:
+    mag = spec.abs().to(torch.float32).contiguous()       # (input sanitation, as lws.run_lws: magnitudes are |.|)
   clips, T, bins = mag.shape
   if bins != nfft // 2 + 1:
     raise ValueError('expected [clips, T, nfft//2+1]')
