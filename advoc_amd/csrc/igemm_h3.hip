@@ -252,8 +252,8 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       // tile kt + u sits in stage u; the next tile to issue goes into stage (u + NS - 1) % NS, vacated by tile kt + u - 1
-      wait_vmcnt<C::DMA_PER_TILE*(NS - 2)>();
-      __builtin_amdgcn_s_barrier();
+      // (lds_dma.h: the rendezvous also waits for this wave's own fragment reads of the stage the DMAs below overwrite)
+      dma_ring_barrier<C::DMA_PER_TILE*(NS - 2)>();
       ADVOC_H3_ISSUE((u + NS - 1) % NS);
       if (ABL != 4 && kt + u < kt_end) ADVOC_H3_COMPUTE(u);
     }

@@ -275,6 +275,14 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // The rendezvous of a step: own DMAs landed (vmcnt 0), OWN FRAGMENT READS RETURNED (lgkmcnt 0: the DMAs the others issue
+  // behind the barrier overwrite the stage those reads came from -- lds_dma.h, dma_ring_barrier), everybody here.
+#define ADVOC_P3_RENDEZVOUS()                                                                             \
+  {                                                                                                       \
+    if (abl & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                         \
+  }
+
   // ---- prologue: the whole halo of slice 0, the B tile of step 0 ----
 #pragma unroll
   for (int t = 0; t < NST; ++t) ADVOC_P3_HALO(0, t, 0);
@@ -304,16 +312,14 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     for (int s = 0; s < nslices; ++s) {
       const int hb = s & 1;
       const bool more = s + 1 < nslices;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (!(abl & 4)) __builtin_amdgcn_s_barrier();
+      ADVOC_P3_RENDEZVOUS();
       ADVOC_P3_TAP(0, 0, {
         ADVOC_P3_B(s, 2, 2);
         ADVOC_P3_B(s, 3, 3);
         if (more) { ADVOC_P3_HALO(s + 1, 0, hb ^ 1); ADVOC_P3_HALO(s + 1, 1, hb ^ 1); }
       })
       ADVOC_P3_TAP(1, 1, {})
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (!(abl & 4)) __builtin_amdgcn_s_barrier();
+      ADVOC_P3_RENDEZVOUS();
       ADVOC_P3_TAP(2, 2, {
         if (more) {
           ADVOC_P3_B(s + 1, 0, 0);
@@ -331,8 +337,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     const bool more = s + 1 < nslices;
     for (int t = 0; t < NST; t += 2) {
       // step t (stage 0)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (!(abl & 4)) __builtin_amdgcn_s_barrier();
+      ADVOC_P3_RENDEZVOUS();
       if (C::DMA_POS == 0) {
         ADVOC_P3_B(s, t + 1, 1);
         if (more) ADVOC_P3_HALO(s + 1, t, hb ^ 1);
@@ -358,8 +363,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
         ADVOC_P3_MFMA(a1, b0);
       }
       // step t + 1 (stage 1)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (!(abl & 4)) __builtin_amdgcn_s_barrier();
+      ADVOC_P3_RENDEZVOUS();
       if (C::DMA_POS == 0) {
         if (t + 2 < NST) {
           ADVOC_P3_B(s, t + 2, 0);
@@ -403,6 +407,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 #undef ADVOC_P3_LOAD_A
 #undef ADVOC_P3_LOAD_B
 #undef ADVOC_P3_MFMA
+#undef ADVOC_P3_RENDEZVOUS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 

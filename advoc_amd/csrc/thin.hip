@@ -624,22 +624,32 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
     unsafeAtomicAdd(p.dw + ((int64_t)(p.tap[rt] >> 16) * ca + ra) * cb + b, v);
   }
   if (p.qsum_table) {
-    // lanes -> LDS (one slot per channel of the column block), then ONE global atomic per channel and workgroup into the
-    // replica this workgroup belongs to (same-address atomics from every workgroup would queue up in the L2)
-    __syncthreads();
-    float* s_sum = &s_patch[0][0];
-    for (int t = threadIdx.x; t < 32 * NT; t += 256) s_sum[t] = 0.f;
-    __syncthreads();
+    // Every loader slot of a lane covers the SAME channel quad (slot i is element lane + 64 i of the tile and 64 is a
+    // multiple of the 8 NT quads of a row), and the lanes that share a quad are 8 NT apart: the slots are summed in the
+    // lane, the lanes by xor shuffles, the four waves through LDS with plain stores, then ONE global atomic per channel
+    // and workgroup into the replica this workgroup belongs to (same-address atomics from every workgroup would queue up in
+    // the L2).  (r3 summed the lanes with ds_add_f32, 8 lanes per address: the bursts jammed the CU's LDS pipe badly enough
+    // to expose a missing wait in the LDS-DMA kernels running beside this one -- lds_dma.h, dma_ring_barrier -- and cost
+    // more than the shuffles.)
+    static_assert(64 % (8 * NT) == 0, "a lane's loader slots share their channel quad");
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < QL; ++i) {
-      if (!q_on[i]) continue;
-      float* d = s_sum + (qch[i] - b0);
-      atomicAdd(d, qs[i].x); atomicAdd(d + 1, qs[i].y); atomicAdd(d + 2, qs[i].z); atomicAdd(d + 3, qs[i].w);
+    for (int i = 0; i < QL; ++i)
+      if (q_on[i]) { tot.x += qs[i].x; tot.y += qs[i].y; tot.z += qs[i].z; tot.w += qs[i].w; }
+#pragma unroll
+    for (int off = 8 * NT; off < 64; off <<= 1) {
+      tot.x += __shfl_xor(tot.x, off, 64); tot.y += __shfl_xor(tot.y, off, 64);
+      tot.z += __shfl_xor(tot.z, off, 64); tot.w += __shfl_xor(tot.w, off, 64);
     }
+    __syncthreads();
+    float* s_sum = &s_patch[0][0];               // [4 waves][32 NT]
+    static_assert(4 * 32 * NT <= 4 * kWgPatch, "the per-wave sums fit in the patch staging area");
+    if (lane < 8 * NT) *reinterpret_cast<float4*>(s_sum + wave * (32 * NT) + 4 * lane) = tot;
     __syncthreads();
     for (int t = threadIdx.x; t < 32 * NT; t += 256)
       if (b0 + t < cb)
-        unsafeAtomicAdd(p.qsum_table + (size_t)(blockIdx.x & (kColsumReplicas - 1)) * cb + b0 + t, s_sum[t]);
+        unsafeAtomicAdd(p.qsum_table + (size_t)(blockIdx.x & (kColsumReplicas - 1)) * cb + b0 + t,
+                        (s_sum[t] + s_sum[32 * NT + t]) + (s_sum[2 * 32 * NT + t] + s_sum[3 * 32 * NT + t]));
   }
 }
 

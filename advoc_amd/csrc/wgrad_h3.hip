@@ -236,8 +236,7 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   for (int kt = 0; kt < nkt; kt += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      dma_ring_barrier<0>();         // (lds_dma.h: own DMAs landed AND own reads of the stage about to be refilled returned)
       ADVOC_WH3_COMPUTE(u);          // (fires the next tile's loads between its MFMAs)
       ADVOC_WH3_ADDR();
     }

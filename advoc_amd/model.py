@@ -826,13 +826,10 @@ class Advoc(Model):
           layers[i].backward_data(g, st['g_d_act'][i - 1][lo:hi], db=DG[s + '/bias'], db_accumulate=acc)
         with self._wgrad_ctx():
           layers[i].backward_weight(g, DG[s + '/kernel'], DG[s + '/bias'], accumulate=acc)
-      if len(passes) > 1:
-        # batch norm (two passes): the next pass starts only when this pass's weight gradients are done.  Measured (r3,
-        # tools/micro/side_race_bisect.py): with the tail of pass 0's weight gradients (the long thin-layer kernel) still
-        # running next to the first backward-data launches of pass 1, a few thousand elements of a backward-data output
-        # came out wrong in ~1 of 3 runs (gradients off by 1e-3) although no buffer is shared between the two; the cause
-        # was not found (agent-scope fences in the workspace K-split did not change it and were removed again), so the overlap is not allowed.
-        self._join_wgrad()
+      # (batch norm, two passes: r3 joined the side stream here because pass 1's backward-data launches gave wrong elements
+      # next to pass 0's thin weight gradient.  The cause was a missing wait in the LDS-DMA kernels -- their fragment reads
+      # could still be queued when the next tile's DMA overwrote the stage, exposed by that kernel's LDS atomics; fixed in
+      # csrc/lds_dma.h (dma_ring_barrier), so the passes overlap again: tests/test_hip_model.py, side stream vs serial.)
     self._join_wgrad()
     self._adam('d')
     st['last_counts_d'] = n

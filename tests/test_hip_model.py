@@ -331,6 +331,88 @@ def test_side_stream_weight_gradients_equal_serial_execution(hip, monkeypatch, b
 
 
 @gpu
+@pytest.mark.parametrize('small,bn', [(True, False), (True, True), (False, False), (False, True)])
+def test_side_stream_step_equals_serial_step_element_by_element(hip, monkeypatch, small, bn):
+  """The r3 "side-stream race" regression (csrc/lds_dma.h, dma_ring_barrier): with the weight gradients
+  on the side stream a D step + G step must produce what the one-stream schedule produces -- EVERY backward-data output
+  (discriminator, encoder and decoder gradients) BIT FOR BIT, every generator / discriminator gradient element-wise within
+  the order-of-atomics noise of the kernels that still add with atomics (measured <= 3e-7 of the tensor's largest element;
+  the race gave 1e-3) -- 20 trials per configuration, batch norm off and on (on: two D passes, pass 0's weight gradients run
+  beside pass 1's backward-data launches, the overlap r3 had to forbid), on AdVoc-small and on AdVoc-full at 16 clips x 128
+  frames, where the full model dispatches the patch kernels (encoder_2-4 / decoder_2-4 / layer_2-3), the per-tap image
+  kernel, its workspace K split for the deep layers and remainder columns, and both weight-gradient tiles.  Two train
+  steps per trial: the second runs on one-pass (delayed-scale) images and producer-written images.  The image weight
+  gradient sums its K slices in order (ADVOC_WGRAD_H3_ORDERED=2) so that it is reproducible on both schedules."""
+  from advoc_amd import _lib
+  from advoc_amd.model import Advoc, AdvocSmall, Modes
+  dev = torch.device('cuda')
+  B, T = 16, 128
+  x, target = batch(B, T, 9)
+  x, target = x.to(dev), target.to(dev)
+  monkeypatch.setenv('ADVOC_WGRAD_H3_ORDERED', '2')
+  _lib.reload_env()
+  names = {}
+
+  def run(side):
+    monkeypatch.setenv('ADVOC_WGRAD_STREAM', '1' if side else '0')
+    m = (AdvocSmall if small else Advoc)(Modes.TRAIN)
+    m.subseq_len, m.train_batch_size, m.use_batchnorm = T, B, bn
+    m.build(batch_size=B, seed=4)
+    st = m._built
+    assert st['side_on'] == side
+    if not names:
+      for k, lay in st['g_layers'].items():
+        names[k] = [lay.kernel_name(d) for d in range(3)]
+      for i, lay in enumerate(st['d_layers_fake']):
+        names['layer_%d' % (i + 1)] = [lay.kernel_name(d) for d in range(3)]
+    m((x, target))
+    exact, noisy = {}, {}
+    for step in range(2):
+      m.d_step((x, target))
+      torch.cuda.synchronize()
+      for i in range(5):
+        exact['%d:d:g_d_act%d' % (step, i)] = st['g_d_act'][i].clone()
+      for k, v in st['d_G'].items():
+        noisy['%d:%s' % (step, k)] = v.detach().clone()
+      m.g_step((x, target))
+      torch.cuda.synchronize()
+      for i in range(5):
+        exact['%d:g:g_d_act%d' % (step, i)] = st['g_d_act'][i][B:].clone()
+      for i, t in enumerate(st['g_enc']):
+        exact['%d:g_enc%d' % (step, i)] = t.clone()
+      for i, t in st['g_dec'].items():
+        exact['%d:g_dec%d' % (step, i)] = t.clone()
+      for k, v in st['g_G'].items():
+        noisy['%d:%s' % (step, k)] = v.detach().clone()
+    return exact, noisy
+
+  try:
+    e0, n0 = run(False)
+    e0b, _ = run(False)
+    for k in e0:      # the one-stream schedule itself is reproducible in every backward-data output
+      assert torch.equal(e0[k], e0b[k]), ('serial rerun', k)
+    if not small:
+      assert any('patch_gemm_h3_kernel' in n for v in names.values() for n in v), names
+      assert any('gather_gemm_h3_kernel' in n for v in names.values() for n in v), names
+      assert any('wgrad_h3' in n for v in names.values() for n in v), names
+    for trial in range(20):
+      e1, n1 = run(True)
+      for k in e0:
+        if not torch.equal(e1[k], e0[k]):
+          d = (e1[k].double() - e0[k].double()).abs()
+          raise AssertionError('trial %d, bn %s: %s differs from the one-stream step in %d elements, max |d| %.3g (tensor max %.3g)'
+                               % (trial, bn, k, int((d != 0).sum()), float(d.max()), float(e0[k].abs().max())))
+      for k in n0:
+        top = float(n0[k].abs().max())
+        d = float((n1[k].double() - n0[k].double()).abs().max())
+        # (a bias in front of a batch norm has an exactly-zero gradient: both sides are pure round-off of sums ~1e-9)
+        assert d <= 2e-5 * top + 1e-7, (trial, bn, k, d, top)
+  finally:
+    monkeypatch.delenv('ADVOC_WGRAD_H3_ORDERED')
+    _lib.reload_env()
+
+
+@gpu
 def test_weight_magnitudes_follow_the_parameters(hip, monkeypatch):
   """One advoc_segmented_amax_f32 launch per arena at the start of every forward pass replaces the per-image magnitude
   passes over the kernels (ADVOC_WEIGHT_AMAX=0 restores them): the table holds max |kernel| of the CURRENT parameters
