@@ -75,6 +75,8 @@ Tuning read_env() {
 #else
   t.h3_patch_ablate = 0;
 #endif
+  t.reserve_cus = env_int("ADVOC_RESERVE_CUS", 0);
+  if (t.reserve_cus < 0) t.reserve_cus = 0;
   t.thin_wgrad_bias = env_int("ADVOC_THIN_WGRAD_BIAS", 1);
   t.thin_wgrad_nt = env_int("ADVOC_THIN_WGRAD_NT", 4);
   if (t.thin_wgrad_nt != 1 && t.thin_wgrad_nt != 2) t.thin_wgrad_nt = 4;

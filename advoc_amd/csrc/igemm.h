@@ -121,6 +121,7 @@ int launch_gather_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
 
 // ---- shared launch helpers (igemm.hip) ----
 int device_cu_count();
+int persistent_cu_count();    // device_cu_count() minus ADVOC_RESERVE_CUS, a multiple of 8
 // taps / columns / K of the weight image a gather launch reads (igemm_h3.hip); false: not on the image kernels
 bool h3_weight_image_shape(const GatherGemmParams& p, int* taps, int* n_total, int* ktot);
 // A launch of T equal workgroups on C compute units costs ceil(T / C) rounds when they are all resident: the last

@@ -575,6 +575,14 @@ int device_cu_count() {
   return cus;
 }
 
+// CUs a persistent launch (one workgroup per CU walking tiles) may fill: all of them, minus ADVOC_RESERVE_CUS (data-parallel
+// runs leave a few for RCCL's kernels), in whole rows of the 8 XCDs
+int persistent_cu_count() {
+  int n = device_cu_count() - tuning().reserve_cus;
+  n = n / 8 * 8;
+  return n >= 8 ? n : 8;
+}
+
 // Arrival counters of the tail split: a ring of slots so that launches in flight on different
 // streams do not share counters; every launch leaves its slot zeroed again (see the kernel).
 constexpr int kTailSlots = 64;

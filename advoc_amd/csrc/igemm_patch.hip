@@ -596,7 +596,7 @@ int launch_patch(const GatherGemmParams& p_in, const PatchGeom& g, hipStream_t s
   const int64_t tiles = (int64_t)p.batch * g.py * g.px * (p.n_total / C::BN);
   int64_t wgs = (tiles + 7) / 8 * 8;
   if (t.h3_patch_persist && (!BWD || t.h3_patch_persist == 2)) {
-    const int64_t cus = device_cu_count() / 8 * 8;
+    const int64_t cus = persistent_cu_count();
     if (wgs > cus && cus >= 8) wgs = cus;
   }
   ADVOC_CLEAR_LAUNCH_ERROR();

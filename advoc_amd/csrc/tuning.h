@@ -38,6 +38,9 @@ struct Tuning {
   int h3_rem_ws;        // ADVOC_H3_REM_WS      1: the K slices of the remainder launch meet in the workspace (no zero fill, no atomics)
   int h3_rem_wgs_per_cu;   // ADVOC_H3_REM_WGS_PER_CU  workgroups per CU the K split of that launch aims at
   int h3_rem_split_div; // ADVOC_H3_REM_SPLIT_DIV  K tiles per slice, at least
+  int reserve_cus;      // ADVOC_RESERVE_CUS     CUs the PERSISTENT launches (patch kernels, image weight gradient) leave free: set by
+                        //                       advoc_amd.parallel from ADVOC_DP_RESERVE_CUS when world_size > 1, so that RCCL's kernels
+                        //                       find a CU next to the 110-160 KB-LDS workgroups (multiples of 8: one CU per XCD)
   int h3_patch_ablate;  // ADVOC_H3_PATCH_ABLATE  (-DADVOC_DIAG builds only) timing experiments: bits 1 no DMA, 2 no MFMA, 4 no barrier (results are garbage)
 };
 

@@ -372,7 +372,7 @@ bool wgrad_h3_plan(const WgradParams& p, WgradPlan& pl) {
   const int tiles_m = (p.ntaps * ca + edge - 1) / edge, tiles_n = (cb + edge - 1) / edge;
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   // 64 KiB of LDS: two workgroups per CU; 128 KiB: one
-  const int64_t resident = (big ? 1 : 2) * (int64_t)device_cu_count();
+  const int64_t resident = (big ? 1 : 2) * (int64_t)(tuning().reserve_cus ? persistent_cu_count() : device_cu_count());
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
   // one round of the chip (ADVOC_WGRAD_H3_ROUNDS=n: n rounds).  Two rounds for chunks of >= 4096 grid points was the rule
   // while the slices met in atomics (no difference then: 45.56 vs 45.60 ms per step); with the slices parked and summed by

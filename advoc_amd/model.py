@@ -567,6 +567,7 @@ class Advoc(Model):
   # ------------------------------------------------------------------------------------------
   def state_dict(self):
     self.build()
+    self._flush_d_adam()
     out = collections.OrderedDict()
     for net in ('g', 'd'):
       for k, v in self._built[net + '_P'].items():
@@ -576,6 +577,7 @@ class Advoc(Model):
 
   def load_state_dict(self, state):
     self.build()
+    self._flush_d_adam()
     for net in ('g', 'd'):
       for k, v in self._built[net + '_P'].items():
         if k in state:
@@ -616,10 +618,12 @@ class Advoc(Model):
     return self._image_header_sum(5)
 
   def optimizer_state(self):
+    self._flush_d_adam()
     st = self._built
     return {k: st[k].detach().clone() for k in ('g_m', 'g_v', 'd_m', 'd_v')}, (st['g_t'], st['d_t'])
 
   def load_optimizer_state(self, tensors, steps):
+    self._flush_d_adam()
     st = self._built
     for k in ('g_m', 'g_v', 'd_m', 'd_v'):
       st[k].copy_(tensors[k])
@@ -704,6 +708,7 @@ class Advoc(Model):
     cond = torch.as_tensor(discrim_inputs).to(dev, torch.float32)
     tgt = torch.as_tensor(discrim_targets).to(dev, torch.float32)
     self.build(batch_size=cond.shape[0])
+    self._flush_d_adam()
     st = self._built
     B = st['B']
     st['d_cond'][B:].copy_(cond)
@@ -731,13 +736,15 @@ class Advoc(Model):
       self._feed = lambda: fixed
     return self
 
-  def _adam(self, net):
+  def _adam(self, net, reduced=False):
     st = self._built
     st[net + '_t'] += 1
     t = st[net + '_t']
     lr_t = self._lr * math.sqrt(1 - self._beta2 ** t) / (1 - self._beta1 ** t)
     flat = st[net + '_grad']
-    if net == 'g' and self._reduce_async is not None:
+    if reduced:
+      pass                                               # (_flush_d_adam: the cross-rank sum was started earlier and joined)
+    elif net == 'g' and self._reduce_async is not None:
       start, finish, _ = self._reduce_async
       start(flat, st.get('g_sent', 0), flat.numel())     # whatever the backward pass has not sent yet
       finish()
@@ -795,6 +802,7 @@ class Advoc(Model):
     st = self._built
     lib = _lib.load()
     B = st['B']
+    self._flush_d_adam()
     self._load_batch(batch)
     self._gen_forward(st['x_in'])
     if st['bn_on']:
@@ -831,8 +839,21 @@ class Advoc(Model):
       # could still be queued when the next tile's DMA overwrote the stage, exposed by that kernel's LDS atomics; fixed in
       # csrc/lds_dma.h (dma_ring_barrier), so the passes overlap again: tests/test_hip_model.py, side stream vs serial.)
     self._join_wgrad()
-    self._adam('d')
+    if self._reduce_async is not None:
+      # data parallel: the discriminator's gradient sum (11 MB) starts now and runs, on RCCL's stream, under the generator
+      # forward of the G step that follows; its Adam step is applied when something needs the discriminator's parameters
+      # (_flush_d_adam: before D(fake) in g_step, before the next d_step, before any read of the parameters)
+      self._reduce_async[0](st['d_grad'], 0, st['d_grad'].numel())
+      st['d_adam_pending'] = True
+    else:
+      self._adam('d')
     st['last_counts_d'] = n
+
+  def _flush_d_adam(self):
+    st = self._built
+    if st and st.pop('d_adam_pending', False):
+      self._reduce_async[1]()
+      self._adam('d', reduced=True)
 
   def _wgrad_ctx(self):
     """Weight / bias gradients are off the critical path of the backward pass (nothing downstream
@@ -885,6 +906,7 @@ class Advoc(Model):
     B = st['B']
     self._load_batch(batch)
     gen = self._gen_forward(st['x_in'])
+    self._flush_d_adam()                    # (data parallel: the D update of the d_step before, its gradient sum joined here)
     use_gan = self.gan_weight > 0
     g_out = st['g_d_target'][B:]            # gradient w.r.t. the generator output
     logits = st['d_act'][4][B:]

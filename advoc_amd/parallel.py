@@ -7,7 +7,9 @@ Each rank owns batch/N clips; after each backward pass the network's flat gradie
 point-to-point, ring all-reduce is per-link bound, so buckets are big (default 8 MiB) -- and the
 fused Adam kernel applies 1/N.  The generator's arena is laid out in backward-completion order
 and its buckets are reduced asynchronously as soon as the backward pass has filled them, next to
-the remaining backward kernels; the (small) discriminator arena is reduced in one go.  Dropout masks are Philox streams keyed by the GLOBAL clip index,
+the remaining backward kernels; the (small) discriminator arena is reduced in one go, asynchronously too: its sum runs
+under the generator forward of the G step that follows and the discriminator's Adam step is applied when that pass is
+through (model._flush_d_adam).  Dropout masks are Philox streams keyed by the GLOBAL clip index,
 so sharding does not change them, and with use_batchnorm=True the batch statistics are summed over the
 replicas (advoc_bn_*_stats / _finalize / _apply) -- synchronised batch norm.
 """
@@ -18,7 +20,11 @@ import torch.distributed as dist
 
 
 class DataParallel(object):
-  def __init__(self, bucket_bytes=8 << 20):
+  def __init__(self, bucket_bytes=None):
+    # ADVOC_DP_BUCKET_MB: size of one all-reduce (MiB, default 8).  xGMI is point-to-point: a ring all-reduce is bound per
+    # link, so buckets are few and large; 8 MiB = 27 collectives for the generator's 217.6 MB arena
+    if bucket_bytes is None:
+      bucket_bytes = int(float(os.environ.get('ADVOC_DP_BUCKET_MB', '8')) * (1 << 20))
     self.bucket_elems = max(1, bucket_bytes // 4)
     self.world_size = 1
     self.rank = 0
@@ -50,6 +56,17 @@ class DataParallel(object):
         dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
       self.backend = dist.get_backend()
       self.enabled = True
+      # ADVOC_DP_RESERVE_CUS=k (default 0; multiples of 8): the persistent launches (patch kernels and image weight
+      # gradient: one 110-160 KB-LDS workgroup per CU for the whole launch) fill CUs - k instead of every CU, so that
+      # RCCL's kernels become co-resident DURING those launches instead of between them.  Only honoured here, i.e. when
+      # there is more than one rank; unmeasured on hardware (no multi-GPU box was available to the builder): k = 8 costs
+      # the persistent kernels 3 % of the chip
+      k = os.environ.get('ADVOC_DP_RESERVE_CUS')
+      if k is not None:
+        os.environ['ADVOC_RESERVE_CUS'] = str(max(0, int(k)))
+        from advoc_amd import _lib
+        if torch.cuda.is_available():
+          _lib.reload_env()
     elif torch.cuda.is_available():
       torch.cuda.set_device(self.local_rank)
     return self
@@ -116,6 +133,7 @@ class DataParallel(object):
     """Rank 0's parameters and optimiser slots to everyone (identical start)."""
     if not self.enabled:
       return
+    model._flush_d_adam()
     st = model._built
     for k in ('g_param', 'd_param', 'g_m', 'g_v', 'd_m', 'd_v'):
       self._collective(dist.broadcast, st[k], src=0)

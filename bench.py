@@ -141,6 +141,60 @@ def cpu_baseline(model_small, threads, batch, iters=3, give_up_s=None):
               sample='%d timed train_loop iterations (1 D + 1 G update each; 1 warm-up before) of %s' % (iters, what))
 
 
+def cpu_baseline_legs(model_small, threads):
+  """BASELINE.md section 3, the legs beside the headline sweep (same restatement, `threads` intra-op threads, synthetic
+  clips of the GPU legs' shape): (a) the train_loop at the reference's default batch 8 (advoc_model.py:18) for the benched
+  model, (b) the OTHER model at batch 8, (c) the extractor alone -- waveform -> |STFT| -> mel -> pseudo-inverse
+  (advoc/spectral.py:60-83, spectral_util.py:29-43) in numpy, (d) generator-only inference on 256-frame chunks
+  (scripts/spectrogram_advoc.py:80-94: mel -> pinv -> G).  Each: one warm-up, then a few timed repetitions (~20 s of CPU
+  work in total)."""
+  import numpy as np
+  import torch
+  from oracle import advoc_torch as A
+  from oracle import spectral_np as S
+  legs = {}
+  r = cpu_baseline(model_small, threads, 8, iters=2)
+  legs['train_batch8'] = dict(value=r['value'], unit=r['unit'], seconds=r['seconds'], iterations=r['iterations'], cores=threads,
+                              sample=r['sample'] + ' (the reference\'s default train_batch_size, advoc_model.py:18)')
+  r = cpu_baseline(not model_small, threads, 8, iters=2 if not model_small else 1)
+  legs['other_model_batch8'] = dict(value=r['value'], unit=r['unit'], seconds=r['seconds'], iterations=r['iterations'],
+                                    cores=threads, sample=r['sample'])
+  torch.set_num_threads(threads)
+  W = S.create_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80).astype(np.float32)
+  Wi = S.create_inverse_mel_filterbank(22050, 1024, fmin=125, fmax=7600, n_mels=80).astype(np.float32)
+  rng = np.random.default_rng(0)
+  B = 8
+  wav = rng.uniform(-0.5, 0.5, size=(B, CLIP_SAMPLES, 1, 1)).astype(np.float32)
+
+  def extract():
+    mag = np.abs(S.stft_tf(wav, 1024, 256, pad_end=False)).astype(np.float32)
+    mel = S.mag_to_mel_linear_spec(mag, W)
+    return mag, mel, S.mel_linear_to_mag_spec(mel, Wi)
+  extract()
+  reps, t0 = 5, time.perf_counter()
+  for _ in range(reps):
+    mag, mel, inv = extract()
+  dt = (time.perf_counter() - t0) / reps
+  legs['extractor'] = dict(value=B / dt, unit='clips/s', us_per_clip=dt / B * 1e6, algorithmic_GBps=1397760.0 * B / dt / 1e9,
+                           cores='numpy (its own BLAS threads for the two projections)', seconds=dt * reps,
+                           sample='%d timed passes over %d clips of %d samples: waveform -> |STFT| (numpy rfft) -> mel -> '
+                                  'pseudo-inverse; 1 397 760 algorithmic bytes per clip (SURVEY.md section 8d)' % (reps, B, CLIP_SAMPLES))
+  cfg = A.Config(small=model_small)
+  P = A.init_params(cfg, seed=0)
+  masks = A.make_dropout_masks(cfg, B, seed=1)
+  x = torch.from_numpy(inv)
+  with torch.no_grad():
+    A.build_generator(P, x, cfg, masks)
+    reps, t0 = 3, time.perf_counter()
+    for _ in range(reps):
+      A.build_generator(P, x, cfg, masks)
+    dt = (time.perf_counter() - t0) / reps
+  legs['generator_inference'] = dict(value=B / dt, unit='256-frame clips/s', cores=threads, seconds=dt * reps,
+                                     sample='%d timed generator forward passes (AdVoc-%s, torch-CPU fp32) over %d chunks of 256 '
+                                            'frames, magnitudes out (no phase reconstruction)' % (reps, 'small' if model_small else 'full', B))
+  return legs
+
+
 def cpu_baseline_sweep(model_small):
   """The reference's CPU path beside the GPU number: the port timed at 8 / 16 / 32 / 64 / all host threads (8 is the
   reference's own extract_parallel_calls, train_evaluate.py:41), >= 3 timed iterations each; the headline is the BEST
@@ -164,6 +218,11 @@ def cpu_baseline_sweep(model_small):
   best = max([r for r in sweep if r['iterations'] >= 3] or sweep, key=lambda r: r['value'])
   out = dict(best)
   out['host_cpus'] = ncores
+  # the other legs BASELINE.md section 3 lists, each a bounded sample at the best thread count of the sweep
+  try:
+    out['legs'] = cpu_baseline_legs(model_small, best['cores'])
+  except Exception as e:     # never take the headline line down
+    out['legs'] = dict(error=repr(e))
   out['sweep'] = [dict(cores=r['cores'], value=r['value'], seconds=r['seconds'], iterations=r['iterations']) for r in sweep] + skipped
   out['note'] = 'headline = best of the thread sweep; a reported baseline, not the optimisation target'
   return out

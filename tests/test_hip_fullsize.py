@@ -321,3 +321,87 @@ def test_full_model_train_loops_at_bench_size_match_the_float64_oracle(hip):
       assert rel(sd[k], P64[k]) < 1e-4, (step, k, rel(sd[k], P64[k]))
       P64[k] = sd[k].double().cpu()
   print('image refits over two steps: %d' % m.image_refits())
+
+
+@gpu
+def test_full_model_with_batch_norm_train_loop_at_bench_size_matches_the_float64_oracle(hip):
+  """use_batchnorm=True at BASELINE configs[2]'s size (AdVoc-full, 64 clips x 256 frames, default dispatch, side stream):
+  one train_loop -- D update (two D passes, real and fake, each with its own batch statistics: advoc_model.py:168-204 is
+  built twice) and G update -- against the float64 oracle (advoc_model.py:77-84,173-177: tf.layers.batch_normalization,
+  training=True).  This is the configuration the r3 side-stream corruption lived in, now with the
+  inter-pass join removed.  The 64 clips are 8 distinct clips tiled 8 times: tiling a batch changes neither its per-channel
+  mean nor its variance, and every loss is a batch mean, so the oracle evaluates the 8 distinct clips in ONE call (batch
+  norm needs the whole batch at once) while the HIP side runs the full 64-clip launches.  Bars as in the test above."""
+  from advoc_amd.model import Advoc, Modes
+  from oracle import advoc_torch as A
+  Bn, T, DISTINCT = 64, 256, 8
+  cfg = A.Config(small=False, subseq_len=T, use_batchnorm=True)
+  P = A.init_params(cfg, seed=21)
+  g = torch.Generator().manual_seed(22)
+  for k in P:
+    if k.endswith('/bias') or k.endswith('/beta'):
+      P[k] = torch.randn(P[k].shape, generator=g) * 0.05
+    elif k.endswith('/gamma'):
+      P[k] = 1.0 + torch.randn(P[k].shape, generator=g) * 0.1
+  m = Advoc(Modes.TRAIN)
+  m.train_batch_size = Bn
+  m.use_batchnorm = True
+  m.build(batch_size=Bn)
+  m.load_state_dict(P)
+  st = m._built
+  assert st['side_on'] and st['bn_on']
+  GL = st['g_layers']
+  for name in PATCH_G:
+    assert 'patch_gemm_h3_kernel' in GL[name].kernel_name(0), (name, GL[name].kernel_name(0))
+    assert 'patch_gemm_h3_kernel' in GL[name].kernel_name(1), (name, GL[name].kernel_name(1))
+  for layers in (st['d_layers_real'], st['d_layers_fake']):
+    for i in (1, 2, 3):
+      assert 'patch_gemm_h3_kernel' in layers[i].kernel_name(1), (i, layers[i].kernel_name(1))
+
+  def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+  def make_batch(seed):
+    gg = torch.Generator().manual_seed(seed)
+    target = torch.rand(DISTINCT, T, 513, 1, generator=gg) * 2
+    x = target * (0.5 + torch.rand(DISTINCT, T, 513, 1, generator=gg)) - 0.1
+    return x, target
+  batches = [make_batch(300 + i) for i in range(2)]
+  masks = [A.make_dropout_masks(cfg, DISTINCT, seed=80 + i) for i in range(2)]
+  tile = lambda t: t.repeat(Bn // DISTINCT, 1, 1, 1)      # noqa: E731
+  dev = torch.device('cuda')
+  it = iter(range(2))
+
+  def feed():
+    i = next(it)
+    m.set_dropout_masks({k: tile(v.to(torch.uint8)) for k, v in masks[i].items()})
+    return tile(batches[i][0]).to(dev), tile(batches[i][1]).to(dev)
+  m(feed)
+
+  P64 = collections.OrderedDict((k, v.double()) for k, v in P.items())
+  Gk, Dk = A.split_vars(P64)
+  d_opt = A.AdamTF(Dk, P64)
+  gD, LD = A.grads(P64, batches[0][0].double(), batches[0][1].double(), cfg, {k: v.double() for k, v in masks[0].items()}, 'D')
+  P_at_d = collections.OrderedDict((k, v.clone()) for k, v in P64.items())
+  d_opt.step(P64, gD)
+  gG, LG = A.grads(P64, batches[1][0].double(), batches[1][1].double(), cfg, {k: v.double() for k, v in masks[1].items()}, 'G')
+  P_at_g = collections.OrderedDict((k, v.clone()) for k, v in P64.items())
+  assert m.train_loop() == 1
+  ls = m.losses()
+  assert abs(ls['disc_loss'] - float(LD['d_loss'])) < 1e-4 * max(1, abs(float(LD['d_loss']))), (ls, LD)
+  assert abs(ls['gen_loss_GAN'] - float(LG['g_gan'])) < 1e-4 * max(1, abs(float(LG['g_gan']))), (ls, LG)
+  assert abs(ls['gen_loss_L1'] - float(LG['g_l1'])) < 1e-4 * max(1, abs(float(LG['g_l1']))), (ls, LG)
+  worst = {}
+  for net, want in (('d_G', gD), ('g_G', gG)):
+    for k, v in want.items():
+      if float(v.norm()) < 1e-9 * (1 + v.numel()) ** 0.5:
+        continue      # a conv bias in front of a batch norm: its gradient is exactly zero, both sides are round-off
+      r = rel(st[net][k], v)
+      worst[k] = r
+      if r > 5e-4:
+        P32 = {kk: vv.float() for kk, vv in (P_at_d if net == 'd_G' else P_at_g).items()}
+        b = 0 if net == 'd_G' else 1
+        g32, _ = A.grads(P32, batches[b][0], batches[b][1], cfg, masks[b], 'D' if net == 'd_G' else 'G')
+        assert r <= 3 * rel(g32[k], v), (k, r, rel(g32[k], v))
+  print('batch norm, one train_loop at 64 x 256: worst gradient rel-L2 vs float64 %.3g (%s)' % (max(worst.values()), max(worst, key=worst.get)))

@@ -341,7 +341,7 @@ def test_side_stream_step_equals_serial_step_element_by_element(hip, monkeypatch
   beside pass 1's backward-data launches, the overlap r3 had to forbid), on AdVoc-small and on AdVoc-full at 16 clips x 128
   frames, where the full model dispatches the patch kernels (encoder_2-4 / decoder_2-4 / layer_2-3), the per-tap image
   kernel, its workspace K split for the deep layers and remainder columns, and both weight-gradient tiles.  Two train
-  steps per trial: the second runs on one-pass (delayed-scale) images and producer-written images.  The image weight
+  steps per trial, the second from the same parameters on one-pass (delayed-scale) and producer-written images.  The image weight
   gradient sums its K slices in order (ADVOC_WGRAD_H3_ORDERED=2) so that it is reproducible on both schedules."""
   from advoc_amd import _lib
   from advoc_amd.model import Advoc, AdvocSmall, Modes
@@ -367,7 +367,18 @@ def test_side_stream_step_equals_serial_step_element_by_element(hip, monkeypatch
         names['layer_%d' % (i + 1)] = [lay.kernel_name(d) for d in range(3)]
     m((x, target))
     exact, noisy = {}, {}
+    start = {k: st[k].clone() for k in ('g_param', 'd_param')}
     for step in range(2):
+      if step:
+        # the second step starts from the SAME parameters (Adam would carry the atomics-order noise of the first step's
+        # gradients into them and no two runs would be bit-comparable any more); what it keeps from the first step is the
+        # operand images' magnitude history: one-pass images, refit checks, producer-written images
+        for k, v in start.items():
+          st[k].copy_(v)
+        for k in ('g_m', 'g_v', 'd_m', 'd_v'):
+          st[k].zero_()
+        st['g_t'] = st['d_t'] = 0
+        m.parameters_changed()
       m.d_step((x, target))
       torch.cuda.synchronize()
       for i in range(5):
