@@ -277,10 +277,15 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 
   // The rendezvous of a step: own DMAs landed (vmcnt 0), OWN FRAGMENT READS RETURNED (lgkmcnt 0: the DMAs the others issue
   // behind the barrier overwrite the stage those reads came from -- lds_dma.h, dma_ring_barrier), everybody here.
+#ifdef ADVOC_RING_NO_LGKM      // (A/B builds only: the r3 rendezvous)
+#define ADVOC_P3_WAIT "s_waitcnt vmcnt(0)"
+#else
+#define ADVOC_P3_WAIT "s_waitcnt vmcnt(0) lgkmcnt(0)"
+#endif
 #define ADVOC_P3_RENDEZVOUS()                                                                             \
   {                                                                                                       \
     if (abl & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                         \
+    else asm volatile(ADVOC_P3_WAIT "\n\ts_barrier" ::: "memory");                                        \
   }
 
   // ---- prologue: the whole halo of slice 0, the B tile of step 0 ----

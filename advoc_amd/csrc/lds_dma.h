@@ -60,7 +60,11 @@ __device__ __forceinline__ void dma16(u32x4s rsrc, unsigned lds_base, int voffse
 template <int VM>
 __device__ __forceinline__ void dma_ring_barrier() {
   static_assert(VM >= 0 && VM < 64, "vmcnt is a 6-bit counter");
+#ifdef ADVOC_RING_NO_LGKM      // (A/B builds only, tools/micro/lib_ab.sh: the r3 rendezvous, which has the race)
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
+#endif
 }
 
 __device__ __forceinline__ unsigned lds_address(const void* generic_lds_pointer) {

@@ -368,23 +368,26 @@ def test_side_stream_step_equals_serial_step_element_by_element(hip, monkeypatch
     m((x, target))
     exact, noisy = {}, {}
     start = {k: st[k].clone() for k in ('g_param', 'd_param')}
+
+    def reset():
+      # every D step and G step starts from the SAME parameters (Adam would carry the atomics-order noise of a step's
+      # gradients into them and no two runs would be bit-comparable any more); what the second round keeps from the first
+      # is the operand images' magnitude history: one-pass images, refit checks, producer-written images
+      for k, v in start.items():
+        st[k].copy_(v)
+      for k in ('g_m', 'g_v', 'd_m', 'd_v'):
+        st[k].zero_()
+      st['g_t'] = st['d_t'] = 0
+      m.parameters_changed()
     for step in range(2):
-      if step:
-        # the second step starts from the SAME parameters (Adam would carry the atomics-order noise of the first step's
-        # gradients into them and no two runs would be bit-comparable any more); what it keeps from the first step is the
-        # operand images' magnitude history: one-pass images, refit checks, producer-written images
-        for k, v in start.items():
-          st[k].copy_(v)
-        for k in ('g_m', 'g_v', 'd_m', 'd_v'):
-          st[k].zero_()
-        st['g_t'] = st['d_t'] = 0
-        m.parameters_changed()
+      reset()
       m.d_step((x, target))
       torch.cuda.synchronize()
       for i in range(5):
         exact['%d:d:g_d_act%d' % (step, i)] = st['g_d_act'][i].clone()
       for k, v in st['d_G'].items():
         noisy['%d:%s' % (step, k)] = v.detach().clone()
+      reset()
       m.g_step((x, target))
       torch.cuda.synchronize()
       for i in range(5):
@@ -399,9 +402,14 @@ def test_side_stream_step_equals_serial_step_element_by_element(hip, monkeypatch
 
   try:
     e0, n0 = run(False)
-    e0b, _ = run(False)
-    for k in e0:      # the one-stream schedule itself is reproducible in every backward-data output
-      assert torch.equal(e0[k], e0b[k]), ('serial rerun', k)
+    # Backward-data outputs that the one-stream schedule itself reproduces bit for bit (three runs): all of them except
+    # where a small launch splits K over workgroups that meet in the destination with fp32 atomics (the r1 kernels of
+    # AdVoc-small's 32-channel layers, a few deep layers); those few are compared like the gradients, within the noise
+    reruns = [run(False)[0] for _ in range(2)]
+    loose = [k for k in e0 if not all(torch.equal(e0[k], r[k]) for r in reruns)]
+    assert len(loose) <= len(e0) // 3, loose
+    for k in loose:
+      n0[k] = e0.pop(k)
     if not small:
       assert any('patch_gemm_h3_kernel' in n for v in names.values() for n in v), names
       assert any('gather_gemm_h3_kernel' in n for v in names.values() for n in v), names
@@ -413,6 +421,7 @@ def test_side_stream_step_equals_serial_step_element_by_element(hip, monkeypatch
           d = (e1[k].double() - e0[k].double()).abs()
           raise AssertionError('trial %d, bn %s: %s differs from the one-stream step in %d elements, max |d| %.3g (tensor max %.3g)'
                                % (trial, bn, k, int((d != 0).sum()), float(d.max()), float(e0[k].abs().max())))
+      n1.update({k: e1[k] for k in loose})
       for k in n0:
         top = float(n0[k].abs().max())
         d = float((n1[k].double() - n0[k].double()).abs().max())
