@@ -82,6 +82,16 @@ struct PCfg {
   static constexpr int OFF_B = 2 * HALO_BYTES;
   // NPH = 3 (24 MFMAs per wave and tap, half the other instances'): FOUR tap buffers, two taps per rendezvous
   static constexpr int NBUF = NPH == 3 ? 4 : 2;
+#ifdef ADVOC_P3_NO_STAGGER     // (A/B builds only: the r3 loop, all eight waves in step)
+  static constexpr bool STAGGER = false;
+#else
+  // two wave groups one phase apart (K loop below): measured on one box against the in-step loop (tools/micro/lib_ab2.sh):
+  // <1,0> 1.957 -> 1.894 ms, <1,1> 1.896 -> 1.879; but <4,0> 0.675 -> 0.730, <2,0> 0.444 -> 0.471, <2,1> 0.697 -> 0.756,
+  // <4,1> 0.584 -> 0.588 -- a single wave per SIMD does not keep the matrix pipe full through its 24-MFMA phase (the
+  // intervals come out at ~925 cycles where 768 were expected), and the instances with more DMA slots per step lose more
+  // than the overlap returns.  Only the 4x4 stride-1 instance keeps it.
+  static constexpr bool STAGGER = W == 8 && NBUF == 2 && NPH == 1;
+#endif
   static constexpr int LDS_BYTES = OFF_B + NBUF * B_STAGE;  // 146 | 160 | 142 | 142 KiB
   static constexpr int PTS_W = 32 * MT;                    // grid points per wave
   static constexpr int EPI_BYTES = WAVES * (32 * 36 * 4 + 2 * PTS_W * 4);
@@ -336,6 +346,72 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       ADVOC_P3_TAP(3, 3, {})
     }
 #undef ADVOC_P3_TAP
+  } else if constexpr (C::STAGGER) {
+    // ---- (r4) TWO WAVE GROUPS, ONE PHASE APART.  A step of a wave is four phases: R1 (fragment reads of the step: A of
+    // both k steps, B of the first), M1 (24 MFMAs), R2 (B of the second k step), M2 (24 MFMAs), a workgroup barrier behind
+    // each.  Waves 4-7 run ONE BARRIER BEHIND waves 0-3 (an extra barrier in front of their loop, one behind the others'),
+    // and wave w shares its SIMD with wave w + 4: whenever one wave of a SIMD multiplies the other one reads, so the matrix
+    // pipe never waits for a fragment read and the LDS never serves all eight waves at once -- what r3 measured as the
+    // "rendezvous window" (section 7 item 5: -33 % with the barrier ablated) without giving up the rendezvous.
+    //   * early waves issue the DMAs of step n + 1 (B tile, halo piece) at the end of their R1(n), late waves theirs at the
+    //     start of their M2(n - 1): the same barrier interval, right behind the barrier at which every wave has retired
+    //     (lgkmcnt 0) its reads of the stage being refilled, and four intervals before anyone reads the new tile;
+    //   * everybody waits for its own DMAs (vmcnt 0) in front of the last barrier before early's R1(n + 1);
+    //   * every barrier is one asm statement with the waits in it and a scheduling fence either side: MFMAs stay in
+    //     their phase.
+    const bool late = wave >= W / 2;
+    const int nsteps = nslices * NST;
+#define ADVOC_P3_BAR(WAITS)                                                                               \
+    {                                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+      asm volatile(WAITS "s_barrier" ::: "memory");                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+    // the DMAs that feed step N: its B tile into stage N & 1, and piece (N - 1) % NST of the halo of the slice behind
+    // step N - 1's -- i.e. the piece the unstaggered loop issues during step N - 1
+#define ADVOC_P3_FEED(N)                                                                                  \
+    {                                                                                                     \
+      const int n_ = (N);                                                                                 \
+      if (n_ < nsteps) {                                                                                  \
+        const int sl_ = n_ / NST, tt_ = n_ - sl_ * NST;                                                   \
+        if (n_ & 1) { ADVOC_P3_B(sl_, tt_, 1); } else { ADVOC_P3_B(sl_, tt_, 0); }                        \
+      }                                                                                                   \
+      if (n_ >= 1) {                                                                                      \
+        const int ps_ = (n_ - 1) / NST, pt_ = (n_ - 1) - ps_ * NST;                                       \
+        if (ps_ + 1 < nslices) {                                                                          \
+          if (ps_ & 1) { ADVOC_P3_HALO(ps_ + 1, pt_, 0); } else { ADVOC_P3_HALO(ps_ + 1, pt_, 1); }       \
+        }                                                                                                 \
+      }                                                                                                   \
+    }
+    if (late) ADVOC_P3_FEED(1);              // (their "M2(-1)")
+    ADVOC_P3_BAR("s_waitcnt vmcnt(0)\n\t");  // slice 0's halo and B(0) have landed, from everybody
+    if (late) ADVOC_P3_BAR("");
+    for (int n = 0; n < nsteps; n += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int s = (n + u) / NST, t = (n + u) - s * NST;
+        const int hb = s & 1;
+        // R1
+        ADVOC_P3_LOAD_A(a0, hb, t, 0);
+        ADVOC_P3_LOAD_B(b0, u, 0);
+        ADVOC_P3_LOAD_A(a1, hb, t, 1);
+        if (!late) ADVOC_P3_FEED(n + u + 1);
+        ADVOC_P3_BAR("s_waitcnt lgkmcnt(0)\n\t");
+        // M1
+        ADVOC_P3_MFMA(a0, b0);
+        ADVOC_P3_BAR("");
+        // R2
+        ADVOC_P3_LOAD_B(b0, u, 1);
+        if (late) ADVOC_P3_BAR("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t") else ADVOC_P3_BAR("s_waitcnt lgkmcnt(0)\n\t");
+        // M2
+        if (late) ADVOC_P3_FEED(n + u + 2);
+        ADVOC_P3_MFMA(a1, b0);
+        if (late) ADVOC_P3_BAR("") else ADVOC_P3_BAR("s_waitcnt vmcnt(0)\n\t");
+      }
+    }
+    if (!late) ADVOC_P3_BAR("");
+#undef ADVOC_P3_FEED
+#undef ADVOC_P3_BAR
   } else
   for (int s = 0; s < nslices; ++s) {
     const int hb = s & 1;
