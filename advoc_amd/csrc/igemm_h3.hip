@@ -90,7 +90,7 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
   const unsigned M = (unsigned)p.batch * (unsigned)p.gh * (unsigned)p.gw;
-  const int ntn = p.n_total / BN;
+  const int ntn = (p.n_total + BN - 1) / BN;       // (n_total = 32: one 64-column tile whose upper half is masked, below)
   int tile, phase, ks_idx = blockIdx.y, ks_cnt = gridDim.y, tail_tile = -1;
   {
     const bool tail_mode = p.tail_split > 1;       // tail_main == 0: EVERY tile is cut into K slices
@@ -146,7 +146,9 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
   for (int g = 0; g < CGB; ++g) {
     const int n = (wave * CGB + g) * 8 + lrow;
     const int gc = lpos ^ ((n >> 1) & 7);
-    b_off[g] = ((n0 + n) * ktot) * 4 + gc * 16;
+    // (rows beyond the weight image -- the 32-channel layers of AdVoc-small on the 64-column tile -- arrive as zeros:
+    // behind the last tap the descriptor's range check would do it, behind the others they would alias the next tap)
+    b_off[g] = n0 + n < p.n_total ? ((n0 + n) * ktot) * 4 + gc * 16 : (int)0x80000000;
   }
   // buffer descriptors over the whole images; the weight-slab / K-slice offsets go into soffset
   // (lds_dma.h: why the DMAs are inline assembly)
@@ -349,6 +351,7 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int nt0 = n0 + (wn * NT + j) * 32;
+    if (nt0 >= p.n_total) continue;                 // (masked half of a 64-column tile over 32 channels)
     const int di = nt0 >= p.n_split ? 1 : 0;
     const GemmDest& d = p.d[di];
     if (d.p == nullptr) continue;
@@ -458,7 +461,7 @@ int launch_h(const GatherGemmParams& p, hipStream_t stream, const char** name_on
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
   if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }
   const int64_t M = (int64_t)p.batch * p.gh * p.gw;
-  const int64_t gx = ceil_div(M, C::BM) * (p.n_total / C::BN);
+  const int64_t gx = ceil_div(M, C::BM) * ceil_div(p.n_total, C::BN);
   GatherGemmParams q = p;
   dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)p.nphase);
   static const bool log_launches = getenv("ADVOC_H3_LOG") != nullptr;     // which launch is which (tools/micro)
@@ -516,7 +519,7 @@ Pick pick_tile(const GatherGemmParams& p) {
   if (t.h3_tile == 0 && k.wgm == 2 && k.nt == 2) {
     // under one round of 128 x 128 tiles (two per CU) the 128 x 64 tile (three per CU) fills the chip better:
     // 1.04-1.2 x on the deep layers (encoder_5 / decoder_6 forward, encoder_6 / decoder_6 backward-data)
-    const int64_t t128 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * (N / 128) * p.nphase;
+    const int64_t t128 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * ceil_div(N, 128) * p.nphase;
     if (t128 < 2 * device_cu_count()) k = {2, 1, 2, 2};
   }
   return k;
@@ -537,7 +540,10 @@ bool h3_eligible(const GatherGemmParams& p) {
   const Tuning& t = tuning();
   if (!t.h3 || !t.igemm_x6) return false;
   const int ktot = p.c0 + p.c1, N = p.n_total;
-  if (ktot % 32 || p.c0 % 32 || p.c1 % 32 || N % 64 || p.n_split % 32) return false;
+  // N = 32 (AdVoc-small's encoder_2 / layer_2 backward-data, decoder_2 forward: advoc_model_small.py:14-15) runs the
+  // 128 x 64 tile with its upper 32 columns masked: half of the tile's MFMAs multiply zeros, which is still 3-4 x the
+  // fp32 kernel these launches used to fall back to
+  if (ktot % 32 || p.c0 % 32 || p.c1 % 32 || (N % 64 && N != 32) || p.n_split % 32) return false;
   if (p.n_valid && p.n_valid != p.n_total) return false;
   const int64_t rows128 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * p.nphase;
   if (rows128 * ((N + 127) / 128) < t.h3_min_tiles) return false;
@@ -573,7 +579,7 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   PatchGeom geom;
   const int patch_nph = patch_plan(p, &geom);       // stride-1 gathers: igemm_patch.hip
   const int BM = 32 * k.mt * k.wgm, BN = 64 * k.nt;
-  const int64_t tiles = ceil_div((int64_t)p.batch * p.gh * p.gw, BM) * (N / BN) * p.nphase;
+  const int64_t tiles = ceil_div((int64_t)p.batch * p.gh * p.gw, BM) * ceil_div(N, BN) * p.nphase;
   const int nkt = ktot / 32 * p.ntaps;
   // Small pixel grids with deep contractions (encoder_5.., decoder_5.. and their gradients) would leave CUs idle:
   // split K until the launch holds ~4 workgroups per CU, keeping >= 8 K tiles per slice (igemm.hip does the same)
@@ -605,7 +611,7 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   // the layer's work): its tiles are cut into K slices that meet in the workspace, like the deep layers' above
   int64_t rtiles = 0;
   if (patch_nph && geom.rem) {
-    rtiles = ceil_div((int64_t)p.batch * p.gh * geom.rem, 128) * (N / 64) * p.nphase;
+    rtiles = ceil_div((int64_t)p.batch * p.gh * geom.rem, 128) * ceil_div(N, 64) * p.nphase;
     if (tuning().h3_rem_ws && rtiles <= 256 && tuning().igemm_splitk) {
       int split = (int)ceil_div((int64_t)tuning().h3_rem_wgs_per_cu * device_cu_count(), rtiles);
       if (split > nkt / tuning().h3_rem_split_div) split = nkt / tuning().h3_rem_split_div;

@@ -76,6 +76,31 @@ def test_full_model_dispatch(name, L, fwd, bwd, wgt):
       assert got[d] == want, (name, d, got[d], want)
 
 
+BS = 32
+PT = 'gather_gemm_h3_kernel<2, 1, 2, 2>'
+# AdVoc-small at B=32 (BASELINE configs[1], advoc_model_small.py:14-15: ngf = ndf = 32): every layer between the 1-channel
+# edges runs on the image kernels -- the 32-column launches (encoder_2 / layer_2 backward-data, decoder_2 forward) on the
+# 128 x 64 tile with its upper half masked (r4; they fell back to the r1 fp32 kernel before)
+SMALL = [
+    ('encoder_2', layer(0, BS, 128, 257, 32, 0, 64, (2, 2)), PT, PT, W128),
+    ('encoder_3', layer(0, BS, 64, 129, 64, 0, 128, (2, 2)), P3F, P4B, W128),
+    ('decoder_3', layer(1, BS, 32, 65, 128, 128, 64, (2, 2), trim=1), P4F, P2B, W128),
+    ('decoder_2', layer(1, BS, 64, 129, 64, 64, 32, (2, 2), trim=1), PT, 'patch_gemm_h3_kernel<3, 1>', W128),
+    ('layer_2', layer(0, 2 * BS, 128, 256, 32, 0, 64, (2, 2)), PT, PT, W128),
+    ('layer_3', layer(0, 2 * BS, 64, 128, 64, 0, 128, (2, 2)), P3F, P4B, W128),
+    ('layer_4', layer(0, 2 * BS, 32, 64, 128, 0, 256, (1, 1)), P1F, None, W256),
+]
+
+
+@pytest.mark.parametrize('name,L,fwd,bwd,wgt', SMALL, ids=[c[0] for c in SMALL])
+def test_small_model_dispatch(name, L, fwd, bwd, wgt):
+  got = names(L)
+  for d, want in enumerate((fwd, bwd, wgt)):
+    if want is not None:
+      assert got[d] == want, (name, d, got[d], want)
+  assert not any(n.startswith('gather_gemm_kernel') or 'wgrad_mfma' in n for n in got), got
+
+
 def test_edge_layers_keep_their_direct_kernels():
   """1-channel inputs / outputs never take the image kernels (channel counts are not multiples of 32)."""
   enc1 = layer(0, BF, 256, 513, 1, 0, 64, (2, 2))

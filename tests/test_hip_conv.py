@@ -257,6 +257,14 @@ H3 = [
     # deep contraction on a small grid: split-K slices meeting with atomics
     ('h3_deep_small', 0, (2, 8, 9), 512, 0, 128, 0, (2, 2), None, 1, False, 0),
 ]
+# 32 output columns (AdVoc-small: encoder_2 / layer_2 backward-data -- 32 input channels --, decoder_2 forward -- 32 output
+# channels; advoc_model_small.py:14-15): the 128 x 64 tile with its upper 32 columns masked (r4; the r1 fp32 kernel before)
+H3_N32 = [
+    (('h3_small_enc2', 0, (3, 32, 33), 32, 0, 64, 0, (2, 2), None, 1, False, 0), {0: 'gather_gemm_h3_kernel<2, 1, 2, 2>', 1: 'gather_gemm_h3_kernel<2, 1, 2, 2>'}),
+    (('h3_small_dec2', 1, (2, 16, 17), 64, 64, 32, 1, (2, 2), (1, 1), 2, False, 0), {0: 'gather_gemm_h3_kernel<2, 1, 2, 2>'}),
+    (('h3_small_dec2_drop', 1, (2, 8, 9), 64, 64, 32, 1, (2, 2), (1, 1), 2, True, 1), {0: 'gather_gemm_h3_kernel<2, 1, 2, 2>'}),
+    (('h3_small_layer2', 0, (4, 16, 32), 32, 0, 64, 0, (2, 2), (1, 1), 1, False, 0), {1: 'gather_gemm_h3_kernel<2, 1, 2, 2>'}),
+]
 H3_VARIANTS = [(1, 2), (4, 2), (5, 2)]        # 128 x 128, 128 x 64, 256 x 256 on 8 waves (the tiles the dispatch uses)
 
 # Patch kernels (igemm_patch.hip): the stride-1 gathers -- four fused sub-pixel phases (transposed-conv forward, conv
@@ -368,6 +376,31 @@ def test_layer_operand_image_kernels(hip, case, variant, hipenv):
     else:
       want = 'gather_gemm_h3_kernel<%s, %d, 2>' % (want_tile, 2 if tile in (2, 3) else stages)
     assert name == want, (direction, name, want)
+  test_layer_all_directions(hip, case)
+
+
+@gpu
+@pytest.mark.parametrize('mode', ['default', 'k_split_workspace'])
+@pytest.mark.parametrize('case,want', H3_N32, ids=[c[0][0] for c in H3_N32])
+def test_layer_32_column_launches_on_the_image_kernel(hip, case, want, mode, hipenv):
+  """N = 32: one 64-column tile per row tile, weight rows 32..63 masked in the DMA (zeros), their column block skipped in
+  the epilogue; all directions against the float64 oracle, also with every tile cut into K slices that meet in the workspace
+  (the partial tiles carry the masked half along)."""
+  from advoc_amd import conv
+  if mode == 'default':
+    hipenv(ADVOC_H3_MIN_TILES=1)
+  else:
+    hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_DEEP_WGS_PER_CU=4, ADVOC_H3_DEEP_SPLIT_DIV=2)
+  c = build_case(case)
+  dev = torch.device('cuda')
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w = c['w'].to(dev)
+  cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+  y = torch.empty(x0.shape[0], c['oh'], c['out_w'], cout, device=dev)
+  L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
+  for direction, name in want.items():
+    assert L.kernel_name(direction) == name, (direction, L.kernel_name(direction))
   test_layer_all_directions(hip, case)
 
 
