@@ -104,6 +104,7 @@ PROTOTYPES = {
     'advoc_gan_g_loss': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _f32, _f32, _p, _p, _i32, _p, _p]),
     'advoc_adam_tf_f32': (ctypes.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p]),
     'advoc_sigmoid_f32': (ctypes.c_int, [_p, _p, _i64, _p]),
+    'advoc_zero_f32': (ctypes.c_int, [_p, _i64, _p]),
     'advoc_dropout_mask_u8': (ctypes.c_int, [_p, _i64, ctypes.c_uint64, ctypes.c_uint64, _f32, _p]),
 }
 

@@ -228,6 +228,33 @@ extern "C" int advoc_adam_tf_f32(float* param, const float* grad, float* m, floa
   return ADVOC_OK;
 }
 
+namespace {
+// 16-byte stores, two workgroups per CU: the zero fill of a gradient arena at the HBM write rate (the framework's generic
+// fill kernel ran the generator's 217 MB arena at 1.4 TB/s: 157 us per step)
+__global__ __launch_bounds__(256) void zero_kernel(float4* __restrict__ p, int64_t n4, float* __restrict__ tail, int ntail) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) p[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
+}  // namespace
+
+// The gradient arenas start every step from zero (tf.gradients sums into fresh tensors; here the weight- and bias-gradient
+// kernels accumulate into the arena): one launch per arena.
+extern "C" int advoc_zero_f32(float* dst, int64_t count, advoc_stream_t stream) {
+  if (!dst) return ADVOC_ERR_NULL;
+  if (count < 0) return ADVOC_ERR_BAD_SHAPE;
+  if (count == 0) return ADVOC_OK;
+  if (reinterpret_cast<uintptr_t>(dst) & 15) return ADVOC_ERR_UNSUPPORTED;
+  const int64_t n4 = count / 4;
+  int64_t blocks = advoc::ceil_div(n4 > 0 ? n4 : 1, 256);
+  if (blocks > 512) blocks = 512;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<float4*>(dst), n4,
+                     dst + 4 * n4, (int)(count - 4 * n4));
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
 extern "C" int advoc_sigmoid_f32(const float* logits, float* prob, int64_t count, advoc_stream_t stream) {
   if (!logits || !prob) return ADVOC_ERR_NULL;
   if (count < 0) return ADVOC_ERR_BAD_SHAPE;

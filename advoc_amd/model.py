@@ -308,9 +308,11 @@ class Advoc(Model):
                   work=torch.zeros(4 * c, **f32), copies=[])
 
     # ---- generator buffers ----
-    st['x_in'] = torch.zeros(B, T, F, 1, **f32)
-    # discriminator inputs for a 2B batch: [real ; fake]; G writes its output into the fake half
+    # discriminator inputs for a 2B batch: [real ; fake]; G writes its output into the fake half.  The generator's input IS
+    # the real half of the discriminator's conditioning input (the same tensor x in advoc_model.py:215-226): one copy less
+    # per update
     st['d_cond'] = torch.zeros(2 * B, T, F, 1, **f32)
+    st['x_in'] = st['d_cond'][:B]
     st['d_target'] = torch.zeros(2 * B, T, F, 1, **f32)
     gen_out = st['d_target'][B:]
     st['gen_out'] = gen_out
@@ -757,12 +759,15 @@ class Advoc(Model):
         _lib.stream()), 'advoc_adam_tf_f32')
     st[net + '_wdirty'] = True
 
+  def _zero_arena(self, net):
+    flat = self._built[net + '_grad']
+    _lib.check(_lib.load().advoc_zero_f32(_lib.ptr(flat), flat.numel(), _lib.stream()), 'advoc_zero_f32')
+
   def _load_batch(self, batch):
     st = self._built
     B = st['B']
     x, target = batch[0], batch[1]
-    st['x_in'].copy_(x)
-    st['d_cond'][:B].copy_(x)
+    st['x_in'].copy_(x)                # (= d_cond[:B])
     st['d_cond'][B:].copy_(x)
     st['d_target'][:B].copy_(target)
     st['last_batch'] = batch
@@ -820,7 +825,7 @@ class Advoc(Model):
     DG = st['d_G']
     # one fill of the whole gradient arena instead of one small memset per kernel / bias / BN vector
     # (every weight-gradient kernel accumulates with atomics into zeroed memory anyway)
-    st['d_grad'].zero_()
+    self._zero_arena('d')
     for k, (layers, bns, lo, hi) in enumerate(passes):
       acc = True
       for i in range(4, -1, -1):
@@ -938,7 +943,7 @@ class Advoc(Model):
         t.zero_()
     s = 'generator/decoder_1/conv2d_transpose'
     st['g_sent'] = 0
-    st['g_grad'].zero_()       # one fill for the whole arena; the kernels below accumulate into it
+    self._zero_arena('g')      # one fill for the whole arena; the kernels below accumulate into it
     last_idx = dec[-1][0] if dec else None
     GL['decoder_1'].backward_data(g_out, gd[last_idx] if dec else ge[-1], ge[0])
     with self._wgrad_ctx():

@@ -455,6 +455,10 @@ int advoc_adam_tf_f32(float* param, const float* grad, float* m, float* v, int64
  * Advoc.build_discriminator; the train step never materialises it (fused into the loss kernels above) */
 int advoc_sigmoid_f32(const float* logits, float* prob, int64_t count, advoc_stream_t stream);
 
+/* dst[0 .. count) = 0 (dst 16-byte aligned): the gradient arenas at the start of a D / G update -- tf.gradients
+ * (models/advoc/advoc_model.py:254-257) builds fresh sums every step, the weight- and bias-gradient kernels here accumulate */
+int advoc_zero_f32(float* dst, int64_t count, advoc_stream_t stream);
+
 int advoc_dropout_mask_u8(uint8_t* mask, int64_t count, uint64_t seed, uint64_t offset, float keep_prob,
                           advoc_stream_t stream);
 
