@@ -399,8 +399,21 @@ class Layer(object):
       self._dy_built = True
     self._dy_current_ptr = dy.data_ptr() if (self.struct.dy_img and 'h3' in self.kernel_name(1)) else None
 
+  _wgrad_scratch_stream = {}     # device -> the stream whose backward_weight calls use the shared K-slice scratch
+
   def backward_weight(self, dy, dw, db=None, accumulate=False):
+    """dw (+ db) <- gradients of the kernel (and bias).  Layers that sum their K slices in order share ONE scratch buffer
+    per device (advoc_conv_layer.wgrad_ws): all such calls of a process must therefore be enqueued on one stream -- the
+    model runs every weight gradient on its side stream, or everything on one.  A call from a second stream while the first
+    one's work may still be in flight would let two launches write the same partial tiles; it is refused."""
     _lib.require_device(dy)
+    if self.struct.wgrad_ws:
+      cur = torch.cuda.current_stream(dy.device)
+      prev = Layer._wgrad_scratch_stream.get(dy.device)
+      if prev is not None and prev.cuda_stream != cur.cuda_stream and not prev.query():
+        raise _lib.AdvocHipError('backward_weight on a second stream while another stream still uses the shared K-slice '
+                                 'scratch of this device: enqueue all weight gradients on one stream, or synchronise')
+      Layer._wgrad_scratch_stream[dy.device] = cur
     _lib.require_device(dw)
     if tuple(dw.shape) != tuple(self.weight.shape):
       raise _lib.AdvocHipError('dw shape mismatch')

@@ -679,7 +679,7 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
                               p.in_shift ? p.in_shift + p.c0 : nullptr, p.in_act, nullptr, 0.f};
       rc = make_operand_image(s0, s1, img0, hdr_a, p.a_img_out && p.a_img_delayed, stream,
                               p.a_colsum && image_colsum_ok(p.c0) ? p.a_colsum : nullptr, p.in_w, p.a0_pitch,
-                              reinterpret_cast<float*>(ws + 256));
+                              reinterpret_cast<float*>(ws + 256), /*keep_history=*/p.a_hdr_out != nullptr);
       if (rc != ADVOC_OK) return rc;
     }
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();

@@ -519,7 +519,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   constexpr int LDT = 36;
   float* T = smem + wave * (32 * LDT);
   const int trow = le >> 3, tq = le & 7;
-  const bool use_grad = BWD && p.grad_act != ADVOC_ACT_NONE;
+  const bool use_grad = BWD && p.grad_act != ADVOC_ACT_NONE && !(abl & 32);     // (DIAG builds, timing only: 32 = no pre-activation loads)
   // forward: consumers' operand images of the output (image_emit.h), one-pass scale from the consumer header
   constexpr bool emit0 = !BWD && NE >= 1, emit1 = !BWD && NE >= 2;
   const float eup0 = emit0 ? emit_up_scale(p.oimg[0].hdr[2]) : 1.f, eup1 = emit1 ? emit_up_scale(p.oimg[1].hdr[2]) : 1.f;

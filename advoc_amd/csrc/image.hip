@@ -555,7 +555,7 @@ int launch_image_refit(const ImageSource& s0, const ImageSource& s1, uint16_t* i
 // One GEMM operand (one or two channel-concatenated sources, ONE scale) -> image at `img` (source 1 behind source 0 at
 // its 256-byte-rounded size) and header `hdr` (16 bytes, caller-owned, persistent across calls for delayed scaling).
 int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* img, unsigned* hdr, bool delayed,
-                       hipStream_t stream, float* colsum0, int w_log, int w_pitch, float* colsum_table) {
+                       hipStream_t stream, float* colsum0, int w_log, int w_pitch, float* colsum_table, bool keep_history) {
   const int64_t b0 = (4 * s0.elems + 255) / 256 * 256;
   uint16_t* img1 = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(img) + b0);
   int rc = ADVOC_OK;
@@ -574,8 +574,9 @@ int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* i
                            stream, nullptr, 0, 0, nullptr);
   if (rc == ADVOC_OK && delayed && s0.elems > 0) {
     rc = launch_image_refit(s0, s1, img, hdr, stream);
-  } else if (rc == ADVOC_OK && s0.elems > 0) {
-    // exact image: leave the header rotated, ready for a one-pass image next time
+  } else if (rc == ADVOC_OK && s0.elems > 0 && keep_history) {
+    // exact image under a persistent header: leave the header rotated, ready for a one-pass image next time (the per-call
+    // images of the deep layers live in the launch workspace: r3 still launched this kernel behind each, 10 per step)
     ADVOC_CLEAR_LAUNCH_ERROR();
     hipLaunchKernelGGL(rotate_hdr_kernel, dim3(1), dim3(1), 0, stream, hdr);
     ADVOC_RETURN_IF_LAUNCH_FAILED();

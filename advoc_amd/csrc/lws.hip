@@ -15,6 +15,8 @@
 //   lws_batch_kernel    one sweep over the whole spectrogram (all bins from the previous iterate), touching only bins
 //                       above the sweep's magnitude threshold; the host launches `batch_iterations` of them, ping-pong.
 // Both are cache / LDS bound: 63 complex taps per bin.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -218,6 +220,9 @@ constexpr int kFQ = 4, kFL = 5, kFKW = 9, kFP = 4;
 #define ADVOC_LWS_SWEEP_FRAMES 8
 #endif
 constexpr int kSweepFrames = ADVOC_LWS_SWEEP_FRAMES;            // frames per tile of the batch sweep
+// advoc_lws_batch_sweeps_c64 documents tile_work as clips * ceil(nframes / 8) floats (include/advoc_hip.h; the Python
+// binding allocates clips * ceil(nframes / 4)): a build with smaller tiles would overrun the caller's buffer
+static_assert(kSweepFrames >= 8, "tile_work is sized for tiles of at least 8 frames");
 
 // The weight of tap (q, p) at bin m = f + p is alpha_q(p) (-i)^(q m): the frame rotation exp(-2 pi i m q nhop / nfft) is a
 // power of -i for hop = nfft / 4.  alpha_q(p) = W[q][p][0] is the same for every thread (scalar loads, no vector
@@ -520,6 +525,14 @@ extern "C" int advoc_lws_mean_mag_f32(const float* mag, int64_t clips, int64_t p
   return ADVOC_OK;
 }
 
+namespace {
+// ADVOC_LWS_GENERIC=1: every geometry on the kernels that read the caller's whole weight table (see advoc_lws_causal_c64)
+bool lws_generic_only() {
+  const char* e = getenv("ADVOC_LWS_GENERIC");      // (read per call: three C calls per vocoded batch)
+  return e && atoi(e) != 0;
+}
+}  // namespace
+
 extern "C" int advoc_lws_causal_c64(float* spec, const float* mag, const float* mean_mag, int64_t clips, int64_t nframes,
                                     int32_t nfft, int32_t nhop, const float* weights, int32_t period, int32_t L,
                                     int32_t look_ahead, const float* nofuture_thresholds_host, int32_t nofuture_steps,
@@ -543,7 +556,10 @@ extern "C" int advoc_lws_causal_c64(float* spec, const float* mag, const float* 
   LwsTables tb = {reinterpret_cast<const float2*>(weights), Q, L, period, nfft, bins};
   const size_t lds = sizeof(float2) * ((size_t)kRing * bins + (size_t)(2 * Q - 1) * (2 * L - 1) * period);
   ADVOC_CLEAR_LAUNCH_ERROR();
-  if (Q == kFQ && L == kFL && period == kFP && bins == kFBins && nofuture_steps <= kMaxNf) {
+  // The kernels for the reference geometry read ONLY weights[q][p][0] and apply the frame rotation (-i)^(q r) themselves
+  // (include/advoc_hip.h states the table form they rely on); ADVOC_LWS_GENERIC=1 sends every geometry through the
+  // kernels that read the whole table -- for callers with a table of another form
+  if (!lws_generic_only() && Q == kFQ && L == kFL && period == kFP && bins == kFBins && nofuture_steps <= kMaxNf) {
     constexpr size_t lds_fast = sizeof(float2) * (size_t)(kRing + 1) * kFRow;
     hipLaunchKernelGGL(lws_causal_fast_kernel, dim3((unsigned)clips), dim3(576), lds_fast, advoc::as_stream(stream), c,
                        reinterpret_cast<const float2*>(weights));
@@ -571,12 +587,13 @@ extern "C" int advoc_lws_batch_c64(const float* spec_in, float* spec_out, const 
   if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
   LwsTables tb = {reinterpret_cast<const float2*>(weights), Q, L, period, nfft, bins};
   ADVOC_CLEAR_LAUNCH_ERROR();
-  if (Q == kFQ && L == kFL && period == kFP && bins == kFBins) {
+  if (!lws_generic_only() && Q == kFQ && L == kFL && period == kFP && bins == kFBins) {
     const int64_t tiles_per_clip = advoc::ceil_div(nframes, kSweepFrames);
     if (clips * tiles_per_clip > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
     constexpr size_t lds_sweep = sizeof(float2) * (size_t)(kSweepFrames + 2 * (kFQ - 1)) * kPRow;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lws_sweep_fast_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep);
+    // (per call, not cached in a static: the attribute is per device)
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lws_sweep_fast_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep);
     if (attr != hipSuccess) { advoc::note_hip_error(attr); return ADVOC_ERR_HIP; }
     hipLaunchKernelGGL(lws_sweep_fast_kernel, dim3((unsigned)(clips * tiles_per_clip)), dim3(576), lds_sweep,
                        advoc::as_stream(stream), reinterpret_cast<const float2*>(spec_in),
@@ -611,7 +628,7 @@ extern "C" int advoc_lws_batch_sweeps_c64(float* spec_a, float* spec_b, const fl
   const int bins = nfft / 2 + 1;
   const int Q = (nfft + nhop - 1) / nhop;
   hipStream_t st = advoc::as_stream(stream);
-  bool sparse = Q == kFQ && L == kFL && period == kFP && bins == kFBins && tile_work != nullptr;
+  bool sparse = !lws_generic_only() && Q == kFQ && L == kFL && period == kFP && bins == kFBins && tile_work != nullptr;
   for (int i = 1; i < n_sweeps && sparse; ++i) sparse = thresholds_host[i] <= thresholds_host[i - 1];
   const size_t bytes = sizeof(float2) * (size_t)clips * (size_t)nframes * (size_t)bins;
   float* cur = spec_a;

@@ -60,9 +60,11 @@ struct ImageSource {
 // colsum0 != null: the image pass of source 0 also adds its per-channel sums over the logical pixels (x < w_log of rows
 // w_pitch pixels apart) to colsum0[c] -- the bias gradient when the operand is an output gradient (image_colsum_ok(c))
 // colsum_table: kColsumBytes of scratch (the sums are collected in kColsumReplicas copies first)
+// keep_history: the header is a persistent one (a layer's x_hdr / dy_hdr): an exact image leaves it rotated for a one-pass
+// image next time.  false for the per-call images in the launch workspace, whose header nobody reads again
 int make_operand_image(const ImageSource& s0, const ImageSource& s1, uint16_t* img, unsigned* hdr, bool delayed,
                        hipStream_t stream, float* colsum0 = nullptr, int w_log = 0, int w_pitch = 0,
-                       float* colsum_table = nullptr);
+                       float* colsum_table = nullptr, bool keep_history = true);
 int launch_image_refit(const ImageSource& s0, const ImageSource& s1, uint16_t* img, unsigned* hdr, hipStream_t stream);
 bool image_colsum_ok(int c);
 // out[ch] += sum over the kColsumReplicas copies of table[r][ch] (the fold of every replica table of this library)

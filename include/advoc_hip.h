@@ -104,6 +104,10 @@ int advoc_polar_c64(const float* mag, const float* unit_phase, float* spec, int6
  *   weights   [2Q-1][2L-1][period] complex64 (caller-computed, read-only), Q = nfft/nhop, period = nfft / gcd(nfft, nhop):
  *             alpha_q(p) * exp(-2 pi i r q nhop / nfft) with alpha_q(p) = 1/nfft sum_n awin[n] swin[n - q nhop]
  *             exp(2 pi i p n / nfft) -- the STFT o iSTFT projection kernel; r = (f + p) mod period
+ *             THE TABLE MUST HAVE THIS FORM: for the reference geometry (nfft 1024, nhop 256: Q = 4, L = 5, period 4) the
+ *             time-ordered pass and the batch sweeps read weights[q][p][0] only and apply the rotation (-i)^(q r) themselves
+ *             (advoc_amd/csrc/lws.hip); a table of another form is honoured only with ADVOC_LWS_GENERIC=1 in the
+ *             environment, which keeps every geometry on the kernels that read the whole table
  *   mean_mag  [clips]: mean magnitude of each clip (advoc_lws_mean_mag_f32); thresholds are multiples of it
  * advoc_lws_causal_c64: the time-ordered pass (no-future initialisation look_ahead frames ahead, with the host array
  *   nofuture_thresholds_host of nofuture_steps descending multiples -- the last must be 0 --, then online_iterations

@@ -76,6 +76,23 @@ def test_kernels_match_the_cpu_restatement(hip, complex_input):
 
 
 @gpu
+def test_generic_kernels_agree_with_the_reference_geometry_kernels(hip, monkeypatch):
+  """The kernels for nfft 1024 / hop 256 read weights[q][p][0] only and apply the frame rotation themselves (the table form
+  include/advoc_hip.h requires); ADVOC_LWS_GENERIC=1 keeps the kernels that read the caller's whole table.  On the standard
+  table the two must agree -- same magnitudes, phases within what ~20 dependent fp32 updates per bin allow."""
+  from advoc_amd import spectral
+  rng = np.random.default_rng(5)
+  x = (rng.standard_normal(12000) * 0.1 + 0.2 * np.sin(np.arange(12000) * 0.07)).astype(np.float32)
+  mag = torch.from_numpy(np.abs(S.stft(x[:, None, None], 1024, 256, pad_end=False)[:, :, 0]).astype(np.float32))[None].cuda()
+  kw = dict(online=(3, 1.0, 0.1), batch=(6, 100.0, 0.1, 1.0))
+  fast = spectral.lws_spectrogram_batch(mag, 1024, 256, **kw).cpu().numpy()
+  monkeypatch.setenv('ADVOC_LWS_GENERIC', '1')
+  gen = spectral.lws_spectrogram_batch(mag, 1024, 256, **kw).cpu().numpy()
+  assert np.allclose(np.abs(fast), np.abs(gen), rtol=2e-5, atol=1e-6)
+  assert np.linalg.norm(fast - gen) / np.linalg.norm(gen) < 2e-2
+
+
+@gpu
 @pytest.mark.parametrize('n_sweeps', [7, 30])
 def test_sparse_sweeps_equal_dense_sweeps(hip, n_sweeps):
   """advoc_lws_batch_sweeps_c64 skips the 8-frame tiles none of whose bins exceeds a sweep's threshold (speech: most of
