@@ -26,7 +26,7 @@ Extra objects on the JSON line:
                 algorithmic flops / measured time against the roof of the pipe the kernel runs on: dense fp32
                 MFMA (157.3 TFLOP/s), or, for the split-bf16 kernels, dense bf16 MFMA / 6 partial products
                 (416.7 TFLOP/s algorithmic).  `traffic` = L2-miss bytes per launch of that kernel from the
-                committed rocprofv3 counter passes of this same command (profiles/r03_traffic.json; FETCH_SIZE
+                committed rocprofv3 counter passes of this same command (the newest profiles/rNN_traffic.json; FETCH_SIZE
                 doubled per the gfx950 correction + WRITE_SIZE), null when not recorded for this workload.  The operand-image
                 passes (amax_kernel + pair_image_kernel) that precede an image-based GEMM are launched and timed on their
                 own during the instrumented steps (`operand_images(...)` in `kernels`); the small weight-image kernels
@@ -68,7 +68,14 @@ H3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
 HBM_PEAK_GBS = 8000.0           # ibid., HBM3E peak BW
 CLIP_FRAMES = 256
 CLIP_SAMPLES = (CLIP_FRAMES - 1) * 256 + 1024   # 66304
-TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r03_traffic.json')
+def _latest_traffic_json():
+  """profiles/rNN_traffic.json of the highest round (tools/run_gpu_prof_r04.sh writes it next to the other summaries)."""
+  import glob
+  found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_traffic.json')))
+  return found[-1] if found else os.path.join(ROOT, 'profiles', 'r03_traffic.json')
+
+
+TRAFFIC_JSON = _latest_traffic_json()
 
 
 def synth_waveforms(batch, seed, device):
@@ -504,6 +511,7 @@ def roofline_from(prof, model, batch, ms_per_step, prof_steps, verbose):
   top = kernels[0]
   roofline = dict(bound=top['bound'], kernel=name, achieved=top['achieved'], peak=top['peak'], unit=top['unit'],
                   frac=top['frac'], traffic=recorded_traffic(name, model, batch),
+                  traffic_source=os.path.relpath(TRAFFIC_JSON, ROOT) + ' (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of `bench.py --steps 3`, committed; not re-measured by this run)',
                   algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
                   launches=r['launches'], avg_launch_ms=r['ms'] / r['launches'],
                   share_of_step=r['ms'] / prof_steps / ms_per_step, instrumented_steps=prof_steps,
