@@ -399,21 +399,21 @@ class Layer(object):
       self._dy_built = True
     self._dy_current_ptr = dy.data_ptr() if (self.struct.dy_img and 'h3' in self.kernel_name(1)) else None
 
-  _wgrad_scratch_stream = {}     # device -> the stream whose backward_weight calls use the shared K-slice scratch
+  _wgrad_scratch_use = {}        # device -> (stream id, event behind the last launch that used the shared K-slice scratch)
 
   def backward_weight(self, dy, dw, db=None, accumulate=False):
     """dw (+ db) <- gradients of the kernel (and bias).  Layers that sum their K slices in order share ONE scratch buffer
-    per device (advoc_conv_layer.wgrad_ws): all such calls of a process must therefore be enqueued on one stream -- the
-    model runs every weight gradient on its side stream, or everything on one.  A call from a second stream while the first
-    one's work may still be in flight would let two launches write the same partial tiles; it is refused."""
+    per device (advoc_conv_layer.wgrad_ws).  Calls on one stream are ordered by the stream (the model runs every weight
+    gradient on its side stream, or everything on one); a call that arrives on ANOTHER stream first makes that stream wait
+    for the last launch that used the scratch (an event), so two models, or a profiled and an unprofiled step, never have
+    two launches writing the same partial tiles."""
     _lib.require_device(dy)
-    if self.struct.wgrad_ws:
+    scratch_user = bool(self.struct.wgrad_ws)
+    if scratch_user:
       cur = torch.cuda.current_stream(dy.device)
-      prev = Layer._wgrad_scratch_stream.get(dy.device)
-      if prev is not None and prev.cuda_stream != cur.cuda_stream and not prev.query():
-        raise _lib.AdvocHipError('backward_weight on a second stream while another stream still uses the shared K-slice '
-                                 'scratch of this device: enqueue all weight gradients on one stream, or synchronise')
-      Layer._wgrad_scratch_stream[dy.device] = cur
+      last = Layer._wgrad_scratch_use.get(dy.device)
+      if last is not None and last[0] != cur.cuda_stream:
+        cur.wait_event(last[1])
     _lib.require_device(dw)
     if tuple(dw.shape) != tuple(self.weight.shape):
       raise _lib.AdvocHipError('dw shape mismatch')
@@ -434,6 +434,10 @@ class Layer(object):
           _lib.stream()), 'advoc_conv_backward_weight'))
     finally:
       self.struct.img_flags = 0
+    if scratch_user:
+      ev = last[1] if last is not None else torch.cuda.Event()     # (one event per device, re-recorded)
+      ev.record(cur)
+      Layer._wgrad_scratch_use[dy.device] = (cur.cuda_stream, ev)
     self._x_current = False                # one use per forward: the caller may rewrite the inputs before the next call
     if 'h3' in self.kernel_name(2):        # the image-based weight gradient has (re)built whatever was not current
       self._x_built = self._x_built or bool(self.struct.x_img)
