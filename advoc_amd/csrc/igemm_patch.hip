@@ -352,7 +352,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     // each.  Waves 4-7 run ONE BARRIER BEHIND waves 0-3 (an extra barrier in front of their loop, one behind the others'),
     // and wave w shares its SIMD with wave w + 4: whenever one wave of a SIMD multiplies the other one reads, so the matrix
     // pipe never waits for a fragment read and the LDS never serves all eight waves at once -- what r3 measured as the
-    // "rendezvous window" (section 7 item 5: -33 % with the barrier ablated) without giving up the rendezvous.
+    // "rendezvous window" (-33 % with the barrier ablated) without giving up the rendezvous.
     //   * early waves issue the DMAs of step n + 1 (B tile, halo piece) at the end of their R1(n), late waves theirs at the
     //     start of their M2(n - 1): the same barrier interval, right behind the barrier at which every wave has retired
     //     (lgkmcnt 0) its reads of the stage being refilled, and four intervals before anyone reads the new tile;
