@@ -24,7 +24,10 @@
 // Algorithmic traffic is 256 new samples in + 513 floats out per frame.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "common.h"
+#include "lds_dma.h"
 
 namespace {
 
@@ -247,6 +250,247 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// (r4) The same transform for hop = 256 = nfft / 4 -- the geometry of every preset the train step and the vocoder use --
+// with fewer instructions per frame pair.  stft1024_kernel above is bound by what its waves ISSUE (rocprofv3:
+// SQ_ACTIVE_INST_ANY x 4 waves per SIMD = 0.95; ~460 vector + 76 LDS instructions per pair, the LDS pipe 69 % busy with
+// them), not by HBM, so the only way up the bandwidth roofline is to issue less:
+//   * frames f and f + 1 overlap in 768 of their 1 024 samples: ten 8-byte loads per lane and pair instead of sixteen;
+//   * the real-FFT split pairs bin k with bin 512 - k, and X[512 - k] = conj((S + T)) where X[k] = S - T: a lane computes
+//     BOTH bins of the pairs whose lower bin it owns (k = lane + 64 r, r < 4), so S, T are formed once per pair of bins and
+//     only half of the partner values cross lanes (16 ds_bpermute instead of 32); the upper bins are stored in descending
+//     lane order (still one contiguous 252-byte run per instruction); lane 0 adds bin 256, which pairs with itself;
+//   * the split's factor 1/2 is folded into the window table (a power of two: the same bits come out);
+//   * the transposes read with ds_read_b64, one instruction per value: the ds_read2_b64 the compiler fuses two reads into
+//     costs 8 LDS cycles per 1 KB against 2 per 512 B (MI355X_MICROARCH.md, LDS table), so the reads are inline assembly the
+//     load/store optimiser does not see, tied to ONE hand-placed s_waitcnt;
+//   * kV bit 0: real and imaginary parts go through TWO planes per wave in one round (half the waits); bit 1: the pass
+//     twiddles live in registers; bit 2: the window too (with both, 37 KB of LDS per workgroup).
+// Same radix-8 x 3 arithmetic as above; results differ from stft1024_kernel in the last bit only (the split's association).
+// ---------------------------------------------------------------------------------------------
+template <int OFF>
+__device__ __forceinline__ f2 lds_read_b64(unsigned addr) {
+  f2 v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+#define ADVOC_LDS_READ8(DST, ADDR, BASE, STEP)                                                                     \
+  {                                                                                                                \
+    DST[0] = lds_read_b64<(BASE) + 0 * (STEP)>(ADDR); DST[1] = lds_read_b64<(BASE) + 1 * (STEP)>(ADDR);            \
+    DST[2] = lds_read_b64<(BASE) + 2 * (STEP)>(ADDR); DST[3] = lds_read_b64<(BASE) + 3 * (STEP)>(ADDR);            \
+    DST[4] = lds_read_b64<(BASE) + 4 * (STEP)>(ADDR); DST[5] = lds_read_b64<(BASE) + 5 * (STEP)>(ADDR);            \
+    DST[6] = lds_read_b64<(BASE) + 6 * (STEP)>(ADDR); DST[7] = lds_read_b64<(BASE) + 7 * (STEP)>(ADDR);            \
+  }
+// every LDS read of this wave has returned; the eight values are "written" by the statement, so nothing that uses them can
+// be scheduled above it
+#define ADVOC_LDS_WAIT8(V)                                                                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                               \
+               : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(V[4]), "+v"(V[5]), "+v"(V[6]), "+v"(V[7])     \
+               :: "memory")
+#define ADVOC_LDS_TIE8(V)                                                                                           \
+  asm volatile("" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(V[4]), "+v"(V[5]), "+v"(V[6]), "+v"(V[7]))
+
+__device__ __forceinline__ float bperm(int byte_index, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_index, __float_as_int(v)));
+}
+
+template <bool kComplexOut, int kV>
+__global__ __launch_bounds__(kWaves * 64) void stft1024_hop256_kernel(
+    const float* __restrict__ wav, int64_t nsamps, const float* __restrict__ window,
+    const float2* __restrict__ twiddle, int64_t nframes, float* __restrict__ out, int pairs_per_clip,
+    int64_t total_pairs) {
+  constexpr bool kTwoPlanes = (kV & 1) != 0, kTwRegs = (kV & 2) != 0, kWinRegs = (kV & 4) != 0;
+  constexpr int kNP = kTwoPlanes ? 2 : 1;
+  constexpr int kWinRow = 0, kT1Row = kWinRegs ? 0 : 8, kT2Row = kT1Row + (kTwRegs ? 0 : 8);
+  constexpr int kTabRows = kT2Row + (kTwRegs ? 0 : 8);
+  __shared__ f2 planes[kWaves][kNP][kPlane];
+  __shared__ float2 s_tab[kTabRows ? kTabRows : 1][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int hi = lane >> 3, lo = lane & 7;
+  f2* const plane = &planes[wave][0][0];
+
+  // ---- per-lane constants (they depend on the lane only) ----
+  float2 win_r[8], t1_r[8], t2_r[8];
+  float tsn[4], tcs[4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    // window, halved: the 1/2 of the real-FFT split
+    const float2 w = *reinterpret_cast<const float2*>(window + 128 * j + 2 * lane);
+    const float2 wh = make_float2(0.5f * w.x, 0.5f * w.y);
+    // pass-1 twiddle W64^(b*p): lane = (b=hi, c=lo), p = j;  pass-2 twiddle W512^(c*(p+8q)): lane = (p=hi, c=lo), q = j
+    const float2 a = twiddle[((hi * j) & 63) * 16];
+    const float2 b = twiddle[((lo * (hi + 8 * j)) & 511) * 2];
+    if (kWinRegs) win_r[j] = wh; else if (wave == 0) s_tab[kWinRow + j][lane] = wh;
+    if (kTwRegs) {
+      t1_r[j] = make_float2(a.x, -a.y);
+      t2_r[j] = make_float2(b.x, -b.y);
+    } else if (wave == 0) {
+      s_tab[kT1Row + j][lane] = make_float2(a.x, -a.y);
+      s_tab[kT2Row + j][lane] = make_float2(b.x, -b.y);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {   // split twiddle of bin k = lane + 64 r: theta = 2 pi k / 1024
+    const float2 c = twiddle[lane + 64 * r];
+    tcs[r] = c.x; tsn[r] = c.y;
+  }
+  if (!(kWinRegs && kTwRegs)) __syncthreads();
+  const int partner = ((64 - lane) & 63) * 4;              // ds_bpermute byte index of the lane that holds Z[512 - k]
+  f2* const wr = plane + hi * 9 + lo;                      // + 72 p: element (8 p + hi) * 9 + lo
+  const unsigned rd1 = advoc::lds_address(plane + 72 * hi + lo);   // + 9 b elements = 72 b bytes
+  const unsigned rd2 = advoc::lds_address(plane + 9 * lane);       // + c elements
+  constexpr int kIm = kTwoPlanes ? kPlane * 8 : 0;         // byte offset of the imaginary plane
+
+  // Everything that says WHICH pair is wave-uniform and kept in scalar registers (the wave index through readfirstlane);
+  // (clip, pair of the clip) advance by a fixed step, so there is no division in the loop and the loads / stores are
+  // "scalar base + lane offset" instructions: no 64-bit vector address arithmetic per pair.
+  const int swave = __builtin_amdgcn_readfirstlane(wave);
+  const int pstride = (int)gridDim.x * kWaves;
+  const int step_clip = pstride / pairs_per_clip, step_fp = pstride - step_clip * pairs_per_clip;
+  const int pair0 = (int)blockIdx.x * kWaves + swave;
+  int clip = pair0 / pairs_per_clip, fp = pair0 - clip * pairs_per_clip;
+  const unsigned lane2 = 2u * (unsigned)lane;
+  for (int pair = pair0; pair < (int)total_pairs; pair += pstride, clip += step_clip, fp += step_fp) {
+    if (fp >= pairs_per_clip) { fp -= pairs_per_clip; ++clip; }
+    const int64_t f = 2 * (int64_t)fp;                        // frames f and f + 1
+    const bool two = f + 1 < nframes;
+    const float* src = wav + (int64_t)clip * nsamps;
+    const int64_t s0 = f * 256;
+    // samples s0 + 128 j + 2 lane (+ 1), j < 10: frame f is j = 0..7, frame f + 1 is j = 2..9; zero beyond the clip (pad_end)
+    float2 raw[10];
+    if (s0 + 256 + kNfft <= nsamps) {
+      const float* p0 = src + s0;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) raw[j] = *reinterpret_cast<const float2*>(p0 + (128u * j + lane2));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const int64_t i0 = s0 + 128 * j + lane2;
+        raw[j].x = i0 < nsamps ? src[i0] : 0.f;
+        raw[j].y = i0 + 1 < nsamps ? src[i0 + 1] : 0.f;
+      }
+    }
+    f2 re[8], im[8];
+    // z[n] = (x[2n] w[2n] + i x[2n+1] w[2n+1]) / 2
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const float2 w = kWinRegs ? win_r[a] : s_tab[kWinRow + a][lane];
+      re[a] = f2{raw[a].x * w.x, raw[a + 2].x * w.x};
+      im[a] = f2{raw[a].y * w.y, raw[a + 2].y * w.y};
+    }
+
+    // pass 1: DFT over a -> p, twiddle, transpose (b,c | p) -> (p,c | b)
+    dft8(re, im);
+    {
+      f2 ti[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        f2 r = re[p], i = im[p];
+        if (p) {                      // W64^0 = 1
+          const float2 t = kTwRegs ? t1_r[p] : s_tab[kT1Row + p][lane];
+          r = re[p] * t.x - im[p] * t.y;
+          i = re[p] * t.y + im[p] * t.x;
+        }
+        wr[72 * p] = r;
+        if (kTwoPlanes) wr[72 * p + kPlane] = i; else ti[p] = i;
+      }
+      ADVOC_LDS_READ8(re, rd1, 0, 72);
+      if (kTwoPlanes) {
+        ADVOC_LDS_READ8(im, rd1, kIm, 72);
+        ADVOC_LDS_WAIT8(re);
+        ADVOC_LDS_TIE8(im);
+      } else {
+        ADVOC_LDS_WAIT8(re);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) wr[72 * p] = ti[p];
+        ADVOC_LDS_READ8(im, rd1, 0, 72);
+        ADVOC_LDS_WAIT8(im);
+      }
+    }
+
+    // pass 2: DFT over b -> q, twiddle, transpose (p,c | q) -> (q,p | c)
+    dft8(re, im);
+    {
+      f2 ti[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float2 t = kTwRegs ? t2_r[q] : s_tab[kT2Row + q][lane];
+        const f2 r = re[q] * t.x - im[q] * t.y;
+        const f2 i = re[q] * t.y + im[q] * t.x;
+        wr[72 * q] = r;
+        if (kTwoPlanes) wr[72 * q + kPlane] = i; else ti[q] = i;
+      }
+      ADVOC_LDS_READ8(re, rd2, 0, 8);
+      if (kTwoPlanes) {
+        ADVOC_LDS_READ8(im, rd2, kIm, 8);
+        ADVOC_LDS_WAIT8(re);
+        ADVOC_LDS_TIE8(im);
+      } else {
+        ADVOC_LDS_WAIT8(re);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wr[72 * q] = ti[q];
+        ADVOC_LDS_READ8(im, rd2, 0, 8);
+        ADVOC_LDS_WAIT8(im);
+      }
+    }
+
+    // pass 3: DFT over c -> r.  Lane now holds Z[lane + 64 r] / 2.
+    dft8(re, im);
+
+    // real-FFT split, two bins per step: with S = Zk + conj(Zm), D = Zk - conj(Zm), m = 512 - k, T = i W1024^k D:
+    //   X[k] = S - T,  X[m] = conj(S + T)        (the halves are in the window)
+    float* orow0 = out + (((int64_t)clip * nframes + f) * kBins) * (kComplexOut ? 2 : 1);
+    float* orow1 = orow0 + kBins * (kComplexOut ? 2 : 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      f2 c, d;
+      c.x = bperm(partner, re[7 - r].x); c.y = bperm(partner, re[7 - r].y);
+      d.x = bperm(partner, im[7 - r].x); d.y = bperm(partner, im[7 - r].y);
+      if (lane == 0) {  // k = 64 r pairs with 64 (8 - r) on the same lane (Z[512] = Z[0])
+        c = re[(8 - r) & 7];
+        d = im[(8 - r) & 7];
+      }
+      const f2 a = re[r], b = im[r];
+      const f2 sr = a + c, si = b - d, dr = a - c, di = b + d;
+      const f2 tr = tsn[r] * dr - tcs[r] * di;
+      const f2 ti = tsn[r] * di + tcs[r] * dr;
+      const f2 xkr = sr - tr, xki = si - ti, xmr = sr + tr, xmi = si + ti;
+      const unsigned k = (unsigned)lane + 64u * r, m = 512u - k;
+      if (kComplexOut) {
+        *reinterpret_cast<float2*>(orow0 + 2 * k) = make_float2(xkr.x, xki.x);
+        *reinterpret_cast<float2*>(orow0 + 2 * m) = make_float2(xmr.x, -xmi.x);
+        if (two) {
+          *reinterpret_cast<float2*>(orow1 + 2 * k) = make_float2(xkr.y, xki.y);
+          *reinterpret_cast<float2*>(orow1 + 2 * m) = make_float2(xmr.y, -xmi.y);
+        }
+      } else {
+        const f2 k2 = xkr * xkr + xki * xki, m2 = xmr * xmr + xmi * xmi;
+        orow0[k] = __builtin_amdgcn_sqrtf(k2.x);   // v_sqrt_f32, <= 1 ulp
+        orow0[m] = __builtin_amdgcn_sqrtf(m2.x);
+        if (two) {
+          orow1[k] = __builtin_amdgcn_sqrtf(k2.y);
+          orow1[m] = __builtin_amdgcn_sqrtf(m2.y);
+        }
+      }
+    }
+    if (lane == 0) {  // bin 256 pairs with itself: X[256] = conj(Z[256])
+      const f2 xr = 2.0f * re[4], xi = -2.0f * im[4];
+      if (kComplexOut) {
+        *reinterpret_cast<float2*>(orow0 + 2 * 256) = make_float2(xr.x, xi.x);
+        if (two) *reinterpret_cast<float2*>(orow1 + 2 * 256) = make_float2(xr.y, xi.y);
+      } else {
+        const f2 m2 = xr * xr + xi * xi;
+        orow0[256] = __builtin_amdgcn_sqrtf(m2.x);
+        if (two) orow1[256] = __builtin_amdgcn_sqrtf(m2.y);
+      }
+    }
+  }
+}
+#undef ADVOC_LDS_READ8
+#undef ADVOC_LDS_WAIT8
+#undef ADVOC_LDS_TIE8
+
+// ---------------------------------------------------------------------------------------------
 // Inverse: one wavefront = one frame.  irfft(1024) runs as the SAME 512-point complex transform
 // (IDFT(Z) = conj(DFT(conj(Z))) / 512) after undoing the real-FFT split:
 //   Ze[k] = (X[k] + conj(X[512-k])) / 2,  Zo[k] = (X[k] - conj(X[512-k])) / 2 * W1024^-k,
@@ -415,6 +659,26 @@ int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* wi
   // amortised; 8 workgroups per CU is more than the register file holds at once
   int64_t blocks = advoc::ceil_div(total_pairs, kWaves);
   if (blocks > 2048) blocks = 2048;
+  // hop 256 with 8-byte aligned clips: the kernel with fewer instructions per frame pair
+  static const int variant = getenv("ADVOC_STFT_V") ? atoi(getenv("ADVOC_STFT_V")) : 0;
+  static const int block_cap = getenv("ADVOC_STFT_BLOCKS") ? atoi(getenv("ADVOC_STFT_BLOCKS")) : 2048;
+  if (nhop == 256 && !(nsamps & 1) && total_pairs < (1LL << 30) && variant >= 0) {
+    if (blocks > block_cap) blocks = block_cap;
+#define ADVOC_STFT_LAUNCH(C, V)                                                                                         \
+  hipLaunchKernelGGL((stft1024_hop256_kernel<C, V>), dim3((unsigned)blocks), dim3(kWaves * 64), 0, stream, wav, nsamps, \
+                     window, reinterpret_cast<const float2*>(twiddle), nframes, out, (int)pairs_per_clip, total_pairs)
+#define ADVOC_STFT_CASE(V) case V: if (complex_out) ADVOC_STFT_LAUNCH(true, V); else ADVOC_STFT_LAUNCH(false, V); break
+    ADVOC_CLEAR_LAUNCH_ERROR();
+    switch (variant) {
+      ADVOC_STFT_CASE(0); ADVOC_STFT_CASE(1); ADVOC_STFT_CASE(2); ADVOC_STFT_CASE(3);
+      ADVOC_STFT_CASE(4); ADVOC_STFT_CASE(5); ADVOC_STFT_CASE(6); ADVOC_STFT_CASE(7);
+      default: return ADVOC_ERR_UNSUPPORTED;
+    }
+#undef ADVOC_STFT_CASE
+#undef ADVOC_STFT_LAUNCH
+    ADVOC_RETURN_IF_LAUNCH_FAILED();
+    return ADVOC_OK;
+  }
   if (complex_out) {
     ADVOC_CLEAR_LAUNCH_ERROR();
     hipLaunchKernelGGL(stft1024_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), 0, stream, wav, nsamps,
