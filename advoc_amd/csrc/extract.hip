@@ -84,7 +84,14 @@ __global__ __launch_bounds__(kXThreads, MINW) void stft_mel_pinv_kernel(
   f2* plane = &sm.planes[wave][0];
 
   // ---- once per workgroup ----
-  if (wave == 0) fill_tables(sm.tables, window, twiddle, lane);
+  if (wave == 0) {
+    fill_tables(sm.tables, window, twiddle, lane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {        // the 1/2 of the real-FFT split, in the window
+      const float2 w = sm.tables.win[j][lane];
+      sm.tables.win[j][lane] = make_float2(0.5f * w.x, 0.5f * w.y);
+    }
+  }
   for (int i = tid; i < packed; i += kXThreads) sm.w[i] = mel_wp[i];
   if (tid < kMels) {
     const int2 b = band[tid];
@@ -124,50 +131,57 @@ __global__ __launch_bounds__(kXThreads, MINW) void stft_mel_pinv_kernel(
       asm volatile("" : "+v"(lf));
       const int hi = lf >> 3, lo = lf & 7;
       if (va) {
+        // hop 256 (the launcher refuses other hops): frames fa and fa + 1 share 768 samples -- ten loads per lane, and the
+        // rest of stft1024_hop256_kernel's economies (stft.hip): 1/2 in the window table, ds_read_b64 transposes, both bins
+        // of a split pair from the lane that owns the lower one
         f2 re[8], im[8];
         {
           const float* src = wav + (int64_t)clip * nsamps;
-          const int64_t s0 = (int64_t)fa * nhop;
-          if (aligned && s0 + nhop + kNfft <= nsamps) {
+          const int64_t s0 = (int64_t)fa * 256;
+          float2 raw[10];
+          if (aligned && s0 + 256 + kNfft <= nsamps) {
+            const float* p0 = src + s0;
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-              const float2 r0 = *reinterpret_cast<const float2*>(src + s0 + 128 * a + 2 * lane);
-              const float2 r1 = *reinterpret_cast<const float2*>(src + s0 + nhop + 128 * a + 2 * lane);
-              const float2 w = sm.tables.win[a][lane];
-              re[a] = f2{r0.x, r1.x} * w.x;
-              im[a] = f2{r0.y, r1.y} * w.y;
-            }
+            for (int j = 0; j < 10; ++j) raw[j] = *reinterpret_cast<const float2*>(p0 + (128u * j + 2u * (unsigned)lane));
           } else {
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-              const int64_t i0 = s0 + 128 * a + 2 * lane, i1 = i0 + nhop;
-              const float2 w = sm.tables.win[a][lane];
-              re[a] = f2{i0 < nsamps ? src[i0] : 0.f, (vb && i1 < nsamps) ? src[i1] : 0.f} * w.x;
-              im[a] = f2{i0 + 1 < nsamps ? src[i0 + 1] : 0.f, (vb && i1 + 1 < nsamps) ? src[i1 + 1] : 0.f} * w.y;
+            for (int j = 0; j < 10; ++j) {
+              const int64_t i0 = s0 + 128 * j + 2 * lane;
+              raw[j].x = i0 < nsamps ? src[i0] : 0.f;
+              raw[j].y = i0 + 1 < nsamps ? src[i0 + 1] : 0.f;
             }
           }
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            const float2 w = sm.tables.win[a][lane];          // halved when the tables were filled
+            re[a] = f2{raw[a].x * w.x, raw[a + 2].x * w.x};
+            im[a] = f2{raw[a].y * w.y, raw[a + 2].y * w.y};
+          }
         }
+        f2* const wr = plane + hi * 9 + lo;                                  // + 72 p: element (8 p + hi) * 9 + lo
+        const unsigned rd1 = advoc::lds_address(plane + 72 * hi + lo);       // + 72 b bytes
+        const unsigned rd2 = advoc::lds_address(plane + 9 * lf);             // + 8 c bytes
         // pass 1: DFT over a -> p, twiddle, transpose (b,c | p) -> (p,c | b)
         dft8(re, im);
         {
           f2 ti[8];
 #pragma unroll
           for (int p = 0; p < 8; ++p) {
-            const float2 t = sm.tables.t1[p][lane];
-            const f2 r = re[p] * t.x - im[p] * t.y;
-            ti[p] = re[p] * t.y + im[p] * t.x;
-            plane[(8 * p + hi) * 9 + lo] = r;
+            f2 r = re[p], i = im[p];
+            if (p) {                      // W64^0 = 1
+              const float2 t = sm.tables.t1[p][lane];
+              r = re[p] * t.x - im[p] * t.y;
+              i = re[p] * t.y + im[p] * t.x;
+            }
+            wr[72 * p] = r;
+            ti[p] = i;
           }
-          advoc::wave_lds_sync();
+          ADVOC_FFT_LDS_READ8(re, rd1, 0, 72);
+          ADVOC_FFT_LDS_WAIT8(re);
 #pragma unroll
-          for (int b = 0; b < 8; ++b) re[b] = plane[(8 * hi + b) * 9 + lo];
-          advoc::wave_lds_sync();
-#pragma unroll
-          for (int p = 0; p < 8; ++p) plane[(8 * p + hi) * 9 + lo] = ti[p];
-          advoc::wave_lds_sync();
-#pragma unroll
-          for (int b = 0; b < 8; ++b) im[b] = plane[(8 * hi + b) * 9 + lo];
-          advoc::wave_lds_sync();
+          for (int p = 0; p < 8; ++p) wr[72 * p] = ti[p];
+          ADVOC_FFT_LDS_READ8(im, rd1, 0, 72);
+          ADVOC_FFT_LDS_WAIT8(im);
         }
         // pass 2: DFT over b -> q, twiddle, transpose (p,c | q) -> (q,p | c)
         dft8(re, im);
@@ -176,55 +190,60 @@ __global__ __launch_bounds__(kXThreads, MINW) void stft_mel_pinv_kernel(
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const float2 t = sm.tables.t2[q][lane];
-            const f2 r = re[q] * t.x - im[q] * t.y;
+            wr[72 * q] = re[q] * t.x - im[q] * t.y;
             ti[q] = re[q] * t.y + im[q] * t.x;
-            plane[(8 * q + hi) * 9 + lo] = r;
           }
-          advoc::wave_lds_sync();
+          ADVOC_FFT_LDS_READ8(re, rd2, 0, 8);
+          ADVOC_FFT_LDS_WAIT8(re);
 #pragma unroll
-          for (int c = 0; c < 8; ++c) re[c] = plane[lane * 9 + c];
-          advoc::wave_lds_sync();
-#pragma unroll
-          for (int q = 0; q < 8; ++q) plane[(8 * q + hi) * 9 + lo] = ti[q];
-          advoc::wave_lds_sync();
-#pragma unroll
-          for (int c = 0; c < 8; ++c) im[c] = plane[lane * 9 + c];
-          advoc::wave_lds_sync();
+          for (int q = 0; q < 8; ++q) wr[72 * q] = ti[q];
+          ADVOC_FFT_LDS_READ8(im, rd2, 0, 8);
+          ADVOC_FFT_LDS_WAIT8(im);
         }
-        // pass 3: DFT over c -> r.  Lane now holds Z[lane + 64 r].
+        // pass 3: DFT over c -> r.  Lane now holds Z[lane + 64 r] / 2.
         dft8(re, im);
-        // real-FFT split, |.|: to HBM and into the wave's plane (every read of the plane above is fenced)
-        const int partner = (64 - lane) & 63;
+        // real-FFT split, two bins per step (X[k] = S - T, X[512 - k] = conj(S + T)), |.|: to HBM and into the wave's plane
+        // (every read of the plane above has returned)
+        const int partner = ((64 - lane) & 63) * 4;
         float* orow0 = mag_out + (row0 + 2 * wave) * kBins;
         float* orow1 = orow0 + kBins;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < 4; ++r) {
           f2 c, d;
-          c.x = __shfl(re[7 - r].x, partner, 64); c.y = __shfl(re[7 - r].y, partner, 64);
-          d.x = __shfl(im[7 - r].x, partner, 64); d.y = __shfl(im[7 - r].y, partner, 64);
-          if (lane == 0) {  // k = 64 r pairs with 512 - 64 r = 64 (8 - r) on the same lane
+          c.x = bperm(partner, re[7 - r].x); c.y = bperm(partner, re[7 - r].y);
+          d.x = bperm(partner, im[7 - r].x); d.y = bperm(partner, im[7 - r].y);
+          if (lane == 0) {  // k = 64 r pairs with 64 (8 - r) on the same lane (Z[512] = Z[0])
             c = re[(8 - r) & 7];
             d = im[(8 - r) & 7];
           }
           const float2 cs = sm.split[r][lane];
           const f2 a = re[r], b = im[r];
           const f2 sr = a + c, si = b - d, dr = a - c, di = b + d;
-          const f2 xr = 0.5f * (sr - (cs.y * dr - cs.x * di));
-          const f2 xi = 0.5f * (si - (cs.y * di + cs.x * dr));
+          const f2 tr = cs.y * dr - cs.x * di;
+          const f2 ti = cs.y * di + cs.x * dr;
+          const f2 xkr = sr - tr, xki = si - ti, xmr = sr + tr, xmi = si + ti;
+          const f2 k2 = xkr * xkr + xki * xki, m2 = xmr * xmr + xmi * xmi;
+          const f2 mk = {__builtin_amdgcn_sqrtf(k2.x), vb ? __builtin_amdgcn_sqrtf(k2.y) : 0.f};
+          const f2 mm = {__builtin_amdgcn_sqrtf(m2.x), vb ? __builtin_amdgcn_sqrtf(m2.y) : 0.f};
+          const unsigned k = (unsigned)lane + 64u * r, m = 512u - k;
+          orow0[k] = mk.x;
+          orow0[m] = mm.x;
+          if (vb) {
+            orow1[k] = mk.y;
+            orow1[m] = mm.y;
+          }
+          plane[k] = mk;
+          plane[m] = mm;
+        }
+        if (lane == 0) {  // bin 256 pairs with itself: X[256] = conj(Z[256])
+          const f2 xr = 2.0f * re[4], xi = 2.0f * im[4];
           const f2 m2 = xr * xr + xi * xi;
           const f2 mg = {__builtin_amdgcn_sqrtf(m2.x), vb ? __builtin_amdgcn_sqrtf(m2.y) : 0.f};
-          orow0[lane + 64 * r] = mg.x;
-          if (vb) orow1[lane + 64 * r] = mg.y;
-          plane[lane + 64 * r] = mg;
-        }
-        {        // Nyquist bin: X[512] = Re Z0 - Im Z0 (lane 0), zero slack behind it for the padded filterbank runs
-          const f2 xn = re[0] - im[0];
-          const f2 nyq = {fabsf(xn.x), vb ? fabsf(xn.y) : 0.f};
-          if (lane == 0) {
-            orow0[kBins - 1] = nyq.x;
-            if (vb) orow1[kBins - 1] = nyq.y;
-          }
-          plane[512 + lane] = lane == 0 ? nyq : (f2){0.f, 0.f};
+          orow0[256] = mg.x;
+          if (vb) orow1[256] = mg.y;
+          plane[256] = mg;
+        } else {
+          plane[512 + lane] = (f2){0.f, 0.f};      // zero slack behind the Nyquist bin for the padded filterbank runs
         }
       } else {
 #pragma unroll
@@ -331,7 +350,7 @@ extern "C" int advoc_stft_mel_pinv_f32(const float* wav, int64_t batch, int64_t 
                                        int32_t n_mels, const void* pinv_pairs, const float* pinv_unscale, float* mag,
                                        float* mel, float* inv, advoc_stream_t stream) {
   if (batch < 0 || nsamps < 0 || nframes < 0 || nhop <= 0) return ADVOC_ERR_BAD_SHAPE;
-  if (nfft != kNfft || (nhop & 1) || nhop > 4096 || bins != kBins || n_mels != kMels || packed_weights < 0 ||
+  if (nfft != kNfft || nhop != 256 || bins != kBins || n_mels != kMels || packed_weights < 0 ||
       packed_weights > kMaxW || packed_weights % 4)
     return ADVOC_ERR_UNSUPPORTED;                      // callers fall back to advoc_stft_mag_f32 + advoc_mel_pinv_f32
   if (batch == 0 || nframes == 0) return ADVOC_OK;

@@ -4,6 +4,7 @@
 // to the hardware.
 #pragma once
 #include "common.h"
+#include "lds_dma.h"
 
 namespace advoc {
 namespace fft1024 {
@@ -147,6 +148,32 @@ __device__ __forceinline__ void split_bin(const f2 (&re)[8], const f2 (&im)[8], 
   const f2 sr = a + c, si = b - d, dr = a - c, di = b + d;
   xr = 0.5f * (sr - (tsn_r * dr - tcs_r * di));
   xi = 0.5f * (si - (tsn_r * di + tcs_r * dr));
+}
+
+
+// ---- pieces of the hop-256 form (stft1024_hop256_kernel in stft.hip explains them) ----
+// ds_read_b64 the load/store optimiser does not fuse into ds_read2_b64 (8 LDS cycles per 1 KB against 2 per 512 B)
+template <int OFF>
+__device__ __forceinline__ f2 lds_read_b64(unsigned addr) {
+  f2 v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+#define ADVOC_FFT_LDS_READ8(DST, ADDR, BASE, STEP)                                                                     \
+  {                                                                                                                    \
+    DST[0] = advoc::fft1024::lds_read_b64<(BASE) + 0 * (STEP)>(ADDR); DST[1] = advoc::fft1024::lds_read_b64<(BASE) + 1 * (STEP)>(ADDR); \
+    DST[2] = advoc::fft1024::lds_read_b64<(BASE) + 2 * (STEP)>(ADDR); DST[3] = advoc::fft1024::lds_read_b64<(BASE) + 3 * (STEP)>(ADDR); \
+    DST[4] = advoc::fft1024::lds_read_b64<(BASE) + 4 * (STEP)>(ADDR); DST[5] = advoc::fft1024::lds_read_b64<(BASE) + 5 * (STEP)>(ADDR); \
+    DST[6] = advoc::fft1024::lds_read_b64<(BASE) + 6 * (STEP)>(ADDR); DST[7] = advoc::fft1024::lds_read_b64<(BASE) + 7 * (STEP)>(ADDR); \
+  }
+// every LDS read of this wave has returned; the eight values are "written" by the statement, so nothing that uses them can
+// be scheduled above it
+#define ADVOC_FFT_LDS_WAIT8(V)                                                                                      \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                               \
+               : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(V[4]), "+v"(V[5]), "+v"(V[6]), "+v"(V[7])     \
+               :: "memory")
+__device__ __forceinline__ float bperm(int byte_index, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_index, __float_as_int(v)));
 }
 
 }  // namespace fft1024

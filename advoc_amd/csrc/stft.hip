@@ -263,8 +263,18 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_kernel(
 //   * the transposes read with ds_read_b64, one instruction per value: the ds_read2_b64 the compiler fuses two reads into
 //     costs 8 LDS cycles per 1 KB against 2 per 512 B (MI355X_MICROARCH.md, LDS table), so the reads are inline assembly the
 //     load/store optimiser does not see, tied to ONE hand-placed s_waitcnt;
-//   * kV bit 0: real and imaginary parts go through TWO planes per wave in one round (half the waits); bit 1: the pass
-//     twiddles live in registers; bit 2: the window too (with both, 37 KB of LDS per workgroup).
+//   * which pair a wave works on is wave-uniform: (clip, pair of the clip) live in scalar registers and advance by a fixed
+//     step (no 64-bit division, no 64-bit vector address arithmetic per load and store -- ~80 vector instructions per pair
+//     in the kernel above).
+// Measured (r4, tools/micro/stft_variants.py, profiles/r04_b_stft_variants.txt): 132.9 -> 109.6 us for 512 clips (0.38 -> 0.46
+// of 8 TB/s), 37.7 -> 30.0 us at the training feed (0.34 -> 0.42).  tools/micro/valu_rate.hip gives the price list the
+// count is weighed with (ns per wave-instruction at a SIMD, four waves per SIMD): v_mov / v_add / v_fma_f32 1.2-1.3, packed
+// f32 2.0-2.1 (a packed operation is 1.6 plain ones, not 1), v_sqrt_f32 3.5, v_cndmask_b32 on an SGPR mask 2.1 but 9.5 (!) in
+// its VCC form, ds_read_b64 3.9, ds_write_b64 10.7, ds_bpermute_b32 10.1: per pair ~0.9 us of vector and ~0.8 us of LDS work
+// in 1.7 us -- the two do not overlap, and starting the waves of a CU out of phase only adds the delay as a tail.
+// kV bit 0 (measured slower, 115 us): real and imaginary parts through TWO planes per wave in one round -- half the waits,
+// but 49 KB of LDS per workgroup, three workgroups per CU.  Variant 8 below (38 v_mov and 20 packed operations fewer):
+// 110.8 us -- the count is no longer what binds.
 // Same radix-8 x 3 arithmetic as above; results differ from stft1024_kernel in the last bit only (the split's association).
 // ---------------------------------------------------------------------------------------------
 template <int OFF>
@@ -486,6 +496,263 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_hop256_kernel(
     }
   }
 }
+
+// ---- the same kernel with two more cuts in the arithmetic (variant 8) ----
+//   * pass 1 runs on (re, im) PAIRS OF ONE FRAME -- an 8-byte load is such a pair, so nothing has to be moved into place
+//     (the frame-packed form costs ~38 v_mov per pair to put sample n of frame f next to sample n of frame f + 1) -- and
+//     the first transpose writes with ds_write2_b32: the real parts of the two frames from two unrelated registers into
+//     one 8-byte slot, i.e. the transposition also converts to the frame-packed form passes 2 and 3 keep (their
+//     magnitudes at the end are one packed multiply-add per two bins);
+//   * the pass twiddles are applied on the way IN to the next pass, inside its first butterflies: with y = t x4,
+//     s = x0 + y and d = 2 x0 - s are six multiply-adds where twiddle + add + subtract are eight.
+// The swizzled packed operations (x (-i), complex products) are inline assembly: the compiler builds them from v_mov / v_xor.
+#define ADVOC_PK_ADD(D, A, B, MODS) asm("v_pk_add_f32 %0, %1, %2 " MODS : "=v"(D) : "v"(A), "v"(B))
+// forward 8-point DFT of complex values held as (re, im) pairs; v[a] <- sum_a v[a] exp(-2 pi i a p / 8)
+__device__ __forceinline__ void dft8_cp(f2 (&v)[8]) {
+  const float h = 0.70710678118654752440f;
+  f2 s[4], d[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    s[n] = v[n] + v[n + 4];
+    d[n] = v[n] - v[n + 4];
+  }
+  {  // d[n] *= W8^n (d[2] x (-i) is folded into its consumers)
+    f2 u;
+    ADVOC_PK_ADD(u, d[1], d[1], "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]");            // (dr + di, di - dr)
+    d[1] = u * h;
+    ADVOC_PK_ADD(u, d[3], d[3], "op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]");   // (di - dr, -dr - di)
+    d[3] = u * h;
+  }
+  {  // even outputs: 4-point DFT of s
+    const f2 b0 = s[0] + s[2], b2 = s[0] - s[2], b1 = s[1] + s[3];
+    f2 b3;
+    ADVOC_PK_ADD(b3, s[1], s[3], "op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]");  // (s1 - s3) x (-i)
+    v[0] = b0 + b1; v[4] = b0 - b1; v[2] = b2 + b3; v[6] = b2 - b3;
+  }
+  {  // odd outputs: 4-point DFT of (d0, d1, d2 x (-i), d3)
+    f2 b0, b2, b3;
+    ADVOC_PK_ADD(b0, d[0], d[2], "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]");              // d0 + d2 x (-i)
+    ADVOC_PK_ADD(b2, d[0], d[2], "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]");              // d0 - d2 x (-i)
+    const f2 b1 = d[1] + d[3];
+    ADVOC_PK_ADD(b3, d[1], d[3], "op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]");
+    v[1] = b0 + b1; v[5] = b0 - b1; v[3] = b2 + b3; v[7] = b2 - b3;
+  }
+}
+#undef ADVOC_PK_ADD
+
+// forward 8-point DFT of x[a] = t[a] v[a] (t[0] = 1), frame-packed; TW(a) gives t[a] as float2 {re, im}
+template <typename TW>
+__device__ __forceinline__ void dft8_tw(f2 (&re)[8], f2 (&im)[8], TW tw) {
+  const float h = 0.70710678118654752440f;
+  f2 sr[4], si[4], dr[4], di[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    f2 yr = re[n], yi = im[n];
+    if (n) {
+      const float2 t = tw(n);
+      yr = re[n] * t.x - im[n] * t.y;
+      yi = re[n] * t.y + im[n] * t.x;
+    }
+    const float2 u = tw(n + 4);
+    sr[n] = yr + re[n + 4] * u.x - im[n + 4] * u.y;        // two multiply-adds each (left to right)
+    si[n] = yi + re[n + 4] * u.y + im[n + 4] * u.x;
+    dr[n] = 2.0f * yr - sr[n];
+    di[n] = 2.0f * yi - si[n];
+  }
+  {
+    f2 r1 = (dr[1] + di[1]) * h, i1 = (di[1] - dr[1]) * h;  // * (1 - i)/sqrt2
+    dr[1] = r1; di[1] = i1;
+    f2 r2 = di[2], i2 = -dr[2];                             // * (-i)
+    dr[2] = r2; di[2] = i2;
+    f2 r3 = (di[3] - dr[3]) * h, i3 = -(dr[3] + di[3]) * h; // * (-1 - i)/sqrt2
+    dr[3] = r3; di[3] = i3;
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f2* xr = half ? dr : sr;
+    f2* xi = half ? di : si;
+    f2 b0r = xr[0] + xr[2], b0i = xi[0] + xi[2];
+    f2 b2r = xr[0] - xr[2], b2i = xi[0] - xi[2];
+    f2 b1r = xr[1] + xr[3], b1i = xi[1] + xi[3];
+    f2 b3r = xi[1] - xi[3], b3i = -(xr[1] - xr[3]);
+    re[0 + half] = b0r + b1r; im[0 + half] = b0i + b1i;
+    re[4 + half] = b0r - b1r; im[4 + half] = b0i - b1i;
+    re[2 + half] = b2r + b3r; im[2 + half] = b2i + b3i;
+    re[6 + half] = b2r - b3r; im[6 + half] = b2i - b3i;
+  }
+}
+
+template <int O0, int O1>
+__device__ __forceinline__ void lds_write2_b32(unsigned addr, float a, float b) {   // dword offsets
+  asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(a), "v"(b), "n"(O0), "n"(O1) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write_b64(unsigned addr, f2 v) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+// rows 8 p + hi, p < 8: element offset 72 p -> byte offset 576 p from the lane's slot (WA: the slot's LDS address)
+#define ADVOC_LDS_WRITE8_B64(V, WA)                                                                              \
+  {                                                                                                              \
+    lds_write_b64<0 * 576>(WA, V[0]); lds_write_b64<1 * 576>(WA, V[1]); lds_write_b64<2 * 576>(WA, V[2]);        \
+    lds_write_b64<3 * 576>(WA, V[3]); lds_write_b64<4 * 576>(WA, V[4]); lds_write_b64<5 * 576>(WA, V[5]);        \
+    lds_write_b64<6 * 576>(WA, V[6]); lds_write_b64<7 * 576>(WA, V[7]);                                          \
+  }
+// the same slots from two frames' registers (member M = x | y of Z0[p] and Z1[p]); ds_write2_b32 offsets are dwords < 256
+#define ADVOC_LDS_WRITE8_2B32(Z0, Z1, M, WA)                                                                     \
+  {                                                                                                              \
+    lds_write2_b32<0, 1>(WA, Z0[0].M, Z1[0].M); lds_write2_b32<144, 145>(WA, Z0[1].M, Z1[1].M);                  \
+    lds_write2_b32<0, 1>(WA + 1152, Z0[2].M, Z1[2].M); lds_write2_b32<144, 145>(WA + 1152, Z0[3].M, Z1[3].M);    \
+    lds_write2_b32<0, 1>(WA + 2304, Z0[4].M, Z1[4].M); lds_write2_b32<144, 145>(WA + 2304, Z0[5].M, Z1[5].M);    \
+    lds_write2_b32<0, 1>(WA + 3456, Z0[6].M, Z1[6].M); lds_write2_b32<144, 145>(WA + 3456, Z0[7].M, Z1[7].M);    \
+  }
+
+template <bool kComplexOut>
+__global__ __launch_bounds__(kWaves * 64) void stft1024_hop256b_kernel(
+    const float* __restrict__ wav, int64_t nsamps, const float* __restrict__ window,
+    const float2* __restrict__ twiddle, int64_t nframes, float* __restrict__ out, int pairs_per_clip,
+    int64_t total_pairs) {
+  __shared__ f2 planes[kWaves][kPlane];
+  __shared__ float2 s_win[8][64], s_t1[8][64], s_t2[8][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int hi = lane >> 3, lo = lane & 7;
+  f2* const plane = &planes[wave][0];
+  float tsn[4], tcs[4];
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float2 w = *reinterpret_cast<const float2*>(window + 128 * j + 2 * lane);
+      s_win[j][lane] = make_float2(0.5f * w.x, 0.5f * w.y);              // the 1/2 of the real-FFT split
+      // twiddle of input b = j of pass 2, W64^(b p): after the first transpose lane = (p = hi, c = lo)
+      const float2 a = twiddle[((hi * j) & 63) * 16];
+      s_t1[j][lane] = make_float2(a.x, -a.y);
+      // twiddle of input c = j of pass 3, W512^(c (p + 8 q)): after the second transpose lane = 8 q + p
+      const float2 b = twiddle[((lane * j) & 511) * 2];
+      s_t2[j][lane] = make_float2(b.x, -b.y);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float2 c = twiddle[lane + 64 * r];
+    tcs[r] = c.x; tsn[r] = c.y;
+  }
+  __syncthreads();
+  const int partner = ((64 - lane) & 63) * 4;
+  const unsigned wa = advoc::lds_address(plane + hi * 9 + lo);
+  const unsigned rd1 = advoc::lds_address(plane + 72 * hi + lo);
+  const unsigned rd2 = advoc::lds_address(plane + 9 * lane);
+
+  const int swave = __builtin_amdgcn_readfirstlane(wave);
+  const int pstride = (int)gridDim.x * kWaves;
+  const int step_clip = pstride / pairs_per_clip, step_fp = pstride - step_clip * pairs_per_clip;
+  const int pair0 = (int)blockIdx.x * kWaves + swave;
+  int clip = pair0 / pairs_per_clip, fp = pair0 - clip * pairs_per_clip;
+  const unsigned lane2 = 2u * (unsigned)lane;
+  for (int pair = pair0; pair < (int)total_pairs; pair += pstride, clip += step_clip, fp += step_fp) {
+    if (fp >= pairs_per_clip) { fp -= pairs_per_clip; ++clip; }
+    const int64_t f = 2 * (int64_t)fp;
+    const bool two = f + 1 < nframes;
+    const float* src = wav + (int64_t)clip * nsamps;
+    const int64_t s0 = f * 256;
+    f2 raw[10];
+    if (s0 + 256 + kNfft <= nsamps) {
+      const float* p0 = src + s0;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) raw[j] = *reinterpret_cast<const f2*>(p0 + (128u * j + lane2));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const int64_t i0 = s0 + 128 * j + lane2;
+        raw[j].x = i0 < nsamps ? src[i0] : 0.f;
+        raw[j].y = i0 + 1 < nsamps ? src[i0 + 1] : 0.f;
+      }
+    }
+    f2 re[8], im[8];
+    {
+      // pass 1 on (re, im) pairs: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1]) / 2, n = 64 a + lane; DFT over a -> p
+      f2 z0[8], z1[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const float2 w2 = s_win[a][lane];
+        const f2 w = {w2.x, w2.y};
+        z0[a] = raw[a] * w;
+        z1[a] = raw[a + 2] * w;
+      }
+      dft8_cp(z0);
+      dft8_cp(z1);
+      // transpose (b,c | p) -> (p,c | b), real parts then imaginary parts through the one plane; the slots come back frame-packed
+      ADVOC_LDS_WRITE8_2B32(z0, z1, x, wa);
+      ADVOC_LDS_READ8(re, rd1, 0, 72);
+      ADVOC_LDS_WAIT8(re);
+      ADVOC_LDS_WRITE8_2B32(z0, z1, y, wa);
+      ADVOC_LDS_READ8(im, rd1, 0, 72);
+      ADVOC_LDS_WAIT8(im);
+    }
+    // pass 2: twiddle W64^(b p) and DFT over b -> q, transpose (p,c | q) -> (q,p | c)
+    dft8_tw(re, im, [&](int b) { return s_t1[b][lane]; });
+    {
+      f2 ti[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ti[q] = im[q];
+      ADVOC_LDS_WRITE8_B64(re, wa);
+      ADVOC_LDS_READ8(re, rd2, 0, 8);
+      ADVOC_LDS_WAIT8(re);
+      ADVOC_LDS_WRITE8_B64(ti, wa);
+      ADVOC_LDS_READ8(im, rd2, 0, 8);
+      ADVOC_LDS_WAIT8(im);
+    }
+    // pass 3: twiddle W512^(c (p + 8 q)) and DFT over c -> r.  Lane now holds Z[lane + 64 r] / 2.
+    dft8_tw(re, im, [&](int c) { return s_t2[c][lane]; });
+
+    float* orow0 = out + (((int64_t)clip * nframes + f) * kBins) * (kComplexOut ? 2 : 1);
+    float* orow1 = orow0 + kBins * (kComplexOut ? 2 : 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      f2 c, d;
+      c.x = bperm(partner, re[7 - r].x); c.y = bperm(partner, re[7 - r].y);
+      d.x = bperm(partner, im[7 - r].x); d.y = bperm(partner, im[7 - r].y);
+      if (lane == 0) {
+        c = re[(8 - r) & 7];
+        d = im[(8 - r) & 7];
+      }
+      const f2 a = re[r], b = im[r];
+      const f2 sr = a + c, si = b - d, dr = a - c, di = b + d;
+      const f2 tr = tsn[r] * dr - tcs[r] * di;
+      const f2 ti = tsn[r] * di + tcs[r] * dr;
+      const f2 xkr = sr - tr, xki = si - ti, xmr = sr + tr, xmi = si + ti;
+      const unsigned k = (unsigned)lane + 64u * r, m = 512u - k;
+      if (kComplexOut) {
+        *reinterpret_cast<float2*>(orow0 + 2 * k) = make_float2(xkr.x, xki.x);
+        *reinterpret_cast<float2*>(orow0 + 2 * m) = make_float2(xmr.x, -xmi.x);
+        if (two) {
+          *reinterpret_cast<float2*>(orow1 + 2 * k) = make_float2(xkr.y, xki.y);
+          *reinterpret_cast<float2*>(orow1 + 2 * m) = make_float2(xmr.y, -xmi.y);
+        }
+      } else {
+        const f2 k2 = xkr * xkr + xki * xki, m2 = xmr * xmr + xmi * xmi;
+        orow0[k] = __builtin_amdgcn_sqrtf(k2.x);
+        orow0[m] = __builtin_amdgcn_sqrtf(m2.x);
+        if (two) {
+          orow1[k] = __builtin_amdgcn_sqrtf(k2.y);
+          orow1[m] = __builtin_amdgcn_sqrtf(m2.y);
+        }
+      }
+    }
+    if (lane == 0) {
+      const f2 xr = 2.0f * re[4], xi = -2.0f * im[4];
+      if (kComplexOut) {
+        *reinterpret_cast<float2*>(orow0 + 2 * 256) = make_float2(xr.x, xi.x);
+        if (two) *reinterpret_cast<float2*>(orow1 + 2 * 256) = make_float2(xr.y, xi.y);
+      } else {
+        const f2 m2 = xr * xr + xi * xi;
+        orow0[256] = __builtin_amdgcn_sqrtf(m2.x);
+        if (two) orow1[256] = __builtin_amdgcn_sqrtf(m2.y);
+      }
+    }
+  }
+}
+#undef ADVOC_LDS_WRITE8_B64
+#undef ADVOC_LDS_WRITE8_2B32
 #undef ADVOC_LDS_READ8
 #undef ADVOC_LDS_WAIT8
 #undef ADVOC_LDS_TIE8
@@ -661,7 +928,7 @@ int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* wi
   if (blocks > 2048) blocks = 2048;
   // hop 256 with 8-byte aligned clips: the kernel with fewer instructions per frame pair
   static const int variant = getenv("ADVOC_STFT_V") ? atoi(getenv("ADVOC_STFT_V")) : 0;
-  static const int block_cap = getenv("ADVOC_STFT_BLOCKS") ? atoi(getenv("ADVOC_STFT_BLOCKS")) : 2048;
+  static const int block_cap = getenv("ADVOC_STFT_BLOCKS") ? atoi(getenv("ADVOC_STFT_BLOCKS")) : 1024;   // four workgroups per CU, resident
   if (nhop == 256 && !(nsamps & 1) && total_pairs < (1LL << 30) && variant >= 0) {
     if (blocks > block_cap) blocks = block_cap;
 #define ADVOC_STFT_LAUNCH(C, V)                                                                                         \
@@ -670,8 +937,15 @@ int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* wi
 #define ADVOC_STFT_CASE(V) case V: if (complex_out) ADVOC_STFT_LAUNCH(true, V); else ADVOC_STFT_LAUNCH(false, V); break
     ADVOC_CLEAR_LAUNCH_ERROR();
     switch (variant) {
-      ADVOC_STFT_CASE(0); ADVOC_STFT_CASE(1); ADVOC_STFT_CASE(2); ADVOC_STFT_CASE(3);
-      ADVOC_STFT_CASE(4); ADVOC_STFT_CASE(5); ADVOC_STFT_CASE(6); ADVOC_STFT_CASE(7);
+      ADVOC_STFT_CASE(0); ADVOC_STFT_CASE(1);
+      case 8:
+        if (complex_out)
+          hipLaunchKernelGGL(stft1024_hop256b_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), 0, stream, wav, nsamps, window,
+                             reinterpret_cast<const float2*>(twiddle), nframes, out, (int)pairs_per_clip, total_pairs);
+        else
+          hipLaunchKernelGGL(stft1024_hop256b_kernel<false>, dim3((unsigned)blocks), dim3(kWaves * 64), 0, stream, wav, nsamps, window,
+                             reinterpret_cast<const float2*>(twiddle), nframes, out, (int)pairs_per_clip, total_pairs);
+        break;
       default: return ADVOC_ERR_UNSUPPORTED;
     }
 #undef ADVOC_STFT_CASE

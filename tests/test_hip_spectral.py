@@ -282,6 +282,41 @@ def test_stft_random_lengths_and_hops(S, case):
 
 
 @gpu
+@pytest.mark.parametrize('variant', ['-1', '0', '1', '8'], ids=['general_kernel', 'hop256', 'hop256_two_planes', 'hop256_pairs_pass1'])
+def test_hop256_kernel_variants_against_the_oracle(hip, variant):
+  """csrc/stft.hip: the hop-256 kernel (the default for even clip lengths), its measured-and-kept alternatives and the
+  general kernel give the float64 oracle's magnitudes and complex bins (advoc/spectral.py:60-83): whole clips, a ragged
+  tail (zero padding inside the last frames), an odd frame count (a pair with one frame), one frame, many clips."""
+  import subprocess
+  import sys
+  code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from advoc_amd import spectral as S
+from oracle import spectral_np as O
+worst = 0.0
+for b, n, pad_end in ((3, 66304, False), (2, 16000, True), (2, 1024 + 256 * 6, False), (1, 1024, True), (2, 5000, True), (37, 1024 + 256 * 9, False)):
+  rng = np.random.default_rng(n + b)
+  x = (0.4 * rng.standard_normal((b, n, 1, 1))).astype(np.float32)
+  want = O.stft_mag_f64(x, 1024, 256, pad_end=pad_end)
+  got = S.stft_magnitude(x, 1024, 256, pad_end=pad_end).cpu().numpy()
+  assert got.shape == want.shape, (got.shape, want.shape)
+  e = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+  wc = O.stft_tf(x, 1024, 256, pad_end=pad_end)
+  gc = S.stft_tf(x, 1024, 256, pad_end=pad_end).cpu().numpy()
+  assert gc.shape == wc.shape
+  ec = float(np.linalg.norm(gc - wc) / np.linalg.norm(wc))
+  worst = max(worst, e, ec)
+  assert e < 5e-7 and ec < 1e-5, (b, n, pad_end, e, ec)
+  assert float(np.abs(gc[..., 0, :].imag).max()) == 0.0 and float(np.abs(gc[..., 512, :].imag).max()) == 0.0
+print('worst', worst)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, ADVOC_STFT_V=variant), capture_output=True, text=True)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@gpu
 def test_fused_mel_and_pseudo_inverse_matches_the_two_projections(hip):
   """advoc_mel_pinv_f32 (csrc/melpinv.hip): mag -> (mel, pinv(mel)) in one launch, against the float64 products of the
   oracle's filterbanks and against the two advoc_matmul_nt_f32 launches it replaces; row counts that are not multiples

@@ -28,8 +28,12 @@ print(json.dumps(res))
 settings = [(-1, 2048), (0, 2048), (1, 2048), (0, 1024), (1, 768), (1, 1536), (0, 4096), (1, 4096)]
 if len(sys.argv) > 1:
   settings = [tuple(int(t) for t in a.split(',')) for a in sys.argv[1:]]
-for v, blocks in settings:
+for st in settings:
+  v, blocks = st[0], st[1]
   env = dict(os.environ, ADVOC_STFT_V=str(v), ADVOC_STFT_BLOCKS=str(blocks))
+  if len(st) > 2:
+    env.update(ADVOC_STFT_SKEW_WG=str(st[2]), ADVOC_STFT_SKEW_WAVE=str(st[3]))
+    print('skew', st[2:], end=' ')
   r = subprocess.run([sys.executable, '-c', CHILD], env=env, capture_output=True, text=True)
   print('V=%2d blocks=%4d  %s %s' % (v, blocks, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else '',
                                     r.stderr.strip()[-400:] if r.returncode else ''), flush=True)
