@@ -239,6 +239,8 @@ int run_gather(const GatherGemmParams& p, bool b_kn, hipStream_t stream, const c
   if (!fits_int32(p.batch, p.a_h, p.a0_pitch, p.c0) || !fits_int32(p.batch, p.a_h, p.a1_pitch, p.c1) ||
       !fits_int32(p.batch, p.out_h, p.d[0].pitch, p.d[0].c) || !fits_int32(p.batch, p.out_h, p.d[1].pitch, p.d[1].c))
     return ADVOC_ERR_UNSUPPORTED;
+  if (two_stage_ok(p) && (b_kn ? N == 1 : true) && tuning().fused_taps && fused_taps_ok(p))
+    return launch_fused_taps(p, stream, name_only);      // the two-stage path in one launch: S stays in LDS
   if (two_stage_ok(p) && ws && ws_bytes >= two_stage_bytes(p) && (b_kn ? N == 1 : true))
     return run_two_stage(p, ws, stream, name_only);
   if (K % 16 == 0 && p.c0 % 16 == 0 && N % 32 == 0 && p.n_split % 32 == 0) {

@@ -22,6 +22,11 @@ int launch_gather_outer(const GatherGemmParams& p, bool b_kn, hipStream_t stream
 int launch_tap_sum(const GatherGemmParams& p, const float* S, int s_channels, hipStream_t stream,
                    const char** name_only = nullptr);
 
+// The two-stage path in one launch (edge.hip, fused_taps_kernel): the per-pixel, per-tap partial dot products stay in LDS.
+// `p` is the original problem; weights [tap][n][k] (k contiguous; for N == 1 the [tap][k][n] layout is the same).
+bool fused_taps_ok(const GatherGemmParams& p);
+int launch_fused_taps(const GatherGemmParams& p, hipStream_t stream, const char** name_only = nullptr);
+
 // MFMA versions of the thin kernels (thin.hip): K = c0 + c1 <= 2 and taps * K <= 32, N % 32 == 0
 int launch_thin_k_gemm(const GatherGemmParams& p, bool b_kn, hipStream_t stream,
                        const char** name_only = nullptr);

@@ -38,11 +38,18 @@ __device__ inline float sum_of(f2 v) { return v.x + v.y; }
 #define A_SQRT(i) "v_sqrt_f32 %" #i ", %" #i "\n"
 #define A_CND(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
 #define A_CND64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[20:21]\n"
+#define A_CND64V(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\n"
+#define A_CNDB(i) "v_cndmask_b32_e32 %" #i ", %8, %" #i ", vcc\n"
+#define A_CMP(i) "v_cmp_lt_f32_e32 vcc, %" #i ", %8\n"
+#define A_CMP64(i) "v_cmp_lt_f32_e64 s[20:21], %" #i ", %8\n"
+#define A_CMPCND(i) "v_cmp_lt_f32_e32 vcc, %" #i ", %8\nv_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n"
+#define A_MAX(i) "v_max_f32 %" #i ", %" #i ", %8\n"
 #define A_SWAP(i) "v_swap_b32 %" #i ", %8\n"
 #define A_PKADDSEL(i) "v_pk_add_f32 %" #i ", %" #i ", %8 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n"
 BODY_T(k_pkfma, A_PKFMA, f2) BODY_T(k_pkadd, A_PKADD, f2) BODY_T(k_pkmul, A_PKMUL, f2) BODY_T(k_pkaddsel, A_PKADDSEL, f2)
 BODY_T(k_fma, A_FMA, float) BODY_T(k_add, A_ADD, float) BODY_T(k_mov, A_MOV, float) BODY_T(k_sqrt, A_SQRT, float)
-BODY_T(k_cnd, A_CND, float) BODY_T(k_fma2, A_FMA2, float) BODY_T(k_cnd64, A_CND64, float)
+BODY_T(k_cnd, A_CND, float) BODY_T(k_fma2, A_FMA2, float) BODY_T(k_cnd64, A_CND64, float) BODY_T(k_cnd64v, A_CND64V, float) BODY_T(k_cndb, A_CNDB, float) BODY_T(k_cmp, A_CMP, float)
+BODY_T(k_cmp64, A_CMP64, float) BODY_T(k_cmpcnd, A_CMPCND, float) BODY_T(k_max, A_MAX, float)
 
 // LDS instructions: each wave works in its own 8 KB of LDS (conflict-free lane-linear addresses)
 #define LBODY(NAME, ASM, T)                                                                                   \
@@ -87,7 +94,8 @@ int main() {
   struct { const char* n; void (*k)(uint64_t*, int, float); int per; } ks[] = {
       {"v_pk_fma_f32", k_pkfma, 32}, {"v_pk_add_f32", k_pkadd, 32}, {"v_pk_mul_f32", k_pkmul, 32}, {"v_pk_add_f32 op_sel", k_pkaddsel, 32},
       {"v_fma_f32", k_fma, 32}, {"2 x v_fma_f32", k_fma2, 64}, {"v_add_f32", k_add, 32}, {"v_mov_b32", k_mov, 32}, {"v_sqrt_f32", k_sqrt, 32},
-      {"v_cndmask_b32", k_cnd, 32}, {"v_cndmask_b32_e64 sgpr", k_cnd64, 32},
+      {"v_cndmask_b32", k_cnd, 32}, {"v_cndmask_b32_e64 sgpr", k_cnd64, 32}, {"v_cndmask_b32_e64 vcc", k_cnd64v, 32}, {"v_cndmask_e32 (src swapped)", k_cndb, 32},
+      {"v_cmp_lt_f32_e32 vcc", k_cmp, 32}, {"v_cmp_lt_f32_e64 sgpr", k_cmp64, 32}, {"v_cmp + v_cndmask vcc", k_cmpcnd, 64}, {"v_max_f32", k_max, 32},
       {"ds_read_b64", l_rd64, 32}, {"ds_read_b32", l_rd32, 32}, {"ds_write_b64", l_wr64, 32}, {"ds_write_b32", l_wr32, 32},
       {"ds_bpermute_b32", l_bperm, 32}};
   const int iters = 2000;
