@@ -311,14 +311,16 @@ __global__ __launch_bounds__(256, 2) void fused_taps_kernel(const GatherGemmPara
   const int steps0 = p.c0 >> 4;                   // k steps that read source 0
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   u32x4 bufA[KS], bufB[KS];
+  float liveA = 0.f, liveB = 0.f;      // 1 where the lane's pixel is inside the image: the zero padding applies to the TRANSFORMED input
   f4v acc[CB];
   int l_gi = wave, l_kc = 0, c_gi = wave, c_kc = 0;        // (16-pixel group, load group) of the next load / compute call
-  auto load = [&](u32x4 (&buf)[KS]) {
+  auto load = [&](u32x4 (&buf)[KS], float& live) {
     const int q = 16 * l_gi + prow;
     const int py = (q * g.rx_magic) >> 20, px = q - py * g.rx;
     const int iy = iy0 + py, ix = ix0 + px;
     const bool in = l_gi < groups && q < R && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
     const int rowi = img * p.a_h + iy;
+    live = in ? 1.f : 0.f;
     const unsigned o0 = in ? (unsigned)((rowi * p.a0_pitch + ix) * p.c0 + 4 * kg) * 4u : kOob;
     const unsigned o1 = in ? (unsigned)((rowi * p.a1_pitch + ix) * p.c1 + 4 * kg) * 4u : kOob;
 #pragma unroll
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void fused_taps_kernel(const GatherGemmPara
     }
     if (++l_kc == nk) { l_kc = 0; l_gi += 4; }
   };
-  auto compute = [&](const u32x4 (&buf)[KS]) {
+  auto compute = [&](const u32x4 (&buf)[KS], float live) {
     if (c_kc == 0) {
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) acc[cb] = (f4v){0.f, 0.f, 0.f, 0.f};
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void fused_taps_kernel(const GatherGemmPara
       if (p.in_scale) {
         const f4v sc = *reinterpret_cast<const f4v*>(aff + 16 * st + 4 * kg);
         const f4v sh = *reinterpret_cast<const f4v*>(aff + K + 16 * st + 4 * kg);
-        a = a * sc + sh;
+        a = (a * sc + sh) * live;          // pixels outside the image are zeros AFTER the affine
       }
       a.x = fmaxf(a.x, slope * a.x); a.y = fmaxf(a.y, slope * a.y);
       a.z = fmaxf(a.z, slope * a.z); a.w = fmaxf(a.w, slope * a.w);
@@ -370,12 +372,12 @@ __global__ __launch_bounds__(256, 2) void fused_taps_kernel(const GatherGemmPara
   // `if (more) load(...)` the compiler has to assume the smaller number of loads in flight at each wait, i.e. it waits for
   // the loads it has just issued as well
   if (n_it > 0) {
-    load(bufA);
+    load(bufA, liveA);
     for (int it = 0; it < n_it; it += 2) {
-      load(bufB);
-      compute(bufA);
-      load(bufA);
-      if (it + 1 < n_it) compute(bufB);
+      load(bufB, liveB);
+      compute(bufA, liveA);
+      load(bufA, liveA);
+      if (it + 1 < n_it) compute(bufB, liveB);
     }
   }
   __syncthreads();

@@ -300,7 +300,7 @@ def extractor_leg(torch, spectral, su, wav, launches=30):
   ms_l, bytes_l = run_stft(512)
   ms_b, bytes_b = run_stft(nb)
   gbs = bytes_l / (ms_l * 1e-3) / 1e9
-  out = dict(kernel='stft1024_kernel', bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
+  out = dict(kernel='stft1024_hop256_kernel', bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
              frac=gbs / HBM_PEAK_GBS, clips_per_launch=512, bytes_per_launch=bytes_l, avg_launch_ms=ms_l,
              frames_per_s=512 * CLIP_FRAMES / (ms_l * 1e-3),
              at_train_feed=dict(clips_per_launch=nb, avg_launch_ms=ms_b, achieved=bytes_b / (ms_b * 1e-3) / 1e9,
@@ -314,7 +314,7 @@ def extractor_leg(torch, spectral, su, wav, launches=30):
     uses_fused = clips * CLIP_FRAMES <= fused_max            # what SpectralUtil.extract_training_triple launches at this size
     ms = ms_f if uses_fused else ms_2
     res[tag] = dict(clips_per_launch=clips, avg_ms=ms, achieved=by / (ms * 1e-3) / 1e9, frac=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    path='one launch (stft_mel_pinv_kernel)' if uses_fused else 'two launches (stft1024_kernel + mel_pinv_kernel)',
+                    path='one launch (stft_mel_pinv_kernel)' if uses_fused else 'two launches (stft1024_hop256_kernel + mel_pinv_kernel)',
                     one_launch_ms=ms_f, two_launches_ms=ms_2)
   out['triple'] = dict(what='waveform -> |X|, mel, pinv(mel) (1 397 760 B per clip) as SpectralUtil.extract_training_triple '
                             'launches it: ONE launch (csrc/extract.hip) up to %d frames per call, two above' % fused_max,

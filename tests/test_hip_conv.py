@@ -585,7 +585,27 @@ def test_fused_taps_equals_the_two_stage_path(hip, hipenv, name):
       assert rel(dx1, dx1_2) < 2e-6 and rel(dx1, dx1_o) < TOL
     # the G step's call: no gradient for the conditioning channel, the target channel's added to what the buffer holds
     # (one column instead of two: half the matrix work and half the LDS per pixel)
-    hipenv(ADVOC_FUSED_TAPS=1)
+  hipenv(ADVOC_FUSED_TAPS=1)
+  if fwd:
+    # the producer's batch-norm affine on the input (in_scale / in_shift): the zero padding applies to the TRANSFORMED
+    # input -- a padded pixel is 0, not act(shift)
+    cin = x0.shape[3] + (x1.shape[3] if x1 is not None else 0)
+    gsc = torch.Generator().manual_seed(9)
+    sc = (torch.rand(cin, generator=gsc) + 0.5).to(dev)
+    sh = (torch.randn(cin, generator=gsc) * 0.5).to(dev)
+
+    def run_aff():
+      ya = torch.full_like(y, float('nan'))
+      La = conv.Layer(c['kind'], x0, ya, w, b, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'],
+                      in_scale=sc, in_shift=sh)
+      La.forward()
+      return La.kernel_name(0), ya
+    na, ya = run_aff()
+    hipenv(ADVOC_FUSED_TAPS=0)
+    nb, yb = run_aff()
+    assert 'fused_taps' in na and 'fused_taps' not in nb, (na, nb)
+    assert rel(ya, yb) < 2e-6, rel(ya, yb)
+  else:
     y3 = torch.empty_like(y)
     L = conv.Layer(c['kind'], x0, y3, w, b, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
     base = torch.randn(dx1.shape, generator=torch.Generator().manual_seed(5)).to(dev)
