@@ -477,7 +477,7 @@ static bool fused_taps_plan(const GatherGemmParams& p, FusedGeom* out, int* cb_o
     else if (p.d[1].p == nullptr && p.d[0].p != nullptr) { N = 1; }
   }
   const int cols = p.nphase * p.ntaps * N;
-  if ((cols != 16 && cols != 32) || K % 64 || p.c0 % 16 || K > 1024 || p.a_mask || p.y_mask) return false;
+  if ((cols != 16 && cols != 32) || K % 32 || p.c0 % 16 || K > 1024 || p.a_mask || p.y_mask) return false;
   if ((int64_t)p.batch * p.a_h * p.a0_pitch * p.c0 * 4 >= 0xffffff00LL || (int64_t)p.batch * p.a_h * p.a1_pitch * p.c1 * 4 >= 0xffffff00LL)
     return false;                                    // 32-bit byte offsets into the sources
   int dy_min = 127, dy_max = -128, dx_min = 127, dx_max = -128;
@@ -532,7 +532,7 @@ static bool fused_taps_plan(const GatherGemmParams& p, FusedGeom* out, int* cb_o
   if ((int64_t)p.batch * g.tiles_y * g.tiles_x > 0x7fffffffLL) return false;
   *out = g;
   *cb_out = cols / 16;
-  *ks_out = K % 128 == 0 ? 8 : 4;
+  *ks_out = K % 128 == 0 ? 8 : (K % 64 == 0 ? 4 : 2);
   *lds_out = fixed + sizeof(float) * (size_t)g.ry * g.rx * ld;
   return true;
 }
@@ -546,12 +546,12 @@ int launch_fused_taps(const GatherGemmParams& p, hipStream_t stream, const char*
   FusedGeom g; int cb, ks; size_t lds;
   if (!fused_taps_plan(p, &g, &cb, &ks, &lds)) return ADVOC_ERR_UNSUPPORTED;
   if (name_only) {
-    *name_only = cb == 1 ? (ks == 8 ? "fused_taps_kernel<1, 8>" : "fused_taps_kernel<1, 4>")
-                         : (ks == 8 ? "fused_taps_kernel<2, 8>" : "fused_taps_kernel<2, 4>");
+    *name_only = cb == 1 ? (ks == 8 ? "fused_taps_kernel<1, 8>" : ks == 4 ? "fused_taps_kernel<1, 4>" : "fused_taps_kernel<1, 2>")
+                         : (ks == 8 ? "fused_taps_kernel<2, 8>" : ks == 4 ? "fused_taps_kernel<2, 4>" : "fused_taps_kernel<2, 2>");
     return ADVOC_OK;
   }
-  const void* fn = cb == 1 ? (ks == 8 ? (const void*)fused_taps_kernel<1, 8> : (const void*)fused_taps_kernel<1, 4>)
-                           : (ks == 8 ? (const void*)fused_taps_kernel<2, 8> : (const void*)fused_taps_kernel<2, 4>);
+  const void* fn = cb == 1 ? (ks == 8 ? (const void*)fused_taps_kernel<1, 8> : ks == 4 ? (const void*)fused_taps_kernel<1, 4> : (const void*)fused_taps_kernel<1, 2>)
+                           : (ks == 8 ? (const void*)fused_taps_kernel<2, 8> : ks == 4 ? (const void*)fused_taps_kernel<2, 4> : (const void*)fused_taps_kernel<2, 2>);
   if (lds > 64 * 1024) {
     const hipError_t attr = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }
@@ -559,9 +559,11 @@ int launch_fused_taps(const GatherGemmParams& p, hipStream_t stream, const char*
   const dim3 grid((unsigned)((int64_t)p.batch * g.tiles_y * g.tiles_x));
   ADVOC_CLEAR_LAUNCH_ERROR();
   if (cb == 1 && ks == 8) hipLaunchKernelGGL((fused_taps_kernel<1, 8>), grid, dim3(256), lds, stream, p, g);
-  else if (cb == 1) hipLaunchKernelGGL((fused_taps_kernel<1, 4>), grid, dim3(256), lds, stream, p, g);
+  else if (cb == 1 && ks == 4) hipLaunchKernelGGL((fused_taps_kernel<1, 4>), grid, dim3(256), lds, stream, p, g);
+  else if (cb == 1) hipLaunchKernelGGL((fused_taps_kernel<1, 2>), grid, dim3(256), lds, stream, p, g);
   else if (ks == 8) hipLaunchKernelGGL((fused_taps_kernel<2, 8>), grid, dim3(256), lds, stream, p, g);
-  else hipLaunchKernelGGL((fused_taps_kernel<2, 4>), grid, dim3(256), lds, stream, p, g);
+  else if (ks == 4) hipLaunchKernelGGL((fused_taps_kernel<2, 4>), grid, dim3(256), lds, stream, p, g);
+  else hipLaunchKernelGGL((fused_taps_kernel<2, 2>), grid, dim3(256), lds, stream, p, g);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }

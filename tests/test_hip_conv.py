@@ -545,7 +545,7 @@ def test_two_stage_path_is_selected(hip, hipenv):
 
 @gpu
 @pytest.mark.parametrize('name', ['dec1_cout1', 'dec1_cout1_big', 'dec1_cout1_tiles', 'd5_cout1', 'd5_cout1_tiles', 'd1_cin2_k64',
-                                  'd1_cin2_k128_tiles'])
+                                  'd1_cin2_k128_tiles', 'd1_cin2'])
 def test_fused_taps_equals_the_two_stage_path(hip, hipenv, name):
   """fused_taps_kernel (edge.hip) against the two launches it replaces (same fp32 matrix-core arithmetic, another
   summation order over the taps) and against the float64 oracle: the generator's last transposed conv (two sources, ReLU

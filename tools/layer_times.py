@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 
 recs = []
 orig = conv.Layer._run
-def run(self, direction, fn):
+def run(self, direction, fn, **kw):
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   e0.record(); fn(); e1.record()
   recs.append((self, direction, e0, e1))
