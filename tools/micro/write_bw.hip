@@ -23,6 +23,30 @@ __global__ __launch_bounds__(256) void fill_chunk(float4* __restrict__ x, int64_
   for (int64_t i = lo + threadIdx.x; i < hi; i += 256) x[i] = f;
 }
 
+// thin_fwd_kernel's pattern: a wave owns 16 pixels of 256 bytes; instruction b writes bytes [64 b, 64 b + 64) of each (lane
+// (pixel, quarter) 16 bytes): 16 half lines per instruction, four instructions per 16 pixels
+__global__ __launch_bounds__(256) void fill_pix64(float4* __restrict__ x, int64_t npix, float v) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pt = lane & 15, kg = lane >> 4;
+  const float4 f = make_float4(v, v, v, v);
+  const int64_t tiles = npix / 16;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
+    float4* px = x + (t * 16 + pt) * 16;        // 256 bytes per pixel
+#pragma unroll
+    for (int b = 0; b < 4; ++b) px[4 * b + kg] = f;
+  }
+}
+// the same bytes, a pixel's 256 bytes by 16 adjacent lanes: four pixels (1 KB contiguous) per instruction
+__global__ __launch_bounds__(256) void fill_pix256(float4* __restrict__ x, int64_t npix, float v) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float4 f = make_float4(v, v, v, v);
+  const int64_t tiles = npix / 16;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) x[(t * 16 + 4 * b) * 16 + lane] = f;
+  }
+}
+
 template <typename F>
 float timeit(F f, int reps = 10) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -42,6 +66,17 @@ int main() {
     rep("fill U=1", blocks, timeit([&] { hipLaunchKernelGGL(fill<1>, dim3(blocks), dim3(256), 0, 0, x, (int64_t)(bytes / 16), 1.f); }));
     rep("fill U=4", blocks, timeit([&] { hipLaunchKernelGGL(fill<4>, dim3(blocks), dim3(256), 0, 0, x, (int64_t)(bytes / 16), 1.f); }));
     rep("fill chunked", blocks, timeit([&] { hipLaunchKernelGGL(fill_chunk, dim3(blocks), dim3(256), 0, 0, x, (int64_t)(bytes / 16), 1.f); }));
+  }
+  for (size_t mb : {256, 1024, 2048}) {
+    float4* y; CK(hipMalloc(&y, mb << 20));
+    const int64_t npix = (int64_t)(mb << 20) / 256;
+    for (int blocks : {768, 1024, 2048}) {
+      float ms = timeit([&] { hipLaunchKernelGGL(fill_pix64, dim3(blocks), dim3(256), 0, 0, y, npix, 1.f); });
+      printf("fill_pix64  (16 x 64 B per instruction)  %4zu MB blocks %5d %8.1f us  %7.1f GB/s\n", mb, blocks, ms * 1e3, (double)(mb << 20) / ms / 1e6);
+      ms = timeit([&] { hipLaunchKernelGGL(fill_pix256, dim3(blocks), dim3(256), 0, 0, y, npix, 1.f); });
+      printf("fill_pix256 (1 KB contiguous per instr.) %4zu MB blocks %5d %8.1f us  %7.1f GB/s\n", mb, blocks, ms * 1e3, (double)(mb << 20) / ms / 1e6);
+    }
+    hipFree(y);
   }
   rep("hipMemsetAsync", 0, timeit([&] { hipMemsetAsync(x, 0, bytes, 0); }));
   return 0;
