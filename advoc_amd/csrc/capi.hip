@@ -79,6 +79,7 @@ Tuning read_env() {
   if (t.reserve_cus < 0) t.reserve_cus = 0;
   t.thin_wgrad_bias = env_int("ADVOC_THIN_WGRAD_BIAS", 1);
   t.fused_taps = env_int("ADVOC_FUSED_TAPS", 1);
+  t.thin_fwd_spec = env_int("ADVOC_THIN_FWD_SPEC", 1);
   t.thin_wgrad_nt = env_int("ADVOC_THIN_WGRAD_NT", 4);
   if (t.thin_wgrad_nt != 1 && t.thin_wgrad_nt != 2) t.thin_wgrad_nt = 4;
   t.h3_deep_wgs_per_cu = env_int("ADVOC_H3_DEEP_WGS_PER_CU", 2);

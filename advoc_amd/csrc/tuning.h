@@ -33,6 +33,7 @@ struct Tuning {
                         //                          1: only the forward instances walk tiles (2, default: all)
   int thin_wgrad_bias;  // ADVOC_THIN_WGRAD_BIAS  0: the thin layers' bias gradient stays a pass of its own over dy
   int fused_taps;       // ADVOC_FUSED_TAPS     0: <= 2 output columns over a wide K stay on the two-stage path (pointwise GEMM to the workspace + tap_sum)
+  int thin_fwd_spec;    // ADVOC_THIN_FWD_SPEC  0: forward calls of the thin layers run the run-time-generic instance of thin_k_gemm_kernel
   int thin_wgrad_nt;    // ADVOC_THIN_WGRAD_NT  widest column tile (32-channel blocks per wave: 1 | 2 | 4) of thin_wgrad_kernel
   int h3_deep_wgs_per_cu;  // ADVOC_H3_DEEP_WGS_PER_CU  workgroups per CU the workspace K split of the deep layers aims at
   int h3_deep_split_div;   // ADVOC_H3_DEEP_SPLIT_DIV   K tiles per slice, at least
