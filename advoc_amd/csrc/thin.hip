@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
   // tile-invariant offsets.  Gathering them from global memory made this kernel latency-bound
   // (213 -> 88 us on discriminator layer_1 with the loads stubbed out).
   __shared__ float s_patch[4][kThinPatch];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform for the compiler too: the tile index and everything derived from it (image, row, origins) is scalar arithmetic
   const int half = lane >> 5, l32 = lane & 31;
   const int phase = blockIdx.z;
   const int ktot = p.c0 + p.c1;            // 1 or 2
@@ -463,7 +464,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p, in
   // the thin operand a tile reads (pr tap rows x pc columns x ca channels), staged per wave with
   // coalesced loads; the per-step operand gathers are ds_reads at tile-invariant offsets
   __shared__ float s_patch[4][kWgPatch];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform for the compiler too (tile ranges, origins: scalar arithmetic)
   const int half = lane >> 5, l32 = lane & 31;
   const int ca = p.P.c0 + p.P.c1;            // 1 or 2
   const int cb = p.Q.c0 + p.Q.c1;
