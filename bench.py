@@ -239,7 +239,7 @@ def event_timed(torch, call, launches, warm=5):
   """Average ms per call over a TIMED REGION of `launches` back-to-back calls: ONE HIP-event pair around the region (the
   gaps between the launches are inside it, so this is an upper bound of the average kernel duration).  An event pair
   per launch -- what this function did until r4 -- puts a marker packet in front of and behind every kernel and reads
-  3-10 %% high on 30-120 us kernels (tools/micro/event_overhead.py: 108-124 us per launch against 104-107 us for the
+  3-10 % high on 30-120 us kernels (tools/micro/event_overhead.py: 108-124 us per launch against 104-107 us for the
   same 30 launches under one pair)."""
   for _ in range(warm):
     call()
