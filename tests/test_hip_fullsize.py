@@ -255,6 +255,11 @@ def test_full_model_train_loops_at_bench_size_match_the_float64_oracle(hip):
       assert 'patch_gemm_h3_kernel' in layers[i].kernel_name(1), (i, layers[i].kernel_name(1))
   for i in (2, 3):
     assert st['d_layers_2b'][i].kernel_name(2) == 'wgrad_h3_256_kernel'
+  # the <= 2-column layers in one launch (r4: fused_taps_kernel, csrc/edge.hip)
+  assert GL['decoder_1'].kernel_name(0) == 'fused_taps_kernel<1, 8>', GL['decoder_1'].kernel_name(0)
+  for layers in (st['d_layers_2b'], st['d_layers_fake']):
+    assert layers[4].kernel_name(0) == 'fused_taps_kernel<1, 8>', layers[4].kernel_name(0)
+  assert 'fused_taps_kernel' in st['d_layers_fake'][0].kernel_name(1), st['d_layers_fake'][0].kernel_name(1)
 
   def rel(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
@@ -357,6 +362,9 @@ def test_full_model_with_batch_norm_train_loop_at_bench_size_matches_the_float64
   for layers in (st['d_layers_real'], st['d_layers_fake']):
     for i in (1, 2, 3):
       assert 'patch_gemm_h3_kernel' in layers[i].kernel_name(1), (i, layers[i].kernel_name(1))
+  # (with batch norm the inputs of these layers carry the producer's affine: fused_taps_kernel applies it before the zero padding)
+  assert GL['decoder_1'].kernel_name(0) == 'fused_taps_kernel<1, 8>', GL['decoder_1'].kernel_name(0)
+  assert st['d_layers_fake'][4].kernel_name(0) == 'fused_taps_kernel<1, 8>', st['d_layers_fake'][4].kernel_name(0)
 
   def rel(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
