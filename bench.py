@@ -241,8 +241,15 @@ def event_timed(torch, call, launches, warm=5):
   per launch -- what this function did until r4 -- puts a marker packet in front of and behind every kernel and reads
   3-10 % high on 30-120 us kernels (tools/micro/event_overhead.py: 108-124 us per launch against 104-107 us for the
   same 30 launches under one pair)."""
-  for _ in range(warm):
-    call()
+  # warm-up by TIME, not by count: the first launches of a leg run before the clocks have come up (a cold first repetition of
+  # the 110 us STFT launch reads 120-127 us, the next ones 105-108); at least `warm` launches and 25 ms of them
+  t0 = time.perf_counter()
+  done = 0
+  while done < warm or time.perf_counter() - t0 < 0.025:
+    for _ in range(warm):
+      call()
+    torch.cuda.synchronize()
+    done += warm
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   e0.record()
   for _ in range(launches):
