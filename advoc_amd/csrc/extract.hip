@@ -41,7 +41,7 @@ constexpr int kTile = 2 * kXWaves;          // frames per tile
 constexpr int kXPlane = 578;                // f2 per wave plane: 513 magnitudes (>= the FFT's 576); consecutive planes are
                                             // 16 bytes apart modulo the 128-byte bank row, so that the same bin of eight
                                             // planes is eight different banks
-constexpr int kMels = 80, kMelPitch = 81, kNBlocks = 17, kSteps = kMels / 16, kMaxW = 2048;
+constexpr int kMels = 80, kMelPitch = 81, kNBlocks = 17 /* 32-bin blocks of the pre-split table; the last holds bin 512 only */, kSteps = kMels / 16, kMaxW = 2048;
 
 struct XSmem {
   Tables tables;                            // 12 288 B
@@ -50,6 +50,7 @@ struct XSmem {
   float w[kMaxW];                           //  8 192 B  packed filterbank runs
   int band[3 * kMels];                      //    960 B  first bin, run length / 4, offset into w
   float mel[kTile * kMelPitch];             //  5 184 B
+  float p512[kMels];                        //    320 B  pseudo-inverse row of bin 512 (fp32), see the pinv phase
 };
 
 __device__ __forceinline__ float pair_scale(float amax) {
@@ -101,6 +102,19 @@ __global__ __launch_bounds__(kXThreads, MINW) void stft_mel_pinv_kernel(
   if (wave == 1) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) sm.split[j][lane] = twiddle[lane + 64 * j];      // split twiddle: theta = 2 pi k / 1024
+  }
+  if (wave == 2 && (lane & 31) == 0) {
+    // bin 512 is the only live column of the 17th 32-bin block: its pseudo-inverse row as plain fp32 (h0 + h1 of the
+    // pre-split table, unscaled), so that the matrix-core loop below runs 16 blocks -- two per wave, none with three
+    const int hf = lane >> 5;
+    const float un = pinv_unscale[512];
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) {
+      const f16x8 h0 = __builtin_bit_cast(f16x8, pinv_pairs[(((kNBlocks - 1) * kSteps + st) * 2 + 0) * 64 + lane]);
+      const f16x8 h1 = __builtin_bit_cast(f16x8, pinv_pairs[(((kNBlocks - 1) * kSteps + st) * 2 + 1) * 64 + lane]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sm.p512[16 * st + 8 * hf + i] = ((float)h0[i] + (float)h1[i]) * un;
+    }
   }
   __syncthreads();
   if (tid < kMels) {
@@ -313,10 +327,19 @@ __global__ __launch_bounds__(kXThreads, MINW) void stft_mel_pinv_kernel(
     float unrow[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) unrow[r] = __shfl(inv_sa, (r & 3) + 8 * (r >> 2) + 4 * half, 64);
+    if (wave == 7) {
+      // bin 512 of the tile's frames on the vector ALUs: lane = (frame, quarter of the 80 mel bands), two xor steps
+      const int f = lp & 15, qd = lp >> 4;
+      float a = 0.f;
 #pragma unroll
-    for (int q = 0; q < (kNBlocks + kXWaves - 1) / kXWaves; ++q) {
+      for (int i = 0; i < kMels / 4; ++i) a = fmaf(sm.mel[f * kMelPitch + qd * (kMels / 4) + i], sm.p512[qd * (kMels / 4) + i], a);
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      if (qd == 0 && f < nrows) inv_out[(row0 + f) * kBins + 512] = a;
+    }
+#pragma unroll
+    for (int q = 0; q < (kNBlocks - 1) / kXWaves; ++q) {
       const int nb = wave + q * kXWaves;
-      if (nb >= kNBlocks) break;
       const int n = nb * 32 + l32;
       const float unsb = pinv_unscale[n];
       floatx16 acc;
