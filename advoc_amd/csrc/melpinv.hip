@@ -78,6 +78,7 @@ __global__ __launch_bounds__(kThreads, 1) void mel_pinv_kernel(const float* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* s_w = sm + kMagFloats;                        // the filterbank's runs of weights, packed (<= kMaxW floats)
   int* s_band = reinterpret_cast<int*>(s_w + kMaxW);   // [3][80]: first bin, run length / 4, offset into s_w
+  float* s_p512 = reinterpret_cast<float*>(s_band + 3 * kMels);      // [80]: the pseudo-inverse row of bin 512 (fp32)
   const int l32 = lane & 31, half = lane >> 5;
 
   const int64_t bytes = rows * kBins * 4;
@@ -114,8 +115,14 @@ __global__ __launch_bounds__(kThreads, 1) void mel_pinv_kernel(const float* __re
     const int2 bnd = band[tid];
     s_band[tid] = bnd.x;
     s_band[kMels + tid] = (bnd.y - bnd.x + 3) >> 2;     // runs are padded to multiples of 4 with zero weights
+    s_p512[tid] = inv_wt[tid * kBins + (kBins - 1)];
   }
-  constexpr int kBPW = (kNBlocks + kWaves - 1) / kWaves;      // output blocks per wave: 3 (wave 0) or 2
+  // (r4) bin 512 is the only live column of the 17th block: it is computed on the vector ALUs by the last wave (32 frames x
+  // 80 bands: 40 multiply-adds per lane), so that the matrix-core loop has 16 blocks -- two per wave, none with three (the
+  // wave with three set the length of the phase) -- and 40 registers less of stationary operand
+  constexpr int kMfmaBlocks = kNBlocks - 1;
+  static_assert(kMfmaBlocks * 32 + 1 == kBins, "the last block holds one bin");
+  constexpr int kBPW = (kMfmaBlocks + kWaves - 1) / kWaves;   // output blocks per wave: 2
   constexpr int kSteps = kMels / 16;                   // 5 MFMA k-steps of 16 mel bands
   // lane (l32, half) of a 32x32x16 MFMA holds k = 16 s + 8 half + 0..7 of row / column l32.  The pseudo-inverse column
   // of output bin n as an fp16 PAIR under its own power-of-two scale (igemm_h3.hip's arithmetic: x 2^s = h0 + h1 to
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(kThreads, 1) void mel_pinv_kernel(const float* __re
 #pragma unroll
   for (int q = 0; q < kBPW; ++q) {
     const int n = (wave + q * kWaves) * 32 + l32;
-    const bool live = wave + q * kWaves < kNBlocks;
+    const bool live = wave + q * kWaves < kMfmaBlocks;
     const float* pcol = inv_wt + (n < kBins ? n : kBins - 1);
     float v[kSteps][8];
     float amax = 0.f;
@@ -212,12 +219,19 @@ __global__ __launch_bounds__(kThreads, 1) void mel_pinv_kernel(const float* __re
     float unrow[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) unrow[r] = __shfl(inv_sa, (r & 3) + 8 * (r >> 2) + 4 * half, 64);
+    float v512 = 0.f;
+    if (wave == kWaves - 1) {                           // bin 512: frame l32, bands [40 half, 40 half + 40)
+#pragma unroll
+      for (int i = 0; i < kMels / 2; ++i) v512 = fmaf(s_mel[l32 * kMelPitch + half * (kMels / 2) + i], s_p512[half * (kMels / 2) + i], v512);
+      v512 += __shfl_xor(v512, 32, 64);
+    }
     __syncthreads();                                    // the mel tile is in registers: the next tile's magnitudes may land
     if (tile + (int)gridDim.x < ntiles) ADVOC_MP_LOAD(tile + (int)gridDim.x);
+    if (wave == kWaves - 1 && half == 0 && l32 < nrows) inv_out[(r0 + l32) * kBins + (kBins - 1)] = v512;
 #pragma unroll
     for (int q = 0; q < kBPW; ++q) {
       const int nb = wave + q * kWaves;
-      if (nb >= kNBlocks) break;
+      if (nb >= kMfmaBlocks) break;
       floatx16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -252,7 +266,7 @@ extern "C" int advoc_mel_pinv_f32(const float* mag, const float* mel_wp, const i
   if (rows == 0) return ADVOC_OK;
   const int64_t blocks = advoc::ceil_div(rows, kFrames);
   if (blocks > 0x7fffffffLL) return ADVOC_ERR_UNSUPPORTED;
-  constexpr int lds = (kMagFloats + kMaxW + 3 * kMels) * (int)sizeof(float);
+  constexpr int lds = (kMagFloats + kMaxW + 4 * kMels) * (int)sizeof(float);
   static_assert(kFrames * kMelPitch <= kMagFloats && lds <= 160 * 1024, "LDS budget");
   if (rows * kBins * 4 > 0xffffffffLL) return ADVOC_ERR_UNSUPPORTED;         // 32-bit buffer offsets
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_pinv_kernel),
