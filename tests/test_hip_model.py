@@ -425,8 +425,9 @@ def test_side_stream_step_equals_serial_step_element_by_element(hip, monkeypatch
       for k in n0:
         top = float(n0[k].abs().max())
         d = float((n1[k].double() - n0[k].double()).abs().max())
-        # (a bias in front of a batch norm has an exactly-zero gradient: both sides are pure round-off of sums ~1e-9)
-        assert d <= 2e-5 * top + 1e-7, (trial, bn, k, d, top)
+        # (a bias in front of a batch norm has an exactly-zero gradient: both sides are pure round-off of sums of ~2 M terms --
+        # seen up to 1.4e-7 on either side, differences up to 1.1e-7; what the race did was 1e-3 of gradients of 1e-3 .. 1)
+        assert d <= 2e-5 * top + 3e-7, (trial, bn, k, d, top)
   finally:
     monkeypatch.delenv('ADVOC_WGRAD_H3_ORDERED')
     _lib.reload_env()
