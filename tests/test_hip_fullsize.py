@@ -112,6 +112,10 @@ def test_three_directions_are_one_trilinear_form(hip, model, case):
     for d, patch in ((0, patch_fwd), (1, patch_bwd)):
       want = 'patch_gemm_h3_kernel' if patch else 'gather_gemm_h3_kernel'
       assert want in L.kernel_name(d), (d, L.kernel_name(d))
+  if model == 'full64' and case[0] in ('decoder_1', 'layer_5'):
+    assert 'fused_taps_kernel' in L.kernel_name(0), L.kernel_name(0)     # (r4) <= 2 output columns: one launch, S in LDS
+  if model == 'full64' and case[0] == 'layer_1':
+    assert 'fused_taps_kernel' in L.kernel_name(1), L.kernel_name(1)
   L.forward()
   lhs = dot(dy, y)
   dx0 = torch.zeros_like(x0)
