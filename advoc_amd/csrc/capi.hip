@@ -69,6 +69,7 @@ Tuning read_env() {
   t.h3_patch_min_wgs = env_int("ADVOC_H3_PATCH_MIN_WGS", 256);
   t.h3_patch_s2 = env_int("ADVOC_H3_PATCH_S2", 1);
   t.h3_patch_rem = env_int("ADVOC_H3_PATCH_REM", 1);
+  t.h3_patch_n32 = env_int("ADVOC_H3_PATCH_N32", 1);
   t.h3_patch_persist = env_int("ADVOC_H3_PATCH_PERSIST", 2);
 #ifdef ADVOC_DIAG
   t.h3_patch_ablate = env_int("ADVOC_H3_PATCH_ABLATE", 0);

@@ -144,7 +144,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // ---- persistent workgroups: the launch holds one workgroup per CU; XCD x walks its own contiguous range of tiles
   // (column tile slowest, so the workgroups an XCD runs together stream the same weights), and the stores of one
   // tile's epilogue drain while the next tile's operands arrive ----
-  const int ntiles = npatch * (p.n_total / BN);
+  const int ntiles = npatch * ((p.n_total + BN - 1) / BN);      // (a 32-column problem runs on the 64-column instance: see patch_plan)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
   const int tq_ = ntiles >> 3, tr_ = ntiles & 7;
   const int t_lo = xcd < tr_ ? xcd * (tq_ + 1) : tr_ * (tq_ + 1) + (xcd - tr_) * tq_;
@@ -188,6 +188,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // column q % 64) for NPH = 4, column q for NPH = 1.  Block k is 8 k rows further (that part goes into the scalar
   // offset); the swizzle of row q, (q >> 1) & 7, is lrow >> 1 for even k and that ^ 4 for odd k ----
   int b_off[2];
+  // (NPH = 4: the wave's stage rows are one phase's columns [32 (wave & 1), + 32); beyond n_total -- a 32-column problem --
+  // they do not exist in the weight image: the DMA gets an out-of-range offset and writes zeros)
+  const bool b_cols = NPH != 4 || n0 + ((wave * (C::BROWS / W)) & 63) < p.n_total;
   {
     const int q = wave * (C::BROWS / W) + lrow;
     const int col = NPH == 4 ? (q & 63) : q;
@@ -234,7 +237,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     _Pragma("unroll") for (int k = 0; k < C::BPW; ++k) {                                                  \
       unsigned char* d_ = smem_b + C::OFF_B + (ST) * C::B_STAGE + (wave * C::BPW + k) * 1024;             \
       if (!(abl & 17))                                                                                    \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_p)(d_), 16, b_off[k & 1],                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_p)(d_), 16, b_cols ? b_off[k & 1] : (int)0x80000000, \
                                                  wslab_ + k * 8 * ktot * 4, 0, 0);                        \
     }                                                                                                     \
   }
@@ -534,7 +537,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     const int nt0 = n0 + ncol0 + j * 32;
     const int di = nt0 >= p.n_split ? 1 : 0;
     float* const dp = di ? p.d[1].p : p.d[0].p;
-    if (dp == nullptr) continue;
+    if (dp == nullptr || nt0 >= p.n_total) continue;
     const float* const d_xpre = di ? p.d[1].xpre : p.d[0].xpre;
     const uint8_t* const d_gmask = di ? p.d[1].gmask : p.d[0].gmask;
     const float d_gmask_scale = di ? p.d[1].gmask_scale : p.d[0].gmask_scale;
@@ -674,7 +677,7 @@ int launch_patch(const GatherGemmParams& p_in, const PatchGeom& g, hipStream_t s
   if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }
   // workgroups in whole rows of the 8 XCDs; persistent (default; ADVOC_H3_PATCH_PERSIST=0 for one tile per workgroup):
   // one per CU (160 KB of LDS each), every workgroup walks tiles -- 2-4 % faster on every layer of the model
-  const int64_t tiles = (int64_t)p.batch * g.py * g.px * (p.n_total / C::BN);
+  const int64_t tiles = (int64_t)p.batch * g.py * g.px * ((p.n_total + C::BN - 1) / C::BN);
   int64_t wgs = (tiles + 7) / 8 * 8;
   if (t.h3_patch_persist && (!BWD || t.h3_patch_persist == 2)) {
     const int64_t cus = persistent_cu_count();
@@ -693,7 +696,12 @@ int patch_plan(const GatherGemmParams& p, PatchGeom* g) {
   const Tuning& t = tuning();
   if (!t.h3_patch) return 0;
   int nph = 0;
-  if (p.sy == 1 && p.sx == 1 && p.nphase == 4 && p.ntaps == 4 && p.osy == 2 && p.osx == 2 && p.n_total % 64 == 0) nph = 4;
+  // (r4) 32 columns (AdVoc-small's decoder_2 forward, encoder_2 / layer_2 backward-data) take the 64-column instance of the
+  // four-phase kernel with the upper half of the weight tile masked in the DMA and never stored: half its matrix work is on
+  // zeros, and it is still 1.4-2.4 x the masked per-tap tile these launches ran on (140 / 75 TFLOP/s)
+  if (p.sy == 1 && p.sx == 1 && p.nphase == 4 && p.ntaps == 4 && p.osy == 2 && p.osx == 2 &&
+      (p.n_total % 64 == 0 || (p.n_total == 32 && t.h3_patch_n32)))
+    nph = 4;
   else if (p.sy == 1 && p.sx == 1 && p.nphase == 1 && p.ntaps == 16 && p.osy == 1 && p.osx == 1 && p.n_total % 256 == 0)
     nph = 1;
   else if (t.h3_patch_s2 && p.sy == 2 && p.sx == 2 && p.nphase == 1 && p.ntaps == 16 && p.osy == 1 && p.osx == 1 &&
@@ -748,7 +756,7 @@ int patch_plan(const GatherGemmParams& p, PatchGeom* g) {
   // rows the patches add beyond the grid are computed and thrown away
   if ((int64_t)g->py * g->px * 256 * 100 > (int64_t)p.gh * gw_cov * 125) return 0;
   const int bn = nph == 4 ? 64 : (nph == 3 ? 128 : 256);
-  const int64_t wgs = (int64_t)p.batch * g->py * g->px * (p.n_total / bn);
+  const int64_t wgs = (int64_t)p.batch * g->py * g->px * ((p.n_total + bn - 1) / bn);
   if (wgs < t.h3_patch_min_wgs) return 0;
   return nph;
 }

@@ -28,6 +28,7 @@ struct Tuning {
   int h3_patch;         // ADVOC_H3_PATCH       0: stride-1 gathers stay on the per-tap tiles of igemm_h3.hip
   int h3_patch_min_wgs; // ADVOC_H3_PATCH_MIN_WGS  smallest launch (workgroups) that takes the patch kernel
   int h3_patch_s2;      // ADVOC_H3_PATCH_S2    0: stride-2 gathers stay on the per-tap tiles (no parity-plane patch kernel)
+  int h3_patch_n32;     // ADVOC_H3_PATCH_N32   0: 32-column four-phase gathers stay on the masked 128 x 64 per-tap tile
   int h3_patch_rem;     // ADVOC_H3_PATCH_REM   0: grids of 16 n + 1..4 columns get a whole extra patch column instead of a per-tap launch
   int h3_patch_persist; // ADVOC_H3_PATCH_PERSIST  0: one tile per workgroup instead of one workgroup per CU walking tiles;
                         //                          1: only the forward instances walk tiles (2, default: all)

@@ -300,6 +300,12 @@ PATCH = [
     (('p3_rem_enc',   0, (2, 32, 65), 64, 0, 256, 0, (2, 2), None, 1, False, 0),
      {0: 'patch_gemm_h3_kernel<2, 0>', 1: 'patch_gemm_h3_kernel<4, 1>'}),
     (('p3_rem_d4',    0, (1, 33, 36), 64, 0, 256, 0, (1, 1), (1, 1), 1, True, 0), {0: 'patch_gemm_h3_kernel<1, 0>'}),
+    # (r4) 32 columns on the 64-column four-phase instance (upper half of the weight tile masked in the DMA, never stored):
+    # AdVoc-small's decoder_2 forward (two sources, trimmed column, clipped output) and encoder_2 / layer_2 backward-data
+    (('p3_n32_dec',   1, (2, 31, 30), 64, 64, 32, 1, (2, 2), (1, 1), 2, False, 1), {0: 'patch_gemm_h3_kernel<4, 0>'}),
+    (('p3_n32_dec_drop', 1, (2, 16, 33), 64, 64, 32, 1, (2, 2), (1, 1), 2, True, 0), {0: 'patch_gemm_h3_kernel<4, 0>'}),
+    (('p3_n32_enc_bwd', 0, (2, 62, 60), 32, 0, 64, 0, (2, 2), None, 1, False, 0), {1: 'patch_gemm_h3_kernel<4, 1>'}),
+    (('p3_n32_d2_bwd', 0, (3, 64, 66), 32, 0, 64, 0, (2, 2), (1, 1), 1, True, 0), {1: 'patch_gemm_h3_kernel<4, 1>'}),
 ]
 
 
