@@ -104,10 +104,13 @@ struct PCfg {
 // destinations)
 // NE: consumers whose operand images the (forward) epilogue writes, in oimg[0 .. NE): a compile-time count, so that a
 // launch pays for the image arithmetic of the consumers it has and no more
-template <int NPH, int W, int BWD, int NE>
+// HALF (NPH = 4 only): a 32-column problem on the 64-column tile -- the wave's second 32-column block does not exist: no
+// fragments, no MFMAs, no epilogue for it, and the waves whose stage rows are those columns issue no weight DMA
+template <int NPH, int W, int BWD, int NE, int HALF = 0>
 __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, const PatchGeom& g) {
   using C = PCfg<NPH, W>;
-  constexpr int NST = C::NST, BN = C::BN, HPS = C::HPS, MT = C::MT, NT = C::NT;
+  static_assert(!HALF || (NPH == 4 && C::NT == 2), "half tiles exist for the four-phase instance");
+  constexpr int NST = C::NST, BN = C::BN, HPS = C::HPS, MT = C::MT, NT = HALF ? 1 : C::NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* smem_b = reinterpret_cast<unsigned char*>(smem);
 
@@ -236,7 +239,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     const int wslab_ = (wtap_ * p.n_total * ktot + (S2 ? (SL) >> 2 : (SL)) * 32) * 4;                     \
     _Pragma("unroll") for (int k = 0; k < C::BPW; ++k) {                                                  \
       unsigned char* d_ = smem_b + C::OFF_B + (ST) * C::B_STAGE + (wave * C::BPW + k) * 1024;             \
-      if (!(abl & 17))                                                                                    \
+      if (!(abl & 17) && (!HALF || b_cols))                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_p)(d_), 16, b_cols ? b_off[k & 1] : (int)0x80000000, \
                                                  wslab_ + k * 8 * ktot * 4, 0, 0);                        \
     }                                                                                                     \
@@ -648,9 +651,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   }  // tiles
 }
 
-template <int NPH, int BWD, int NE>
+template <int NPH, int BWD, int NE, int HALF = 0>
 __global__ __launch_bounds__(512, 1) void patch_gemm_h3_kernel(const GatherGemmParams p, const PatchGeom g) {
-  patch_gemm_h3_body<NPH, 8, BWD, NE>(p, g);
+  patch_gemm_h3_body<NPH, 8, BWD, NE, HALF>(p, g);
 }
 
 template <int NPH, int BWD, int NE = 0>
@@ -671,7 +674,7 @@ int launch_patch(const GatherGemmParams& p_in, const PatchGeom& g, hipStream_t s
     *name_only = name.c_str();
     return ADVOC_OK;
   }
-  auto kern = patch_gemm_h3_kernel<NPH, BWD, NE>;
+  auto kern = (NPH == 4 && p.n_total == 32) ? patch_gemm_h3_kernel<NPH, BWD, NE, NPH == 4 ? 1 : 0> : patch_gemm_h3_kernel<NPH, BWD, NE>;
   const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
   if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }
