@@ -58,7 +58,9 @@ constexpr int kThinPatch = kThinPatchRows * kThinPatchCols * 2;   // x up to 2 c
 
 // PL: patch elements per lane (ceil(pr * pc * ktot / 64)); a template parameter because the fetch
 // registers (value + mask factor + coordinates per element) decide the occupancy of the wide-N cases
-// FW (r4): -1 = everything decided at run time (backward-data calls, masks, accumulation: the r2 kernel); 0 / 1 / 2 = a FORWARD
+// FW (r4): -1 = everything decided at run time (masks, accumulation, images: the r2 kernel); -2 = a BACKWARD-DATA call that only
+// gates on the pre-activation values (no masks, no accumulation, no image consumers: what the models' calls are) -- the generic
+// instance executed the image arithmetic of two absent consumers for every value, half its epilogue; 0 / 1 / 2 = a FORWARD
 // call without masks / gating / accumulation and with that many image consumers in oimg[0 .. FW): the epilogue loads (12
 // buffer instructions per 32-channel block, out of range and dropped -- but issued) are not there and the image arithmetic
 // of a consumer that does not exist is not executed.  The kernel is bound by what it ISSUES (rocprofv3: issuing 0.98 at three
@@ -196,8 +198,10 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
       if (FW < 0) {                                                                                               \
         const unsigned ob = pix < 0 ? kThinOob : e_.off[ps] * 4u;                                                 \
         e_.xp[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_x_, ob, 0, 0);                                       \
-        e_.gm[ps] = __builtin_amdgcn_raw_buffer_load_b32(rs_g_, e_.off[ps], 0, 0);                                \
-        e_.ym[ps] = __builtin_amdgcn_raw_buffer_load_b32(rs_y_, e_.off[ps], 0, 0);                                \
+        if (FW == -1) {                                                                                           \
+          e_.gm[ps] = __builtin_amdgcn_raw_buffer_load_b32(rs_g_, e_.off[ps], 0, 0);                              \
+          e_.ym[ps] = __builtin_amdgcn_raw_buffer_load_b32(rs_y_, e_.off[ps], 0, 0);                              \
+        }                                                                                                         \
       }                                                                                                           \
     }                                                                                                             \
   }
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         v[ps] = *reinterpret_cast<const float4*>(T + (trow + 8 * ps) * 36 + 4 * tq);
-        if (FW < 0 && p.y_mask) {
+        if (FW == -1 && p.y_mask) {
           const unsigned mk = e.ym[ps];
           v[ps].x *= (float)(mk & 0xffu) * p.y_mask_scale; v[ps].y *= (float)((mk >> 8) & 0xffu) * p.y_mask_scale;
           v[ps].z *= (float)((mk >> 16) & 0xffu) * p.y_mask_scale; v[ps].w *= (float)(mk >> 24) * p.y_mask_scale;
@@ -313,14 +317,14 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
           v[ps].x *= x.x > 0.f ? 1.f : gslope; v[ps].y *= x.y > 0.f ? 1.f : gslope;
           v[ps].z *= x.z > 0.f ? 1.f : gslope; v[ps].w *= x.w > 0.f ? 1.f : gslope;
         }
-        if (FW < 0 && d.gmask) {
+        if (FW == -1 && d.gmask) {
           const unsigned mk = e.gm[ps];
           v[ps].x *= (float)(mk & 0xffu) * d.gmask_scale; v[ps].y *= (float)((mk >> 8) & 0xffu) * d.gmask_scale;
           v[ps].z *= (float)((mk >> 16) & 0xffu) * d.gmask_scale; v[ps].w *= (float)(mk >> 24) * d.gmask_scale;
         }
         so[ps] = e.off[ps] == kThinOob ? kThinOob : e.off[ps] * 4u;
       }
-      if (FW < 0 && okj && d.accum) {            // (no thin layer of the models accumulates: not worth 16 registers of prefetch)
+      if (FW == -1 && okj && d.accum) {          // (no thin layer of the models accumulates: not worth 16 registers of prefetch)
         const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(d.p, 0, kThinOob, 0x00020000);
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -342,8 +346,8 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         const bool ok = okj && di == 0 && so[ps] != kThinOob;
-        if (FW < 0 || FW >= 1) emit4_buffer(rs_e0, o0.slope, eup0, v[ps], ok ? so[ps] : kThinOob, ok && emit0, evmax0);
-        if (FW < 0 || FW >= 2) emit4_buffer(rs_e1, o1.slope, eup1, v[ps], ok ? so[ps] : kThinOob, ok && emit1, evmax1);
+        if (FW == -1 || FW >= 1) emit4_buffer(rs_e0, o0.slope, eup0, v[ps], ok ? so[ps] : kThinOob, ok && emit0, evmax0);
+        if (FW == -1 || FW >= 2) emit4_buffer(rs_e1, o1.slope, eup1, v[ps], ok ? so[ps] : kThinOob, ok && emit1, evmax1);
       }
       wave_lds_sync();
     }
@@ -398,6 +402,9 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
       !p.d[1].accum) {
     if (!q.oimg[0].img && q.oimg[1].img) { q.oimg[0] = q.oimg[1]; q.oimg[1].img = nullptr; }
     fw = q.oimg[0].img ? (q.oimg[1].img ? 2 : 1) : 0;
+  } else if (tuning().thin_fwd_spec && p.grad_act != ADVOC_ACT_NONE && !p.y_mask && !p.d[0].gmask && !p.d[1].gmask && !p.d[0].accum &&
+             !p.d[1].accum && !p.oimg[0].img && !p.oimg[1].img) {
+    fw = -2;
   }
   const int pl = (pr * pc * (p.c0 + p.c1) + 63) / 64;
   dim3 grid(1, (unsigned)by, (unsigned)p.nphase);
@@ -417,7 +424,10 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
     const int64_t cap = (int64_t)per_cu * device_cu_count() / (by * p.nphase);                        \
     if (bx > cap) bx = cap > 0 ? cap : 1;                                                             \
     grid.x = (unsigned)bx;                                                                            \
-    if (B_KN && NT_ <= 2 && fw >= 0) {      /* the forward calls of the models (32 / 64 output channels) */ \
+    if (NT_ >= 2 && fw == -2) {             /* the backward-data calls of the models */                      \
+      hipLaunchKernelGGL((thin_k_gemm_kernel<KP, NT_, B_KN, PL_, -2>), grid, dim3(256), 0, stream, p, dy_min, dx_min, pr, \
+                         pc, tiles_x);                                                                \
+    } else if (B_KN && NT_ <= 2 && fw >= 0) {      /* the forward calls of the models (32 / 64 output channels) */ \
       if (fw == 0) hipLaunchKernelGGL((thin_k_gemm_kernel<KP, NT_ <= 2 ? NT_ : 1, true, PL_, 0>), grid, dim3(256), 0, stream, q, dy_min, dx_min, pr, pc, tiles_x); \
       else if (fw == 1) hipLaunchKernelGGL((thin_k_gemm_kernel<KP, NT_ <= 2 ? NT_ : 1, true, PL_, 1>), grid, dim3(256), 0, stream, q, dy_min, dx_min, pr, pc, tiles_x); \
       else hipLaunchKernelGGL((thin_k_gemm_kernel<KP, NT_ <= 2 ? NT_ : 1, true, PL_, 2>), grid, dim3(256), 0, stream, q, dy_min, dx_min, pr, pc, tiles_x); \
