@@ -80,13 +80,14 @@ BS = 32
 PT = 'gather_gemm_h3_kernel<2, 1, 2, 2>'
 # AdVoc-small at B=32 (BASELINE configs[1], advoc_model_small.py:14-15: ngf = ndf = 32): every layer between the 1-channel
 # edges runs on the image kernels -- the 32-column launches (encoder_2 / layer_2 backward-data, decoder_2 forward) on the
-# 128 x 64 tile with its upper half masked (r4; they fell back to the r1 fp32 kernel before)
+# 64-column four-phase patch instance without the column block that does not exist (r4, second half; the 128 x 64 per-tap
+# tile with its upper half masked before that, the r1 fp32 kernel before that)
 SMALL = [
-    ('encoder_2', layer(0, BS, 128, 257, 32, 0, 64, (2, 2)), PT, PT, W128),
+    ('encoder_2', layer(0, BS, 128, 257, 32, 0, 64, (2, 2)), PT, P4B, W128),
     ('encoder_3', layer(0, BS, 64, 129, 64, 0, 128, (2, 2)), P3F, P4B, W128),
     ('decoder_3', layer(1, BS, 32, 65, 128, 128, 64, (2, 2), trim=1), P4F, P2B, W128),
-    ('decoder_2', layer(1, BS, 64, 129, 64, 64, 32, (2, 2), trim=1), PT, 'patch_gemm_h3_kernel<3, 1>', W128),
-    ('layer_2', layer(0, 2 * BS, 128, 256, 32, 0, 64, (2, 2)), PT, PT, W128),
+    ('decoder_2', layer(1, BS, 64, 129, 64, 64, 32, (2, 2), trim=1), P4F, 'patch_gemm_h3_kernel<3, 1>', W128),
+    ('layer_2', layer(0, 2 * BS, 128, 256, 32, 0, 64, (2, 2)), PT, P4B, W128),
     ('layer_3', layer(0, 2 * BS, 64, 128, 64, 0, 128, (2, 2)), P3F, P4B, W128),
     ('layer_4', layer(0, 2 * BS, 32, 64, 128, 0, 256, (1, 1)), P1F, None, W256),
 ]
