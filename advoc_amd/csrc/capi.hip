@@ -90,6 +90,9 @@ Tuning read_env() {
   t.h3_rem_ws = env_int("ADVOC_H3_REM_WS", 1);
   t.h3_rem_wgs_per_cu = env_int("ADVOC_H3_REM_WGS_PER_CU", 2);
   t.h3_rem_split_div = env_int("ADVOC_H3_REM_SPLIT_DIV", 8);
+  t.h3_deep_stages = env_int("ADVOC_H3_DEEP_STAGES", 2);
+  t.h3_deep_split = env_int("ADVOC_H3_DEEP_SPLIT", 0);
+  t.h3_deep_plan = env_int("ADVOC_H3_DEEP_PLAN", 1);
   if (t.h3_rem_wgs_per_cu < 1) t.h3_rem_wgs_per_cu = 1;
   if (t.h3_rem_split_div < 2) t.h3_rem_split_div = 2;
   return t;

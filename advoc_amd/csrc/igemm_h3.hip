@@ -245,7 +245,8 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
   // ---- K loop: NS stages, one barrier per K tile ----
   // prologue: tiles kt_begin .. kt_begin + NS - 2 into stages 0 .. NS - 2
   ADVOC_H3_ISSUE(0);
-  if constexpr (NS == 3) ADVOC_H3_ISSUE(1);
+  if constexpr (NS >= 3) ADVOC_H3_ISSUE(1);
+  if constexpr (NS >= 4) ADVOC_H3_ISSUE(2);
 
   int kt = kt_begin;
   // NS iterations per trip so that stage indices are compile-time constants; a trip may overshoot kt_end by
@@ -270,16 +271,29 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
   // ---- tail slices (igemm.hip): park the partial tile; the LAST slice to arrive sums all of them in slice
   // order and carries on into the ordinary epilogue ----
   if (tail_tile >= 0) {
+    // A partial tile is parked block by block (32 x 32 accumulators of one wave), the lane's 16 values as four 16-byte
+    // pieces: piece q of every lane is 1 KB contiguous.  All accesses are agent-scope (sc1: past the XCD's own L2, which
+    // is not coherent with the others'), as the relaxed agent-scope atomics they replace were -- but 16 bytes per lane
+    // instead of 4, and the reader keeps FOUR slices of a block in flight instead of one: the last slice to arrive used
+    // to pay one memory round trip (> 1 us at this scope) per slice and block, 32 of them in a row for a 16-slice tile
+    // (r4: 65 us for the 1.6 GFLOP of encoder_8, two thirds of it here).
     constexpr int TILE = BM * BN;
-    float* part = p.tail_ws + ((size_t)tail_tile * ks_cnt + ks_idx) * TILE;
+    constexpr int kAgent = 16;                          // cache policy bit sc1
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(p.tail_ws, 0, 0xffffff00u, 0x00020000);
+    const unsigned tile_b = (unsigned)tail_tile * (unsigned)ks_cnt * (unsigned)(TILE * 4);    // (host: the workspace < 4 GB)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          __hip_atomic_store(part + (((wave * MT + i) * NT + j) * 16 + r) * 64 + lane, acc[i][j][r],
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 4; ++q) {
+          u32x4 v;
+          v.x = __float_as_uint(acc[i][j][4 * q]); v.y = __float_as_uint(acc[i][j][4 * q + 1]);
+          v.z = __float_as_uint(acc[i][j][4 * q + 2]); v.w = __float_as_uint(acc[i][j][4 * q + 3]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs_t, tile_b + ((((wave * MT + i) * NT + j) * 4 + q) * 64 + lane) * 16,
+                                                 ks_idx * (TILE * 4), kAgent);
+        }
     // (r3: an agent-scope RELEASE fence here -- buffer_wbl2, a write-back of this XCD's whole L2 -- was tried while chasing
     // a side-stream race and cost +46 % on this kernel (58 -> 85 us average, +1 ms per step) without changing the race:
     // the partial tiles are written with agent-scope stores that bypass the non-coherent L2 path already.)
@@ -294,7 +308,7 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
     if (arrived != ks_cnt - 1) return;
     if (tid == 0)                         // ready for the next launch
       __hip_atomic_store(p.tail_cnt + tail_tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float* all = p.tail_ws + (size_t)tail_tile * ks_cnt * TILE;
+    // the sum runs in slice order whatever the order of arrival: results do not depend on the schedule
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -302,11 +316,33 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
         floatx16 sum;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum[r] = 0.f;
-        for (int sl = 0; sl < ks_cnt; ++sl) {
-          const float* src = all + (size_t)sl * TILE + (((wave * MT + i) * NT + j) * 16) * 64 + lane;
+        const unsigned blk = tile_b + ((((wave * MT + i) * NT + j) * 4) * 64 + lane) * 16;
+        int sl = 0;
+        for (; sl + 4 <= ks_cnt; sl += 4) {
+          u32x4 t[4][4];
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            sum[r] += __hip_atomic_load(src + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              t[u][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_t, blk + q * 1024, (sl + u) * (TILE * 4), kAgent);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              sum[4 * q] += __uint_as_float(t[u][q].x); sum[4 * q + 1] += __uint_as_float(t[u][q].y);
+              sum[4 * q + 2] += __uint_as_float(t[u][q].z); sum[4 * q + 3] += __uint_as_float(t[u][q].w);
+            }
+        }
+        for (; sl < ks_cnt; ++sl) {
+          u32x4 t[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_t, blk + q * 1024, sl * (TILE * 4), kAgent);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            sum[4 * q] += __uint_as_float(t[q].x); sum[4 * q + 1] += __uint_as_float(t[q].y);
+            sum[4 * q + 2] += __uint_as_float(t[q].z); sum[4 * q + 3] += __uint_as_float(t[q].w);
+          }
         }
         acc[i][j] = sum;
       }
@@ -497,6 +533,15 @@ int launch_h(const GatherGemmParams& p, hipStream_t stream, const char** name_on
 
 struct Pick { int mt, nt, ns, wgm; };
 
+// the 128 x 64 per-tap tile on 2, 3 or 4 LDS stages (ADVOC_H3_DEEP_STAGES)
+int launch_h21(const GatherGemmParams& p, hipStream_t stream, const char** name_only, const TailPlan& tail,
+               float* tail_ws, int* tail_cnt, int ksplit) {
+  const int ns = tuning().h3_deep_stages;
+  if (ns == 3) return launch_h<2, 1, 3>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
+  if (ns == 4) return launch_h<2, 1, 4>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
+  return launch_h<2, 1, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
+}
+
 // Tile choice (tools/micro/h3_sweep.py).  ADVOC_H3_TILE=1|2|3 forces 128x128 | 128x256 | 256x128,
 // ADVOC_H3_STAGES=2|3 the LDS stages.
 Pick pick_tile(const GatherGemmParams& p) {
@@ -514,13 +559,28 @@ Pick pick_tile(const GatherGemmParams& p) {
     // (re-measured without split-K, tools/micro/deep_sweep.py: from ONE such tile per CU on it is already 1.2 x the
     // 128 x 128 tile -- 422 vs 522 us on encoder_4 forward, 424 vs 526 on decoder_5 forward)
     const int64_t t256 = ceil_div((int64_t)p.batch * p.gh * p.gw, 256) * (N / 256) * p.nphase;
-    if (t256 >= device_cu_count()) k = {2, 4, 2, 4};
+    const int cus = device_cu_count();
+    if (!t.h3_deep_plan) {
+      if (t256 >= cus) k = {2, 4, 2, 4};
+    } else {
+      // (r4, kernel-only times from a trace, profiles/r04_g_deep_split_*.txt) barely more than one such tile per CU is a
+      // round and a nearly empty one: the four-phase launches of encoder_5 backward-data / decoder_5 forward (272 tiles on
+      // 256 CUs) take 249 / 386 us on it and 220 / 385 us on 128 x 128 tiles; a single-phase launch with a quarter to half a
+      // tile per CU and a long contraction (encoder_5 forward: 68 tiles x 256 K tiles) is cut into K slices that meet in
+      // the workspace instead (launch_gather_gemm_h3): 224 us against 250 (128 x 128) and 291 (128 x 64)
+      const int nkt = (p.c0 + p.c1) / 32 * p.ntaps;
+      if (2 * t256 >= 3 * cus) k = {2, 4, 2, 4};
+      else if (p.nphase == 1 && 4 * t256 >= cus && 2 * t256 <= cus && nkt >= 128 && t.igemm_splitk) k = {2, 4, 2, 4};
+    }
   }
   if (t.h3_tile == 0 && k.wgm == 2 && k.nt == 2) {
     // under one round of 128 x 128 tiles (two per CU) the 128 x 64 tile (three per CU) fills the chip better:
     // 1.04-1.2 x on the deep layers (encoder_5 / decoder_6 forward, encoder_6 / decoder_6 backward-data)
+    // (r4: not for single-phase launches from half a round on -- decoder_6 backward-data, 144 tiles x 256 K tiles: 190 us on
+    // 128 x 64, 129 us on 128 x 128 tiles cut into three K slices each)
     const int64_t t128 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * ceil_div(N, 128) * p.nphase;
-    if (t128 < 2 * device_cu_count()) k = {2, 1, 2, 2};
+    const bool keep128 = t.h3_deep_plan && p.nphase == 1 && 2 * t128 >= device_cu_count() && t.igemm_splitk;
+    if (t128 < 2 * device_cu_count() && !keep128) k = {2, 1, 2, 2};
   }
   return k;
 }
@@ -588,7 +648,8 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   // forward 365 -> 213 us, encoder_5 forward 487 -> 393 us without the split; and never on 64 Ki-output tiles)
   int ksplit = 1;
   TailPlan tail;
-  if (!patch_nph && tiles < device_cu_count() && tiles <= 256 && k.wgm == 2 && tuning().igemm_splitk) {
+  if (!patch_nph && tiles < device_cu_count() && tiles <= 256 && (k.wgm == 2 || tuning().h3_deep_split > 0 || tuning().h3_deep_plan) &&
+      tuning().igemm_splitk) {
     // Few tiles, deep contraction (the 8 x 17-point layers and below): every tile is cut into K slices that meet in the
     // WORKSPACE -- the tail-split mechanism with no whole tiles: the last slice to arrive sums the parked partial tiles
     // in slice order and runs the ordinary epilogue (no zero fill, no atomics, bias and activation gradient fused as
@@ -596,6 +657,17 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     int split = (int)ceil_div((int64_t)tuning().h3_deep_wgs_per_cu * device_cu_count(), tiles);
     if (split > nkt / tuning().h3_deep_split_div) split = nkt / tuning().h3_deep_split_div;
     if (split > 16) split = 16;
+    if (tuning().h3_deep_plan) {
+      // (r4, profiles/r04_g_deep_split_*.txt) the rule above aims just past two workgroups per CU (576, 520, 640, 560 for the
+      // model's layers: a round and a bit); the fastest split of every layer measured holds 430-480 workgroups of the 128-row
+      // tiles, i.e. just UNDER two per CU, with at least 16 K tiles per slice (8 left the 64-K-tile four-phase launches of
+      // encoder_8 / decoder_8 with more fixed cost than work); 256 x 256 tiles: one workgroup per CU
+      const int cus = device_cu_count();
+      split = k.wgm == 4 ? cus / (int)tiles : (int)((15 * cus / 8 + tiles / 2) / tiles);
+      if (split > nkt / 16) split = nkt / 16;
+      if (split > 16) split = 16;
+    }
+    if (tuning().h3_deep_split > 0) split = tuning().h3_deep_split < nkt / 2 ? tuning().h3_deep_split : nkt / 2;   // (experiments)
     if (split >= 2) { tail.main = 0; tail.rem = (int)tiles; tail.split = split; }
   }
   if (tail.split < 2 && !patch_nph && tiles < device_cu_count() / 2 && k.wgm == 2 && tuning().igemm_splitk) {
@@ -700,17 +772,17 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     int rsplit = 1;
     const Tuning& tn = tuning();
     if (tail.split > 1 && tail_ws && tail_cnt)
-      return launch_h<2, 1, 2>(pr, stream, nullptr, tail, tail_ws, tail_cnt, 1);
+      return launch_h21(pr, stream, nullptr, tail, tail_ws, tail_cnt, 1);
     if (!want_emit && nkt >= 4 * tn.h3_rem_split_div && rtiles < (int64_t)tn.h3_rem_wgs_per_cu * device_cu_count() && tn.igemm_splitk) {
       rsplit = (int)ceil_div((int64_t)tn.h3_rem_wgs_per_cu * device_cu_count(), rtiles);
       if (rsplit > nkt / tn.h3_rem_split_div) rsplit = nkt / tn.h3_rem_split_div;
       if (rsplit > 16) rsplit = 16;
       if (rsplit < 1) rsplit = 1;
     }
-    return launch_h<2, 1, 2>(pr, stream, nullptr, TailPlan(), nullptr, nullptr, rsplit);
+    return launch_h21(pr, stream, nullptr, TailPlan(), nullptr, nullptr, rsplit);
   }
   if (k.wgm == 4 && k.nt == 4) return launch_h<2, 4, 2, 4>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
-  if (k.nt == 1) return launch_h<2, 1, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
+  if (k.nt == 1) return launch_h21(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
   return launch_h<2, 2, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
 }
 

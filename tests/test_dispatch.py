@@ -53,11 +53,16 @@ FULL = [
     ('encoder_2', layer(0, BF, 128, 257, 64, 0, 128, (2, 2)), P3F, P4B, W128),
     ('encoder_3', layer(0, BF, 64, 129, 128, 0, 256, (2, 2)), P2F, P4B, W256),
     ('encoder_4', layer(0, BF, 32, 65, 256, 0, 512, (2, 2)), P2F, P4B, W256),
-    ('encoder_5', layer(0, BF, 16, 33, 512, 0, 512, (2, 2)), 'gather_gemm_h3_kernel<2, 1, 2, 2>',
-     'gather_gemm_h3_kernel<2, 4, 2, 4>', W256),
+    # (r4: under one round of tiles the tile follows the launch's shape, igemm_h3.hip pick_tile -- encoder_5 forward, 68
+    # 256 x 256 tiles, on that tile cut into three K slices; its four-phase backward-data and decoder_5 forward, 272 such
+    # tiles on 256 CUs, on 128 x 128 tiles; decoder_6 backward-data, 144 128 x 128 tiles, on those cut into three K slices)
+    ('encoder_5', layer(0, BF, 16, 33, 512, 0, 512, (2, 2)), 'gather_gemm_h3_kernel<2, 4, 2, 4>',
+     'gather_gemm_h3_kernel<2, 2, 2, 2>', W256),
+    ('decoder_6', layer(1, BF, 4, 9, 512, 512, 512, (2, 2), trim=1), 'gather_gemm_h3_kernel<2, 1, 2, 2>',
+     'gather_gemm_h3_kernel<2, 2, 2, 2>', None),
     ('encoder_7', layer(0, BF, 4, 9, 512, 0, 512, (2, 2)), 'gather_gemm_h3_kernel<2, 1, 2, 2>',
      'gather_gemm_h3_kernel<2, 1, 2, 2>', None),
-    ('decoder_5', layer(1, BF, 8, 17, 512, 512, 512, (2, 2), trim=1), 'gather_gemm_h3_kernel<2, 4, 2, 4>',
+    ('decoder_5', layer(1, BF, 8, 17, 512, 512, 512, (2, 2), trim=1), 'gather_gemm_h3_kernel<2, 2, 2, 2>',
      'gather_gemm_h3_kernel<2, 2, 2, 2>', W256),
     ('decoder_4', layer(1, BF, 16, 33, 512, 512, 256, (2, 2), trim=1), P4F, P2B, W256),
     ('decoder_3', layer(1, BF, 32, 65, 256, 256, 128, (2, 2), trim=1), P4F, P2B, W256),

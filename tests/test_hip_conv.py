@@ -390,6 +390,47 @@ def test_layer_operand_image_kernels(hip, case, variant, hipenv):
   test_layer_all_directions(hip, case)
 
 
+DEEP_SLICES = [c for c in H3 if c[0] in ('h3_enc', 'h3_dec_skip', 'h3_dec_mixed', 'h3_deep_small')]
+
+
+@gpu
+@pytest.mark.parametrize('split', [3, 5])
+@pytest.mark.parametrize('tile', [4, 1, 5], ids=['128x64', '128x128', '256x256'])
+@pytest.mark.parametrize('case', DEEP_SLICES, ids=[c[0] for c in DEEP_SLICES])
+def test_deep_launches_cut_into_k_slices_on_every_tile(hip, case, tile, split, hipenv):
+  """Launches under one round of tiles have EVERY tile cut into K slices that meet in the workspace (igemm_h3.hip: the last
+  slice to arrive adds the parked partial tiles in slice order -- 16-byte agent-scope pieces, four slices in flight -- and
+  runs the ordinary epilogue).  Since r4 the 128 x 128 and 256 x 256 tiles take that path too (encoder_5 forward, decoder_6
+  backward-data of the full model): each tile shape with 3 and 5 slices (one and two passes of the four-slice reader, plus
+  its one-slice remainder) against the float64 oracle in all directions, and the forward result bit-reproducible and within
+  the order of one sum of the unsplit launch."""
+  from advoc_amd import conv
+  c = build_case(case)
+  dev = torch.device('cuda')
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w = c['w'].to(dev)
+  cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+
+  def forward():
+    y = torch.full((x0.shape[0], c['oh'], c['out_w'], cout), float('nan'), device=dev)
+    L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
+    L.forward()
+    return L, y
+
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_TILE=tile, ADVOC_H3_DEEP_SPLIT=split)
+  L, y_a = forward()
+  assert 'gather_gemm_h3_kernel' in L.kernel_name(0), L.kernel_name(0)
+  _, y_b = forward()
+  assert torch.equal(y_a, y_b)
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_TILE=tile, ADVOC_H3_DEEP_SPLIT=None, ADVOC_IGEMM_SPLITK=0)
+  _, y_plain = forward()
+  assert not torch.equal(y_a, y_plain)              # (the slices were really taken: another order of the same sum)
+  assert rel(y_a, y_plain.double()) < 1e-6
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_TILE=tile, ADVOC_H3_DEEP_SPLIT=split, ADVOC_IGEMM_SPLITK=None)
+  test_layer_all_directions(hip, case)
+
+
 @gpu
 @pytest.mark.parametrize('mode', ['default', 'k_split_workspace'])
 @pytest.mark.parametrize('case,want', H3_N32, ids=[c[0][0] for c in H3_N32])
