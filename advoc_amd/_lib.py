@@ -33,6 +33,11 @@ class ImageOut(ctypes.Structure):
   _fields_ = [('img', _p), ('hdr', _p), ('act', _i32), ('reserved', _i32)]
 
 
+class DxImage(ctypes.Structure):
+  """advoc_conv_layer.dx_img (include/advoc_hip.h)."""
+  _fields_ = [('img', _p), ('hdr', _p), ('colsum', _p), ('table', _p)]
+
+
 class ConvLayer(ctypes.Structure):
   """struct advoc_conv_layer (include/advoc_hip.h)."""
   _fields_ = [
@@ -50,6 +55,7 @@ class ConvLayer(ctypes.Structure):
       ('wgrad_table', _p),
       ('y_img', ImageOut * 2),
       ('wgrad_ws', _p), ('wgrad_ws_bytes', _i64),
+      ('dx_img', DxImage),
   ]
 
 WGRAD_TABLE_BYTES = 262144      # ADVOC_WGRAD_TABLE_BYTES
@@ -85,6 +91,7 @@ PROTOTYPES = {
     'advoc_conv_image_bytes': (_i64, [_p, _i32]),
     'advoc_conv_bias_fusable': (ctypes.c_int, [_p]),
     'advoc_conv_emits_images': (ctypes.c_int, [_p]),
+    'advoc_conv_emits_dx_image': (ctypes.c_int, [_p]),
     'advoc_segmented_amax_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p]),
     'advoc_conv_weight_image_desc': (ctypes.c_int, [_p, _i32, _p]),
     'advoc_weight_images_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p, _p]),

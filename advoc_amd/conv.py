@@ -90,6 +90,12 @@ class Layer(object):
   # operand images from its own forward epilogue (advoc_conv_layer.y_img, csrc/image_emit.h) once the consumer's header
   # holds a previous magnitude -- the consumer's image pass (a read and a write of the whole tensor) disappears
   emit_images = os.environ.get('ADVOC_EMIT_IMAGES', '1') == '1'
+  # ADVOC_EMIT_DX=1 turns it on: a backward_data call given `grad_consumer` -- the layer below, whose output gradient this
+  # call's dx0 is -- writes THAT layer's output-gradient image (and its bias column sums) from its own epilogue
+  # (advoc_conv_layer.dx_img): the image pass of the layer below disappears.  Off by default: measured on the one producer
+  # that has it (discriminator layer_5 -> layer_4, the largest image pass of the step) the passes lose 0.31 ms per step and
+  # the producer, an issue-bound kernel, gains 0.18 ms; the step does not move (profiles/r04_i_*)
+  emit_dx = os.environ.get('ADVOC_EMIT_DX', '0') == '1'
 
   @staticmethod
   def _workspace_for(device, nbytes):
@@ -197,6 +203,9 @@ class Layer(object):
     self._emits = None             # advoc_conv_emits_images(), asked once
     self._x_emitted = set()        # sources of x_img written by their producers since the last forward
     self._db_done_for = None
+    self._emits_dx = None          # advoc_conv_emits_dx_image(), asked once
+    self._dx_table = None          # replica table of the column sums that ride in the dx image emission
+    self._dy_emitted_for = None    # (dy pointer, db pointer or None): dy_img was written by the layer above's backward_data
     self._bias_fusable = bool(_lib.load().advoc_conv_bias_fusable(ctypes.byref(s)))
     self._thin_bias = False
     if kind == CONV and cin <= 2 and workspace:
@@ -366,10 +375,32 @@ class Layer(object):
     self._x_current = bool(self.struct.x_img) and 'h3' in self.kernel_name(0)
     return self.y
 
-  def backward_data(self, dy, dx0=None, dx1=None, accum0=False, accum1=False, db=None, db_accumulate=True):
+  def _dx_target(self, dx0, dx1, accum0, accum1, consumer, consumer_db):
+    """The layer below (`consumer`) whose output-gradient image this backward_data call can write, or None."""
+    if consumer is None or not Layer.emit_dx or dx0 is None or dx1 is not None or accum0 or accum1:
+      return None
+    cs = consumer.struct
+    if not (self.delayed_scale and consumer.delayed_scale and consumer._dy_built and cs.dy_img and cs.dy_hdr):
+      return None
+    if cs.drop_mask or 'h3' not in consumer.kernel_name(1) or 'h3' not in consumer.kernel_name(2):
+      return None
+    if self.x0.data_ptr() != consumer.y.data_ptr() or tuple(dx0.shape) != tuple(consumer.y.shape):
+      raise _lib.AdvocHipError('this layer\'s input is not the consumer layer\'s output')
+    if consumer_db is not None and not consumer._bias_fusable:
+      return None
+    if self._emits_dx is None:
+      self._emits_dx = bool(_lib.load().advoc_conv_emits_dx_image(ctypes.byref(self.struct)))
+    return consumer if self._emits_dx else None
+
+  def backward_data(self, dy, dx0=None, dx1=None, accum0=False, accum1=False, db=None, db_accumulate=True,
+                    grad_consumer=None, consumer_db=None, consumer_db_accumulate=True):
     """dx0 / dx1 <- gradient w.r.t. the inputs.  db (optional): the bias gradient buffer of this layer -- where the call
     builds the image of dy (image kernels, advoc_conv_bias_fusable) the per-channel sums are taken in the same pass and
-    the backward_weight call that follows with the same dy skips its bias kernel."""
+    the backward_weight call that follows with the same dy skips its bias kernel.
+    grad_consumer (optional): the Layer whose output y this layer reads as x0, i.e. whose output GRADIENT dx0 is; where the
+    kernels allow (advoc_conv_emits_dx_image) this call writes that layer's output-gradient image itself, and with
+    consumer_db its bias gradient (per-channel sums of dx0): its backward_data / backward_weight calls that follow with
+    dx0 (and consumer_db) then build neither."""
     _lib.require_device(dy)
     if tuple(dy.shape) != tuple(self.y.shape):
       raise _lib.AdvocHipError('dy shape {} != y shape {}'.format(tuple(dy.shape), tuple(self.y.shape)))
@@ -379,21 +410,49 @@ class Layer(object):
         if x is None or tuple(d.shape) != tuple(x.shape):
           raise _lib.AdvocHipError('dx must have the shape of the matching input')
     self._db_done_for = None
-    fuse_db = db is not None and self._bias_fusable and 'h3' in self.kernel_name(1)
+    # the layer above wrote dy_img (and possibly this layer's bias gradient) from its backward_data epilogue
+    emitted, self._dy_emitted_for = self._dy_emitted_for, None
+    if emitted is not None and not (emitted[0] == dy.data_ptr() and 'h3' in self.kernel_name(1)):
+      emitted = None
+    db_by_producer = emitted is not None and db is not None and emitted[1] == db.data_ptr()
+    fuse_db = db is not None and self._bias_fusable and 'h3' in self.kernel_name(1) and emitted is None
     if fuse_db:
       _lib.require_device(db)
       if not db_accumulate:
         db.zero_()
       self.struct.db_fused = _lib.ptr(db)
+    target = self._dx_target(dx0, dx1, accum0, accum1, grad_consumer, consumer_db)
+    if target is not None:
+      if consumer_db is not None:
+        _lib.require_device(consumer_db)
+        if not consumer_db_accumulate:
+          consumer_db.zero_()
+        if self._dx_table is None:
+          self._dx_table = torch.empty(_lib.WGRAD_TABLE_BYTES // 4, dtype=torch.float32, device=dy.device)
+        self.struct.dx_img.colsum = _lib.ptr(consumer_db)
+        self.struct.dx_img.table = self._dx_table.data_ptr()
+      self.struct.dx_img.img = target.struct.dy_img
+      self.struct.dx_img.hdr = target.struct.dy_hdr
     try:
-      self.struct.img_flags = self._timed_image(1, dy) | self._delayed_bits()
+      if emitted is not None:
+        flags = 2 | 32                       # ADVOC_IMG_DY_CURRENT | ADVOC_IMG_DY_EMITTED: refit check instead of an image pass
+      else:
+        flags = self._timed_image(1, dy)
+      self.struct.img_flags = flags | self._delayed_bits()
       self._run(1, lambda: _lib.check(_lib.load().advoc_conv_backward_data(
           ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dx0), _lib.ptr(dx1), int(accum0),
-          int(accum1), _lib.stream()), 'advoc_conv_backward_data'))
+          int(accum1), _lib.stream()), 'advoc_conv_backward_data'),
+                extra_bytes=4.0 * dx0.numel() if target is not None else 0.0)
     finally:                     # a failed call must not leave a stale bias pointer / flags behind
       self.struct.img_flags = 0
       self.struct.db_fused = None
-    if fuse_db:
+      self.struct.dx_img.img = None
+      self.struct.dx_img.hdr = None
+      self.struct.dx_img.colsum = None
+      self.struct.dx_img.table = None
+    if target is not None:
+      target._dy_emitted_for = (dx0.data_ptr(), consumer_db.data_ptr() if consumer_db is not None else None)
+    if fuse_db or db_by_producer:
       self._db_done_for = (dy.data_ptr(), db.data_ptr())
     if self.struct.dy_img and 'h3' in self.kernel_name(1):
       self._dy_built = True

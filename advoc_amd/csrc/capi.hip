@@ -93,6 +93,7 @@ Tuning read_env() {
   t.h3_deep_stages = env_int("ADVOC_H3_DEEP_STAGES", 2);
   t.h3_deep_split = env_int("ADVOC_H3_DEEP_SPLIT", 0);
   t.h3_deep_plan = env_int("ADVOC_H3_DEEP_PLAN", 1);
+  t.emit_dx = env_int("ADVOC_EMIT_DX", 1);
   if (t.h3_rem_wgs_per_cu < 1) t.h3_rem_wgs_per_cu = 1;
   if (t.h3_rem_split_div < 2) t.h3_rem_split_div = 2;
   return t;

@@ -101,6 +101,11 @@ struct GatherGemmParams {
   // the image kernels' non-atomic epilogues only (launch_gather_gemm_h3 reports through emit_report what it will do)
   ImgOut oimg[2];
   int* emit_report;        // host pointer, name_only launches: set to 1 when this launch would write oimg
+  // backward-data launches of the thin matrix kernel (thin.hip): per-channel sums of destination 0 over its pixels, added to
+  // ocolsum_out[c] through the replica table ocolsum_table (kColsumBytes, zeroed by the launcher) -- the bias gradient of
+  // the layer below when oimg[0] is that layer's output-gradient image
+  float* ocolsum_out;
+  float* ocolsum_table;
   float* a_colsum;         // != null: the image pass of source 0 adds its per-channel sums over the logical pixels here (the
                            // bias gradient, when A is an output gradient); only honoured where image_colsum_ok(c0)
   // ---- tail split (filled in by the launcher, see launch_cfg) ----

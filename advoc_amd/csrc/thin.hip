@@ -63,7 +63,9 @@ constexpr int kThinPatch = kThinPatchRows * kThinPatchCols * 2;   // x up to 2 c
 // instance executed the image arithmetic of two absent consumers for every value, half its epilogue; 0 / 1 / 2 = a FORWARD
 // call without masks / gating / accumulation and with that many image consumers in oimg[0 .. FW): the epilogue loads (12
 // buffer instructions per 32-channel block, out of range and dropped -- but issued) are not there and the image arithmetic
-// of a consumer that does not exist is not executed.  The kernel is bound by what it ISSUES (rocprofv3: issuing 0.98 at three
+// of a consumer that does not exist is not executed; -3 = as -2 plus ONE image: the output-gradient image of the layer below
+// and that tensor's per-channel sums, its bias gradient (advoc_conv_layer.dx_img; 176 registers, two waves per SIMD -- at
+// three, 8 spilled, it is slower: profiles/r04_i_emit_dx_ab.txt).  The kernel is bound by what it ISSUES (rocprofv3: issuing 0.98 at three
 // waves per SIMD, ~1 500 vector instructions per tile; an unused consumer's share is 15 % of them).
 template <int KP, int NT, bool B_KN, int PL, int FW>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const GatherGemmParams p, int dy_min, int dx_min,
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
   const bool emit0 = o0.img != nullptr, emit1 = o1.img != nullptr;
   const float eup0 = emit0 ? emit_up_scale(o0.hdr[2]) : 1.f, eup1 = emit1 ? emit_up_scale(o1.hdr[2]) : 1.f;
   float evmax0 = 0.f, evmax1 = 0.f;
+  float csum[FW == -3 ? NT : 1][4] = {};
   if (threadIdx.x == 0) {
     if (emit0) o0.hdr[1] = __float_as_uint(1.f / eup0);
     if (emit1) o1.hdr[1] = __float_as_uint(1.f / eup1);
@@ -346,8 +349,13 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         const bool ok = okj && di == 0 && so[ps] != kThinOob;
-        if (FW == -1 || FW >= 1) emit4_buffer(rs_e0, o0.slope, eup0, v[ps], ok ? so[ps] : kThinOob, ok && emit0, evmax0);
+        if (FW == -1 || FW >= 1 || FW == -3) emit4_buffer(rs_e0, o0.slope, eup0, v[ps], ok ? so[ps] : kThinOob, ok && emit0, evmax0);
         if (FW == -1 || FW >= 2) emit4_buffer(rs_e1, o1.slope, eup1, v[ps], ok ? so[ps] : kThinOob, ok && emit1, evmax1);
+        if constexpr (FW == -3) {         // column sums of the destination: the lane's four channels over the rows it stores
+          const float m = ok ? 1.f : 0.f;
+          csum[j][0] = fmaf(m, v[ps].x, csum[j][0]); csum[j][1] = fmaf(m, v[ps].y, csum[j][1]);
+          csum[j][2] = fmaf(m, v[ps].z, csum[j][2]); csum[j][3] = fmaf(m, v[ps].w, csum[j][3]);
+        }
       }
       wave_lds_sync();
     }
@@ -355,6 +363,22 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
 #undef ADVOC_THIN_PRELOAD
   if (emit0) emit_finish(o0, eup0, evmax0);
   if (emit1) emit_finish(o1, eup1, evmax1);
+  if constexpr (FW == -3) if (p.ocolsum_table) {
+    // lanes (row lane >> 3, channel quad lane & 7): fold the eight rows, then one atomic per channel and wave into one of the
+    // replica tables (image.hip: thousands of waves adding to the same N addresses serialise in the L2)
+    float* tab = p.ocolsum_table + (size_t)((blockIdx.x * 4 + wave) & (kColsumReplicas - 1)) * N;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float t = csum[j][c];
+        t += __shfl_xor(t, 8, 64);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        const int n = n0 + 32 * j + 4 * (lane & 7) + c;
+        if (lane < 8 && n < N) unsafeAtomicAdd(tab + n, t);
+      }
+  }
 }
 
 #undef PE_ROW
@@ -389,7 +413,11 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
       names[i] = std::string("thin_k_gemm_kernel<") + std::to_string(KP) + ", " + std::to_string(nt) + ", " +
                  (B_KN ? "true" : "false") + ">";
     *name_only = names[i].c_str();
-    if (p.emit_report) *p.emit_report = 1;      // the epilogue writes GatherGemmParams.oimg (image_emit.h)
+    // the epilogue writes GatherGemmParams.oimg (image_emit.h); 2: as a backward-data call that only gates on the
+    // pre-activation values, into ONE image (the layer below's output gradient) with that tensor's column sums on the way
+    if (p.emit_report)
+      *p.emit_report = (nt >= 2 && p.grad_act != ADVOC_ACT_NONE && !p.y_mask && !p.d[0].gmask && !p.d[1].gmask && !p.d[0].accum &&
+                        !p.d[1].accum && !p.d[1].p && p.oimg[0].img && !p.oimg[1].img && tuning().thin_fwd_spec) ? 2 : 1;
     return ADVOC_OK;
   }
   int64_t bx = ceil_div(tiles, 4);
@@ -405,7 +433,16 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
   } else if (tuning().thin_fwd_spec && p.grad_act != ADVOC_ACT_NONE && !p.y_mask && !p.d[0].gmask && !p.d[1].gmask && !p.d[0].accum &&
              !p.d[1].accum && !p.oimg[0].img && !p.oimg[1].img) {
     fw = -2;
+  } else if (tuning().thin_fwd_spec && nt >= 2 && p.grad_act != ADVOC_ACT_NONE && !p.y_mask && !p.d[0].gmask && !p.d[1].gmask &&
+             !p.d[0].accum && !p.d[1].accum && !p.d[1].p && p.oimg[0].img && !p.oimg[1].img) {
+    fw = -3;        // ... and writes the layer below's output-gradient image (+ its bias column sums)
+    if (p.ocolsum_out) {
+      if (!p.ocolsum_table) return ADVOC_ERR_NULL;
+      hipError_t e = hipMemsetAsync(p.ocolsum_table, 0, sizeof(float) * kColsumReplicas * (size_t)N, stream);
+      if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    }
   }
+  if (fw != -3 && (p.ocolsum_out || (p.grad_act != ADVOC_ACT_NONE && p.oimg[0].img))) return ADVOC_ERR_UNSUPPORTED;
   const int pl = (pr * pc * (p.c0 + p.c1) + 63) / 64;
   dim3 grid(1, (unsigned)by, (unsigned)p.nphase);
   ADVOC_CLEAR_LAUNCH_ERROR();
@@ -427,6 +464,9 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
     if (NT_ >= 2 && fw == -2) {             /* the backward-data calls of the models */                      \
       hipLaunchKernelGGL((thin_k_gemm_kernel<KP, NT_, B_KN, PL_, -2>), grid, dim3(256), 0, stream, p, dy_min, dx_min, pr, \
                          pc, tiles_x);                                                                \
+    } else if (NT_ >= 2 && fw == -3) {                                                                \
+      hipLaunchKernelGGL((thin_k_gemm_kernel<KP, NT_ >= 2 ? NT_ : 2, B_KN, PL_, -3>), grid, dim3(256), 0, stream, p, dy_min, \
+                         dx_min, pr, pc, tiles_x);                                                    \
     } else if (B_KN && NT_ <= 2 && fw >= 0) {      /* the forward calls of the models (32 / 64 output channels) */ \
       if (fw == 0) hipLaunchKernelGGL((thin_k_gemm_kernel<KP, NT_ <= 2 ? NT_ : 1, true, PL_, 0>), grid, dim3(256), 0, stream, q, dy_min, dx_min, pr, pc, tiles_x); \
       else if (fw == 1) hipLaunchKernelGGL((thin_k_gemm_kernel<KP, NT_ <= 2 ? NT_ : 1, true, PL_, 1>), grid, dim3(256), 0, stream, q, dy_min, dx_min, pr, pc, tiles_x); \
@@ -448,6 +488,7 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
 #undef ADVOC_THIN_LAUNCH_PL
 #undef ADVOC_THIN_LAUNCH
   ADVOC_RETURN_IF_LAUNCH_FAILED();
+  if (fw == -3 && p.ocolsum_out) return launch_colsum_reduce(p.ocolsum_table, p.ocolsum_out, N, stream);
   return ADVOC_OK;
 }
 

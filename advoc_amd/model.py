@@ -828,15 +828,22 @@ class Advoc(Model):
     self._zero_arena('d')
     for k, (layers, bns, lo, hi) in enumerate(passes):
       acc = True
+      for lay in layers:
+        lay.set_dy_role('d')
       for i in range(4, -1, -1):
-        layers[i].set_dy_role('d')
         s = 'discriminator/layer_%d/conv2d' % (i + 1)
         g = st['g_d_act'][i][lo:hi]
         if i in bns:
           self._bn_backward(bns[i], g, accumulate=acc)
         # backward-data first: it leaves the fp16 pair image of g behind, which the weight gradient reads again
         if i > 0:
-          layers[i].backward_data(g, st['g_d_act'][i - 1][lo:hi], db=DG[s + '/bias'], db_accumulate=acc)
+          # (layer_5 -> layer_4 without batch norm in between: layer_5's epilogue writes layer_4's output-gradient image and
+          # its bias gradient -- the largest of the image passes, conv.Layer.backward_data)
+          below = layers[i - 1] if i == 4 and (i - 1) not in bns else None
+          layers[i].backward_data(g, st['g_d_act'][i - 1][lo:hi], db=DG[s + '/bias'], db_accumulate=acc,
+                                  grad_consumer=below,
+                                  consumer_db=DG['discriminator/layer_%d/conv2d/bias' % i] if below is not None else None,
+                                  consumer_db_accumulate=acc)
         with self._wgrad_ctx():
           layers[i].backward_weight(g, DG[s + '/kernel'], DG[s + '/bias'], accumulate=acc)
       # (batch norm, two passes: r3 joined the side stream here because pass 1's backward-data launches gave wrong elements
@@ -929,7 +936,8 @@ class Advoc(Model):
       for i in range(4, 0, -1):
         if i in bnf:   # through the discriminator's batch norm; its parameter gradients are not used here
           self._bn_backward(bnf[i], st['g_d_act'][i][B:], discard_param_grads=True)
-        Lf[i].backward_data(st['g_d_act'][i][B:], st['g_d_act'][i - 1][B:])
+        Lf[i].backward_data(st['g_d_act'][i][B:], st['g_d_act'][i - 1][B:],
+                            grad_consumer=Lf[i - 1] if i == 4 and (i - 1) not in bnf else None)
       Lf[0].backward_data(st['g_d_act'][0][B:], None, g_out, accum1=True)
     # generator backward: decoder_1 .. decoder_N, then encoder_N .. encoder_1
     GL, GG = st['g_layers'], st['g_G']

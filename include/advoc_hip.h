@@ -304,6 +304,17 @@ typedef struct advoc_conv_layer {
    * backward-weight calls run on one stream; like wgrad_table it is not part of `workspace`.  NULL: atomics. */
   float* wgrad_ws;
   int64_t wgrad_ws_bytes;
+  /* optional (backward-data calls, r4): dx0 of this call IS the output gradient of the layer below, and its operand image
+   * -- the one that layer's backward-data / backward-weight calls would otherwise build with a pass over dx0 -- is written
+   * by this call's epilogue next to dx0 itself: `img` / `hdr` = the lower layer's dy_img / dy_hdr (header of the caller
+   * role in use), under the one-pass scale (that header must hold a previous image's magnitude).  The lower layer's
+   * backward-data call must then be made with ADVOC_IMG_DY_CURRENT | ADVOC_IMG_DY_EMITTED (refit check instead of an
+   * image pass).  Since that pass also carried the lower layer's bias gradient (db_fused), the sums move here as well:
+   * `colsum` non-null = sum over the logical pixels of dx0 is ADDED to colsum[c0] (the caller zeroes it first if it does
+   * not accumulate), through `table`, ADVOC_WGRAD_TABLE_BYTES of device scratch owned by this layer.  Honoured where
+   * advoc_conv_emits_dx_image() says so (the <= 2-output-channel layers' matrix kernel, one source, no accumulation);
+   * img == NULL: none. */
+  struct { uint16_t* img; uint32_t* hdr; float* colsum; float* table; } dx_img;
 } advoc_conv_layer;
 #define ADVOC_WGRAD_TABLE_BYTES 262144
 
@@ -329,6 +340,8 @@ int advoc_conv_bias_fusable(const advoc_conv_layer* layer);
 /* 1: a forward call on this layer writes the consumers' images of advoc_conv_layer.y_img (it runs on the image kernels
  * and has the workspace they need); 0: y_img is ignored and the consumers must build their images themselves */
 int advoc_conv_emits_images(const advoc_conv_layer* layer);
+/* 1: a backward-data call on this layer (dx0 only) writes advoc_conv_layer.dx_img; 0: dx_img is ignored */
+int advoc_conv_emits_dx_image(const advoc_conv_layer* layer);
 
 #define ADVOC_IMG_X_CURRENT 1
 #define ADVOC_IMG_DY_CURRENT 2
@@ -343,6 +356,9 @@ int advoc_conv_emits_images(const advoc_conv_layer* layer);
 /* with ADVOC_IMG_X_CURRENT: x_img was written by the producers of the inputs (advoc_conv_layer.y_img of their layers)
  * under the one-pass scale since the last forward call: this call runs the refit check / header rotation first */
 #define ADVOC_IMG_X_EMITTED 16
+/* with ADVOC_IMG_DY_CURRENT: dy_img was written by the backward-data call of the layer above (its advoc_conv_layer.dx_img)
+ * under the one-pass scale: this call runs the refit check / header rotation first */
+#define ADVOC_IMG_DY_EMITTED 32
 
 /* Bytes of the persistent operand image `which` (0: inputs, 1: output gradient) the layer can use; 0 when the layer's
  * shapes are outside the image-based kernels. */

@@ -1029,6 +1029,63 @@ def test_thin_producers_write_operand_images(hip, hipenv, cin, cout):
 
 
 @gpu
+@pytest.mark.parametrize('cmid', [128, 512])
+def test_backward_data_writes_the_output_gradient_image_of_the_layer_below(hip, hipenv, monkeypatch, cmid):
+  """r4: the backward-data call of a 1-output-channel layer (the discriminator's layer_5, csrc/thin.hip) writes the
+  output-gradient image of the layer below (layer_4: the largest image pass of the train step) from its own epilogue, and
+  that layer's bias gradient (the column sums the image pass used to carry): image and header value-identical to the lower
+  layer's own image pass, so its backward-data result is bit-identical; weight and bias gradients to the
+  order of one sum; ragged widths; a 1000 x jump is refitted exactly."""
+  from advoc_amd import conv
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1)
+  monkeypatch.setattr(conv.Layer, 'emit_dx', True)          # (off by default: it does not pay on the train step, conv.py)
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(41)
+  xin = torch.randn(2, 32, 37, 64, generator=g).to(dev)
+  wc = (torch.randn(4, 4, 64, cmid, generator=g) * 0.05).to(dev)
+  bc = (torch.randn(cmid, generator=g) * 0.1).to(dev)
+  wp = (torch.randn(4, 4, cmid, 1, generator=g) * 0.05).to(dev)
+  bp = (torch.randn(1, generator=g) * 0.1).to(dev)
+  dyp = torch.randn(2, 30, 35, 1, generator=g).to(dev)
+
+  def make():
+    yc = torch.empty(2, 31, 36, cmid, device=dev)
+    C = conv.Layer(conv.CONV, xin.clone(), yc, wc, bc, stride=(1, 1), pad=(1, 1), in_act=conv.ACT_LRELU)
+    P = conv.Layer(conv.CONV, yc, torch.empty(2, 30, 35, 1, device=dev), wp, bp, stride=(1, 1), pad=(1, 1),
+                   in_act=conv.ACT_LRELU)
+    for L in (P, C):
+      L.delayed_scale, L.reuse_images = True, True
+    assert 'thin_k' in P.kernel_name(1) and 'h3' in C.kernel_name(1) and 'h3' in C.kernel_name(2), \
+        (P.kernel_name(1), C.kernel_name(1), C.kernel_name(2))
+    bufs = dict(gc=torch.empty_like(yc), dx=torch.empty_like(xin), dw=torch.zeros_like(wc), db=torch.zeros_like(bc))
+    return P, C, bufs
+  A, R = make(), make()
+  took = 0
+  for step, scale in enumerate((1.0, 0.7, 1.2, 1000.0, 1000.0)):
+    for (P, C, t), emit in ((A, True), (R, False)):
+      C.forward()
+      P.forward()
+      t['dw'].zero_()
+      P.backward_data(dyp * scale, t['gc'], grad_consumer=C if emit else None, consumer_db=t['db'] if emit else None,
+                      consumer_db_accumulate=False)
+      if emit:
+        took += C._dy_emitted_for is not None
+        assert (C._dy_emitted_for is not None) == (step >= 1), step      # (the first step has no magnitude history yet)
+      C.backward_data(t['gc'], t['dx'], db=t['db'], db_accumulate=False)
+      C.backward_weight(t['gc'], t['dw'], t['db'])
+    (Pa, Ca, ta), (Pr, Cr, tr) = A, R
+    assert torch.equal(ta['gc'], tr['gc']), step
+    assert torch.equal(Ca._img[2].view(torch.float16), Cr._img[2].view(torch.float16)), step
+    ha, hr = Ca._img[3].cpu(), Cr._img[3].cpu()
+    assert int(ha[1]) == int(hr[1]) and int(ha[2]) == int(hr[2]) and int(ha[5]) == int(hr[5]), (step, ha, hr)
+    assert torch.equal(ta['dx'], tr['dx']), step
+    assert rel(ta['dw'], tr['dw']) < 2e-6, (step, rel(ta['dw'], tr['dw']))      # (same image; K slices may meet with atomics)
+    assert rel(ta['db'], tr['db'].double().cpu()) < 2e-6, (step, rel(ta['db'], tr['db'].double().cpu()))
+  assert took == 4
+  assert int(A[1]._img[3].cpu()[5]) == 1            # one exact refit: the 1000 x jump
+
+
+@gpu
 def test_output_gradient_roles_keep_separate_magnitude_histories(hip, hipenv):
   """Layer.set_dy_role: one layer object that sees gradients of two losses per step (the discriminator's fake pass with
   batch norm: D-loss gradients in the D step, ~1000 x larger G-loss gradients in the G step) keeps one header per role,
