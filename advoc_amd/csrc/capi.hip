@@ -94,6 +94,7 @@ Tuning read_env() {
   t.h3_deep_split = env_int("ADVOC_H3_DEEP_SPLIT", 0);
   t.h3_deep_plan = env_int("ADVOC_H3_DEEP_PLAN", 1);
   t.emit_dx = env_int("ADVOC_EMIT_DX", 1);
+  t.h3_patch_s1n128 = env_int("ADVOC_H3_PATCH_S1N128", 1);
   if (t.h3_rem_wgs_per_cu < 1) t.h3_rem_wgs_per_cu = 1;
   if (t.h3_rem_split_div < 2) t.h3_rem_split_div = 2;
   return t;

@@ -53,30 +53,33 @@ __device__ __forceinline__ float act_slope_p(int act) {
 //      17 x 17 pixels of ONE plane -- every other pixel of the ordinary image, de-interleaved by the DMA's source
 //      addresses, so the planes exist in LDS only: 256 points x 256 columns
 //   3  as 2 with 128 columns (the 128-channel layers): 8 waves = 4 point quarters x 2 column halves
+//   5  as 1 with 128 columns (r4: AdVoc-small's layer_4 backward-data, 256 -> 128 channels), waves as in 3
 // (W = 4 wavefronts, one per SIMD with 512 registers and register-carried fragments, was built and measured 0.85-1.0 x
 // the 8-wave form: the code paths are kept behind CARRY / DOUBLE_B, only W = 8 is instantiated.)
 template <int NPH, int W>
 struct PCfg {
   static constexpr bool S2 = NPH == 2 || NPH == 3;
   static constexpr int WAVES = W, THREADS = 64 * W;
-  static constexpr int NST = NPH == 1 ? 16 : 4;            // tap steps per K slice
-  static constexpr int BN = NPH == 4 ? 64 : (NPH == 3 ? 128 : 256);   // output channels per workgroup
-  static constexpr int BROWS = NPH == 3 ? 128 : 256;       // rows of a B stage (NPH = 4: four phases x 64 columns)
-  static constexpr int MT = NPH == 3 ? 2 : ((NPH == 4 && W == 4) ? 8 : 4);   // 32-point blocks per wave
+  static constexpr bool S1 = NPH == 1 || NPH == 5;         // the 4x4 stride-1 gather
+  static constexpr bool N128 = NPH == 3 || NPH == 5;       // 128 columns per workgroup
+  static constexpr int NST = S1 ? 16 : 4;                  // tap steps per K slice
+  static constexpr int BN = NPH == 4 ? 64 : (N128 ? 128 : 256);   // output channels per workgroup
+  static constexpr int BROWS = N128 ? 128 : 256;           // rows of a B stage (NPH = 4: four phases x 64 columns)
+  static constexpr int MT = N128 ? 2 : ((NPH == 4 && W == 4) ? 8 : 4);   // 32-point blocks per wave
   static constexpr int NT = (NPH == 1 && W == 4) ? 4 : 2;  // 32-column blocks per wave
   static constexpr bool CARRY = W == 4;                    // next step's first A fragments fetched before the barrier
   static constexpr bool DOUBLE_B = W == 4;                 // B fragments of both k steps in registers at once (W = 8: the
                                                            // second set costs the 16 registers that tip the loop into scratch)
-  static constexpr int HW = NPH == 4 ? 18 : (NPH == 1 ? 19 : 17);   // halo width = height (patch_plan takes only these)
-  static constexpr int HP = NPH == 1 ? 20 : 18;            // halo row pitch in LDS, EVEN: address bit 7 (the half of the
+  static constexpr int HW = NPH == 4 ? 18 : (S1 ? 19 : 17);   // halo width = height (patch_plan takes only these)
+  static constexpr int HP = S1 ? 20 : 18;                  // halo row pitch in LDS, EVEN: address bit 7 (the half of the
                                                            // 256-byte bank row) must follow the column's parity
   static constexpr int HALO_BLOCKS = (HW * HP + 7) / 8;    // 8-pixel DMA blocks: 41 | 48 | 39
-  static constexpr int HPS = NPH == 1 ? 1 : (W == 4 ? 3 : 2);   // halo DMA slots per wave and step
+  static constexpr int HPS = S1 ? 1 : (W == 4 ? 3 : 2);   // halo DMA slots per wave and step
   static constexpr int BPW = BROWS / 8 / W;                // B DMA blocks (8 rows) per wave and step
   // where in a step the DMAs of the next one are issued: 1 after the step's fragment reads, 2 after its first MFMA group
   // (measured with a run-time switch: +4-5 % on the four-phase kernel, neutral on the 4x4 one; at the top of the step, 0,
   // the DMA's LDS writes collide with the fragment reads that follow the barrier)
-  static constexpr int DMA_POS = NPH == 1 ? 1 : 2;
+  static constexpr int DMA_POS = S1 ? 1 : 2;
   static constexpr int HALO_BYTES = HALO_BLOCKS * 1024;
   static constexpr int B_STAGE = BROWS * 128;
   static constexpr int OFF_B = 2 * HALO_BYTES;
@@ -121,9 +124,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   //   NPH = 4: (half wave / 4, phase = wave % 4), 64 columns;  NPH = 1, 2: (half wave / 4, column quarter wave % 4);
   //   NPH = 3: (quarter wave / 2, column half wave % 2)
   constexpr bool S2 = C::S2;
-  const int wm = NPH == 3 ? wave >> 1 : (W == 8 ? wave >> 2 : (NPH == 4 ? 0 : wave >> 1));
+  const int wm = C::N128 ? wave >> 1 : (W == 8 ? wave >> 2 : (NPH == 4 ? 0 : wave >> 1));
   const int phase = NPH == 4 ? (wave & 3) : 0;
-  const int ncol0 = NPH == 4 ? 0 : (NPH == 3 ? (wave & 1) * 64 : (W == 8 ? (wave & 3) * 64 : (wave & 1) * 128));
+  const int ncol0 = NPH == 4 ? 0 : (C::N128 ? (wave & 1) * 64 : (W == 8 ? (wave & 3) * 64 : (wave & 1) * 128));
   const int brow0 = NPH == 4 ? phase * 64 : ncol0;         // first B-stage row of the wave's columns
   const int b_phase = NPH == 4 ? wave * (256 / W) / 64 : 0;   // phase of the B rows this wave LOADS
   const int ppi = g.py * g.px;                       // patches per image
@@ -707,6 +710,9 @@ int patch_plan(const GatherGemmParams& p, PatchGeom* g) {
     nph = 4;
   else if (p.sy == 1 && p.sx == 1 && p.nphase == 1 && p.ntaps == 16 && p.osy == 1 && p.osx == 1 && p.n_total % 256 == 0)
     nph = 1;
+  else if (t.h3_patch_s1n128 && p.sy == 1 && p.sx == 1 && p.nphase == 1 && p.ntaps == 16 && p.osy == 1 && p.osx == 1 &&
+           p.n_total % 128 == 0)
+    nph = 5;        // (r4) 128 columns: AdVoc-small's layer_4 backward-data ran the per-tap 128 x 128 tile at 290 TFLOP/s
   else if (t.h3_patch_s2 && p.sy == 2 && p.sx == 2 && p.nphase == 1 && p.ntaps == 16 && p.osy == 1 && p.osx == 1 &&
            p.n_total % 128 == 0)
     nph = p.n_total % 256 == 0 ? 2 : 3;
@@ -758,7 +764,7 @@ int patch_plan(const GatherGemmParams& p, PatchGeom* g) {
   g->ablate = t.h3_patch_ablate;
   // rows the patches add beyond the grid are computed and thrown away
   if ((int64_t)g->py * g->px * 256 * 100 > (int64_t)p.gh * gw_cov * 125) return 0;
-  const int bn = nph == 4 ? 64 : (nph == 3 ? 128 : 256);
+  const int bn = nph == 4 ? 64 : ((nph == 3 || nph == 5) ? 128 : 256);
   const int64_t wgs = (int64_t)p.batch * g->py * g->px * ((p.n_total + bn - 1) / bn);
   if (wgs < t.h3_patch_min_wgs) return 0;
   return nph;
@@ -771,6 +777,7 @@ int launch_patch_gemm_h3(const GatherGemmParams& p, const PatchGeom& g, int nph,
   if (nph == 4) return bwd ? launch_patch<4, 1>(p, g, stream, name_only) : launch_patch<4, 0>(p, g, stream, name_only);
   if (nph == 2) return bwd ? launch_patch<2, 1>(p, g, stream, name_only) : launch_patch<2, 0>(p, g, stream, name_only);
   if (nph == 3) return bwd ? launch_patch<3, 1>(p, g, stream, name_only) : launch_patch<3, 0>(p, g, stream, name_only);
+  if (nph == 5) return bwd ? launch_patch<5, 1>(p, g, stream, name_only) : launch_patch<5, 0>(p, g, stream, name_only);
   return bwd ? launch_patch<1, 1>(p, g, stream, name_only) : launch_patch<1, 0>(p, g, stream, name_only);
 }
 

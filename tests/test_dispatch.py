@@ -94,7 +94,7 @@ SMALL = [
     ('decoder_2', layer(1, BS, 64, 129, 64, 64, 32, (2, 2), trim=1), P4F, 'patch_gemm_h3_kernel<3, 1>', W128),
     ('layer_2', layer(0, 2 * BS, 128, 256, 32, 0, 64, (2, 2)), PT, P4B, W128),
     ('layer_3', layer(0, 2 * BS, 64, 128, 64, 0, 128, (2, 2)), P3F, P4B, W128),
-    ('layer_4', layer(0, 2 * BS, 32, 64, 128, 0, 256, (1, 1)), P1F, None, W256),
+    ('layer_4', layer(0, 2 * BS, 32, 64, 128, 0, 256, (1, 1)), P1F, 'patch_gemm_h3_kernel<5, 1>', W256),
 ]
 
 

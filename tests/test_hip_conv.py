@@ -306,6 +306,12 @@ PATCH = [
     (('p3_n32_dec_drop', 1, (2, 16, 33), 64, 64, 32, 1, (2, 2), (1, 1), 2, True, 0), {0: 'patch_gemm_h3_kernel<4, 0>'}),
     (('p3_n32_enc_bwd', 0, (2, 62, 60), 32, 0, 64, 0, (2, 2), None, 1, False, 0), {1: 'patch_gemm_h3_kernel<4, 1>'}),
     (('p3_n32_d2_bwd', 0, (3, 64, 66), 32, 0, 64, 0, (2, 2), (1, 1), 1, True, 0), {1: 'patch_gemm_h3_kernel<4, 1>'}),
+    # (r4) the 4x4 stride-1 gather with 128 columns per workgroup (<5, .>): AdVoc-small's layer_4 backward-data (256 -> 128
+    # channels) and a 128-channel forward; ragged grids, dropout, a 16 n + 3 wide grid with its remainder columns
+    (('p3_d4_small',  0, (2, 32, 31), 128, 0, 256, 0, (1, 1), (1, 1), 1, False, 0),
+     {0: 'patch_gemm_h3_kernel<1, 0>', 1: 'patch_gemm_h3_kernel<5, 1>'}),
+    (('p3_d4_n128',   0, (1, 29, 33), 64, 0, 128, 0, (1, 1), (1, 1), 1, True, 0), {0: 'patch_gemm_h3_kernel<5, 0>'}),
+    (('p3_rem_d4_n384', 0, (1, 33, 36), 128, 0, 384, 0, (1, 1), (1, 1), 1, False, 0), {0: 'patch_gemm_h3_kernel<5, 0>'}),
 ]
 
 
