@@ -145,7 +145,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 
   const float gslope = act_slope_p(p.grad_act);
   const int src_c0 = p.c0, src_c1 = p.c1, src_p0 = p.a0_pitch, src_p1 = p.a1_pitch;
-  const int abl = g.ablate;       // timing experiments only (ADVOC_H3_PATCH_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier, 8 no halo DMA, 16 no B DMA
+  const int abl = g.ablate;       // timing experiments only (ADVOC_H3_PATCH_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier, 8 no halo DMA, 16 no B DMA, 64 no epilogue, 128 epilogue stores dropped
 
   // ---- persistent workgroups: the launch holds one workgroup per CU; XCD x walks its own contiguous range of tiles
   // (column tile slowest, so the workgroups an XCD runs together stream the same weights), and the stores of one
@@ -500,6 +500,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 #undef ADVOC_P3_RENDEZVOUS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (abl & 64) continue;         // (timing experiments only: the K loop without its epilogue)
 
   // ---- epilogue (igemm_h3.hip's, per wave): pixel table of the wave's points for its phase, LDS transpose,
   // 16-byte stores with the fused bias / dropout / activation-gradient / two-destination logic ----
@@ -626,7 +627,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
           v[ps].x += __uint_as_float(old[ps].x); v[ps].y += __uint_as_float(old[ps].y);
           v[ps].z += __uint_as_float(old[ps].z); v[ps].w += __uint_as_float(old[ps].w);
         }
-        so[ps] = off[ps] == kOob ? kOob : off[ps] * 4u;
+        so[ps] = (off[ps] == kOob || (abl & 128)) ? kOob : off[ps] * 4u;       // (128: timing only, every store dropped by the range check)
       }
       if (i + 1 < MT) { ADVOC_P3_PRELOAD(i + 1); }
 #pragma unroll
