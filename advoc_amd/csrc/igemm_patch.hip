@@ -33,6 +33,7 @@
 #include "igemm.h"
 #include "tuning.h"
 #include "image_emit.h"
+#include "lds_dma.h"
 
 namespace advoc {
 namespace {
@@ -97,9 +98,33 @@ struct PCfg {
 #endif
   static constexpr int LDS_BYTES = OFF_B + NBUF * B_STAGE;  // 146 | 160 | 142 | 142 KiB
   static constexpr int PTS_W = 32 * MT;                    // grid points per wave
-  static constexpr int EPI_BYTES = WAVES * (32 * 36 * 4 + 2 * PTS_W * 4);
+  // (r5) the epilogue's scratch -- per wave a 32 x 36-word transpose tile and the pixel table of its points -- in the LDS the
+  // NEXT tile's prologue does not write (halo buffer 0, weight stage 0 and, with four stages, 1): the tiles in halo buffer
+  // 1, the tables in weight stage 1 (2)
+#ifdef ADVOC_P3_LATE_PROLOGUE   // (A/B builds only: the r4 order, every tile's prologue behind the previous tile's epilogue)
+  static constexpr bool EARLY_PROLOGUE = false;
+#else
+  static constexpr bool EARLY_PROLOGUE = true;
+#endif
+  // (r5) With the run-time ablation switches gone from the product build the K loop is one basic block per step, and the
+  // scheduler moves fragment reads, DMA issue and MFMAs across what used to be block boundaries: <1,.> -5 %, <3,0> -8 %, but
+  // <4,.> / <2,.> +1...4 % (same box, alternating: profiles/r05_a_*) -- their hand-placed DMA issue point (DMA_POS = 2:
+  // behind the first MFMA group) is what the boundaries had been protecting.  PIN puts a scheduling fence where those
+  // boundaries were (around every MFMA group and DMA slot) for the instances that lost.
+#ifdef ADVOC_P3_PIN_ALL
+  static constexpr bool PIN = true;
+#elif defined(ADVOC_P3_PIN_NONE)
+  static constexpr bool PIN = false;
+#else
+  static constexpr bool PIN = NPH == 4 || NPH == 2;
+#endif
+  static constexpr int EPI_T_BYTES = WAVES * 32 * 36 * 4, EPI_PIX_BYTES = WAVES * 2 * PTS_W * 4;
+  static constexpr int EPI_T_OFF = HALO_BYTES;
+  static constexpr int EPI_PIX_OFF = OFF_B + (NBUF == 4 ? 2 : 1) * B_STAGE;
   static_assert(WAVES * NST * HPS >= HALO_BLOCKS, "every halo block has a DMA slot");
-  static_assert(LDS_BYTES <= 160 * 1024 && EPI_BYTES <= LDS_BYTES, "LDS budget");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(EPI_T_BYTES <= HALO_BYTES && EPI_PIX_BYTES <= B_STAGE && EPI_PIX_OFF + EPI_PIX_BYTES <= LDS_BYTES,
+                "the epilogue's scratch fits the buffers the next tile's prologue leaves alone");
 };
 
 // BWD = 0: forward epilogue (bias, dropout mask on the result, one destination); BWD = 1: backward-data epilogue
@@ -143,9 +168,40 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(p.wq), 0, p.wq_taps * p.n_total * ktot * 4, 0x00020000);
 
+  // (r5) the same three descriptors for the inline-assembly DMA of lds_dma.h: the next tile's prologue is issued in front of
+  // the epilogue, and behind a DMA the compiler knows about it waits for vmcnt(0) before the epilogue's first LDS access
+  // (ISA checked) -- the round trip the early issue is there to hide.  Untracked, those DMAs are simply the oldest entries
+  // of the memory queue: every counted wait of the epilogue covers them.
+  const u32x4s ra_a0 = dma_rsrc(p.a0_img, (unsigned)p.a0_img_bytes);
+  const u32x4s ra_a1 = dma_rsrc(p.a1_img ? p.a1_img : p.a0_img, (unsigned)p.a1_img_bytes);
+  const u32x4s ra_b = dma_rsrc(p.wq, (unsigned)(p.wq_taps * p.n_total * ktot * 4));
+  constexpr bool kAsmDma = false;       // shadowed by `true` where the next tile's prologue is issued
+  // Launch constants of the epilogue, read ONCE per workgroup (r5; per tile before): a load whose value the epilogue uses
+  // waits for everything older in the wave's memory queue, i.e. for the next tile's prologue DMAs issued in front of it.
+  auto sgpr_f = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+  const float unscale = sgpr_f(__uint_as_float(p.a_hdr[1]) * __uint_as_float(p.b_hdr[1]));   // exact: powers of two
+  // forward: consumers' operand images of the output (image_emit.h), one-pass scale from the consumer header
+  constexpr bool emit0 = !BWD && NE >= 1, emit1 = !BWD && NE >= 2;
+  const float eup0 = emit0 ? sgpr_f(emit_up_scale(p.oimg[0].hdr[2])) : 1.f;
+  const float eup1 = emit1 ? sgpr_f(emit_up_scale(p.oimg[1].hdr[2])) : 1.f;
+  if (!BWD && threadIdx.x == 0) {
+    if (emit0) p.oimg[0].hdr[1] = __float_as_uint(1.f / eup0);
+    if (emit1) p.oimg[1].hdr[1] = __float_as_uint(1.f / eup1);
+  }
+  // largest |activation x scale| this wave has emitted, over ALL its tiles: emit_finish (cross-lane reduction, a header load
+  // whose wait drains every store of the epilogue, two atomics) runs once per launch instead of once per tile
+  float evmax0 = 0.f, evmax1 = 0.f;
+
   const float gslope = act_slope_p(p.grad_act);
   const int src_c0 = p.c0, src_c1 = p.c1, src_p0 = p.a0_pitch, src_p1 = p.a1_pitch;
+#ifdef ADVOC_DIAG
   const int abl = g.ablate;       // timing experiments only (ADVOC_H3_PATCH_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier, 8 no halo DMA, 16 no B DMA, 64 no epilogue, 128 epilogue stores dropped
+#else
+  // (r5) a compile-time zero in the product library: as a run-time value every `if (abl & ...)` was a branch in the K loop --
+  // one in front of each rendezvous, MFMA group and DMA slot -- i.e. a basic-block boundary the scheduler does not move
+  // fragment reads, DMA issue or MFMAs across
+  constexpr int abl = 0;
+#endif
 
   // ---- persistent workgroups: the launch holds one workgroup per CU; XCD x walks its own contiguous range of tiles
   // (column tile slowest, so the workgroups an XCD runs together stream the same weights), and the stores of one
@@ -209,6 +265,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // halo buffer HB.  Slots beyond the halo issue nothing (every wait in the K loop is vmcnt(0): no counting to keep).
 #define ADVOC_P3_HALO(SL, T, HB)                                                                          \
   {                                                                                                       \
+    if (C::PIN) __builtin_amdgcn_sched_barrier(0);                                                        \
     const int k0_ = (S2 ? (SL) >> 2 : (SL)) * 32;                                                         \
     const int ppy_ = ((SL) >> 1) & 1, ppx_ = (SL) & 1;        /* S2: parity plane of the slice */           \
     const bool second_ = k0_ >= p.c0;                                                                     \
@@ -230,22 +287,28 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
                             : (int)0x80000000;                                                            \
       unsigned char* d_ = smem_b + (HB) * C::HALO_BYTES + blk_ * 1024;                                    \
       if (blk_ >= C::HALO_BLOCKS || (abl & 9)) continue;                                                  \
-      if (second_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_void_p)(d_), 16, voff_, 0, 0, 0); \
+      if (kAsmDma) dma16(second_ ? ra_a1 : ra_a0, lds_address(d_), voff_, 0);                             \
+      else if (second_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_void_p)(d_), 16, voff_, 0, 0, 0); \
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (lds_void_p)(d_), 16, voff_, 0, 0, 0);         \
     }                                                                                                     \
+    if (C::PIN) __builtin_amdgcn_sched_barrier(0);                                                        \
   }
 
   // The B tile of (slice SL, tap step T) into stage ST
 #define ADVOC_P3_B(SL, T, ST)                                                                             \
   {                                                                                                       \
+    if (C::PIN) __builtin_amdgcn_sched_barrier(0);                                                        \
     const int wtap_ = __builtin_amdgcn_readlane(tapv_b, S2 ? ((SL) & 3) * 4 + (T) : (T)) >> 16;           \
     const int wslab_ = (wtap_ * p.n_total * ktot + (S2 ? (SL) >> 2 : (SL)) * 32) * 4;                     \
     _Pragma("unroll") for (int k = 0; k < C::BPW; ++k) {                                                  \
       unsigned char* d_ = smem_b + C::OFF_B + (ST) * C::B_STAGE + (wave * C::BPW + k) * 1024;             \
-      if (!(abl & 17) && (!HALF || b_cols))                                                               \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_p)(d_), 16, b_cols ? b_off[k & 1] : (int)0x80000000, \
-                                                 wslab_ + k * 8 * ktot * 4, 0, 0);                        \
+      if (!(abl & 17) && (!HALF || b_cols)) {                                                             \
+        if (kAsmDma) dma16(ra_b, lds_address(d_), b_cols ? b_off[k & 1] : (int)0x80000000, wslab_ + k * 8 * ktot * 4); \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_p)(d_), 16, b_cols ? b_off[k & 1] : (int)0x80000000, \
+                                                      wslab_ + k * 8 * ktot * 4, 0, 0);                   \
+      }                                                                                                   \
     }                                                                                                     \
+    if (C::PIN) __builtin_amdgcn_sched_barrier(0);                                                        \
   }
 
   // A fragments of tap step T, k step KS, from halo buffer HB into REG[MT][2]
@@ -271,6 +334,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // three fp16 products per 32x32x16 block, small terms first (a0 b1, a1 b0, a0 b0); product-major so that consecutive
   // MFMAs write different accumulators
 #define ADVOC_P3_MFMA(AR, BR)                                                                             \
+  if (C::PIN) __builtin_amdgcn_sched_barrier(0);                                                          \
   if (abl & 2) {                                                                                          \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(AR[i][0]), "v"(AR[i][1]));       \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(BR[j][0]), "v"(BR[j][1]));       \
@@ -284,7 +348,8 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                        \
       _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                      \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AR[i][0], BR[j][0], acc[i][j], 0, 0, 0);       \
-  }
+  }                                                                                                       \
+  if (C::PIN) __builtin_amdgcn_sched_barrier(0);
 
   floatx16 acc[MT][NT];
 #pragma unroll
@@ -307,11 +372,15 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     else asm volatile(ADVOC_P3_WAIT "\n\ts_barrier" ::: "memory");                                        \
   }
 
-  // ---- prologue: the whole halo of slice 0, the B tile of step 0 ----
+  // ---- prologue: the whole halo of slice 0, the B tile of step 0.  (r5) Only a workgroup's FIRST tile issues it here: the
+  // prologue of every later tile goes out behind the previous tile's K loop, in front of its epilogue (below), so that the
+  // DMAs' round trip runs under the epilogue instead of in front of an idle matrix pipe ----
+  if (!C::EARLY_PROLOGUE || tile == t_lo + slot) {
 #pragma unroll
-  for (int t = 0; t < NST; ++t) ADVOC_P3_HALO(0, t, 0);
-  ADVOC_P3_B(0, 0, 0);
-  if (C::NBUF == 4) ADVOC_P3_B(0, 1, 1);
+    for (int t = 0; t < NST; ++t) ADVOC_P3_HALO(0, t, 0);
+    ADVOC_P3_B(0, 0, 0);
+    if (C::NBUF == 4) ADVOC_P3_B(0, 1, 1);
+  }
 
   // ---- K loop: one barrier per step.  Wait for the own DMAs of this step's B tile (and, at a slice boundary, of the
   // halo), barrier (everyone's data landed, everyone finished the step before), issue the next step's B tile into the
@@ -492,14 +561,56 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       }
     }
   }
-#undef ADVOC_P3_HALO
-#undef ADVOC_P3_B
 #undef ADVOC_P3_LOAD_A
 #undef ADVOC_P3_LOAD_B
 #undef ADVOC_P3_MFMA
 #undef ADVOC_P3_RENDEZVOUS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // the bias of the wave's column blocks, loaded in front of the next tile's prologue (see `unscale` above)
+  float4 bias4v[NT];
+  {
+    int lb = lane;
+    asm volatile("" : "+v"(lb));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bias4v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int nb = n0 + ncol0 + j * 32 + 4 * (lb & 7);
+      if (!BWD && p.bias && nb < p.n_total) bias4v[j] = *reinterpret_cast<const float4*>(p.bias + nb);
+    }
+  }
+  // ---- (r5) the NEXT tile's prologue, issued before this tile's epilogue: halo buffer 0 and weight stage 0 (1) are dead from
+  // here on -- every fragment read of the tile has returned behind the barrier above -- and the epilogue's scratch lives in
+  // halo buffer 1 and the weight stage the prologue does not fill (EPI_T_OFF / EPI_PIX_OFF).  The DMAs are the oldest
+  // entries of the wave's memory queue: every counted wait of the epilogue covers them, the K loop's first rendezvous
+  // (vmcnt 0) finds them landed.
+  if (C::EARLY_PROLOGUE) {
+    const int tile_n = tile + per_xcd;
+    if (tile_n < t_hi) {
+      const int nt = tile_n / npatch;
+      const int pid = tile_n - nt * npatch;
+      const int img = pid / ppi;
+      const int pin = pid - img * ppi;
+      const int gy0 = (pin / g.px) * 16, gx0 = (pin % g.px) * 16;
+      const int n0 = nt * BN;
+      int b_off[2];
+      const bool b_cols = NPH != 4 || n0 + ((wave * (C::BROWS / W)) & 63) < p.n_total;
+      {
+        const int q = wave * (C::BROWS / W) + lrow;
+        const int col = NPH == 4 ? (q & 63) : q;
+        const int rowb = ((n0 + col) * ktot) * 4;
+        b_off[0] = rowb + ((lpos ^ (lrow >> 1)) * 16);
+        b_off[1] = rowb + ((lpos ^ (lrow >> 1) ^ 4) * 16);
+      }
+      constexpr bool kAsmDma = true;
+#pragma unroll
+      for (int t = 0; t < NST; ++t) ADVOC_P3_HALO(0, t, 0);
+      ADVOC_P3_B(0, 0, 0);
+      if (C::NBUF == 4) ADVOC_P3_B(0, 1, 1);
+    }
+  }
+#undef ADVOC_P3_HALO
+#undef ADVOC_P3_B
   if (abl & 64) continue;         // (timing experiments only: the K loop without its epilogue)
 
   // ---- epilogue (igemm_h3.hip's, per wave): pixel table of the wave's points for its phase, LDS transpose,
@@ -508,7 +619,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   asm volatile("" : "+v"(le));
   const int half_e = le >> 5, l32_e = le & 31;
   constexpr int PW_ = C::PTS_W;
-  int* s_pix = reinterpret_cast<int*>(smem + C::WAVES * 32 * 36) + wave * 2 * PW_;
+  int* s_pix = reinterpret_cast<int*>(smem_b + C::EPI_PIX_OFF) + wave * 2 * PW_;
   for (int r = le; r < PW_; r += 64) {
     const int pt = wm * PW_ + r;
     const int gy = gy0 + (pt >> 4), gx = gx0 + (pt & 15);
@@ -525,19 +636,10 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   }
   wave_lds_sync();
 
-  const float unscale = __uint_as_float(p.a_hdr[1]) * __uint_as_float(p.b_hdr[1]);   // exact: powers of two
   constexpr int LDT = 36;
-  float* T = smem + wave * (32 * LDT);
+  float* T = reinterpret_cast<float*>(smem_b + C::EPI_T_OFF) + wave * (32 * LDT);
   const int trow = le >> 3, tq = le & 7;
   const bool use_grad = BWD && p.grad_act != ADVOC_ACT_NONE && !(abl & 32);     // (DIAG builds, timing only: 32 = no pre-activation loads)
-  // forward: consumers' operand images of the output (image_emit.h), one-pass scale from the consumer header
-  constexpr bool emit0 = !BWD && NE >= 1, emit1 = !BWD && NE >= 2;
-  const float eup0 = emit0 ? emit_up_scale(p.oimg[0].hdr[2]) : 1.f, eup1 = emit1 ? emit_up_scale(p.oimg[1].hdr[2]) : 1.f;
-  float evmax0 = 0.f, evmax1 = 0.f;
-  if (!BWD && tid == 0) {
-    if (emit0) p.oimg[0].hdr[1] = __float_as_uint(1.f / eup0);
-    if (emit1) p.oimg[1].hdr[1] = __float_as_uint(1.f / eup1);
-  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     // destination of this column block (channels [0, n_split) -> d[0], the rest -> d[1]) and its per-channel vectors
@@ -551,8 +653,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     const int d_c = di ? p.d[1].c : p.d[0].c;
     const bool d_accum = (di ? p.d[1].accum : p.d[0].accum) != 0;
     const int ch = (di ? nt0 - p.n_split : nt0) + 4 * tq;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!BWD && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + nt0 + 4 * tq);
+    const float4 bias4 = bias4v[j];
     float4 gs4 = make_float4(1.f, 1.f, 1.f, 1.f), gh4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* const gsc = di ? p.d[1].gscale : p.d[0].gscale;
     const float* const gsh = di ? p.d[1].gshift : p.d[0].gshift;
@@ -649,10 +750,10 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     }
 #undef ADVOC_P3_PRELOAD
   }
-  if (emit0) emit_finish(p.oimg[0], eup0, evmax0);
-  if (emit1) emit_finish(p.oimg[1], eup1, evmax1);
   __syncthreads();          // the next tile's DMAs overwrite the LDS this epilogue read
   }  // tiles
+  if (emit0) emit_finish(p.oimg[0], eup0, evmax0);
+  if (emit1) emit_finish(p.oimg[1], eup1, evmax1);
 }
 
 template <int NPH, int BWD, int NE, int HALF = 0>
