@@ -35,7 +35,8 @@ class ImageOut(ctypes.Structure):
 
 class DxImage(ctypes.Structure):
   """advoc_conv_layer.dx_img (include/advoc_hip.h)."""
-  _fields_ = [('img', _p), ('hdr', _p), ('colsum', _p), ('table', _p)]
+  _fields_ = [('img', _p), ('hdr', _p), ('colsum', _p), ('table', _p), ('mode', _i32), ('reserved', _i32),
+              ('bound_add', _p)]
 
 
 class ConvLayer(ctypes.Structure):

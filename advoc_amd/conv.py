@@ -96,6 +96,12 @@ class Layer(object):
   # that has it (discriminator layer_5 -> layer_4, the largest image pass of the step) the passes lose 0.31 ms per step and
   # the producer, an issue-bound kernel, gains 0.18 ms; the step does not move (profiles/r04_i_*)
   emit_dx = os.environ.get('ADVOC_EMIT_DX', '0') == '1'
+  # (r5) ADVOC_DX_BOUNDED=0 turns it off: where the backward-data call of a layer runs on a patch kernel and the layer below
+  # reads its output gradient only as an operand image, that image is written by this call's epilogue under a scale derived
+  # from an a-priori bound of |dx| (max|dy| max|w| taps K: nothing can leave the fp16 range, so no history, no refit, no fp32
+  # tensor to refit from) and the fp32 dx0 is NOT written: the image pass of the layer below (a read and a write of the
+  # tensor) disappears at no extra store in the epilogue.  Needs reuse_images (the train step's guarantees).
+  dx_bounded = os.environ.get('ADVOC_DX_BOUNDED', '1') == '1'
 
   @staticmethod
   def _workspace_for(device, nbytes):
@@ -376,21 +382,32 @@ class Layer(object):
     return self.y
 
   def _dx_target(self, dx0, dx1, accum0, accum1, consumer, consumer_db):
-    """The layer below (`consumer`) whose output-gradient image this backward_data call can write, or None."""
-    if consumer is None or not Layer.emit_dx or dx0 is None or dx1 is not None or accum0 or accum1:
-      return None
+    """(the layer below (`consumer`) whose output-gradient image this backward_data call can write, kind) or (None, 0);
+    kind 2: the thin matrix kernel under the one-pass scale (fp32 dx0 written too), 3: a patch kernel under the a-priori
+    scale, image only."""
+    if consumer is None or dx0 is None or accum0 or accum1:
+      return None, 0
     cs = consumer.struct
-    if not (self.delayed_scale and consumer.delayed_scale and consumer._dy_built and cs.dy_img and cs.dy_hdr):
-      return None
+    if not (cs.dy_img and cs.dy_hdr):
+      return None, 0
     if cs.drop_mask or 'h3' not in consumer.kernel_name(1) or 'h3' not in consumer.kernel_name(2):
-      return None
+      return None, 0
+    if consumer_db is not None and not consumer._bias_fusable:
+      return None, 0
+    if self._emits_dx is None:
+      self._emits_dx = int(_lib.load().advoc_conv_emits_dx_image(ctypes.byref(self.struct)))
+    kind = self._emits_dx
+    if kind == 2:
+      if not (Layer.emit_dx and dx1 is None and self.delayed_scale and consumer.delayed_scale and consumer._dy_built):
+        return None, 0
+    elif kind == 3:
+      if not (Layer.dx_bounded and self.reuse_images and consumer.reuse_images):
+        return None, 0
+    else:
+      return None, 0
     if self.x0.data_ptr() != consumer.y.data_ptr() or tuple(dx0.shape) != tuple(consumer.y.shape):
       raise _lib.AdvocHipError('this layer\'s input is not the consumer layer\'s output')
-    if consumer_db is not None and not consumer._bias_fusable:
-      return None
-    if self._emits_dx is None:
-      self._emits_dx = bool(_lib.load().advoc_conv_emits_dx_image(ctypes.byref(self.struct)))
-    return consumer if self._emits_dx else None
+    return consumer, kind
 
   def backward_data(self, dy, dx0=None, dx1=None, accum0=False, accum1=False, db=None, db_accumulate=True,
                     grad_consumer=None, consumer_db=None, consumer_db_accumulate=True):
@@ -421,8 +438,9 @@ class Layer(object):
       if not db_accumulate:
         db.zero_()
       self.struct.db_fused = _lib.ptr(db)
-    target = self._dx_target(dx0, dx1, accum0, accum1, grad_consumer, consumer_db)
+    target, dx_kind = self._dx_target(dx0, dx1, accum0, accum1, grad_consumer, consumer_db)
     if target is not None:
+      self.struct.dx_img.mode = 3 if dx_kind == 3 else 0        # ADVOC_DX_BOUNDED | ADVOC_DX_IMAGE_ONLY
       if consumer_db is not None:
         _lib.require_device(consumer_db)
         if not consumer_db_accumulate:
@@ -435,7 +453,8 @@ class Layer(object):
       self.struct.dx_img.hdr = target.struct.dy_hdr
     try:
       if emitted is not None:
-        flags = 2 | 32                       # ADVOC_IMG_DY_CURRENT | ADVOC_IMG_DY_EMITTED: refit check instead of an image pass
+        # ADVOC_IMG_DY_CURRENT | ADVOC_IMG_DY_EMITTED (refit check instead of an image pass) or | ADVOC_IMG_DY_BOUNDED (final)
+        flags = 2 | (64 if emitted[2] else 32)
       else:
         flags = self._timed_image(1, dy)
       self.struct.img_flags = flags | self._delayed_bits()
@@ -450,8 +469,9 @@ class Layer(object):
       self.struct.dx_img.hdr = None
       self.struct.dx_img.colsum = None
       self.struct.dx_img.table = None
+      self.struct.dx_img.mode = 0
     if target is not None:
-      target._dy_emitted_for = (dx0.data_ptr(), consumer_db.data_ptr() if consumer_db is not None else None)
+      target._dy_emitted_for = (dx0.data_ptr(), consumer_db.data_ptr() if consumer_db is not None else None, dx_kind == 3)
     if fuse_db or db_by_producer:
       self._db_done_for = (dy.data_ptr(), db.data_ptr())
     if self.struct.dy_img and 'h3' in self.kernel_name(1):

@@ -435,19 +435,28 @@ extern "C" int64_t advoc_conv_workspace_bytes(const advoc_conv_layer* L, int32_t
 namespace {
 // does this backward-data call run on the kernel that can write advoc_conv_layer.dx_img (thin.hip: launch_thin_k_gemm with
 // one destination, gating only)?
-bool dx_image_launch(const advoc_conv_layer* L, const float* dy, float* dx0, float* dx1, int accum0, int accum1) {
-  if (!dx0 || dx1 || accum0 || accum1 || L->x1.p || !tuning().emit_dx) return false;
+// 0: no; 2: the thin matrix kernel's backward-data instance (one-pass scale, dx0 only); 3: a patch kernel under the a-priori
+// scale (ADVOC_DX_BOUNDED; dx1, when the layer has a second source, is an ordinary fp32 destination)
+int dx_image_launch(const advoc_conv_layer* L, const float* dy, float* dx0, float* dx1, int accum0, int accum1) {
+  if (!dx0 || accum0 || accum1 || !tuning().emit_dx) return 0;
   GatherGemmParams p;
   bool b_kn;
-  if (build_backward_data(L, dy, dx0, nullptr, 0, 0, p, b_kn) != ADVOC_OK) return false;
-  if (p.y_mask || p.d[0].gmask || p.d[0].accum || p.d[1].p || p.n_total % 64 || p.n_total > 1024 || !image_colsum_ok(p.n_total))
-    return false;
+  if (build_backward_data(L, dy, dx0, dx1, 0, 0, p, b_kn) != ADVOC_OK) return 0;
+  if (p.y_mask || p.d[0].gmask || p.d[0].accum || p.d[0].c % 64 || p.d[0].c > 1024 || !image_colsum_ok(p.d[0].c)) return 0;
+  p.a_img_out = L->dy_img; p.a_hdr_out = L->dy_img ? L->dy_hdr : nullptr;
+  p.w_amax = L->w_amax;
+  p.w_img = L->w_img[1]; p.w_img_hdr = L->w_img_hdr[1];
   p.oimg[0].img = reinterpret_cast<uint16_t*>(dx0);       // (any non-null value: asks the launcher what it would do)
+  p.oimg[0].hdr = reinterpret_cast<unsigned*>(dx0);
   int emits = 0;
   const char* nm = nullptr;
   p.emit_report = &emits;
-  if (run_gather(p, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes) != ADVOC_OK) return false;
-  return emits == 2;                                      // 2: the thin matrix kernel's backward-data instance
+  if (!dx1 && !L->x1.p && run_gather(p, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes) == ADVOC_OK && emits == 2)
+    return 2;
+  emits = 0;
+  p.oimg_bounded = 1;
+  if (run_gather(p, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes) != ADVOC_OK) return 0;
+  return emits == 3 ? 3 : 0;
 }
 }  // namespace
 
@@ -466,18 +475,27 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
   p.a_img_current = (L->img_flags & ADVOC_IMG_DY_CURRENT) != 0;
   p.a_img_delayed = (L->img_flags & ADVOC_IMG_DY_DELAYED) != 0;
   p.a_img_emitted = (L->img_flags & ADVOC_IMG_DY_EMITTED) != 0;
+  p.a_img_bounded = (L->img_flags & ADVOC_IMG_DY_BOUNDED) != 0;
   p.a_colsum = L->dy_img ? L->db_fused : nullptr;       // the bias gradient rides in the dy image pass (igemm_h3.hip)
   p.w_amax = L->w_amax;
   p.w_img = L->w_img[1]; p.w_img_hdr = L->w_img_hdr[1];
   if (L->dx_img.img) {
     // the lower layer's output-gradient image from this call's epilogue (advoc_conv_layer.dx_img)
     if (!L->dx_img.hdr || (L->dx_img.colsum && !L->dx_img.table)) return ADVOC_ERR_NULL;
-    if (!dx_image_launch(L, dy, dx0, dx1, accum0, accum1)) return ADVOC_ERR_UNSUPPORTED;
+    const int kind = dx_image_launch(L, dy, dx0, dx1, accum0, accum1);
+    const bool bounded = (L->dx_img.mode & ADVOC_DX_BOUNDED) != 0;
+    // (the thin kernel writes under the one-pass scale and always stores dx0; the patch kernels only under the bound)
+    if (kind == 0 || (kind == 2) == bounded || (kind == 2 && (L->dx_img.mode & ADVOC_DX_IMAGE_ONLY))) return ADVOC_ERR_UNSUPPORTED;
     p.oimg[0].img = L->dx_img.img;
     p.oimg[0].hdr = L->dx_img.hdr;
     p.oimg[0].slope = 1.f;
     p.ocolsum_out = L->dx_img.colsum;
     p.ocolsum_table = L->dx_img.table;
+    if (kind == 3) {
+      p.oimg_bounded = 1;
+      p.obound_add = L->dx_img.bound_add;
+      p.d0_no_store = (L->dx_img.mode & ADVOC_DX_IMAGE_ONLY) ? 1 : 0;
+    }
   }
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
@@ -485,7 +503,7 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
 extern "C" int advoc_conv_emits_dx_image(const advoc_conv_layer* L) {
   if (validate_layer(L) != ADVOC_OK) return 0;
   float dummy = 0.f;
-  return dx_image_launch(L, &dummy, &dummy, nullptr, 0, 0) ? 1 : 0;
+  return dx_image_launch(L, &dummy, &dummy, L->x1.p ? &dummy : nullptr, 0, 0);
 }
 
 extern "C" int64_t advoc_conv_wgrad_ws_bytes(const advoc_conv_layer* L) {

@@ -428,9 +428,14 @@ __global__ __launch_bounds__(256, 2) void fused_taps_kernel(const GatherGemmPara
           float* dst = d.p + ((int64_t)img * p.out_h + oy) * d.pitch + ox;       // one channel per destination
           float2 r = make_float2(v[2 * py][n] + bias, v[2 * py + 1][n] + bias);
           if (ox + 1 < p.out_w) {         // 4-byte aligned only (odd pitches): global dwordx2 accesses take that
-            typedef float2 __attribute__((aligned(4))) float2_a4;
-            if (d.accum) { const float2 o = *reinterpret_cast<const float2_a4*>(dst); r.x += o.x; r.y += o.y; }
-            *reinterpret_cast<float2_a4*>(dst) = r;
+            // (a plain two-float vector with 4-byte alignment: HIP's float2 class takes 8-byte aligned `this`, and
+            // -Walign-mismatch says so at every instantiation)
+            typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+            f32x2_a4* const d2 = reinterpret_cast<f32x2_a4*>(dst);
+            if (d.accum) { const f32x2_a4 o = *d2; r.x += o.x; r.y += o.y; }
+            f32x2_a4 rv;
+            rv.x = r.x; rv.y = r.y;
+            *d2 = rv;
           } else {
             dst[0] = d.accum ? r.x + dst[0] : r.x;
           }

@@ -95,6 +95,8 @@ struct GatherGemmParams {
   unsigned* a_hdr_out;
   int a_img_current;       // != 0: a_img_out / a_hdr_out already hold this operand's image (skip the image passes)
   int a_img_delayed;       // != 0: a_hdr_out holds the magnitude of a previous image of this operand: one-pass image
+  int a_img_bounded;       // != 0 (with a_img_current): written by the layer above under an a-priori scale (oimg_bounded
+                           // below): final -- no refit check, header word 0 = its largest magnitude
   int a_img_emitted;       // != 0 (with a_img_current): the image was written by the producers' epilogues under the delayed
                            // scale (image_emit.h): run the refit check (and the header rotation) before reading it
   // forward launches: up to two consumers' images of the OUTPUT d[0], written by the epilogue (image_emit.h); honoured by
@@ -106,6 +108,16 @@ struct GatherGemmParams {
   // the layer below when oimg[0] is that layer's output-gradient image
   float* ocolsum_out;
   float* ocolsum_table;
+  // (r5) backward-data launches of the PATCH kernels (igemm_patch.hip) under an A-PRIORI scale: oimg[0] is the output-gradient
+  // image of the layer below and its scale comes from a bound of |dx| known before the launch --
+  //     |dx| <= max|dy| * max|w| * (taps per output * K)  (+ obound_add: a bound of what is already in the destination)
+  // -- placed at [2^14, 2^15): no value can leave the fp16 range, so there is no history, no refit check and no need for
+  // the fp32 tensor to rebuild the image from; the largest magnitude actually written is raised in oimg[0].hdr[0] (zeroed
+  // by the launcher), 2^-s goes to hdr[1].  a_amax / b_hdr[0] = float bits of max |A operand| / max |w| on the device.
+  int oimg_bounded;
+  const unsigned* a_amax;
+  const unsigned* obound_add;
+  int d0_no_store;         // != 0: destination 0 exists as the image only, its fp32 tensor is not written
   float* a_colsum;         // != null: the image pass of source 0 adds its per-channel sums over the logical pixels here (the
                            // bias gradient, when A is an output gradient); only honoured where image_colsum_ok(c0)
   // ---- tail split (filled in by the launcher, see launch_cfg) ----

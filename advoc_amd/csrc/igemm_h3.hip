@@ -700,6 +700,15 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   const bool want_emit = p.oimg[0].img != nullptr || p.oimg[1].img != nullptr;
   if (want_emit) ksplit = 1;
   if (p.emit_report) *p.emit_report = 1;
+  // (r5) the output-gradient image of the layer below under the a-priori scale (GatherGemmParams::oimg_bounded): the patch
+  // kernels' lean backward-data instances, grids without remainder columns
+  if (p.oimg_bounded) {
+    const bool ok = patch_nph != 0 && geom.rem == 0 && p.oimg[0].img && p.oimg[0].hdr && !p.oimg[1].img && !p.y_mask &&
+                    !p.d[0].gmask && !p.d[1].gmask && !p.d[0].accum && !p.d[1].accum && p.grad_act != ADVOC_ACT_NONE &&
+                    (!p.ocolsum_out || (p.ocolsum_table && p.d[0].c <= 1024));
+    if (p.emit_report) *p.emit_report = ok ? 3 : 0;
+    if (!ok) return ADVOC_ERR_UNSUPPORTED;
+  }
   p.k_order = tuning().igemm_korder >= 0 ? tuning().igemm_korder : 1;
   char* ws = reinterpret_cast<char*>(scratch);
   unsigned* hdr_b = reinterpret_cast<unsigned*>(ws) + 2;
@@ -735,7 +744,7 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
       rc = launch_pair_weights(p.w, wq, taps, N, ktot, b_kn, hdr_b, stream, p.w_amax);
       if (rc != ADVOC_OK) return rc;
     }
-    if (p.a_img_out && p.a_img_current && p.a_img_emitted) {
+    if (p.a_img_out && p.a_img_current && p.a_img_emitted && !p.a_img_bounded) {
       // the producers' epilogues wrote this image under the one-pass scale: the refit check (exact re-image from the fp32
       // tensors when a value left the window) and the header rotation, as behind a one-pass image built here
       const ImageSource s0 = {p.a0, e0, p.c0, p.in_scale, p.in_shift, p.in_act, p.a_mask, p.a_mask_scale};
@@ -755,6 +764,19 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
       if (rc != ADVOC_OK) return rc;
     }
     if (tail.split > 1 && tail_ws) tail_cnt = tail_counter_slot();
+  }
+  // max |A operand| for the a-priori bound of a launch that writes the layer below's image: word 0 of a header the layer
+  // above wrote under its own bound or of a per-call header, word 2 ("largest magnitude of the image in the buffer") of a
+  // persistent header behind its rotation
+  p.a_amax = hdr_a + ((p.a_img_bounded || !p.a_hdr_out) ? 0 : 2);
+  if (patch_nph && p.oimg_bounded && !name_only) {
+    hipError_t e = hipMemsetAsync(p.oimg[0].hdr, 0, 4, stream);
+    if (e == hipSuccess && p.ocolsum_out)
+      e = hipMemsetAsync(p.ocolsum_table, 0, sizeof(float) * kColsumReplicas * (size_t)p.d[0].c, stream);
+    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    int rc = launch_patch_gemm_h3(p, geom, patch_nph, stream, nullptr);
+    if (rc == ADVOC_OK && p.ocolsum_out) rc = launch_colsum_reduce(p.ocolsum_table, p.ocolsum_out, p.d[0].c, stream);
+    return rc;
   }
   if (patch_nph) {
     if (geom.rem == 0) return launch_patch_gemm_h3(p, geom, patch_nph, stream, name_only);

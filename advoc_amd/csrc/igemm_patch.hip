@@ -34,6 +34,7 @@
 #include "tuning.h"
 #include "image_emit.h"
 #include "lds_dma.h"
+#include "x6.h"
 
 namespace advoc {
 namespace {
@@ -118,6 +119,11 @@ struct PCfg {
 #else
   static constexpr bool PIN = NPH == 4 || NPH == 2;
 #endif
+#ifdef ADVOC_P3_PIN_DMA_ONLY    // (A/B builds only)
+  static constexpr bool PIN_MFMA = false;
+#else
+  static constexpr bool PIN_MFMA = PIN;
+#endif
   static constexpr int EPI_T_BYTES = WAVES * 32 * 36 * 4, EPI_PIX_BYTES = WAVES * 2 * PTS_W * 4;
   static constexpr int EPI_T_OFF = HALO_BYTES;
   static constexpr int EPI_PIX_OFF = OFF_B + (NBUF == 4 ? 2 : 1) * B_STAGE;
@@ -180,11 +186,29 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // waits for everything older in the wave's memory queue, i.e. for the next tile's prologue DMAs issued in front of it.
   auto sgpr_f = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
   const float unscale = sgpr_f(__uint_as_float(p.a_hdr[1]) * __uint_as_float(p.b_hdr[1]));   // exact: powers of two
-  // forward: consumers' operand images of the output (image_emit.h), one-pass scale from the consumer header
-  constexpr bool emit0 = !BWD && NE >= 1, emit1 = !BWD && NE >= 2;
-  const float eup0 = emit0 ? sgpr_f(emit_up_scale(p.oimg[0].hdr[2])) : 1.f;
+  // forward: consumers' operand images of the output (image_emit.h), one-pass scale from the consumer header.
+  // (r5) backward-data, NE = 1: oimg[0] is the OUTPUT-GRADIENT image of the layer below (destination 0 seen as that layer's
+  // dy), under the a-priori scale of GatherGemmParams::oimg_bounded: |dx| <= max|dy| max|w| (taps per output x K) [+ what
+  // the destination already holds] -- known before the first MFMA, so nothing can leave the fp16 range, nothing is ever
+  // refitted, and the fp32 tensor need not exist (d0_no_store); the per-channel sums of the tensor -- the lower layer's
+  // bias gradient, which used to ride in its image pass -- are taken here too (ocolsum_table).
+  constexpr bool emit0 = NE >= 1, emit1 = !BWD && NE >= 2;
+  float eup0_ = 1.f;
+  if (emit0) {
+    if (BWD) {
+      float bound = __uint_as_float(*p.a_amax) * __uint_as_float(p.b_hdr[0]) * (float)(p.ntaps * ktot);
+      if (p.obound_add) bound += __uint_as_float(*p.obound_add);
+      eup0_ = emit_up_scale_bounded(bound);
+    } else {
+      eup0_ = emit_up_scale(p.oimg[0].hdr[2]);
+    }
+  }
+  const float eup0 = sgpr_f(eup0_);
   const float eup1 = emit1 ? sgpr_f(emit_up_scale(p.oimg[1].hdr[2])) : 1.f;
-  if (!BWD && threadIdx.x == 0) {
+  // (the BWD-emitting instances are LEAN: no dropout mask on the destination, no accumulation -- the launcher checks -- so
+  // that the epilogue's prefetched operands, the image arithmetic and the column sums fit the registers next to the tile)
+  constexpr bool kLean = BWD && NE >= 1;
+  if (emit0 && threadIdx.x == 0) {
     if (emit0) p.oimg[0].hdr[1] = __float_as_uint(1.f / eup0);
     if (emit1) p.oimg[1].hdr[1] = __float_as_uint(1.f / eup1);
   }
@@ -334,7 +358,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // three fp16 products per 32x32x16 block, small terms first (a0 b1, a1 b0, a0 b0); product-major so that consecutive
   // MFMAs write different accumulators
 #define ADVOC_P3_MFMA(AR, BR)                                                                             \
-  if (C::PIN) __builtin_amdgcn_sched_barrier(0);                                                          \
+  if (C::PIN_MFMA) __builtin_amdgcn_sched_barrier(0);                                                     \
   if (abl & 2) {                                                                                          \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(AR[i][0]), "v"(AR[i][1]));       \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(BR[j][0]), "v"(BR[j][1]));       \
@@ -349,7 +373,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                      \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AR[i][0], BR[j][0], acc[i][j], 0, 0, 0);       \
   }                                                                                                       \
-  if (C::PIN) __builtin_amdgcn_sched_barrier(0);
+  if (C::PIN_MFMA) __builtin_amdgcn_sched_barrier(0);
 
   floatx16 acc[MT][NT];
 #pragma unroll
@@ -439,6 +463,12 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     //     their phase.
     const bool late = wave >= W / 2;
     const int nsteps = nslices * NST;
+    // (A/B builds only, ADVOC_P3_SETPRIO: the wave that multiplies outranks the wave of its SIMD that reads / issues DMAs)
+#ifdef ADVOC_P3_SETPRIO
+#define ADVOC_P3_PRIO(X) __builtin_amdgcn_s_setprio(X)
+#else
+#define ADVOC_P3_PRIO(X)
+#endif
 #define ADVOC_P3_BAR(WAITS)                                                                               \
     {                                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                  \
@@ -476,20 +506,25 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
         if (!late) ADVOC_P3_FEED(n + u + 1);
         ADVOC_P3_BAR("s_waitcnt lgkmcnt(0)\n\t");
         // M1
+        ADVOC_P3_PRIO(1);
         ADVOC_P3_MFMA(a0, b0);
+        ADVOC_P3_PRIO(0);
         ADVOC_P3_BAR("");
         // R2
         ADVOC_P3_LOAD_B(b0, u, 1);
         if (late) ADVOC_P3_BAR("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t") else ADVOC_P3_BAR("s_waitcnt lgkmcnt(0)\n\t");
         // M2
         if (late) ADVOC_P3_FEED(n + u + 2);
+        ADVOC_P3_PRIO(1);
         ADVOC_P3_MFMA(a1, b0);
+        ADVOC_P3_PRIO(0);
         if (late) ADVOC_P3_BAR("") else ADVOC_P3_BAR("s_waitcnt vmcnt(0)\n\t");
       }
     }
     if (!late) ADVOC_P3_BAR("");
 #undef ADVOC_P3_FEED
 #undef ADVOC_P3_BAR
+#undef ADVOC_P3_PRIO
   } else
   for (int s = 0; s < nslices; ++s) {
     const int hb = s & 1;
@@ -672,7 +707,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     // loads leaves block i's four stores in flight (s_waitcnt vmcnt(4)) -- with `if (row valid) store` the compiler had
     // to wait for vmcnt(0), i.e. for the round trip of every block's stores.
     constexpr unsigned kOob = 0xffffff00u;              // >= num_records of every descriptor below
-    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(dp, 0, kOob, 0x00020000);
+    // (d0_no_store: destination 0 exists as the image only -- every fp32 store to it is dropped by the range check)
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
+        dp, 0, (BWD && emit0 && di == 0 && p.d0_no_store) ? 0u : kOob, 0x00020000);
     const bool has_mask = BWD ? d_gmask != nullptr : p.y_mask != nullptr;
     const uint8_t* const mask_p = BWD ? d_gmask : p.y_mask;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
@@ -688,6 +725,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     unsigned off[4];                                   // element offset of the row's 4 channels, kOob for rows without a pixel
     u32x4 xp[4], old[4];
     unsigned mk[4];
+    // per-channel sums of this column block over the tile's points (BWD emission: the lower layer's bias gradient): this
+    // lane's 4 channels, reduced over the 8 lanes that share them and added to one of kColsumReplicas copies per tile
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #define ADVOC_P3_PRELOAD(I)                                                                               \
     _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                    \
       const int pix = s_pix[di * PW_ + (I) * 32 + trow + 8 * ps];                                         \
@@ -695,9 +735,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       const unsigned ob = pix < 0 ? kOob : off[ps] * 4u;                                                  \
       if (BWD) {                                                                                          \
         xp[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ob, 0, 0);                                   \
-        old[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, ob, 0, 0);                                  \
+        if (!kLean) old[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, ob, 0, 0);                      \
       }                                                                                                   \
-      mk[ps] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, off[ps], 0, 0);                                 \
+      if (!kLean) mk[ps] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, off[ps], 0, 0);                     \
     }
     ADVOC_P3_PRELOAD(0);
 #pragma unroll
@@ -719,12 +759,12 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
           v[ps].x *= x.x > 0.f ? 1.f : gslope; v[ps].y *= x.y > 0.f ? 1.f : gslope;
           v[ps].z *= x.z > 0.f ? 1.f : gslope; v[ps].w *= x.w > 0.f ? 1.f : gslope;
         }
-        if (has_mask) {
+        if (!kLean && has_mask) {
           const float ms = BWD ? d_gmask_scale : p.y_mask_scale;
           v[ps].x *= (float)(mk[ps] & 0xffu) * ms; v[ps].y *= (float)((mk[ps] >> 8) & 0xffu) * ms;
           v[ps].z *= (float)((mk[ps] >> 16) & 0xffu) * ms; v[ps].w *= (float)(mk[ps] >> 24) * ms;
         }
-        if (BWD && d_accum) {
+        if (!kLean && BWD && d_accum) {
           v[ps].x += __uint_as_float(old[ps].x); v[ps].y += __uint_as_float(old[ps].y);
           v[ps].z += __uint_as_float(old[ps].z); v[ps].w += __uint_as_float(old[ps].w);
         }
@@ -738,17 +778,31 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
         sv.z = __float_as_uint(v[ps].z); sv.w = __float_as_uint(v[ps].w);
         __builtin_amdgcn_raw_buffer_store_b128(sv, rs_d, so[ps], 0, 0);
       }
-      if (!BWD) {            // (compile-time; unconditional buffer stores: see emit4_buffer)
+      if (emit0 || emit1) {  // (compile-time; unconditional buffer stores: see emit4_buffer)
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const bool ok = so[ps] != kOob && di == 0;
-          if (emit0) emit4_buffer(rs_e0, p.oimg[0].slope, eup0, v[ps], ok ? so[ps] : kOob, ok, evmax0);
+          if (emit0) emit4_buffer(rs_e0, BWD ? 1.f : p.oimg[0].slope, eup0, v[ps], ok ? so[ps] : kOob, ok, evmax0);
           if (emit1) emit4_buffer(rs_e1, p.oimg[1].slope, eup1, v[ps], ok ? so[ps] : kOob, ok, evmax1);
+          if (BWD && emit0 && ok) {
+            cs.x += v[ps].x; cs.y += v[ps].y; cs.z += v[ps].z; cs.w += v[ps].w;
+          }
         }
       }
       wave_lds_sync();
     }
 #undef ADVOC_P3_PRELOAD
+    if (BWD && emit0 && p.ocolsum_table) {
+#pragma unroll
+      for (int sh = 8; sh < 64; sh <<= 1) {
+        cs.x += __shfl_xor(cs.x, sh, 64); cs.y += __shfl_xor(cs.y, sh, 64);
+        cs.z += __shfl_xor(cs.z, sh, 64); cs.w += __shfl_xor(cs.w, sh, 64);
+      }
+      if (trow == 0 && di == 0) {
+        float* row = p.ocolsum_table + (size_t)(blockIdx.x & (kColsumReplicas - 1)) * d_c + ch;
+        unsafeAtomicAdd(row, cs.x); unsafeAtomicAdd(row + 1, cs.y); unsafeAtomicAdd(row + 2, cs.z); unsafeAtomicAdd(row + 3, cs.w);
+      }
+    }
   }
   __syncthreads();          // the next tile's DMAs overwrite the LDS this epilogue read
   }  // tiles
@@ -764,6 +818,7 @@ __global__ __launch_bounds__(512, 1) void patch_gemm_h3_kernel(const GatherGemmP
 template <int NPH, int BWD, int NE = 0>
 int launch_patch(const GatherGemmParams& p_in, const PatchGeom& g, hipStream_t stream, const char** name_only) {
   using C = PCfg<NPH, 8>;
+  if (BWD && NE == 0 && !name_only && p_in.oimg[0].img) return launch_patch<NPH, BWD, BWD ? 1 : 0>(p_in, g, stream, name_only);
   if (!BWD && NE == 0 && !name_only && (p_in.oimg[0].img || p_in.oimg[1].img)) {
     // forward launch with image consumers: the instance compiled for their number, consumers packed into oimg[0 .. n)
     GatherGemmParams q = p_in;

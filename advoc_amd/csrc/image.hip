@@ -373,7 +373,10 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   float up = 1.f;
   if (pairs) {
     up = up_scale(amax_src ? amax_src[0] : hdr[0]);       // amax_src: the largest |w| from advoc_segmented_amax_f32
-    if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = __float_as_uint(1.f / up);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      hdr[1] = __float_as_uint(1.f / up);
+      if (amax_src) hdr[0] = amax_src[0];     // (r5) word 0 of a weight header = max |w|: the a-priori bound of igemm_patch.hip reads it
+    }
   }
   for (int b = blockIdx.x; b < taps * tk * tn; b += gridDim.x) {
     const int t = b / (tk * tn), r = b - t * (tk * tn);
@@ -436,7 +439,10 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const float* __restr
   const int tk = ktot / 32, tn = (n_total + 31) / 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const float up = up_scale(amax[row[5]]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[1] = __float_as_uint(1.f / up);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hdr[1] = __float_as_uint(1.f / up);
+    hdr[0] = amax[row[5]];                    // (r5) max |w|, see split_weights_kernel
+  }
   for (int b = blockIdx.x; b < taps * tk * tn; b += gridDim.x) {
     const int t = b / (tk * tn), r = b - t * (tk * tn);
     const int k0 = (r / tn) * 32, n0 = (r % tn) * 32;

@@ -21,6 +21,17 @@ __device__ __forceinline__ float emit_up_scale(unsigned prev_bits) {
   return __uint_as_float((unsigned)(s + 127) << 23);
 }
 
+// (r5) power of two that puts an a-priori BOUND of the tensor's magnitude at [2^14, 2^15): nothing can leave the fp16 range
+// (the 1.0001 covers the rounding of the fp32 products the bound was computed with)
+__device__ __forceinline__ float emit_up_scale_bounded(float bound) {
+  const unsigned b = __float_as_uint(bound * 1.0001f);
+  const int e = (int)((b >> 23) & 0xffu);
+  if (e == 0 || e == 255) return 1.f;
+  int s = 14 - (e - 127);
+  s = s > 120 ? 120 : (s < -120 ? -120 : s);
+  return __uint_as_float((unsigned)(s + 127) << 23);
+}
+
 typedef float emit_f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 emit_h2 __attribute__((ext_vector_type(2)));
 

@@ -189,6 +189,11 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
 // The three products of one 32 x 32 block, then one DMA instruction of the NEXT tile: the 2 SL loads of a tile go out
 // one per block instead of as a burst behind the barrier (8 waves x 8 loads at once back up in the address path, and an
 // in-order wave cannot issue its MFMAs from behind a stalled load).
+#ifdef ADVOC_WH3_NO_SB          // (A/B builds only: no scheduling fence behind the interleaved DMA)
+#define WH3_DMA_FENCE
+#else
+#define WH3_DMA_FENCE __builtin_amdgcn_sched_barrier(0)
+#endif
 #define WH3_MFMAS \
       _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                     \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                 \
@@ -199,7 +204,7 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
           if (d_ < 2 * SL) {                                                                             \
             if (d_ & 1) dma16(rs_q, nst_ + (C::PB + wave) * BLK + (d_ >> 1) * 1024, qvn[d_ >> 1]);       \
             else dma16(rs_p, nst_ + wave * BLK + (d_ >> 1) * 1024, pvn[d_ >> 1]);                        \
-            __builtin_amdgcn_sched_barrier(0);                                                           \
+            WH3_DMA_FENCE;                                                                               \
           }                                                                                              \
         }
 #define ADVOC_WH3_COMPUTE(ST)                                                                            \

@@ -839,7 +839,9 @@ class Advoc(Model):
         if i > 0:
           # (layer_5 -> layer_4 without batch norm in between: layer_5's epilogue writes layer_4's output-gradient image and
           # its bias gradient -- the largest of the image passes, conv.Layer.backward_data)
-          below = layers[i - 1] if i == 4 and (i - 1) not in bns else None
+          # (r5: every link of the chain -- conv.Layer._dx_target takes the ones whose kernels can: layer_4 -> layer_3 and
+          # layer_3 -> layer_2 on the patch kernels under the a-priori scale, image only)
+          below = layers[i - 1] if (i - 1) not in bns else None
           layers[i].backward_data(g, st['g_d_act'][i - 1][lo:hi], db=DG[s + '/bias'], db_accumulate=acc,
                                   grad_consumer=below,
                                   consumer_db=DG['discriminator/layer_%d/conv2d/bias' % i] if below is not None else None,
@@ -937,7 +939,7 @@ class Advoc(Model):
         if i in bnf:   # through the discriminator's batch norm; its parameter gradients are not used here
           self._bn_backward(bnf[i], st['g_d_act'][i][B:], discard_param_grads=True)
         Lf[i].backward_data(st['g_d_act'][i][B:], st['g_d_act'][i - 1][B:],
-                            grad_consumer=Lf[i - 1] if i == 4 and (i - 1) not in bnf else None)
+                            grad_consumer=Lf[i - 1] if (i - 1) not in bnf else None)
       Lf[0].backward_data(st['g_d_act'][0][B:], None, g_out, accum1=True)
     # generator backward: decoder_1 .. decoder_N, then encoder_N .. encoder_1
     GL, GG = st['g_layers'], st['g_G']
@@ -1005,6 +1007,9 @@ class Advoc(Model):
       batch = self._feed()
     self.build(batch_size=batch[0].shape[0])
     self.d_step(batch)
+    # (data parallel: inside train_loop the D update is applied after the generator forward of the G step, under which its
+    # gradient sum runs; a caller of the op on its own gets the updated parameters back, whatever it reads next -- ADVICE r4)
+    self._flush_d_adam()
 
   def train_loop(self, sess=None):
     """D update on one batch, G update on the NEXT batch; returns the global step

@@ -31,6 +31,7 @@ class DataParallel(object):
     self.local_rank = 0
     self.enabled = False
     self.backend = None
+    self.reserve_source = 'none'   # who set ADVOC_RESERVE_CUS for the persistent launches: 'user' | 'dp' | 'none'
     self._pending = []
 
   def init_from_env(self, backend=None):
@@ -61,8 +62,13 @@ class DataParallel(object):
       # RCCL's kernels become co-resident DURING those launches instead of between them.  Only honoured here, i.e. when
       # there is more than one rank; unmeasured on hardware (no multi-GPU box was available to the builder): k = 8 costs
       # the persistent kernels 3 % of the chip
+      # (r5) an ADVOC_RESERVE_CUS the user set explicitly wins (it used to be overwritten); bench.py passes 8
+      # for N > 1 unless told otherwise.  Still experimental: no multi-GPU box has measured it.
       k = os.environ.get('ADVOC_DP_RESERVE_CUS')
-      if k is not None:
+      if 'ADVOC_RESERVE_CUS' in os.environ:
+        self.reserve_source = 'user'
+      elif k is not None:
+        self.reserve_source = 'dp'
         os.environ['ADVOC_RESERVE_CUS'] = str(max(0, int(k)))
         from advoc_amd import _lib
         if torch.cuda.is_available():

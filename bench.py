@@ -484,17 +484,37 @@ def loader_leg(torch, seconds=6.0, n_files=48, batch=64):
     shutil.rmtree(d, ignore_errors=True)
 
 
+def kernel_source_sha16():
+  """sha256[:16] of the HIP sources the library is built from (csrc/*.hip, *.h, include/*.h): what a counter pass was taken
+  ON.  (The GPU box has no .git: a commit id is not available where bench.py runs; the sources are.)"""
+  import glob
+  import hashlib
+  h = hashlib.sha256()
+  files = sorted(glob.glob(os.path.join(ROOT, 'advoc_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'advoc_amd', 'csrc', '*.h'))
+                 + glob.glob(os.path.join(ROOT, 'include', '*.h')))
+  for f in files:
+    h.update(os.path.basename(f).encode())
+    h.update(open(f, 'rb').read())
+  return h.hexdigest()[:16]
+
+
 def recorded_traffic(kernel, model, batch):
-  """L2-miss bytes per launch from the committed counter passes (tools/pmc_summary.py), if they
-  were taken on this workload."""
+  """(L2-miss bytes per launch, provenance) from the committed counter passes (tools/pmc_summary.py) -- None with the
+  reason when they were taken on another workload or on OTHER KERNEL SOURCES than the ones this run was built from (r5: the
+  file used to be trusted whatever its age)."""
+  rel = os.path.relpath(TRAFFIC_JSON, ROOT)
   if not os.path.exists(TRAFFIC_JSON):
-    return None
+    return None, rel + ': not found'
   rec = json.load(open(TRAFFIC_JSON))
   meta = rec.get('_workload', {})
+  how = ' (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of `%s`, committed; not re-measured by this run)' % meta.get('command', '?')
   if meta.get('model') != model or meta.get('batch') != batch:
-    return None
+    return None, rel + ': taken on another workload' + how
+  now, then = kernel_source_sha16(), meta.get('kernel_source_sha16')
+  if then != now:
+    return None, '%s: STALE -- taken on kernel sources %s, this build is %s; traffic withheld%s' % (rel, then, now, how)
   row = rec.get(kernel)
-  return row['traffic_bytes'] if row else None
+  return (row['traffic_bytes'] if row else None), '%s: kernel sources %s = this build%s' % (rel, then, how)
 
 
 def roofline_from(prof, model, batch, ms_per_step, prof_steps, verbose):
@@ -519,9 +539,9 @@ def roofline_from(prof, model, batch, ms_per_step, prof_steps, verbose):
     kernels.append(entry)
   name, r = max(rows.items(), key=lambda kv: kv[1]['ms'])
   top = kernels[0]
+  traffic, traffic_source = recorded_traffic(name, model, batch)
   roofline = dict(bound=top['bound'], kernel=name, achieved=top['achieved'], peak=top['peak'], unit=top['unit'],
-                  frac=top['frac'], traffic=recorded_traffic(name, model, batch),
-                  traffic_source=os.path.relpath(TRAFFIC_JSON, ROOT) + ' (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of `bench.py --steps 3`, committed; not re-measured by this run)',
+                  frac=top['frac'], traffic=traffic, traffic_source=traffic_source,
                   algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
                   launches=r['launches'], avg_launch_ms=r['ms'] / r['launches'],
                   share_of_step=r['ms'] / prof_steps / ms_per_step, instrumented_steps=prof_steps,
@@ -602,8 +622,15 @@ def dist_report(torch, dp, model):
     return None
   import torch.distributed as dist
   props = torch.cuda.get_device_properties(dp.local_rank)
+  import hashlib
+  st = model._built
+  model._flush_d_adam()
+  torch.cuda.synchronize()
+  digest = hashlib.sha1(st['g_param'].cpu().numpy().tobytes() + st['d_param'].cpu().numpy().tobytes()).hexdigest()[:16]
   mine = dict(rank=dp.rank, local_rank=dp.local_rank, device='cuda:%d' % dp.local_rank, name=props.name,
-              gcn_arch=getattr(props, 'gcnArchName', ''), host=socket.gethostname(), pid=os.getpid())
+              gcn_arch=getattr(props, 'gcnArchName', ''), host=socket.gethostname(), pid=os.getpid(),
+              # every rank's parameters after the timed steps: data parallel is right iff these are all equal
+              param_sha1_16=digest)
   ranks = [None] * dp.world_size
   dist.all_gather_object(ranks, mine)
   flat = model._built['g_grad']
@@ -619,6 +646,10 @@ def dist_report(torch, dp, model):
   ms = dp.max_over_ranks(min(times[1:])) * 1e3
   nbytes = flat.numel() * 4
   return dict(backend=dp.backend, world_size=dp.world_size, ranks=ranks, bucket_bytes=dp.bucket_elems * 4,
+              reserve_cus=int(os.environ.get('ADVOC_RESERVE_CUS', '0') or 0),
+              reserve_cus_source=('ADVOC_RESERVE_CUS' if 'ADVOC_RESERVE_CUS' in os.environ and dp.reserve_source == 'user'
+                                  else 'ADVOC_DP_RESERVE_CUS (bench.py default 8 for N > 1)' if dp.reserve_source == 'dp' else 'none'),
+              params_equal_across_ranks=len(set(r['param_sha1_16'] for r in ranks)) == 1,
               g_arena_bytes=nbytes, g_arena_allreduce_ms=ms,
               g_arena_allreduce_busbw_gbs=nbytes * 2 * (dp.world_size - 1) / dp.world_size / (ms * 1e-3) / 1e9,
               rccl='torch.distributed backend "nccl" = RCCL on ROCm' if dp.backend == 'nccl' else 'host-staged (wiring check)')
@@ -661,6 +692,11 @@ def main():
   from advoc_amd.model import Advoc, AdvocSmall, Modes
   from advoc_amd.parallel import DataParallel
 
+  # N > 1: the persistent launches leave 8 CUs (one per XCD) to RCCL's kernels unless the caller chose (r5; recorded in
+  # `dist.reserve_cus`).  An explicit ADVOC_RESERVE_CUS / ADVOC_DP_RESERVE_CUS is never overridden.
+  if int(os.environ.get('WORLD_SIZE', '1')) > 1 and 'ADVOC_DP_RESERVE_CUS' not in os.environ \
+      and 'ADVOC_RESERVE_CUS' not in os.environ:
+    os.environ['ADVOC_DP_RESERVE_CUS'] = '8'
   dp = DataParallel().init_from_env()
   if dp.world_size != args.gpus:
     raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, dp.world_size))

@@ -313,9 +313,23 @@ typedef struct advoc_conv_layer {
    * `colsum` non-null = sum over the logical pixels of dx0 is ADDED to colsum[c0] (the caller zeroes it first if it does
    * not accumulate), through `table`, ADVOC_WGRAD_TABLE_BYTES of device scratch owned by this layer.  Honoured where
    * advoc_conv_emits_dx_image() says so (the <= 2-output-channel layers' matrix kernel, one source, no accumulation);
-   * img == NULL: none. */
-  struct { uint16_t* img; uint32_t* hdr; float* colsum; float* table; } dx_img;
+   * img == NULL: none.
+   * (r5) `mode`: ADVOC_DX_BOUNDED -- the scale of the image comes from a bound of |dx0| known BEFORE the launch
+   *     |dx0| <= max |dy| * max |w| * (taps per output x output channels of this layer)  [+ *bound_add]
+   * (placed at [2^14, 2^15): no value can leave the fp16 range), so the image is final when the call returns: no previous
+   * magnitude is needed in `hdr`, no refit check follows, and the lower layer's calls are made with ADVOC_IMG_DY_CURRENT |
+   * ADVOC_IMG_DY_BOUNDED.  hdr[0] receives the largest magnitude written (zeroed by this call first), hdr[1] = 2^-s.
+   * With ADVOC_DX_IMAGE_ONLY the fp32 tensor dx0 is NOT written at all (the pointer still gives the geometry): the image,
+   * the column sums and the magnitude are the only outputs -- the lower layer's image pass (a read and a write of the
+   * whole tensor) disappears without the epilogue storing one byte more than it did.  Honoured by the patch kernels'
+   * backward-data launches on grids without remainder columns (advoc_conv_emits_dx_image() == 3), without dropout
+   * mask / accumulation on either destination; `bound_add` (optional, device): float bits of a bound of what the
+   * destination already holds (reserved for accumulating calls). */
+  struct { uint16_t* img; uint32_t* hdr; float* colsum; float* table; int32_t mode; int32_t reserved;
+           const uint32_t* bound_add; } dx_img;
 } advoc_conv_layer;
+#define ADVOC_DX_BOUNDED 1
+#define ADVOC_DX_IMAGE_ONLY 2
 #define ADVOC_WGRAD_TABLE_BYTES 262144
 
 /* amax_out[i] = float bits of max |base[offsets[i] .. offsets[i] + sizes[i])| for `count` tensors of one arena, in one
@@ -340,7 +354,8 @@ int advoc_conv_bias_fusable(const advoc_conv_layer* layer);
 /* 1: a forward call on this layer writes the consumers' images of advoc_conv_layer.y_img (it runs on the image kernels
  * and has the workspace they need); 0: y_img is ignored and the consumers must build their images themselves */
 int advoc_conv_emits_images(const advoc_conv_layer* layer);
-/* 1: a backward-data call on this layer (dx0 only) writes advoc_conv_layer.dx_img; 0: dx_img is ignored */
+/* != 0: a backward-data call on this layer writes advoc_conv_layer.dx_img (2: the <= 2-output-channel matrix kernel, one-pass
+ * scale; 3: a patch kernel, ADVOC_DX_BOUNDED [| ADVOC_DX_IMAGE_ONLY] required); 0: dx_img is refused */
 int advoc_conv_emits_dx_image(const advoc_conv_layer* layer);
 
 #define ADVOC_IMG_X_CURRENT 1
@@ -359,6 +374,9 @@ int advoc_conv_emits_dx_image(const advoc_conv_layer* layer);
 /* with ADVOC_IMG_DY_CURRENT: dy_img was written by the backward-data call of the layer above (its advoc_conv_layer.dx_img)
  * under the one-pass scale: this call runs the refit check / header rotation first */
 #define ADVOC_IMG_DY_EMITTED 32
+/* with ADVOC_IMG_DY_CURRENT: dy_img was written by the layer above under ADVOC_DX_BOUNDED: final as it stands (dy_hdr[0] =
+ * its largest magnitude, dy_hdr[1] = 2^-s), no refit check, no header rotation */
+#define ADVOC_IMG_DY_BOUNDED 64
 
 /* Bytes of the persistent operand image `which` (0: inputs, 1: output gradient) the layer can use; 0 when the layer's
  * shapes are outside the image-based kernels. */

@@ -57,3 +57,27 @@ def test_plain_python_bench_gpus_2_spawns_its_own_ranks(hip):
   assert d['backend'] == 'gloo' and d['world_size'] == 2 and sorted(x['rank'] for x in d['ranks']) == [0, 1]
   assert all(x['device'] == 'cuda:0' and x['name'] for x in d['ranks'])
   assert d['g_arena_bytes'] > 0 and d['g_arena_allreduce_ms'] > 0
+
+
+@gpu
+def test_bench_gpus_8_first_run_wiring_on_one_device(hip):
+  """The driver may run `bench.py --gpus 8` on an 8-GPU node without anybody having run it there before: the same command
+  with eight ranks sharing this box's one GPU (host-staged collectives) has to come back with eight ranks in `dist`, the CU
+  reserve the N > 1 path picks for RCCL recorded, and IDENTICAL parameters on every rank after the optimizer steps."""
+  r = _run(['--gpus', '8', '--model', 'small', '--batch', '2', '--steps', '2', '--warmup', '0', '--prof-steps', '0',
+            '--train-only', '--no-cpu-baseline'],
+           extra_env={'ADVOC_DP_BACKEND': 'gloo', 'ADVOC_DP_DEVICE': '0'}, timeout=1500)
+  assert r['n_gpus'] == 8 and r['config']['global_batch'] == 16 and r['config']['parallelism'] == 'dp8'
+  d = r['dist']
+  assert d['world_size'] == 8 and sorted(x['rank'] for x in d['ranks']) == list(range(8))
+  assert len(set(x['pid'] for x in d['ranks'])) == 8
+  assert d['reserve_cus'] == 8 and 'bench.py default' in d['reserve_cus_source']
+  assert d['params_equal_across_ranks'] is True and len(set(x['param_sha1_16'] for x in d['ranks'])) == 1
+
+
+@gpu
+def test_an_explicit_cu_reserve_is_not_overridden(hip):
+  r = _run(['--gpus', '2', '--model', 'small', '--batch', '2', '--steps', '1', '--warmup', '0', '--prof-steps', '0',
+            '--train-only', '--no-cpu-baseline'],
+           extra_env={'ADVOC_DP_BACKEND': 'gloo', 'ADVOC_DP_DEVICE': '0', 'ADVOC_RESERVE_CUS': '16'})
+  assert r['dist']['reserve_cus'] == 16 and r['dist']['reserve_cus_source'] == 'ADVOC_RESERVE_CUS'

@@ -1092,6 +1092,87 @@ def test_backward_data_writes_the_output_gradient_image_of_the_layer_below(hip, 
 
 
 @gpu
+@pytest.mark.parametrize('shape', ['d4_s1', 'd3_s2', 'dec_two_sources'])
+def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_priori_scale(hip, hipenv, shape):
+  """r5: the backward-data call of a layer on a PATCH kernel writes the output-gradient image of the layer below from its
+  epilogue under a scale derived from a bound of |dx| known before the launch (max|dy| max|w| taps K: nothing can leave the
+  fp16 range -- no history, no refit check), with that layer's bias column sums, and does NOT write the fp32 tensor at
+  all (advoc_conv_layer.dx_img, ADVOC_DX_BOUNDED | ADVOC_DX_IMAGE_ONLY): the lower layer's backward-data, weight and bias
+  gradients equal the ones it computes from the fp32 tensor through its own image pass (a power-of-two scale apart: 2e-6),
+  the fp32 buffer keeps its poison, the header holds the tensor's largest magnitude; 1000 x and 1e-4 x jumps of the
+  incoming gradient from one step to the next change nothing (there is no window to leave); on a 4x4 stride-1 layer
+  (discriminator layer_4 -> layer_3), a stride-2 layer (layer_3 -> layer_2) and a two-source transposed layer whose second
+  destination stays an ordinary fp32 tensor (the generator's decoders)."""
+  from advoc_amd import conv
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1, ADVOC_WGRAD_H3_MIN_M=1)
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(77)
+  if shape == 'd4_s1':            # lower: 64 -> 128 stride 2; upper: 4x4 stride 1, 128 -> 256 on a 32 x 32 grid
+    xin = torch.randn(2, 64, 64, 64, generator=g)
+    low = dict(kind=conv.CONV, w=(4, 4, 64, 128), y=(2, 32, 32, 128), stride=(2, 2), pad=(1, 1))
+    up = dict(kind=conv.CONV, w=(4, 4, 128, 256), y=(2, 31, 31, 256), stride=(1, 1), pad=(1, 1), x1=None)
+    want = 'patch_gemm_h3_kernel<5, 1>'
+  elif shape == 'd3_s2':          # upper: stride 2, 128 -> 256: backward-data = four sub-pixel phases over a 16 x 32 grid
+    xin = torch.randn(3, 64, 128, 64, generator=g)
+    low = dict(kind=conv.CONV, w=(4, 4, 64, 128), y=(3, 32, 64, 128), stride=(2, 2), pad=(1, 1))
+    up = dict(kind=conv.CONV, w=(4, 4, 128, 256), y=(3, 16, 32, 256), stride=(2, 2), pad=(1, 1), x1=None)
+    want = 'patch_gemm_h3_kernel<4, 1>'
+  else:                           # upper: transposed conv over concat(lower output, skip): dx0 image only, dx1 fp32
+    xin = torch.randn(2, 16, 16, 64, generator=g)
+    low = dict(kind=conv.DECONV, w=(4, 4, 128, 64), y=(2, 32, 32, 128), stride=(2, 2), pad=(1, 1))
+    up = dict(kind=conv.DECONV, w=(4, 4, 64, 256), y=(2, 64, 64, 64), stride=(2, 2), pad=(1, 1), x1=(2, 32, 32, 128))
+    want = 'patch_gemm_h3_kernel<2, 1>'
+  w_lo = (torch.randn(*low['w'], generator=g) * 0.05).to(dev)
+  b_lo = (torch.randn(low['y'][3], generator=g) * 0.1).to(dev)
+  w_up = (torch.randn(*up['w'], generator=g) * 0.05).to(dev)
+  skip = torch.randn(*up['x1'], generator=g).to(dev) if up['x1'] else None
+  dy_up = torch.randn(*up['y'], generator=g).to(dev)
+  xin = xin.to(dev)
+
+  def make():
+    y_lo = torch.empty(*low['y'], device=dev)
+    Lo = conv.Layer(low['kind'], xin.clone(), y_lo, w_lo, b_lo, stride=low['stride'], pad=low['pad'], in_act=conv.ACT_LRELU)
+    Up = conv.Layer(up['kind'], y_lo, torch.empty(*up['y'], device=dev), w_up, None, x1=skip, stride=up['stride'],
+                    pad=up['pad'], in_act=conv.ACT_RELU if up['kind'] == conv.DECONV else conv.ACT_LRELU)
+    for L in (Up, Lo):
+      L.delayed_scale, L.reuse_images = True, True
+    assert Up.kernel_name(1) == want and 'h3' in Lo.kernel_name(1) and 'h3' in Lo.kernel_name(2), \
+        (Up.kernel_name(1), Lo.kernel_name(1), Lo.kernel_name(2))
+    t = dict(g=torch.empty_like(y_lo), dskip=torch.empty_like(skip) if skip is not None else None,
+             dx=torch.empty_like(xin), dw=torch.zeros_like(w_lo), db=torch.zeros_like(b_lo))
+    return Up, Lo, t
+  A, R = make(), make()
+  for step, scale in enumerate((1.0, 0.8, 1000.0, 1e-4, 1.0)):
+    for (Up, Lo, t), emit in ((A, True), (R, False)):
+      Lo.forward()
+      Up.forward()
+      t['dw'].zero_()
+      t['g'].fill_(float('nan'))
+      Up.backward_data(dy_up * scale, t['g'], t['dskip'], grad_consumer=Lo if emit else None,
+                       consumer_db=t['db'] if emit else None, consumer_db_accumulate=False)
+      if emit:
+        assert Lo._dy_emitted_for is not None and Lo._dy_emitted_for[2], step       # from the first step on: no history needed
+        assert bool(torch.isnan(t['g']).all()), step                                 # the fp32 tensor is NOT written
+      Lo.backward_data(t['g'], t['dx'], db=t['db'], db_accumulate=False)
+      Lo.backward_weight(t['g'], t['dw'], t['db'])
+    (Ua, La, ta), (Ur, Lr, tr) = A, R
+    assert rel(ta['dx'], tr['dx']) < 2e-6, (step, rel(ta['dx'], tr['dx']))
+    assert rel(ta['dw'], tr['dw']) < 2e-6, (step, rel(ta['dw'], tr['dw']))
+    assert rel(ta['db'], tr['db'].double().cpu()) < 2e-6, (step, rel(ta['db'], tr['db'].double().cpu()))
+    if skip is not None:
+      assert torch.equal(ta['dskip'], tr['dskip']), step
+    # the header of the emitted image: word 0 = the tensor's largest magnitude, word 1 = 2^-s with the bound at [2^14, 2^15):
+    # the largest scaled value stays below 2^15 and -- a bound over <= 8192 products -- above 2^1
+    hdr = La.struct.dy_hdr
+    ha = [h for h in La.image_headers() if h.data_ptr() == hdr][0].cpu().view(torch.float32)
+    amax = float(tr['g'].abs().max())
+    assert abs(float(ha[0]) - amax) <= 2e-6 * amax, (step, float(ha[0]), amax)
+    top = amax / float(ha[1])
+    assert 2.0 <= top < 32768.0, (step, top)
+  assert int(La.image_headers()[-1].cpu()[5]) == 0      # nothing was ever refitted
+
+
+@gpu
 def test_output_gradient_roles_keep_separate_magnitude_histories(hip, hipenv):
   """Layer.set_dy_role: one layer object that sees gradients of two losses per step (the discriminator's fake pass with
   batch norm: D-loss gradients in the D step, ~1000 x larger G-loss gradients in the G step) keeps one header per role,

@@ -13,7 +13,7 @@ pids=()
 for f in $SRC/*.hip; do
   o=$OBJ/$(basename ${f%.hip}).o
   if [ ! -f $o ] || [ $f -nt $o ] || [ -n "$FORCE" ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$INC -Wall -Wno-unused-function $EXTRA -c $f -o $o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$INC -Wall -Wno-unused-function -Wno-pass-failed $EXTRA -c $f -o $o &
     pids+=($!)
     if [ ${#pids[@]} -ge 8 ]; then wait ${pids[0]}; pids=("${pids[@]:1}"); fi
   fi

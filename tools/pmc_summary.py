@@ -42,7 +42,10 @@ def main():
     out[k] = dict(launches=len(fetch[k]), fetch_kib_raw=f, write_kib=w, traffic_bytes=traffic)
     print('| `%s` | %d | %.2f | %.2f | %.1f |' % (k, len(fetch[k]), f / 1024, w / 1024, traffic / 1e6))
   if '--json' in sys.argv:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     out['_workload'] = dict(model=os.environ.get('PMC_MODEL', 'regular'), batch=int(os.environ.get('PMC_BATCH', '64')),
+                            kernel_source_sha16=bench.kernel_source_sha16(),     # bench.py withholds `traffic` when the sources moved on
                             command='python bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-only --prof-steps 0')
     json.dump(out, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1, sort_keys=True)
 
