@@ -186,7 +186,9 @@ class Layer(object):
       for which, img_field, hdr_field in ((0, 'x_img', 'x_hdr'), (1, 'dy_img', 'dy_hdr')):
         nbytes = _lib.load().advoc_conv_image_bytes(ctypes.byref(s), which)
         if nbytes > 0:
-          img = torch.empty(nbytes // 2, dtype=torch.int16, device=x0.device)
+          # (zeros, once: a producer that writes this image from its epilogue -- dx_img -- writes the LOGICAL pixels only; a
+          # trimmed column of the tensor must read as the zero gradient it is, as it does behind an image pass)
+          img = torch.zeros(nbytes // 2, dtype=torch.int16, device=x0.device)
           hdr = torch.zeros(8, dtype=torch.int32, device=x0.device)
           setattr(s, img_field, img.data_ptr())
           setattr(s, hdr_field, hdr.data_ptr())
@@ -397,13 +399,18 @@ class Layer(object):
     if self._emits_dx is None:
       self._emits_dx = int(_lib.load().advoc_conv_emits_dx_image(ctypes.byref(self.struct)))
     kind = self._emits_dx
+    # 3 / 4: a patch kernel / the thin matrix kernel under the a-priori scale (a launch that reports 2 runs as 4 when max |w|
+    # is on the device); 2: the thin kernel under the one-pass scale (r4, off by default)
+    if kind in (3, 4) or (kind == 2 and self.struct.w_amax):
+      bounded_ok = Layer.dx_bounded and self.reuse_images and consumer.reuse_images
+      if bounded_ok:
+        kind = 3
+      elif kind != 2:
+        return None, 0
     if kind == 2:
       if not (Layer.emit_dx and dx1 is None and self.delayed_scale and consumer.delayed_scale and consumer._dy_built):
         return None, 0
-    elif kind == 3:
-      if not (Layer.dx_bounded and self.reuse_images and consumer.reuse_images):
-        return None, 0
-    else:
+    elif kind != 3:
       return None, 0
     if self.x0.data_ptr() != consumer.y.data_ptr() or tuple(dx0.shape) != tuple(consumer.y.shape):
       raise _lib.AdvocHipError('this layer\'s input is not the consumer layer\'s output')

@@ -456,7 +456,9 @@ int dx_image_launch(const advoc_conv_layer* L, const float* dy, float* dx0, floa
   emits = 0;
   p.oimg_bounded = 1;
   if (run_gather(p, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes) != ADVOC_OK) return 0;
-  return emits == 3 ? 3 : 0;
+  // 4: the thin matrix kernel under the bound (it needs max |w| on the device: advoc_conv_layer.w_amax), a second source's
+  // gradient as an ordinary fp32 destination
+  return emits == 3 ? 3 : (emits == 2 ? 4 : 0);
 }
 }  // namespace
 
@@ -482,19 +484,40 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
   if (L->dx_img.img) {
     // the lower layer's output-gradient image from this call's epilogue (advoc_conv_layer.dx_img)
     if (!L->dx_img.hdr || (L->dx_img.colsum && !L->dx_img.table)) return ADVOC_ERR_NULL;
-    const int kind = dx_image_launch(L, dy, dx0, dx1, accum0, accum1);
+    int kind = dx_image_launch(L, dy, dx0, dx1, accum0, accum1);
     const bool bounded = (L->dx_img.mode & ADVOC_DX_BOUNDED) != 0;
-    // (the thin kernel writes under the one-pass scale and always stores dx0; the patch kernels only under the bound)
-    if (kind == 0 || (kind == 2) == bounded || (kind == 2 && (L->dx_img.mode & ADVOC_DX_IMAGE_ONLY))) return ADVOC_ERR_UNSUPPORTED;
+    // (2: the thin kernel under the one-pass scale, fp32 dx0 stored; 3 / 4: a patch kernel / the thin kernel under the bound;
+    // a launch that reports 2 can also run as 4 when max |w| is on the device)
+    if (kind == 2 && bounded) {
+      GatherGemmParams q = p;
+      q.oimg_bounded = 1; q.oimg[0].img = L->dx_img.img; q.oimg[0].hdr = L->dx_img.hdr;
+      int emits = 0;
+      const char* nm = nullptr;
+      q.emit_report = &emits;
+      kind = run_gather(q, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes) == ADVOC_OK && emits == 2 ? 4 : 0;
+    }
+    if (kind == 0 || (kind == 2 && (L->dx_img.mode & ADVOC_DX_IMAGE_ONLY)) || (kind >= 3 && !bounded)) return ADVOC_ERR_UNSUPPORTED;
     p.oimg[0].img = L->dx_img.img;
     p.oimg[0].hdr = L->dx_img.hdr;
     p.oimg[0].slope = 1.f;
     p.ocolsum_out = L->dx_img.colsum;
     p.ocolsum_table = L->dx_img.table;
-    if (kind == 3) {
+    if (kind >= 3) {
       p.oimg_bounded = 1;
       p.obound_add = L->dx_img.bound_add;
       p.d0_no_store = (L->dx_img.mode & ADVOC_DX_IMAGE_ONLY) ? 1 : 0;
+    }
+    if (kind == 4) {
+      // the thin operand is an fp32 tensor without an image: its largest magnitude by a pass of its own (1-2 channels), into
+      // the reserved word 7 of the header the launch writes
+      if (L->y.w_pitch != L->y.w) return ADVOC_ERR_UNSUPPORTED;     // (columns beyond the logical width hold anything)
+      unsigned* word = L->dx_img.hdr + 7;
+      hipError_t e = hipMemsetAsync(word, 0, 4, as_stream(stream));
+      if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+      const int64_t elems = (int64_t)L->y.n * L->y.h * L->y.w_pitch * L->y.c;
+      rc = launch_amax_any(dy, elems, word, as_stream(stream));
+      if (rc != ADVOC_OK) return rc;
+      p.a_amax = word;
     }
   }
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);

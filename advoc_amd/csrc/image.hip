@@ -505,6 +505,16 @@ int launch_amax(const float* x, int64_t elems, int c, const float* scale, const 
   return ADVOC_OK;
 }
 
+// max |x| over a flat fp32 array of any length, raised in *amax (float bits; the caller zeroes it)
+int launch_amax_any(const float* x, int64_t elems, unsigned* amax, hipStream_t stream) {
+  if (!x || !amax) return ADVOC_ERR_NULL;
+  if (elems <= 0) return ADVOC_OK;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(amax_flat_kernel, dim3(grid_for_reduce(elems, 256 * 16)), dim3(256), 0, stream, x, elems, amax);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
 int launch_colsum_reduce(const float* table, float* out, int c, hipStream_t stream) {
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, table, out, c);

@@ -215,7 +215,16 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
   // forward launches: the consumers' operand images of the output (image_emit.h)
   const ImgOut o0 = p.oimg[0], o1 = p.oimg[1];
   const bool emit0 = o0.img != nullptr, emit1 = o1.img != nullptr;
-  const float eup0 = emit0 ? emit_up_scale(o0.hdr[2]) : 1.f, eup1 = emit1 ? emit_up_scale(o1.hdr[2]) : 1.f;
+  // (r5, FW == -3 with GatherGemmParams::oimg_bounded) the a-priori scale of igemm_patch.hip: |dx| <= max|dy| max|w| taps K,
+  // here with max|dy| in *a_amax (a magnitude pass over the thin operand in front of the launch) and max|w| in *w_amax
+  float eup0_ = 1.f;
+  if (emit0) {
+    if (FW == -3 && p.oimg_bounded)
+      eup0_ = emit_up_scale_bounded(__uint_as_float(*p.a_amax) * __uint_as_float(*p.w_amax) * (float)(p.ntaps * (p.c0 + p.c1)));
+    else
+      eup0_ = emit_up_scale(o0.hdr[2]);
+  }
+  const float eup0 = eup0_, eup1 = emit1 ? emit_up_scale(o1.hdr[2]) : 1.f;
   float evmax0 = 0.f, evmax1 = 0.f;
   float csum[FW == -3 ? NT : 1][4] = {};
   if (threadIdx.x == 0) {
@@ -336,7 +345,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
           v[ps].z += __uint_as_float(o.z); v[ps].w += __uint_as_float(o.w);
         }
       }
-      const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(d.p, 0, okj ? kThinOob : 0u, 0x00020000);
+      // (FW == -3, d0_no_store: destination 0 exists as the image only)
+      const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
+          d.p, 0, (okj && !(FW == -3 && p.d0_no_store && di == 0)) ? kThinOob : 0u, 0x00020000);
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         u32x4 sv;
@@ -366,7 +377,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
   if constexpr (FW == -3) if (p.ocolsum_table) {
     // lanes (row lane >> 3, channel quad lane & 7): fold the eight rows, then one atomic per channel and wave into one of the
     // replica tables (image.hip: thousands of waves adding to the same N addresses serialise in the L2)
-    float* tab = p.ocolsum_table + (size_t)((blockIdx.x * 4 + wave) & (kColsumReplicas - 1)) * N;
+    // (the table's rows are the channels of destination 0: a second destination -- the skip source of a decoder -- has no sums)
+    const int cs_c = p.d[0].c;
+    float* tab = p.ocolsum_table + (size_t)((blockIdx.x * 4 + wave) & (kColsumReplicas - 1)) * cs_c;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
         t += __shfl_xor(t, 16, 64);
         t += __shfl_xor(t, 32, 64);
         const int n = n0 + 32 * j + 4 * (lane & 7) + c;
-        if (lane < 8 && n < N) unsafeAtomicAdd(tab + n, t);
+        if (lane < 8 && n < N && n < p.n_split && n < cs_c) unsafeAtomicAdd(tab + n, t);
       }
   }
 }
@@ -417,7 +430,8 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
     // pre-activation values, into ONE image (the layer below's output gradient) with that tensor's column sums on the way
     if (p.emit_report)
       *p.emit_report = (nt >= 2 && p.grad_act != ADVOC_ACT_NONE && !p.y_mask && !p.d[0].gmask && !p.d[1].gmask && !p.d[0].accum &&
-                        !p.d[1].accum && !p.d[1].p && p.oimg[0].img && !p.oimg[1].img && tuning().thin_fwd_spec) ? 2 : 1;
+                        !p.d[1].accum && (!p.d[1].p || p.oimg_bounded) && p.oimg[0].img && !p.oimg[1].img &&
+                        (!p.oimg_bounded || (p.w_amax && p.d[0].c % 32 == 0 && p.n_split % 32 == 0)) && tuning().thin_fwd_spec) ? 2 : 1;
     return ADVOC_OK;
   }
   int64_t bx = ceil_div(tiles, 4);
@@ -434,11 +448,16 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
              !p.d[1].accum && !p.oimg[0].img && !p.oimg[1].img) {
     fw = -2;
   } else if (tuning().thin_fwd_spec && nt >= 2 && p.grad_act != ADVOC_ACT_NONE && !p.y_mask && !p.d[0].gmask && !p.d[1].gmask &&
-             !p.d[0].accum && !p.d[1].accum && !p.d[1].p && p.oimg[0].img && !p.oimg[1].img) {
+             !p.d[0].accum && !p.d[1].accum && (!p.d[1].p || p.oimg_bounded) && p.oimg[0].img && !p.oimg[1].img) {
     fw = -3;        // ... and writes the layer below's output-gradient image (+ its bias column sums)
+    if (p.oimg_bounded && (!p.w_amax || !p.a_amax || !p.oimg[0].hdr)) return ADVOC_ERR_NULL;
     if (p.ocolsum_out) {
       if (!p.ocolsum_table) return ADVOC_ERR_NULL;
-      hipError_t e = hipMemsetAsync(p.ocolsum_table, 0, sizeof(float) * kColsumReplicas * (size_t)N, stream);
+      hipError_t e = hipMemsetAsync(p.ocolsum_table, 0, sizeof(float) * kColsumReplicas * (size_t)p.d[0].c, stream);
+      if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    }
+    if (p.oimg_bounded) {      // the magnitude accumulator of the image this launch writes
+      hipError_t e = hipMemsetAsync(p.oimg[0].hdr, 0, 4, stream);
       if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
     }
   }
@@ -488,7 +507,7 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
 #undef ADVOC_THIN_LAUNCH_PL
 #undef ADVOC_THIN_LAUNCH
   ADVOC_RETURN_IF_LAUNCH_FAILED();
-  if (fw == -3 && p.ocolsum_out) return launch_colsum_reduce(p.ocolsum_table, p.ocolsum_out, N, stream);
+  if (fw == -3 && p.ocolsum_out) return launch_colsum_reduce(p.ocolsum_table, p.ocolsum_out, p.d[0].c, stream);
   return ADVOC_OK;
 }
 

@@ -69,6 +69,8 @@ int launch_image_refit(const ImageSource& s0, const ImageSource& s1, uint16_t* i
 bool image_colsum_ok(int c);
 // out[ch] += sum over the kColsumReplicas copies of table[r][ch] (the fold of every replica table of this library)
 int launch_colsum_reduce(const float* table, float* out, int c, hipStream_t stream);
+// max |x| over a flat fp32 array, raised in *amax (float bits, zeroed by the caller)
+int launch_amax_any(const float* x, int64_t elems, unsigned* amax, hipStream_t stream);
 constexpr int kColsumReplicas = 64;
 constexpr int64_t kColsumBytes = (int64_t)kColsumReplicas * 1024 * 4;
 // weights [tap][k][n] (b_kn) or [tap][n][k] -> wq[tap][n_total][ktot / 32][plane][32] fp16 (amax pass included;

@@ -955,7 +955,16 @@ class Advoc(Model):
     st['g_sent'] = 0
     self._zero_arena('g')      # one fill for the whole arena; the kernels below accumulate into it
     last_idx = dec[-1][0] if dec else None
-    GL['decoder_1'].backward_data(g_out, gd[last_idx] if dec else ge[-1], ge[0])
+    # (r5) every decoder hands the layer that produced its first source that layer's output-gradient IMAGE (and bias sums)
+    # instead of the fp32 tensor where its backward-data kernel can (conv.Layer._dx_target: no batch norm, no dropout mask
+    # in between)
+    def below(idx_):
+      name_ = 'decoder_%d' % idx_
+      if name_ in gbn:
+        return None, None
+      return GL[name_], GG['generator/%s/conv2d_transpose/bias' % name_]
+    lower, lower_db = below(last_idx) if dec else (None, None)
+    GL['decoder_1'].backward_data(g_out, gd[last_idx] if dec else ge[-1], ge[0], grad_consumer=lower, consumer_db=lower_db)
     with self._wgrad_ctx():
       GL['decoder_1'].backward_weight(g_out, GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
       self._g_grads_ready(self._last_param_of('generator/decoder_1'))
@@ -968,7 +977,9 @@ class Advoc(Model):
       if j == 0:
         lay.backward_data(gd[idx], ge[-1], db=GG[s + '/bias'])
       else:
-        lay.backward_data(gd[idx], gd[dec[j - 1][0]], ge[idx - 1], db=GG[s + '/bias'])
+        lower, lower_db = below(dec[j - 1][0])
+        lay.backward_data(gd[idx], gd[dec[j - 1][0]], ge[idx - 1], db=GG[s + '/bias'], grad_consumer=lower,
+                          consumer_db=lower_db)
       with self._wgrad_ctx():
         lay.backward_weight(gd[idx], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
         self._g_grads_ready(self._last_param_of('generator/decoder_%d' % idx))

@@ -1092,7 +1092,7 @@ def test_backward_data_writes_the_output_gradient_image_of_the_layer_below(hip, 
 
 
 @gpu
-@pytest.mark.parametrize('shape', ['d4_s1', 'd3_s2', 'dec_two_sources'])
+@pytest.mark.parametrize('shape', ['d4_s1', 'd3_s2', 'dec_two_sources', 'thin_cout1', 'thin_two_sources'])
 def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_priori_scale(hip, hipenv, shape):
   """r5: the backward-data call of a layer on a PATCH kernel writes the output-gradient image of the layer below from its
   epilogue under a scale derived from a bound of |dx| known before the launch (max|dy| max|w| taps K: nothing can leave the
@@ -1117,6 +1117,16 @@ def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_
     low = dict(kind=conv.CONV, w=(4, 4, 64, 128), y=(3, 32, 64, 128), stride=(2, 2), pad=(1, 1))
     up = dict(kind=conv.CONV, w=(4, 4, 128, 256), y=(3, 16, 32, 256), stride=(2, 2), pad=(1, 1), x1=None)
     want = 'patch_gemm_h3_kernel<4, 1>'
+  elif shape == 'thin_cout1':     # upper: one output channel (the discriminator's layer_5): the thin matrix kernel, max |w| given
+    xin = torch.randn(2, 32, 37, 64, generator=g)
+    low = dict(kind=conv.CONV, w=(4, 4, 64, 128), y=(2, 31, 36, 128), stride=(1, 1), pad=(1, 1))
+    up = dict(kind=conv.CONV, w=(4, 4, 128, 1), y=(2, 30, 35, 1), stride=(1, 1), pad=(1, 1), x1=None)
+    want = 'thin_k_gemm_kernel<16, 4, false>'
+  elif shape == 'thin_two_sources':   # upper: the generator's decoder_1 (transposed, one output channel, two 64-channel sources)
+    xin = torch.randn(2, 16, 18, 64, generator=g)
+    low = dict(kind=conv.DECONV, w=(4, 4, 64, 64), y=(2, 32, 36, 64), stride=(2, 2), pad=(1, 1))
+    up = dict(kind=conv.DECONV, w=(4, 4, 1, 128), y=(2, 64, 72, 1), stride=(2, 2), pad=(1, 1), x1=(2, 32, 36, 64))
+    want = 'thin_k_gemm_kernel<16, 4, true>'
   else:                           # upper: transposed conv over concat(lower output, skip): dx0 image only, dx1 fp32
     xin = torch.randn(2, 16, 16, 64, generator=g)
     low = dict(kind=conv.DECONV, w=(4, 4, 128, 64), y=(2, 32, 32, 128), stride=(2, 2), pad=(1, 1))
@@ -1132,8 +1142,10 @@ def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_
   def make():
     y_lo = torch.empty(*low['y'], device=dev)
     Lo = conv.Layer(low['kind'], xin.clone(), y_lo, w_lo, b_lo, stride=low['stride'], pad=low['pad'], in_act=conv.ACT_LRELU)
+    # (max |w| on the device, as the train step keeps it: the thin kernel's bound reads it from there)
+    w_amax = w_up.abs().max().reshape(1).view(torch.int32)
     Up = conv.Layer(up['kind'], y_lo, torch.empty(*up['y'], device=dev), w_up, None, x1=skip, stride=up['stride'],
-                    pad=up['pad'], in_act=conv.ACT_RELU if up['kind'] == conv.DECONV else conv.ACT_LRELU)
+                    pad=up['pad'], in_act=conv.ACT_RELU if up['kind'] == conv.DECONV else conv.ACT_LRELU, w_amax=w_amax)
     for L in (Up, Lo):
       L.delayed_scale, L.reuse_images = True, True
     assert Up.kernel_name(1) == want and 'h3' in Lo.kernel_name(1) and 'h3' in Lo.kernel_name(2), \

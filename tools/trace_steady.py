@@ -14,6 +14,7 @@ lo = adam[-1 - 2 * loops]
 agg = {}
 for s, e, n in rows[lo + 1:hi + 1]:
   n = re.sub(r'^void ', '', n)
+  n = n.replace('(anonymous namespace)::', '')
   n = re.sub(r'advoc::\(anonymous namespace\)::|advoc::', '', n)
   n = re.sub(r'\(.*$', '', n)
   a = agg.setdefault(n, [0, 0])
