@@ -70,8 +70,12 @@ struct PCfg {
   static constexpr int MT = N128 ? 2 : ((NPH == 4 && W == 4) ? 8 : 4);   // 32-point blocks per wave
   static constexpr int NT = (NPH == 1 && W == 4) ? 4 : 2;  // 32-column blocks per wave
   static constexpr bool CARRY = W == 4;                    // next step's first A fragments fetched before the barrier
+#ifdef ADVOC_P3_DOUBLE_B        // (A/B builds only: with the ablation switches compile-time the 4x4 instances have the registers)
+  static constexpr bool DOUBLE_B = W == 4 || NPH == 1 || NPH == 5;
+#else
   static constexpr bool DOUBLE_B = W == 4;                 // B fragments of both k steps in registers at once (W = 8: the
                                                            // second set costs the 16 registers that tip the loop into scratch)
+#endif
   static constexpr int HW = NPH == 4 ? 18 : (S1 ? 19 : 17);   // halo width = height (patch_plan takes only these)
   static constexpr int HP = S1 ? 20 : 18;                  // halo row pitch in LDS, EVEN: address bit 7 (the half of the
                                                            // 256-byte bank row) must follow the column's parity
@@ -530,6 +534,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     const int hb = s & 1;
     const bool more = s + 1 < nslices;
     for (int t = 0; t < NST; t += 2) {
+#ifdef ADVOC_P3_IGLP
+      __builtin_amdgcn_iglp_opt(ADVOC_P3_IGLP);
+#endif
       // step t (stage 0)
       ADVOC_P3_RENDEZVOUS();
       if (C::DMA_POS == 0) {

@@ -189,10 +189,13 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
 // The three products of one 32 x 32 block, then one DMA instruction of the NEXT tile: the 2 SL loads of a tile go out
 // one per block instead of as a burst behind the barrier (8 waves x 8 loads at once back up in the address path, and an
 // in-order wave cannot issue its MFMAs from behind a stalled load).
-#ifdef ADVOC_WH3_NO_SB          // (A/B builds only: no scheduling fence behind the interleaved DMA)
-#define WH3_DMA_FENCE
-#else
+// (r5) no scheduling fence behind the interleaved DMA, and the compiler's MFMA / LDS-read interleaving strategy 0 for the K
+// tile (__builtin_amdgcn_iglp_opt): wgrad_h3_256_kernel 0.712 -> 0.700 ms, 0.710 -> 0.7025 same box, alternating; without the
+// strategy the missing fence alone changes nothing, strategy 1 loses 1 % (ADVOC_WH3_SB: the r4 form, A/B builds)
+#ifdef ADVOC_WH3_SB
 #define WH3_DMA_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define WH3_DMA_FENCE
 #endif
 #define WH3_MFMAS \
       _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                     \
@@ -241,6 +244,9 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   for (int kt = 0; kt < nkt; kt += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+#ifndef ADVOC_WH3_SB
+      __builtin_amdgcn_iglp_opt(0);
+#endif
       dma_ring_barrier<0>();         // (lds_dma.h: own DMAs landed AND own reads of the stage about to be refilled returned)
       ADVOC_WH3_COMPUTE(u);          // (fires the next tile's loads between its MFMAs)
       ADVOC_WH3_ADDR();

@@ -224,30 +224,58 @@ def make_dropout_masks(cfg, batch, seed, dtype=torch.float32):
           for k, s in dropout_shapes(cfg, batch).items()}
 
 
-def build_generator(P, x, cfg, masks, collect=None):
+def _gated(t, gate, slope):
+  """slope = 0.2: lrelu, 0: relu -- with the GATE (x > 0) given from outside instead of taken from t: the activation a
+  consumer applies when the sign pattern is frozen (tests: a comparison that cannot be decided by which side of zero a
+  round-off error puts a pre-activation value; gate None = the ordinary activation)."""
+  if gate is None:
+    return lrelu(t, slope) if slope else torch.relu(t)
+  return torch.where(gate, t, slope * t)
+
+
+def build_generator(P, x, cfg, masks, collect=None, gates=None):
+  """gates (optional, tests only): {layer name: bool tensor shaped like that layer's output} -- the sign pattern every
+  consumer of that output uses in its (leaky) ReLU instead of the output's own signs."""
+  gates = gates or {}
   es = encoder_strides(cfg)
   n_stride1 = sum(1 for st in es if st == (1, 2))
   bnorm = (lambda t, s: batchnorm(t, P[s + '/batch_normalization/gamma'],
                                   P[s + '/batch_normalization/beta'])) if cfg.use_batchnorm else (lambda t, s: t)
-  layers = []
+  layers, names = [], []
+
+  def gate_of(k):          # of layers[k], or None
+    return gates.get(names[k])
+
+  def cat_gate(a, b):      # gate of cat([layers[a] trimmed, layers[b]]): both given or neither
+    ga, gb = gate_of(a), gate_of(b)
+    if ga is None and gb is None:
+      return None
+    ga = ga if ga is not None else layers[a] > 0
+    gb = gb if gb is not None else layers[b] > 0
+    return torch.cat([ga[:, :, :-1, :], gb], dim=3)
   s = 'generator/encoder_1'
   layers.append(gen_conv(x, P[s + '/conv2d/kernel'], P[s + '/conv2d/bias']))
+  names.append('encoder_1')
   for i in range(1, 1 + cfg.num_enc_layers):
     s = 'generator/encoder_%d' % (i + 1)
-    out = gen_conv(lrelu(layers[-1]), P[s + '/conv2d/kernel'], P[s + '/conv2d/bias'], strides=es[i])
+    out = gen_conv(_gated(layers[-1], gate_of(-1), 0.2), P[s + '/conv2d/kernel'], P[s + '/conv2d/bias'], strides=es[i])
     layers.append(bnorm(out, s))
+    names.append('encoder_%d' % (i + 1))
   for j, (idx, c, drop) in enumerate(cfg.decoder_specs()):
     s = 'generator/decoder_%d' % idx
     inp = layers[-1] if j == 0 else torch.cat([layers[-1][:, :, :-1, :], layers[idx - 1]], dim=3)
-    out = gen_deconv(torch.relu(inp), P[s + '/conv2d_transpose/kernel'], P[s + '/conv2d_transpose/bias'],
+    g_in = gate_of(-1) if j == 0 else cat_gate(len(layers) - 1, idx - 1)
+    out = gen_deconv(_gated(inp, g_in, 0.0), P[s + '/conv2d_transpose/kernel'], P[s + '/conv2d_transpose/bias'],
                      strides=(1, 2) if j < n_stride1 else (2, 2))       # advoc_model.py:139-142
     out = bnorm(out, s)
     if drop > 0:
       out = dropout(out, masks['decoder_%d' % idx], 1 - drop)
     layers.append(out)
+    names.append('decoder_%d' % idx)
   s = 'generator/decoder_1'
   inp = torch.cat([layers[-1][:, :, :-1, :], layers[0]], dim=3)
-  out = gen_deconv(torch.relu(inp), P[s + '/conv2d_transpose/kernel'], P[s + '/conv2d_transpose/bias'])
+  out = gen_deconv(_gated(inp, cat_gate(len(layers) - 1, 0), 0.0), P[s + '/conv2d_transpose/kernel'],
+                   P[s + '/conv2d_transpose/bias'])
   out = out[:, :, :-1, :]
   layers.append(out)
   if collect is not None:
@@ -255,17 +283,21 @@ def build_generator(P, x, cfg, masks, collect=None):
   return out
 
 
-def build_discriminator(P, cond, target, cfg, collect=None):
+def build_discriminator(P, cond, target, cfg, collect=None, gates=None, tag=''):
+  """gates (optional, tests only): {tag + 'layer_k': bool tensor} -- the sign pattern of layer k's leaky ReLU, k = 1 .. 4
+  (see build_generator)."""
+  gates = gates or {}
   bnorm = (lambda t, s: batchnorm(t, P[s + '/batch_normalization/gamma'],
                                   P[s + '/batch_normalization/beta'])) if cfg.use_batchnorm else (lambda t, s: t)
   x = torch.cat([cond, target], dim=3)
   s = 'discriminator/layer_1'
-  h = lrelu(discrim_conv(x, P[s + '/conv2d/kernel'], P[s + '/conv2d/bias'], 2))
+  h = _gated(discrim_conv(x, P[s + '/conv2d/kernel'], P[s + '/conv2d/bias'], 2), gates.get(tag + 'layer_1'), 0.2)
   acts = [h]
   for i in range(3):
     s = 'discriminator/layer_%d' % (i + 2)
     stride = 1 if i == 2 else 2
-    h = lrelu(bnorm(discrim_conv(h, P[s + '/conv2d/kernel'], P[s + '/conv2d/bias'], stride), s))
+    h = _gated(bnorm(discrim_conv(h, P[s + '/conv2d/kernel'], P[s + '/conv2d/bias'], stride), s),
+               gates.get(tag + 'layer_%d' % (i + 2)), 0.2)
     acts.append(h)
   s = 'discriminator/layer_5'
   out = torch.sigmoid(discrim_conv(h, P[s + '/conv2d/kernel'], P[s + '/conv2d/bias'], 1))
@@ -275,11 +307,11 @@ def build_discriminator(P, cond, target, cfg, collect=None):
   return out
 
 
-def losses(P, x, target, cfg, masks):
+def losses(P, x, target, cfg, masks, gates=None):
   """advoc_model.py:217-245 -> dict of scalars + gen output."""
-  gen = build_generator(P, x, cfg, masks)
-  p_real = build_discriminator(P, x, target, cfg)
-  p_fake = build_discriminator(P, x, gen, cfg)
+  gen = build_generator(P, x, cfg, masks, gates=gates)
+  p_real = build_discriminator(P, x, target, cfg, gates=gates, tag='D/real/')
+  p_fake = build_discriminator(P, x, gen, cfg, gates=gates, tag='D/fake/')
   d_loss = torch.mean(-(torch.log(p_real + EPS) + torch.log(1 - p_fake + EPS)))
   g_gan = torch.mean(-torch.log(p_fake + EPS))
   g_l1 = torch.mean(torch.abs(target - gen))
@@ -291,12 +323,12 @@ def losses(P, x, target, cfg, masks):
               g_loss=g_loss)
 
 
-def grads(P, x, target, cfg, masks, which):
-  """d(loss)/d(vars): which='D' -> discrim_loss wrt D vars; 'G' -> gen_loss wrt G vars."""
+def grads(P, x, target, cfg, masks, which, gates=None):
+  """d(loss)/d(vars): which='D' -> discrim_loss wrt D vars; 'G' -> gen_loss wrt G vars.  gates: build_generator."""
   Gk, Dk = split_vars(P)
   keys = Dk if which == 'D' else Gk
   Q = collections.OrderedDict((k, v.detach().clone().requires_grad_(k in keys)) for k, v in P.items())
-  L = losses(Q, x, target, cfg, masks)
+  L = losses(Q, x, target, cfg, masks, gates=gates)
   loss = L['d_loss'] if which == 'D' else L['g_loss']
   g = torch.autograd.grad(loss, [Q[k] for k in keys])
   return collections.OrderedDict(zip(keys, g)), {k: v.detach() for k, v in L.items()}

@@ -399,46 +399,92 @@ def test_full_model_with_batch_norm_train_loop_at_bench_size_matches_the_float64
   gD, LD = A.grads(P64, batches[0][0].double(), batches[0][1].double(), cfg, {k: v.double() for k, v in masks[0].items()}, 'D')
   P_at_d = collections.OrderedDict((k, v.clone()) for k, v in P64.items())
   d_opt.step(P64, gD)
-  gG, LG = A.grads(P64, batches[1][0].double(), batches[1][1].double(), cfg, {k: v.double() for k, v in masks[1].items()}, 'G')
-  P_at_g = collections.OrderedDict((k, v.clone()) for k, v in P64.items())
-  assert m.train_loop() == 1
+  # the train_loop, in its two halves, so that the generator's sign patterns of BOTH forward passes can be read back
+  names = ['encoder_%d' % (i + 1) for i in range(len(st['enc']))] + ['decoder_%d' % idx for idx in st['dec']]
+
+  def read_gates():
+    """{layer: (value its consumers put through their (leaky) ReLU) > 0} of the forward pass just run, distinct clips only"""
+    out = {}
+    for n in names:
+      z = (st['enc'][int(n.split('_')[1]) - 1] if n.startswith('enc') else st['dec'][int(n.split('_')[1])])[:DISTINCT]
+      b = st['g_bn'].get(n)
+      v = z * b['scale'] + b['shift'] if b is not None else z
+      gate = v > 0
+      if n.startswith('dec') and int(n.split('_')[1]) in st['masks']:      # dropout behind the batch norm: a dropped value is 0
+        gate = gate & (st['masks'][int(n.split('_')[1])][0][:DISTINCT] > 0)
+      out[n] = gate.cpu()
+    return out
+
+  def read_d_gates(out, layers_bns):
+    """+ the discriminator's leaky-ReLU sign patterns: {'D/real/layer_k' | 'D/fake/layer_k': gate}, k = 1 .. 4"""
+    for tag, bns, lo in layers_bns:
+      for i in range(4):
+        z = st['d_act'][i][lo:lo + DISTINCT]
+        b = bns.get(i)
+        out['D/%s/layer_%d' % (tag, i + 1)] = ((z * b['scale'] + b['shift'] if b is not None else z) > 0).cpu()
+    return out
+  b0 = m._feed()
+  m.d_step(b0)
+  gates_d = read_d_gates(read_gates(), (('real', st['d_bn_real'], 0), ('fake', st['d_bn_fake'], Bn)))
+  # The generator update is differentiated at the parameters THIS run holds after its discriminator update (r5).  Adam's
+  # first step is +-lr for every parameter whatever the size of its gradient, so a discriminator parameter whose gradient is
+  # round-off on both sides (e.g. a conv bias in front of a batch norm) moves by +lr here and -lr in the oracle; r4 compared
+  # the generator's gradients across that difference and read the result as ill-conditioning of the bottleneck.
+  sd = m.state_dict()
+  d_dev = max(rel(sd[k], P64[k]) for k in Dk)
+  print('discriminator parameters after the update vs the oracle\'s own update: worst rel-L2 %.3g' % d_dev)
+  P_at_g = collections.OrderedDict((k, sd[k].double().cpu()) for k in P64)
+  gG, LG = A.grads(P_at_g, batches[1][0].double(), batches[1][1].double(), cfg, {k: v.double() for k, v in masks[1].items()}, 'G')
+  b1 = m._feed()
+  m.g_step(b1)
+  gates_g = read_d_gates(read_gates(), (('fake', st['d_bn_fake'], Bn),))
+  assert m.step == 1
   ls = m.losses()
   assert abs(ls['disc_loss'] - float(LD['d_loss'])) < 1e-4 * max(1, abs(float(LD['d_loss']))), (ls, LD)
   assert abs(ls['gen_loss_GAN'] - float(LG['g_gan'])) < 1e-4 * max(1, abs(float(LG['g_gan']))), (ls, LG)
   assert abs(ls['gen_loss_L1'] - float(LG['g_l1'])) < 1e-4 * max(1, abs(float(LG['g_l1']))), (ls, LG)
-  worst, over = {}, []
-  for net, want in (('d_G', gD), ('g_G', gG)):
-    g32 = None
-    for k, v in want.items():
-      if float(v.norm()) < 1e-9 * (1 + v.numel()) ** 0.5:
-        continue      # a conv bias in front of a batch norm: its gradient is exactly zero, both sides are round-off
-      r = rel(st[net][k], v)
-      worst[k] = r
-      if r > 5e-4:
-        if g32 is None:      # what plain float32 evaluation of the same graph achieves (one evaluation per network)
-          P32 = {kk: vv.float() for kk, vv in (P_at_d if net == 'd_G' else P_at_g).items()}
-          b = 0 if net == 'd_G' else 1
-          g32, _ = A.grads(P32, batches[b][0], batches[b][1], cfg, masks[b], 'D' if net == 'd_G' else 'G')
-        over.append((k, r, rel(g32[k], v)))
+
+  def compare(want_d, want_g):
+    worst = {}
+    for net, want in (('d_G', want_d), ('g_G', want_g)):
+      for k, v in want.items():
+        if float(v.norm()) < 1e-9 * (1 + v.numel()) ** 0.5:
+          continue      # a conv bias in front of a batch norm: its gradient is exactly zero, both sides are round-off
+        worst[k] = rel(st[net][k], v)
+    return worst
+  # (1) END TO END against the free-running float64 oracle.  r3 / r4 saw 1.0e-2 .. 2.7e-2 here on the tensors behind the
+  # 1 x 3-point bottleneck, in two "modes" that followed the order of a few fp32 additions, explained it with ReLU gates
+  # flipping on round-off and held it to a multiple of float32's own distance -- a bar that moved with the observation.  r5
+  # measured the explanation: 25 of 65 million generator gates differ from the float64 forward pass, and freezing them changes
+  # NOTHING (2.6e-2 either way); differentiating the generator at the discriminator parameters this run actually holds after
+  # its update (above) takes the same comparison to 2.9e-3 .. 3.2e-3 -- the distance a float32 torch-CPU evaluation of the
+  # graph has from float64 (3.5e-3).  The two modes were the +-lr of Adam's first step on parameters with round-off
+  # gradients.  Fixed bars: generator 1e-2, discriminator 2e-3; the kernels' precision is pinned by (2).
+  worst = compare(gD, gG)
   top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
-  print('batch norm, one train_loop at 64 x 256: worst gradients rel-L2 vs float64: %s' % ', '.join('%s %.3g' % kv for kv in top))
-  for k, r, r32 in over:
-    print('   over 5e-4: %s %.3g (float32 torch-CPU: %.3g)' % (k, r, r32))
-  # With batch norm the full model is ill-conditioned at this size: encoder_8's output is 1 x 3 points, its batch
-  # statistics span 24 distinct samples, and a ReLU gate of the bottleneck that flips on round-off moves every gradient
-  # that passes it -- a float32 torch-CPU evaluation of the same graph is itself 3.5e-3 .. 4e-3 away from float64 on those
-  # tensors (measured: ours 1.0e-2 .. 1.4e-2, i.e. 3.6 x, uniformly over the tensors behind the bottleneck; the
-  # discriminator's gradients and the three losses meet the 5e-4 / 1e-4 bars).  The bar is therefore relative to what
-  # float32 achieves on the SAME tensor.  Which gates flip differs from run to run (the batch statistics are summed with
-  # atomics), and so does the set of tensors over 5e-4: one run had 40 of them at 3.6 x float32's distance, the next two at
-  # 4.2 x and 5.4 x (1.5e-3).  The ORDER of a few fp32 additions in front of the bottleneck decides it as well: seven settings
-  # that only change into how many K slices some deep / remainder launches are cut (same per-layer error against float64,
-  # tools/micro/deep_numerics.py) landed in two modes, 1.3e-2 .. 1.5e-2 (five of them) and 2.4e-2 .. 2.7e-2 (two), i.e. ~4 x
-  # and ~7.5-7.9 x float32's own distance, with the discriminator's layer_1 bias gradient (float32 itself: 9.7e-4) between
-  # 7.2e-4 and 1.01e-3 (profiles/r04_g_bn_test_summation_order_sensitivity.txt).  Bar: within 12 x of float32's own distance,
-  # or 2e-3, whichever is larger; the discriminator's gradients (well conditioned, but fed by the generator's output) within
-  # 1e-3 or twice float32's own distance.
-  assert all(r <= max(12 * r32, 2e-3) for _, r, r32 in over), over
-  d_over = {k: r32 for k, _, r32 in over if k.startswith('discriminator/')}
-  assert all(r <= max(1e-3, 2 * d_over.get(k, 0.0)) for k, r in worst.items() if k.startswith('discriminator/')), \
-      [kv for kv in worst.items() if kv[0].startswith('discriminator/')]
+  print('batch norm, one train_loop at 64 x 256, free-running oracle: worst gradients rel-L2 vs float64: %s'
+        % ', '.join('%s %.3g' % kv for kv in top))
+  assert all(r <= (2e-3 if k.startswith('discriminator/') else 1e-2) for k, r in worst.items()), top
+  # (2) GATE-FROZEN (VERDICT r4 item 6): the float64 oracle evaluated with the sign pattern of every (leaky) ReLU of the
+  # generator AND of the discriminator's passes (measured: generator gates alone 1.5e-3, with the discriminator's 4.0e-4)
+  # taken from THIS run's forward passes (read back above: pre-activation tensors and the batch-norm affines the
+  # kernels computed) instead of from its own values.  What is compared is then a smooth function of the parameters on both
+  # sides -- no gate can be decided by a round-off error -- and every gradient tensor, the ones behind the 1 x 3 bottleneck
+  # included, has to meet the bar of the model without batch norm: 5e-4.  A kernel that lost precision behind the bottleneck
+  # (the fp16-pair images, the K-slice sums, the batch-norm reductions) fails here, however the gates fall.
+  flips = tot = 0
+  col = []
+  A.build_generator(P_at_g, batches[1][0].double(), cfg, {k: v.double() for k, v in masks[1].items()}, collect=col)
+  for n, c in zip(names, col):
+    flips += int((gates_g[n] != (c > 0)).sum())
+    tot += c.numel()
+  print('gates that differ from the float64 forward pass: %d of %d' % (flips, tot))
+  assert flips <= 1e-4 * tot, (flips, tot)        # the read-back gates ARE the forward pass's, up to round-off ties
+  fD, _ = A.grads(P_at_d, batches[0][0].double(), batches[0][1].double(), cfg, {k: v.double() for k, v in masks[0].items()},
+                  'D', gates=gates_d)
+  fG, _ = A.grads(P_at_g, batches[1][0].double(), batches[1][1].double(), cfg, {k: v.double() for k, v in masks[1].items()},
+                  'G', gates=gates_g)
+  frozen = compare(fD, fG)
+  top = sorted(frozen.items(), key=lambda kv: -kv[1])[:6]
+  print('gate-frozen oracle: worst gradients rel-L2 vs float64: %s' % ', '.join('%s %.3g' % kv for kv in top))
+  assert all(r <= 5e-4 for r in frozen.values()), top
