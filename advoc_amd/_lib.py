@@ -30,7 +30,7 @@ class Tensor4(ctypes.Structure):
 
 class ImageOut(ctypes.Structure):
   """advoc_conv_layer.y_img[k] (include/advoc_hip.h)."""
-  _fields_ = [('img', _p), ('hdr', _p), ('act', _i32), ('reserved', _i32)]
+  _fields_ = [('img', _p), ('hdr', _p), ('act', _i32), ('mode', _i32)]
 
 
 class DxImage(ctypes.Structure):
@@ -93,9 +93,11 @@ PROTOTYPES = {
     'advoc_conv_bias_fusable': (ctypes.c_int, [_p]),
     'advoc_conv_emits_images': (ctypes.c_int, [_p]),
     'advoc_conv_emits_dx_image': (ctypes.c_int, [_p]),
+    'advoc_conv_gates_on_image': (ctypes.c_int, [_p]),
     'advoc_segmented_amax_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p]),
     'advoc_conv_weight_image_desc': (ctypes.c_int, [_p, _i32, _p]),
     'advoc_weight_images_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p, _p]),
+    'advoc_weight_images_l1_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p]),
     'advoc_conv_make_image': (ctypes.c_int, [_p, _i32, _p, _p]),
     'advoc_conv_forward': (ctypes.c_int, [_p, _p]),
     'advoc_conv_backward_data': (ctypes.c_int, [_p, _p, _p, _p, _i32, _i32, _p]),

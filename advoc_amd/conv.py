@@ -102,6 +102,12 @@ class Layer(object):
   # tensor to refit from) and the fp32 dx0 is NOT written: the image pass of the layer below (a read and a write of the
   # tensor) disappears at no extra store in the epilogue.  Needs reuse_images (the train step's guarantees).
   dx_bounded = os.environ.get('ADVOC_DX_BOUNDED', '1') == '1'
+  # (r5) ADVOC_Y_IMAGE_ONLY=0 turns it off: a layer whose output has ONE reader (add_image_consumer(..., exclusive=True)) that
+  # reads it as an operand image and gates its backward-data pass on that image's signs (a patch kernel) writes the IMAGE
+  # ONLY, under a scale from an a-priori bound of |y| (max|x| max|w| taps K + max|b|): the fp32 tensor -- half the bytes the
+  # forward epilogue stores, twice the bytes the consumer's gating reads -- is never written.  Where the producer's kernel
+  # can (advoc_conv_emits_images() == 2: the <= 2-input-channel matrix kernel, i.e. the discriminator's layer_1).
+  y_image_only = os.environ.get('ADVOC_Y_IMAGE_ONLY', '1') == '1'
 
   @staticmethod
   def _workspace_for(device, nbytes):
@@ -208,6 +214,11 @@ class Layer(object):
     self._dy_role = None
     self._names = {}
     self._consumers = []           # [(consumer layer, source index)] whose x_img this layer's forward can write
+    self._exclusive = False        # the one consumer is the only reader of y (add_image_consumer)
+    self._x_final = False          # x_img was written under an a-priori scale since the last forward: no refit check
+    self._x_gates = False          # ... and the fp32 input was not written: backward_data gates on the image
+    self._gates_ok = None
+    self._w_l1 = 0                 # ADVOC_IMG_W_L1 when set_weight_image was given 32-word headers
     self._emits = None             # advoc_conv_emits_images(), asked once
     self._x_emitted = set()        # sources of x_img written by their producers since the last forward
     self._db_done_for = None
@@ -246,10 +257,12 @@ class Layer(object):
                'advoc_conv_weight_image_desc')
     return tuple(int(v) for v in out) if out[4] > 0 else None
 
-  def set_weight_image(self, direction, img_ptr, hdr_ptr):
-    """Persistent weight image of this direction (advoc_weight_images_f32 keeps it current; None: per-call images)."""
+  def set_weight_image(self, direction, img_ptr, hdr_ptr, l1=False):
+    """Persistent weight image of this direction (advoc_weight_images_f32 keeps it current; None: per-call images).
+    l1=True: the headers are the 32-word ones of advoc_weight_images_l1_f32 (per-tap row-L1 maxima: ADVOC_IMG_W_L1)."""
     self.struct.w_img[direction] = img_ptr
     self.struct.w_img_hdr[direction] = hdr_ptr
+    self._w_l1 = 512 if l1 else 0
 
   def kernel_name(self, direction):
     """Kernel template instance this layer launches for direction 0 fwd / 1 bwd-data / 2 bwd-weight."""
@@ -317,24 +330,29 @@ class Layer(object):
         out.append(hdr)
     return out
 
-  def add_image_consumer(self, consumer, source):
+  def add_image_consumer(self, consumer, source, exclusive=False):
     """`consumer` (a Layer) reads this layer's output y as its input `source` (0: x0, 1: x1): from the second step on this
-    layer's forward writes the consumer's operand image itself."""
+    layer's forward writes the consumer's operand image itself.  exclusive=True: the caller guarantees that NOTHING else
+    reads y (no other layer, no summary, no batch norm): where the kernels allow, y then exists as that image only
+    (Layer.y_image_only)."""
     want = consumer.x0 if source == 0 else consumer.x1
     if want is None or want.data_ptr() != self.y.data_ptr() or tuple(want.shape) != tuple(self.y.shape):
       raise _lib.AdvocHipError('the consumer\'s input {} is not this layer\'s output'.format(source))
     if len(self._consumers) >= 2:
       raise _lib.AdvocHipError('at most two image consumers per layer')
     self._consumers.append((consumer, source))
+    self._exclusive = bool(exclusive) and len(self._consumers) == 1
 
   def _emit_targets(self):
     """[(slot, consumer, source)] this forward call writes images for."""
     if not (Layer.emit_images and self.delayed_scale and self._consumers):
       return []
     if self._emits is None:
-      self._emits = bool(_lib.load().advoc_conv_emits_images(ctypes.byref(self.struct)))
+      self._emits = int(_lib.load().advoc_conv_emits_images(ctypes.byref(self.struct)))
     if not self._emits:
       return []
+    if self._image_only_consumer() is not None:
+      return [(0,) + self._consumers[0]]        # under the a-priori scale: no magnitude history needed
     out = []
     for k, (c, src) in enumerate(self._consumers):
       cs = c.struct
@@ -345,6 +363,20 @@ class Layer(object):
       out.append((k, c, src))
     return out
 
+  def _image_only_consumer(self):
+    """The one consumer this layer's output exists for as an image only (Layer.y_image_only), or None."""
+    if not (Layer.y_image_only and self._exclusive and self._emits == 2 and self.reuse_images and len(self._consumers) == 1):
+      return None
+    c, src = self._consumers[0]
+    cs = c.struct
+    if src != 0 or c.x1 is not None or not (c.reuse_images and cs.x_img) or cs.in_scale or cs.in_mask:
+      return None
+    if not c.kernel_name(1).startswith('patch_gemm_h3_kernel') or 'h3' not in c.kernel_name(0):
+      return None
+    if c._gates_ok is None:      # the consumer's backward-data launch must be one that can gate on the image: asked once
+      c._gates_ok = bool(_lib.load().advoc_conv_gates_on_image(ctypes.byref(cs)))
+    return c if c._gates_ok else None
+
   def _delayed_bits(self):
     if not self.delayed_scale:
       return 0
@@ -353,19 +385,24 @@ class Layer(object):
   def forward(self):
     nsrc = 2 if self.x1 is not None else 1
     if len(self._x_emitted) == nsrc and self.struct.x_img:
-      flags = 1 | 16                       # ADVOC_IMG_X_CURRENT | ADVOC_IMG_X_EMITTED: refit check instead of an image pass
+      # ADVOC_IMG_X_CURRENT | ADVOC_IMG_X_EMITTED (refit check instead of an image pass) or | ADVOC_IMG_X_BOUNDED (final)
+      flags = 1 | (128 if self._x_final else 16)
     else:
       flags = self._timed_image(0)
+      self._x_final = self._x_gates = False
     self._x_emitted = set()
     targets = self._emit_targets()
+    only = self._image_only_consumer() if targets else None
     for k in (0, 1):
       self.struct.y_img[k].img = None
+      self.struct.y_img[k].mode = 0
     for k, c, src in targets:
       off = 0 if src == 0 else (4 * c.x0.numel() + 255) // 256 * 256
       self.struct.y_img[k].img = c.struct.x_img + off
       self.struct.y_img[k].hdr = c.struct.x_hdr
       self.struct.y_img[k].act = c.struct.in_act
-    self.struct.img_flags = flags | self._delayed_bits()
+      self.struct.y_img[k].mode = 3 if only is not None else 0      # ADVOC_Y_BOUNDED | ADVOC_Y_IMAGE_ONLY
+    self.struct.img_flags = flags | self._delayed_bits() | self._w_l1
     try:
       # (the consumers' operand images this launch writes: 2 fp16 terms = 4 bytes per element and consumer)
       self._run(0, lambda: _lib.check(
@@ -375,8 +412,10 @@ class Layer(object):
       self.struct.img_flags = 0
       for k in (0, 1):
         self.struct.y_img[k].img = None
+        self.struct.y_img[k].mode = 0
     for k, c, src in targets:
       c._x_emitted.add(src)
+      c._x_final = c._x_gates = only is not None
     if self.struct.x_img and 'h3' in self.kernel_name(0):
       self._x_built = True
     # the image-based forward kernel has just left the input image in x_img
@@ -464,7 +503,8 @@ class Layer(object):
         flags = 2 | (64 if emitted[2] else 32)
       else:
         flags = self._timed_image(1, dy)
-      self.struct.img_flags = flags | self._delayed_bits()
+      # (ADVOC_IMG_X_GATES: the fp32 input was never written, its producer left the image only)
+      self.struct.img_flags = flags | self._delayed_bits() | (256 if self._x_gates else 0) | self._w_l1
       self._run(1, lambda: _lib.check(_lib.load().advoc_conv_backward_data(
           ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(dx0), _lib.ptr(dx1), int(accum0),
           int(accum1), _lib.stream()), 'advoc_conv_backward_data'),

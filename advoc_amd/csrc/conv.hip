@@ -342,7 +342,15 @@ extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stre
     p.oimg[k].slope = L->y_img[k].act == ADVOC_ACT_LRELU02 ? 0.2f : (L->y_img[k].act == ADVOC_ACT_RELU ? 0.f : 1.f);
   }
   p.w_amax = L->w_amax;
-  p.w_img = L->w_img[0]; p.w_img_hdr = L->w_img_hdr[0];
+  p.w_img = L->w_img[0]; p.w_img_hdr = L->w_img_hdr[0]; p.w_img_l1 = (L->img_flags & ADVOC_IMG_W_L1) != 0;
+  p.a_img_bounded = (L->img_flags & ADVOC_IMG_X_BOUNDED) != 0;
+  const int ymode = L->y_img[0].img ? L->y_img[0].mode : 0;
+  if ((ymode & ADVOC_Y_IMAGE_ONLY) && !(ymode & ADVOC_Y_BOUNDED)) return ADVOC_ERR_UNSUPPORTED;
+  if (ymode & ADVOC_Y_BOUNDED) {
+    if (L->y_img[1].img) return ADVOC_ERR_UNSUPPORTED;
+    p.oimg_bounded = 1;
+    p.d0_no_store = (ymode & ADVOC_Y_IMAGE_ONLY) ? 1 : 0;
+  }
   int emits = 0;
   if (p.oimg[0].img || p.oimg[1].img) {
     // (a launch outside the image kernels would silently ignore y_img and leave the consumers with stale images)
@@ -351,7 +359,27 @@ extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stre
     q.emit_report = &emits;
     rc = run_gather(q, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes);
     if (rc != ADVOC_OK) return rc;
-    if (!emits) return ADVOC_ERR_UNSUPPORTED;
+    if (!emits || (p.oimg_bounded && emits != 5)) return ADVOC_ERR_UNSUPPORTED;
+  }
+  const char* fwd_name = nullptr;
+  if (p.oimg_bounded) {
+    GatherGemmParams q = p;
+    rc = run_gather(q, b_kn, nullptr, &fwd_name, L->workspace, L->workspace_bytes);
+    if (rc != ADVOC_OK) return rc;
+  }
+  if (p.oimg_bounded && fwd_name && !strstr(fwd_name, "_h3_kernel")) {
+    // max |input| for the bound: the inputs of the thin matrix kernel are fp32 tensors without an image (1-2 channels): a
+    // magnitude pass over each source, into the reserved word 7 of the header the launch writes (the image kernels read the
+    // magnitude of their input image from its header)
+    if (L->x0.w_pitch != L->x0.w || (L->x1.p && L->x1.w_pitch != L->x1.w)) return ADVOC_ERR_UNSUPPORTED;
+    unsigned* word = L->y_img[0].hdr + 7;
+    hipError_t e = hipMemsetAsync(word, 0, 4, as_stream(stream));
+    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    rc = launch_amax_any(L->x0.p, (int64_t)L->x0.n * L->x0.h * L->x0.w_pitch * L->x0.c, word, as_stream(stream));
+    if (rc == ADVOC_OK && L->x1.p)
+      rc = launch_amax_any(L->x1.p, (int64_t)L->x1.n * L->x1.h * L->x1.w_pitch * L->x1.c, word, as_stream(stream));
+    if (rc != ADVOC_OK) return rc;
+    p.a_amax = word;
   }
   return run_gather(p, b_kn, as_stream(stream), nullptr, L->workspace, L->workspace_bytes);
 }
@@ -362,13 +390,21 @@ extern "C" int advoc_conv_emits_images(const advoc_conv_layer* L) {
   bool b_kn;
   if (build_forward(L, p, b_kn) != ADVOC_OK) return 0;
   p.w_amax = L->w_amax;
-  p.w_img = L->w_img[0]; p.w_img_hdr = L->w_img_hdr[0];
+  p.w_img = L->w_img[0]; p.w_img_hdr = L->w_img_hdr[0]; p.w_img_l1 = (L->img_flags & ADVOC_IMG_W_L1) != 0;
   p.a_img_out = L->x_img; p.a_hdr_out = L->x_img ? L->x_hdr : nullptr;
   int emits = 0;
   const char* nm = nullptr;
   p.emit_report = &emits;
   if (run_gather(p, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes) != ADVOC_OK) return 0;
-  return emits;
+  if (!emits) return 0;
+  // 2: also under the a-priori scale, fp32 tensor optional (ADVOC_Y_BOUNDED / ADVOC_Y_IMAGE_ONLY)
+  GatherGemmParams q = p;
+  int e2 = 0;
+  q.emit_report = &e2;
+  q.oimg_bounded = 1;
+  q.oimg[0].img = reinterpret_cast<uint16_t*>(L->y.p); q.oimg[0].hdr = reinterpret_cast<unsigned*>(L->y.p);
+  if (run_gather(q, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes) == ADVOC_OK && e2 == 5) return 2;
+  return 1;
 }
 
 extern "C" int advoc_conv_bias_fusable(const advoc_conv_layer* L) {
@@ -445,7 +481,7 @@ int dx_image_launch(const advoc_conv_layer* L, const float* dy, float* dx0, floa
   if (p.y_mask || p.d[0].gmask || p.d[0].accum || p.d[0].c % 64 || p.d[0].c > 1024 || !image_colsum_ok(p.d[0].c)) return 0;
   p.a_img_out = L->dy_img; p.a_hdr_out = L->dy_img ? L->dy_hdr : nullptr;
   p.w_amax = L->w_amax;
-  p.w_img = L->w_img[1]; p.w_img_hdr = L->w_img_hdr[1];
+  p.w_img = L->w_img[1]; p.w_img_hdr = L->w_img_hdr[1]; p.w_img_l1 = (L->img_flags & ADVOC_IMG_W_L1) != 0;
   p.oimg[0].img = reinterpret_cast<uint16_t*>(dx0);       // (any non-null value: asks the launcher what it would do)
   p.oimg[0].hdr = reinterpret_cast<unsigned*>(dx0);
   int emits = 0;
@@ -478,9 +514,20 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
   p.a_img_delayed = (L->img_flags & ADVOC_IMG_DY_DELAYED) != 0;
   p.a_img_emitted = (L->img_flags & ADVOC_IMG_DY_EMITTED) != 0;
   p.a_img_bounded = (L->img_flags & ADVOC_IMG_DY_BOUNDED) != 0;
+  if (L->img_flags & ADVOC_IMG_X_GATES) {
+    // the fp32 inputs were never written: gate on the sign of x_img (source 1 behind source 0 at its 256-byte-rounded size)
+    if (!L->x_img || L->in_scale || L->in_mask) return ADVOC_ERR_UNSUPPORTED;
+    const int64_t b0 = ((int64_t)4 * L->x0.n * L->x0.h * L->x0.w_pitch * L->x0.c + 255) / 256 * 256;
+    p.d[0].ximg = L->x_img;
+    p.d[1].ximg = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(L->x_img) + b0);
+    const char* nm = nullptr;
+    rc = run_gather(p, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes);
+    if (rc != ADVOC_OK) return rc;
+    if (!nm || !strstr(nm, "patch_gemm_h3_kernel")) return ADVOC_ERR_UNSUPPORTED;
+  }
   p.a_colsum = L->dy_img ? L->db_fused : nullptr;       // the bias gradient rides in the dy image pass (igemm_h3.hip)
   p.w_amax = L->w_amax;
-  p.w_img = L->w_img[1]; p.w_img_hdr = L->w_img_hdr[1];
+  p.w_img = L->w_img[1]; p.w_img_hdr = L->w_img_hdr[1]; p.w_img_l1 = (L->img_flags & ADVOC_IMG_W_L1) != 0;
   if (L->dx_img.img) {
     // the lower layer's output-gradient image from this call's epilogue (advoc_conv_layer.dx_img)
     if (!L->dx_img.hdr || (L->dx_img.colsum && !L->dx_img.table)) return ADVOC_ERR_NULL;
@@ -527,6 +574,21 @@ extern "C" int advoc_conv_emits_dx_image(const advoc_conv_layer* L) {
   if (validate_layer(L) != ADVOC_OK) return 0;
   float dummy = 0.f;
   return dx_image_launch(L, &dummy, &dummy, L->x1.p ? &dummy : nullptr, 0, 0);
+}
+
+extern "C" int advoc_conv_gates_on_image(const advoc_conv_layer* L) {
+  if (validate_layer(L) != ADVOC_OK || !L->x_img || L->in_scale || L->in_mask || L->in_act == ADVOC_ACT_NONE) return 0;
+  GatherGemmParams p;
+  bool b_kn;
+  float dummy = 0.f;
+  if (build_backward_data(L, &dummy, &dummy, L->x1.p ? &dummy : nullptr, 0, 0, p, b_kn) != ADVOC_OK) return 0;
+  p.a_img_out = L->dy_img; p.a_hdr_out = L->dy_img ? L->dy_hdr : nullptr;
+  p.w_amax = L->w_amax;
+  p.w_img = L->w_img[1]; p.w_img_hdr = L->w_img_hdr[1]; p.w_img_l1 = (L->img_flags & ADVOC_IMG_W_L1) != 0;
+  p.d[0].ximg = L->x_img; p.d[1].ximg = L->x_img;
+  const char* nm = nullptr;
+  if (run_gather(p, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes) != ADVOC_OK) return 0;
+  return nm && strstr(nm, "patch_gemm_h3_kernel") ? 1 : 0;
 }
 
 extern "C" int64_t advoc_conv_wgrad_ws_bytes(const advoc_conv_layer* L) {

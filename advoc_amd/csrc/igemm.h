@@ -39,6 +39,10 @@ struct GemmDest {
   const float* gshift;
   const uint8_t* gmask;
   float gmask_scale;
+  // (r5) != null: the tensor behind xpre was never written -- its producer left only the operand image of it (the consuming
+  // layer's x_img: act(x) 2^s as fp16 pairs) -- and the activation gradient is gated by the SIGN of the image's high plane
+  // (h0 > 0 <=> x > 0 up to values below 2^-25 of the scaled range): 2 bytes per value instead of 4.  Patch kernels only.
+  const uint16_t* ximg;
 };
 
 struct GatherGemmParams {
@@ -65,6 +69,7 @@ struct GatherGemmParams {
   const unsigned* w_amax;  // optional: float bits of max |w| already on the device (advoc_segmented_amax_f32)
   const uint16_t* w_img;   // optional: the CURRENT fp16 pair image of w for this direction (advoc_weight_images_f32) and
   const unsigned* w_img_hdr;   // its 4-word header ([1] = 2^-s): the call builds no weight image
+  int w_img_l1;            // != 0: w_img_hdr is an ADVOC_WEIGHT_HDR_L1_WORDS-word header (advoc_weight_images_l1_f32)
   int n_total;
   int k_order;             // 0: channel slices inner, taps outer; 1: taps inner
   int n_valid;             // 0 = n_total; else only the first n_valid columns exist in w / are stored
@@ -115,6 +120,8 @@ struct GatherGemmParams {
   // the fp32 tensor to rebuild the image from; the largest magnitude actually written is raised in oimg[0].hdr[0] (zeroed
   // by the launcher), 2^-s goes to hdr[1].  a_amax / b_hdr[0] = float bits of max |A operand| / max |w| on the device.
   int oimg_bounded;
+  const unsigned* w_l1;    // persistent weight header with per-tap row-L1 maxima (advoc_weight_images_l1_f32: word 2 = taps,
+                           // word 3 = K, words 4.. = max_n sum_k |w[tap][n][k]|), or null: the bound uses max|w| * taps * K
   const unsigned* a_amax;
   const unsigned* obound_add;
   int d0_no_store;         // != 0: destination 0 exists as the image only, its fp32 tensor is not written

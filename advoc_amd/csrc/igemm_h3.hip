@@ -702,11 +702,23 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   if (p.emit_report) *p.emit_report = 1;
   // (r5) the output-gradient image of the layer below under the a-priori scale (GatherGemmParams::oimg_bounded): the patch
   // kernels' lean backward-data instances, grids without remainder columns
-  if (p.oimg_bounded) {
+  // gates from the consuming layer's operand image (GemmDest::ximg): the patch kernels' backward-data instances, no
+  // remainder columns
+  if ((p.d[0].ximg || p.d[1].ximg) && (patch_nph == 0 || geom.rem != 0 || p.n_total == 32)) return ADVOC_ERR_UNSUPPORTED;
+  const bool bounded_fwd = p.oimg_bounded && p.grad_act == ADVOC_ACT_NONE && !p.d[0].xpre && !p.d[1].p;
+  if (p.oimg_bounded && !bounded_fwd) {
     const bool ok = patch_nph != 0 && geom.rem == 0 && p.oimg[0].img && p.oimg[0].hdr && !p.oimg[1].img && !p.y_mask &&
                     !p.d[0].gmask && !p.d[1].gmask && !p.d[0].accum && !p.d[1].accum && p.grad_act != ADVOC_ACT_NONE &&
                     (!p.ocolsum_out || (p.ocolsum_table && p.d[0].c <= 1024));
     if (p.emit_report) *p.emit_report = ok ? 3 : 0;
+    if (!ok) return ADVOC_ERR_UNSUPPORTED;
+  }
+  if (bounded_fwd) {
+    // a FORWARD launch that writes ONE consumer's image under the a-priori scale (fp32 output optional): patch kernels, grids
+    // without remainder columns, no dropout mask on the output
+    const bool ok = patch_nph != 0 && geom.rem == 0 && p.oimg[0].img && p.oimg[0].hdr && !p.oimg[1].img && !p.y_mask &&
+                    !p.d[0].accum && p.n_total != 32;
+    if (p.emit_report) *p.emit_report = ok ? 5 : 0;
     if (!ok) return ADVOC_ERR_UNSUPPORTED;
   }
   p.k_order = tuning().igemm_korder >= 0 ? tuning().igemm_korder : 1;
@@ -719,9 +731,11 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   char* img_home = p.a_img_out ? reinterpret_cast<char*>(p.a_img_out) : ws + hdr_bytes + wq_bytes;
   uint16_t* img0 = reinterpret_cast<uint16_t*>(img_home);
   uint16_t* img1 = reinterpret_cast<uint16_t*>(img_home + i0_bytes);
+  p.w_l1 = nullptr;
   if (p.w_img && p.w_img_hdr) {          // persistent, current weight image (advoc_weight_images_f32)
     wq = const_cast<uint16_t*>(p.w_img);
     hdr_b = const_cast<unsigned*>(p.w_img_hdr);
+    if (p.w_img_l1) p.w_l1 = hdr_b;      // ... with the per-tap row-L1 maxima behind it (advoc_weight_images_l1_f32)
   }
   p.a_hdr = hdr_a; p.b_hdr = hdr_b;
   p.wq = wq;
@@ -769,6 +783,11 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   // above wrote under its own bound or of a per-call header, word 2 ("largest magnitude of the image in the buffer") of a
   // persistent header behind its rotation
   p.a_amax = hdr_a + ((p.a_img_bounded || !p.a_hdr_out) ? 0 : 2);
+  if (patch_nph && bounded_fwd && !name_only) {
+    hipError_t e = hipMemsetAsync(p.oimg[0].hdr, 0, 4, stream);      // the magnitude accumulator of the image
+    if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    return launch_patch_gemm_h3(p, geom, patch_nph, stream, nullptr);
+  }
   if (patch_nph && p.oimg_bounded && !name_only) {
     hipError_t e = hipMemsetAsync(p.oimg[0].hdr, 0, 4, stream);
     if (e == hipSuccess && p.ocolsum_out)

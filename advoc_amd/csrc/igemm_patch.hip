@@ -144,7 +144,10 @@ struct PCfg {
 // launch pays for the image arithmetic of the consumers it has and no more
 // HALF (NPH = 4 only): a 32-column problem on the 64-column tile -- the wave's second 32-column block does not exist: no
 // fragments, no MFMAs, no epilogue for it, and the waves whose stage rows are those columns issue no weight DMA
-template <int NPH, int W, int BWD, int NE, int HALF = 0>
+// GI (backward-data): the activation gradient is gated by the sign of the consuming layer's operand image (GemmDest::ximg:
+// the fp32 pre-activation tensor was never written) -- 8 bytes per 4 values instead of 16, no batch-norm affine (the image
+// has it applied)
+template <int NPH, int W, int BWD, int NE, int HALF = 0, int GI = 0>
 __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, const PatchGeom& g) {
   using C = PCfg<NPH, W>;
   static_assert(!HALF || (NPH == 4 && C::NT == 2), "half tiles exist for the four-phase instance");
@@ -200,9 +203,17 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   float eup0_ = 1.f;
   if (emit0) {
     if (BWD) {
-      float bound = __uint_as_float(*p.a_amax) * __uint_as_float(p.b_hdr[0]) * (float)(p.ntaps * ktot);
+      float bound = __uint_as_float(*p.a_amax) * emit_weight_bound(p, ktot);
       if (p.obound_add) bound += __uint_as_float(*p.obound_add);
       eup0_ = emit_up_scale_bounded(bound);
+    } else if (p.oimg_bounded) {
+      // forward under the a-priori scale: |y| <= max|act(x)| max|w| taps K + max|b| (the consumer's activation has slope <= 1)
+      float bm = 0.f;
+      if (p.bias)
+        for (int n = lane; n < p.n_total; n += 64) bm = fmaxf(bm, fabsf(p.bias[n]));
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) bm = fmaxf(bm, __shfl_xor(bm, off, 64));
+      eup0_ = emit_up_scale_bounded(__uint_as_float(*p.a_amax) * emit_weight_bound(p, ktot) + bm);
     } else {
       eup0_ = emit_up_scale(p.oimg[0].hdr[2]);
     }
@@ -690,6 +701,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     float* const dp = di ? p.d[1].p : p.d[0].p;
     if (dp == nullptr || nt0 >= p.n_total) continue;
     const float* const d_xpre = di ? p.d[1].xpre : p.d[0].xpre;
+    const uint16_t* const d_ximg = di ? p.d[1].ximg : p.d[0].ximg;
     const uint8_t* const d_gmask = di ? p.d[1].gmask : p.d[0].gmask;
     const float d_gmask_scale = di ? p.d[1].gmask_scale : p.d[0].gmask_scale;
     const int d_c = di ? p.d[1].c : p.d[0].c;
@@ -716,11 +728,12 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     constexpr unsigned kOob = 0xffffff00u;              // >= num_records of every descriptor below
     // (d0_no_store: destination 0 exists as the image only -- every fp32 store to it is dropped by the range check)
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
-        dp, 0, (BWD && emit0 && di == 0 && p.d0_no_store) ? 0u : kOob, 0x00020000);
+        dp, 0, (emit0 && di == 0 && p.d0_no_store) ? 0u : kOob, 0x00020000);
     const bool has_mask = BWD ? d_gmask != nullptr : p.y_mask != nullptr;
     const uint8_t* const mask_p = BWD ? d_gmask : p.y_mask;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(use_grad ? d_xpre : dp), 0, use_grad ? kOob : 0u, 0x00020000);
+        GI ? reinterpret_cast<void*>(const_cast<uint16_t*>(use_grad ? d_ximg : reinterpret_cast<const uint16_t*>(dp)))
+           : reinterpret_cast<void*>(const_cast<float*>(use_grad ? d_xpre : dp)), 0, use_grad ? kOob : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(
         has_mask ? const_cast<uint8_t*>(mask_p) : reinterpret_cast<uint8_t*>(dp), 0, has_mask ? kOob : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(dp, 0, (BWD && d_accum) ? kOob : 0u, 0x00020000);
@@ -740,10 +753,15 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       const int pix = s_pix[di * PW_ + (I) * 32 + trow + 8 * ps];                                         \
       off[ps] = pix < 0 ? kOob : (unsigned)(pix * d_c + ch);                                              \
       const unsigned ob = pix < 0 ? kOob : off[ps] * 4u;                                                  \
-      if (BWD) {                                                                                          \
+      if (BWD && GI) {       /* element e -> image halves (e >> 5) * 64 + (e & 31), high plane: 8 bytes for 4 channels */ \
+        typedef unsigned u32x2g __attribute__((ext_vector_type(2)));                                      \
+        const unsigned ib = pix < 0 ? kOob : (((off[ps] >> 5) << 6) + (off[ps] & 31)) * 2u;               \
+        const u32x2g t_ = __builtin_amdgcn_raw_buffer_load_b64(rs_x, ib, 0, 0);                           \
+        xp[ps].x = t_.x; xp[ps].y = t_.y;                                                                 \
+      } else if (BWD) {                                                                                   \
         xp[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ob, 0, 0);                                   \
-        if (!kLean) old[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, ob, 0, 0);                      \
       }                                                                                                   \
+      if (BWD && !kLean) old[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, ob, 0, 0);                 \
       if (!kLean) mk[ps] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, off[ps], 0, 0);                     \
     }
     ADVOC_P3_PRELOAD(0);
@@ -759,7 +777,12 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
         v[ps] = *reinterpret_cast<const float4*>(T + (trow + 8 * ps) * LDT + 4 * tq);
         v[ps].x = fmaf(v[ps].x, unscale, bias4.x); v[ps].y = fmaf(v[ps].y, unscale, bias4.y);
         v[ps].z = fmaf(v[ps].z, unscale, bias4.z); v[ps].w = fmaf(v[ps].w, unscale, bias4.w);
-        if (use_grad) {
+        if (GI && use_grad) {
+          // fp16 h > 0 <=> its bits, minus one, are below 0x7fff as an unsigned (zero, negatives and -0 fall out)
+          const unsigned lo = xp[ps].x, hi = xp[ps].y;
+          v[ps].x *= ((lo & 0xffffu) - 1u) < 0x7fffu ? 1.f : gslope; v[ps].y *= ((lo >> 16) - 1u) < 0x7fffu ? 1.f : gslope;
+          v[ps].z *= ((hi & 0xffffu) - 1u) < 0x7fffu ? 1.f : gslope; v[ps].w *= ((hi >> 16) - 1u) < 0x7fffu ? 1.f : gslope;
+        } else if (use_grad) {
           float4 x = make_float4(__uint_as_float(xp[ps].x), __uint_as_float(xp[ps].y), __uint_as_float(xp[ps].z),
                                  __uint_as_float(xp[ps].w));
           x.x = x.x * gs4.x + gh4.x; x.y = x.y * gs4.y + gh4.y; x.z = x.z * gs4.z + gh4.z; x.w = x.w * gs4.w + gh4.w;
@@ -817,9 +840,9 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   if (emit1) emit_finish(p.oimg[1], eup1, evmax1);
 }
 
-template <int NPH, int BWD, int NE, int HALF = 0>
+template <int NPH, int BWD, int NE, int HALF = 0, int GI = 0>
 __global__ __launch_bounds__(512, 1) void patch_gemm_h3_kernel(const GatherGemmParams p, const PatchGeom g) {
-  patch_gemm_h3_body<NPH, 8, BWD, NE, HALF>(p, g);
+  patch_gemm_h3_body<NPH, 8, BWD, NE, HALF, GI>(p, g);
 }
 
 template <int NPH, int BWD, int NE = 0>
@@ -842,6 +865,11 @@ int launch_patch(const GatherGemmParams& p_in, const PatchGeom& g, hipStream_t s
     return ADVOC_OK;
   }
   auto kern = (NPH == 4 && p.n_total == 32) ? patch_gemm_h3_kernel<NPH, BWD, NE, NPH == 4 ? 1 : 0> : patch_gemm_h3_kernel<NPH, BWD, NE>;
+  if (p.d[0].ximg) {       // (r5) gates from the consuming layer's image: both destinations, full tiles, backward-data
+    if (!BWD || (NPH == 4 && p.n_total == 32) || (p.d[1].p && !p.d[1].ximg) || p.d[0].gscale || p.d[1].gscale)
+      return ADVOC_ERR_UNSUPPORTED;
+    kern = patch_gemm_h3_kernel<NPH, BWD, NE, 0, BWD ? 1 : 0>;
+  }
   const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
   if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }

@@ -426,16 +426,23 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 // int64 in device memory {w offset from base (elements), taps, n_total, ktot, b_kn, index into the magnitude table, byte
 // offset of the image in the pool, index of its 4-word header}; same arithmetic and layout as split_weights_kernel's
 // fp16-pair form, the scale from the arena's magnitude table (advoc_segmented_amax_f32).
+// (r5) l1 != null (hdr_words >= 4 + kL1Taps): also sum_k |w[tap][n][k]| for every (tap, n) of the image, as 2^40 fixed point
+// (rounded up; integer atomics: the sums do not depend on the order) in l1[image][tap][n], n < kL1Cols -- what
+// weight_l1_finalize_kernel turns into the per-tap maxima the a-priori bounds of igemm_patch.hip read from the header
+constexpr int kL1Taps = 16, kL1Cols = 1024;
 __global__ __launch_bounds__(256) void weight_images_kernel(const float* __restrict__ base,
                                                             const unsigned* __restrict__ amax,
                                                             const int64_t* __restrict__ table,
-                                                            char* __restrict__ pool, unsigned* __restrict__ hdrs) {
+                                                            char* __restrict__ pool, unsigned* __restrict__ hdrs,
+                                                            int hdr_words, unsigned long long* __restrict__ l1) {
   __shared__ float tile[32][33];
   const int64_t* row = table + 8 * (int64_t)blockIdx.y;
   const float* w = base + row[0];
   const int taps = (int)row[1], n_total = (int)row[2], ktot = (int)row[3], b_kn = (int)row[4];
   uint16_t* wq = reinterpret_cast<uint16_t*>(pool + row[6]);
-  unsigned* hdr = hdrs + 4 * row[7];
+  unsigned* hdr = hdrs + (int64_t)hdr_words * row[7];
+  const bool want_l1 = l1 != nullptr && taps <= kL1Taps && n_total <= kL1Cols;
+  unsigned long long* l1_img = l1 + (int64_t)blockIdx.y * kL1Taps * kL1Cols;
   const int tk = ktot / 32, tn = (n_total + 31) / 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const float up = up_scale(amax[row[5]]);
@@ -473,9 +480,48 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const float* __restr
         q[0] = __half_as_ushort(a0);
         q[32] = __half_as_ushort(a1);
       }
+      if (want_l1) {       // (uniform: the 32 lanes tx of a half wave hold the 32 k of one n)
+        float sa = n < n_total ? fabsf(tile[tx][ty + 8 * i]) : 0.f;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) sa += __shfl_xor(sa, off, 64);
+        if (tx == 0 && n < n_total)
+          atomicAdd(l1_img + (int64_t)t * kL1Cols + n, __double2ull_ru((double)sa * 1.0000005 * 1099511627776.0));
+      }
     }
     __syncthreads();
   }
+}
+
+// hdr[4 + t] = float bits of max over n of l1[image][t][n] 2^-40 (rounded up), hdr[2] = the number of taps (the flag the
+// kernels test), hdr[3] = K; the sums are cleared on the way: the scratch is all zeros between launches
+__global__ __launch_bounds__(256) void weight_l1_finalize_kernel(const int64_t* __restrict__ table, unsigned* __restrict__ hdrs,
+                                                                 unsigned long long* __restrict__ l1) {
+  __shared__ unsigned long long red[256];
+  const int64_t* row = table + 8 * (int64_t)blockIdx.x;
+  const int taps = (int)row[1], n_total = (int)row[2], ktot = (int)row[3];
+  unsigned* hdr = hdrs + (int64_t)ADVOC_WEIGHT_HDR_L1_WORDS * row[7];
+  if (taps > kL1Taps || n_total > kL1Cols) {
+    if (threadIdx.x == 0) hdr[2] = 0u;
+    return;
+  }
+  unsigned long long* img = l1 + (int64_t)blockIdx.x * kL1Taps * kL1Cols;
+  for (int t = 0; t < taps; ++t) {
+    unsigned long long m = 0;
+    for (int n = threadIdx.x; n < n_total; n += 256) {
+      const unsigned long long v = img[(int64_t)t * kL1Cols + n];
+      img[(int64_t)t * kL1Cols + n] = 0;
+      m = v > m ? v : m;
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s_ = 128; s_ > 0; s_ >>= 1) {
+      if ((int)threadIdx.x < s_) red[threadIdx.x] = red[threadIdx.x + s_] > red[threadIdx.x] ? red[threadIdx.x + s_] : red[threadIdx.x];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) hdr[4 + t] = __float_as_uint(__double2float_ru((double)red[0] * (1.0 / 1099511627776.0)));
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { hdr[2] = (unsigned)taps; hdr[3] = (unsigned)ktot; }
 }
 
 int grid_for(int64_t items, int per_block) {
@@ -640,7 +686,24 @@ extern "C" int advoc_weight_images_f32(const float* base, const uint32_t* amax, 
   if (count > 65535) return ADVOC_ERR_UNSUPPORTED;
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(advoc::weight_images_kernel, dim3(256, (unsigned)count), dim3(256), 0, advoc::as_stream(stream), base,
-                     amax, table, reinterpret_cast<char*>(pool), hdrs);
+                     amax, table, reinterpret_cast<char*>(pool), hdrs, 4, (unsigned long long*)nullptr);
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  return ADVOC_OK;
+}
+
+extern "C" int advoc_weight_images_l1_f32(const float* base, const uint32_t* amax, const int64_t* table, int32_t count,
+                                          void* pool, uint32_t* hdrs, uint64_t* l1_scratch, advoc_stream_t stream) {
+  if (count < 0) return ADVOC_ERR_BAD_SHAPE;
+  if (count == 0) return ADVOC_OK;
+  if (!base || !amax || !table || !pool || !hdrs || !l1_scratch) return ADVOC_ERR_NULL;
+  if (count > 65535) return ADVOC_ERR_UNSUPPORTED;
+  ADVOC_CLEAR_LAUNCH_ERROR();
+  hipLaunchKernelGGL(advoc::weight_images_kernel, dim3(256, (unsigned)count), dim3(256), 0, advoc::as_stream(stream), base,
+                     amax, table, reinterpret_cast<char*>(pool), hdrs, ADVOC_WEIGHT_HDR_L1_WORDS,
+                     reinterpret_cast<unsigned long long*>(l1_scratch));
+  ADVOC_RETURN_IF_LAUNCH_FAILED();
+  hipLaunchKernelGGL(advoc::weight_l1_finalize_kernel, dim3((unsigned)count), dim3(256), 0, advoc::as_stream(stream), table,
+                     hdrs, reinterpret_cast<unsigned long long*>(l1_scratch));
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }

@@ -21,15 +21,38 @@ __device__ __forceinline__ float emit_up_scale(unsigned prev_bits) {
   return __uint_as_float((unsigned)(s + 127) << 23);
 }
 
-// (r5) power of two that puts an a-priori BOUND of the tensor's magnitude at [2^14, 2^15): nothing can leave the fp16 range
-// (the 1.0001 covers the rounding of the fp32 products the bound was computed with)
+// (r5) power of two that puts an a-priori BOUND of the tensor's magnitude just below the top of the fp16 range -- at [2^15,
+// 65000] when its mantissa allows, else at [2^14, 2^15): nothing can leave the range (the 1.0001 covers the rounding of the
+// fp32 products the bound was computed with)
 __device__ __forceinline__ float emit_up_scale_bounded(float bound) {
-  const unsigned b = __float_as_uint(bound * 1.0001f);
+  const float bb = bound * 1.0001f;
+  const unsigned b = __float_as_uint(bb);
   const int e = (int)((b >> 23) & 0xffu);
   if (e == 0 || e == 255) return 1.f;
-  int s = 14 - (e - 127);
+  int s = 15 - (e - 127);
   s = s > 120 ? 120 : (s < -120 ? -120 : s);
-  return __uint_as_float((unsigned)(s + 127) << 23);
+  float up = __uint_as_float((unsigned)(s + 127) << 23);
+  if (bb * up > 65000.f) up *= 0.5f;
+  return up;
+}
+
+// sum_k |w| factor of the a-priori bound of a launch: the largest, over the launch's phases, of the sum over the phase's taps
+// of the per-tap row-L1 maxima of the weight image (advoc_weight_images_l1_f32) -- or max|w| * taps * K without them
+__device__ __forceinline__ float emit_weight_bound(const GatherGemmParams& p, int ktot) {
+  const float crude = __uint_as_float(p.b_hdr[0]) * (float)(p.ntaps * ktot);
+  if (!p.w_l1 || p.w_l1[2] == 0u || (int)p.w_l1[3] != ktot) return crude;
+  float m = 0.f;
+  for (int ph = 0; ph < p.nphase; ++ph) {
+    float sum = 0.f;
+    for (int i = 0; i < p.ntaps; ++i) {
+      const int tp = p.tap[ph][i];
+      if ((int)(int8_t)(tp & 0xff) == -128) continue;        // a padding tap of a short phase
+      const unsigned wt = (unsigned)(tp >> 16);
+      sum += wt < p.w_l1[2] ? __uint_as_float(p.w_l1[4 + wt]) : __uint_as_float(p.b_hdr[0]) * (float)ktot;
+    }
+    m = fmaxf(m, sum);
+  }
+  return fminf(m * 1.00001f, crude);
 }
 
 typedef float emit_f2 __attribute__((ext_vector_type(2)));

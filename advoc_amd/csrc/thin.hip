@@ -219,10 +219,19 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
   // here with max|dy| in *a_amax (a magnitude pass over the thin operand in front of the launch) and max|w| in *w_amax
   float eup0_ = 1.f;
   if (emit0) {
-    if (FW == -3 && p.oimg_bounded)
+    if (FW == -3 && p.oimg_bounded) {
       eup0_ = emit_up_scale_bounded(__uint_as_float(*p.a_amax) * __uint_as_float(*p.w_amax) * (float)(p.ntaps * (p.c0 + p.c1)));
-    else
+    } else if (FW >= 1 && p.oimg_bounded) {
+      // forward: |y| <= max|x| max|w| taps K + max|b| (the input activation has slope <= 1)
+      float bm = 0.f;
+      if (p.bias)
+        for (int n = lane; n < N; n += 64) bm = fmaxf(bm, fabsf(p.bias[n]));
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) bm = fmaxf(bm, __shfl_xor(bm, off, 64));
+      eup0_ = emit_up_scale_bounded(__uint_as_float(*p.a_amax) * __uint_as_float(*p.w_amax) * (float)(p.ntaps * (p.c0 + p.c1)) + bm);
+    } else {
       eup0_ = emit_up_scale(o0.hdr[2]);
+    }
   }
   const float eup0 = eup0_, eup1 = emit1 ? emit_up_scale(o1.hdr[2]) : 1.f;
   float evmax0 = 0.f, evmax1 = 0.f;
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void thin_k_gemm_kernel(const
       }
       // (FW == -3, d0_no_store: destination 0 exists as the image only)
       const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
-          d.p, 0, (okj && !(FW == -3 && p.d0_no_store && di == 0)) ? kThinOob : 0u, 0x00020000);
+          d.p, 0, (okj && !((FW == -3 || FW >= 1) && p.d0_no_store && di == 0)) ? kThinOob : 0u, 0x00020000);
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         u32x4 sv;
@@ -428,6 +437,12 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
     *name_only = names[i].c_str();
     // the epilogue writes GatherGemmParams.oimg (image_emit.h); 2: as a backward-data call that only gates on the
     // pre-activation values, into ONE image (the layer below's output gradient) with that tensor's column sums on the way
+    if (p.emit_report && p.oimg_bounded && p.grad_act == ADVOC_ACT_NONE) {
+      // 5: a FORWARD call that writes ONE consumer's image under the a-priori scale (and may leave the fp32 tensor out)
+      *p.emit_report = (tuning().thin_fwd_spec && B_KN && nt <= 2 && !p.y_mask && !p.d[0].gmask && !p.d[1].gmask && !p.d[0].accum &&
+                        !p.d[1].accum && !p.d[1].p && p.oimg[0].img && !p.oimg[1].img && p.w_amax) ? 5 : 0;
+      return ADVOC_OK;
+    }
     if (p.emit_report)
       *p.emit_report = (nt >= 2 && p.grad_act != ADVOC_ACT_NONE && !p.y_mask && !p.d[0].gmask && !p.d[1].gmask && !p.d[0].accum &&
                         !p.d[1].accum && (!p.d[1].p || p.oimg_bounded) && p.oimg[0].img && !p.oimg[1].img &&
@@ -444,6 +459,11 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
       !p.d[1].accum) {
     if (!q.oimg[0].img && q.oimg[1].img) { q.oimg[0] = q.oimg[1]; q.oimg[1].img = nullptr; }
     fw = q.oimg[0].img ? (q.oimg[1].img ? 2 : 1) : 0;
+    if (p.oimg_bounded) {
+      if (fw != 1 || !B_KN || nt > 2 || !p.w_amax || !p.a_amax || !q.oimg[0].hdr || p.d[1].p) return ADVOC_ERR_UNSUPPORTED;
+      hipError_t e = hipMemsetAsync(q.oimg[0].hdr, 0, 4, stream);      // the magnitude accumulator of the image
+      if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
+    }
   } else if (tuning().thin_fwd_spec && p.grad_act != ADVOC_ACT_NONE && !p.y_mask && !p.d[0].gmask && !p.d[1].gmask && !p.d[0].accum &&
              !p.d[1].accum && !p.oimg[0].img && !p.oimg[1].img) {
     fw = -2;
@@ -462,6 +482,7 @@ int launch_thin_k(const GatherGemmParams& p, hipStream_t stream, const char** na
     }
   }
   if (fw != -3 && (p.ocolsum_out || (p.grad_act != ADVOC_ACT_NONE && p.oimg[0].img))) return ADVOC_ERR_UNSUPPORTED;
+  if (p.oimg_bounded && fw != -3 && fw != 1) return ADVOC_ERR_UNSUPPORTED;
   const int pl = (pr * pc * (p.c0 + p.c1) + 63) / 64;
   dim3 grid(1, (unsigned)by, (unsigned)p.nphase);
   ADVOC_CLEAR_LAUNCH_ERROR();

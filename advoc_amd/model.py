@@ -469,7 +469,9 @@ class Advoc(Model):
         out.append(lay)
       if not bn_on:
         for i in range(4):
-          out[i].add_image_consumer(out[i + 1], 0)
+          # (layer_1 .. layer_3: the next layer is the ONLY reader of the output -- where the kernels can, the output exists
+          # as that layer's operand image only, conv.Layer.y_image_only; layer_4's reader, layer_5, reads fp32)
+          out[i].add_image_consumer(out[i + 1], 0, exclusive=i < 3)
       return out, bns
     st['d_layers_fake'], st['d_bn_fake'] = d_layers(B, 2 * B)
     if bn_on:
@@ -515,11 +517,14 @@ class Advoc(Model):
     if not rows:
       return
     pool = torch.empty(pool_bytes, dtype=torch.uint8, device=dev)
-    hdrs = torch.zeros(4 * len(rows), dtype=torch.int32, device=dev)
+    # (r5) 32-word headers: {max |w|, 2^-s, taps, K, per-tap row-L1 maxima} (advoc_weight_images_l1_f32) -- the a-priori bounds of
+    # the launches that write operand images from their epilogues read them; its scratch (16 x 1024 sums per image) stays zero
+    hdrs = torch.zeros(32 * len(rows), dtype=torch.int32, device=dev)
+    l1 = torch.zeros(len(rows) * 16 * 1024, dtype=torch.int64, device=dev)
     table = torch.tensor(rows, dtype=torch.int64, device=dev)
     for lay, direction, off, idx in uses:
-      lay.set_weight_image(direction, pool.data_ptr() + off, hdrs.data_ptr() + 16 * idx)
-    st[net + '_wimg'] = dict(pool=pool, hdrs=hdrs, table=table, count=len(rows), uses=uses)
+      lay.set_weight_image(direction, pool.data_ptr() + off, hdrs.data_ptr() + 128 * idx, l1=True)
+    st[net + '_wimg'] = dict(pool=pool, hdrs=hdrs, table=table, count=len(rows), uses=uses, l1=l1)
 
   # ------------------------------------------------------------------------------------------
   # batch-norm plumbing
@@ -672,9 +677,9 @@ class Advoc(Model):
         out.numel(), _lib.ptr(out), _lib.stream()), 'advoc_segmented_amax_f32')
     wi = st.get(net + '_wimg')
     if wi:
-      _lib.check(_lib.load().advoc_weight_images_f32(
+      _lib.check(_lib.load().advoc_weight_images_l1_f32(
           _lib.ptr(st[net + '_param']), _lib.ptr(out), _lib.ptr(wi['table']), wi['count'], _lib.ptr(wi['pool']),
-          _lib.ptr(wi['hdrs']), _lib.stream()), 'advoc_weight_images_f32')
+          _lib.ptr(wi['hdrs']), _lib.ptr(wi['l1']), _lib.stream()), 'advoc_weight_images_l1_f32')
 
   def _gen_forward(self, x):
     st = self._built

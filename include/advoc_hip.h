@@ -295,8 +295,14 @@ typedef struct advoc_conv_layer {
    * Only under the one-pass (delayed) scale: the consumer's header must hold a previous image's magnitude, and the
    * consumer's next forward call must be made with ADVOC_IMG_X_CURRENT | ADVOC_IMG_X_EMITTED (it then runs the refit
    * check instead of an image pass).  Honoured by the image kernels only: advoc_conv_emits_images() says whether this
-   * layer's forward call will write them; img == NULL: none. */
-  struct { uint16_t* img; uint32_t* hdr; int32_t act; int32_t reserved; } y_img[2];
+   * layer's forward call will write them; img == NULL: none.
+   * (r5) `mode`: ADVOC_Y_BOUNDED -- the scale comes from a bound of |y| known before the launch (max|x| max|w| taps K +
+   * max|b|) instead of a previous magnitude: the image is final, the consumer's next forward call is made with
+   * ADVOC_IMG_X_CURRENT | ADVOC_IMG_X_BOUNDED (no refit check); with ADVOC_Y_IMAGE_ONLY the fp32 tensor y is NOT written --
+   * for a tensor whose only reader is that one consumer: its backward-data call must then gate on the image
+   * (ADVOC_IMG_X_GATES).  One consumer only; where advoc_conv_emits_images() == 2 (the <= 2-input-channel matrix kernel with
+   * max |w| on the device). */
+  struct { uint16_t* img; uint32_t* hdr; int32_t act; int32_t mode; } y_img[2];
   /* optional (backward-weight calls of the image kernels): device scratch for the partial tiles of the K slices the
    * pixel grid is cut into, advoc_conv_wgrad_ws_bytes() of it.  With it the slices are stored plainly and summed in
    * slice order by a second launch -- no zero fill of dw, no fp32 atomics (a quarter of the kernel's time on the large
@@ -330,6 +336,8 @@ typedef struct advoc_conv_layer {
 } advoc_conv_layer;
 #define ADVOC_DX_BOUNDED 1
 #define ADVOC_DX_IMAGE_ONLY 2
+#define ADVOC_Y_BOUNDED 1
+#define ADVOC_Y_IMAGE_ONLY 2
 #define ADVOC_WGRAD_TABLE_BYTES 262144
 
 /* amax_out[i] = float bits of max |base[offsets[i] .. offsets[i] + sizes[i])| for `count` tensors of one arena, in one
@@ -347,13 +355,26 @@ int advoc_conv_weight_image_desc(const advoc_conv_layer* layer, int32_t directio
  * aligned), index of its 4-word header in `hdrs`}.  Feeds advoc_conv_layer.w_img / w_img_hdr. */
 int advoc_weight_images_f32(const float* base, const uint32_t* amax, const int64_t* table, int32_t count, void* pool,
                             uint32_t* hdrs, advoc_stream_t stream);
+/* (r5) The same with ADVOC_WEIGHT_HDR_L1_WORDS-word headers (index of table column 7 in units of that many words): besides
+ * {max |w|, 2^-s} in words 0, 1 a header receives word 2 = taps (0: none of the following), word 3 = K and words 4 .. 4 + taps
+ * = float bits of max over the image's rows n of sum_k |w[tap][n][k]| -- the per-tap factors of the a-priori bounds the
+ * backward-data / forward launches that write an operand image under ADVOC_DX_BOUNDED / ADVOC_Y_BOUNDED use instead of
+ * max |w| * K (about 5 x tighter: two more bits for the small values of the image).  l1_scratch: count * 16 * 1024
+ * uint64 of device memory, ZERO on entry and left zero. */
+#define ADVOC_WEIGHT_HDR_L1_WORDS 32
+int advoc_weight_images_l1_f32(const float* base, const uint32_t* amax, const int64_t* table, int32_t count, void* pool,
+                               uint32_t* hdrs, uint64_t* l1_scratch, advoc_stream_t stream);
 
 /* 1: the layer's output-gradient image pass can carry the bias gradient (db_fused above): dy_img present and cout such
  * that a thread of the image pass keeps one group of 8 channels (32 <= cout <= 1024, 256 % (cout / 8) == 0) */
 int advoc_conv_bias_fusable(const advoc_conv_layer* layer);
-/* 1: a forward call on this layer writes the consumers' images of advoc_conv_layer.y_img (it runs on the image kernels
- * and has the workspace they need); 0: y_img is ignored and the consumers must build their images themselves */
+/* != 0: a forward call on this layer writes the consumers' images of advoc_conv_layer.y_img (it runs on the image kernels
+ * and has the workspace they need; 2: ADVOC_Y_BOUNDED / ADVOC_Y_IMAGE_ONLY are honoured too); 0: y_img is ignored and the
+ * consumers must build their images themselves */
 int advoc_conv_emits_images(const advoc_conv_layer* layer);
+/* 1: this layer's backward-data call can gate its activation gradient on the signs of x_img (ADVOC_IMG_X_GATES): a patch
+ * kernel on a grid without remainder columns, inputs with an activation and without batch-norm affine / dropout mask */
+int advoc_conv_gates_on_image(const advoc_conv_layer* layer);
 /* != 0: a backward-data call on this layer writes advoc_conv_layer.dx_img (2: the <= 2-output-channel matrix kernel, one-pass
  * scale; 3: a patch kernel, ADVOC_DX_BOUNDED [| ADVOC_DX_IMAGE_ONLY] required); 0: dx_img is refused */
 int advoc_conv_emits_dx_image(const advoc_conv_layer* layer);
@@ -377,6 +398,14 @@ int advoc_conv_emits_dx_image(const advoc_conv_layer* layer);
 /* with ADVOC_IMG_DY_CURRENT: dy_img was written by the layer above under ADVOC_DX_BOUNDED: final as it stands (dy_hdr[0] =
  * its largest magnitude, dy_hdr[1] = 2^-s), no refit check, no header rotation */
 #define ADVOC_IMG_DY_BOUNDED 64
+/* with ADVOC_IMG_X_CURRENT: x_img was written by the producer under ADVOC_Y_BOUNDED: final as it stands, no refit check */
+#define ADVOC_IMG_X_BOUNDED 128
+/* backward-data calls: the fp32 inputs x0 / x1 were never written (ADVOC_Y_IMAGE_ONLY producers); the activation gradient is
+ * gated by the sign of x_img's high plane.  Patch kernels only (ADVOC_ERR_UNSUPPORTED elsewhere). */
+#define ADVOC_IMG_X_GATES 256
+/* w_img_hdr[] are ADVOC_WEIGHT_HDR_L1_WORDS-word headers filled by advoc_weight_images_l1_f32 (per-tap row-L1 maxima for the
+ * a-priori bounds); without the flag the bounds use max |w| * taps * K */
+#define ADVOC_IMG_W_L1 512
 
 /* Bytes of the persistent operand image `which` (0: inputs, 1: output gradient) the layer can use; 0 when the layer's
  * shapes are outside the image-based kernels. */

@@ -334,7 +334,7 @@ def grads(P, x, target, cfg, masks, which, gates=None):
   return collections.OrderedDict(zip(keys, g)), {k: v.detach() for k, v in L.items()}
 
 
-def grads_in_chunks(P, x, target, cfg, masks, which, chunk):
+def grads_in_chunks(P, x, target, cfg, masks, which, chunk, gates=None):
   """grads() evaluated `chunk` clips at a time (bounded memory at BASELINE batch sizes).  Valid WITHOUT batch norm only:
   every loss of advoc_model.py:238-245 is a mean over the batch of per-clip terms, so the batch gradient is the
   clip-count-weighted mean of the chunk gradients and the losses are the weighted means of the chunk losses."""
@@ -344,7 +344,8 @@ def grads_in_chunks(P, x, target, cfg, masks, which, chunk):
   for lo in range(0, B, chunk):
     hi = min(B, lo + chunk)
     wgt = (hi - lo) / float(B)
-    g, L = grads(P, x[lo:hi], target[lo:hi], cfg, {k: v[lo:hi] for k, v in masks.items()}, which)
+    g, L = grads(P, x[lo:hi], target[lo:hi], cfg, {k: v[lo:hi] for k, v in masks.items()}, which,
+                 gates={k: v[lo:hi] for k, v in gates.items()} if gates else None)
     if total is None:
       total = collections.OrderedDict((k, v * wgt) for k, v in g.items())
     else:

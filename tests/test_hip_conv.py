@@ -1185,6 +1185,85 @@ def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_
 
 
 @gpu
+@pytest.mark.parametrize('producer', ['thin', 'patch_s2', 'patch_s1_reader'])
+def test_a_sole_reader_gets_the_output_as_its_operand_image_only(hip, hipenv, producer):
+  """r5: a layer whose output has ONE reader -- the next layer, which reads it as an operand image and gates its
+  backward-data pass on that image (a patch kernel) -- writes the image ONLY (advoc_conv_layer.y_img.mode =
+  ADVOC_Y_BOUNDED | ADVOC_Y_IMAGE_ONLY): under a scale from an a-priori bound of |y| (max|x| max|w| taps K + max|b|), so
+  there is no history and no refit, and the fp32 tensor is never written.  On the discriminator's layer_1 -> layer_2 shapes
+  (two 1-channel sources, thin matrix kernel -> stride-2 conv whose backward-data runs the four-phase patch kernel): the
+  reader's forward output, its backward-data result (gated by the image's signs, ADVOC_IMG_X_GATES), its weight and bias
+  gradients equal the fp32 path's (2e-6: the two images differ by a power of two), the fp32 buffer keeps its poison, and a
+  1000 x jump of the input from one step to the next changes nothing."""
+  from advoc_amd import conv
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1, ADVOC_WGRAD_H3_MIN_M=1)
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(91)
+  if producer == 'thin':          # layer_1 -> layer_2: two 1-channel sources, thin matrix kernel
+    c0 = torch.randn(2, 64, 129, 1, generator=g).to(dev)
+    c1 = torch.randn(2, 64, 129, 1, generator=g).to(dev)
+    cin, cmid, cout, s2, y1s, y2s, act1 = 2, 64, 128, (2, 2), (2, 32, 64, 64), (2, 16, 32, 128), conv.ACT_NONE
+    want1, want2 = 'thin_k_gemm_kernel', 'patch_gemm_h3_kernel<4, 1>'
+  elif producer == 'patch_s2':    # layer_2 -> layer_3: the producer's forward on the stride-2 patch kernel (128 columns)
+    c0 = torch.randn(2, 64, 128, 64, generator=g).to(dev)
+    c1 = None
+    cin, cmid, cout, s2, y1s, y2s, act1 = 64, 128, 256, (2, 2), (2, 32, 64, 128), (2, 16, 32, 256), conv.ACT_LRELU
+    want1, want2 = 'patch_gemm_h3_kernel<3, 0>', 'patch_gemm_h3_kernel<4, 1>'
+  else:                           # layer_3 -> layer_4: 256 columns forward, the reader a 4x4 stride-1 layer
+    c0 = torch.randn(2, 64, 64, 128, generator=g).to(dev)
+    c1 = None
+    cin, cmid, cout, s2, y1s, y2s, act1 = 128, 256, 256, (1, 1), (2, 32, 32, 256), (2, 31, 31, 256), conv.ACT_LRELU
+    want1, want2 = 'patch_gemm_h3_kernel<2, 0>', 'patch_gemm_h3_kernel<1, 1>'
+  w1 = (torch.randn(4, 4, cin, cmid, generator=g) * (0.2 if cin == 2 else 0.05)).to(dev)
+  b1 = (torch.randn(cmid, generator=g) * 0.1).to(dev)
+  w2 = (torch.randn(4, 4, cmid, cout, generator=g) * 0.05).to(dev)
+  b2 = (torch.randn(cout, generator=g) * 0.1).to(dev)
+  dy2 = torch.randn(*y2s, generator=g).to(dev)
+
+  def make(exclusive):
+    y1 = torch.full(y1s, float('nan'), device=dev)
+    x0, x1 = c0.clone(), (c1.clone() if c1 is not None else None)
+    L1 = conv.Layer(conv.CONV, x0, y1, w1, b1, x1=x1, stride=(2, 2), pad=(1, 1), in_act=act1,
+                    w_amax=w1.abs().max().reshape(1).view(torch.int32))
+    L2 = conv.Layer(conv.CONV, y1, torch.empty(*y2s, device=dev), w2, b2, stride=s2, pad=(1, 1),
+                    in_act=conv.ACT_LRELU)
+    for L in (L1, L2):
+      L.delayed_scale, L.reuse_images = True, True
+    assert want1 in L1.kernel_name(0) and L2.kernel_name(1) == want2, (L1.kernel_name(0), L2.kernel_name(1))
+    L1.add_image_consumer(L2, 0, exclusive=exclusive)
+    t = dict(x0=x0, x1=x1, y1=y1, dx=torch.empty_like(y1), dw=torch.zeros_like(w2), db=torch.zeros_like(b2))
+    return L1, L2, t
+  A, R = make(True), make(False)
+  for step, scale in enumerate((1.0, 0.9, 1000.0, 1.0)):
+    for (L1, L2, t), only in ((A, True), (R, False)):
+      t['x0'].copy_(c0 * scale)
+      if c1 is not None:
+        t['x1'].copy_(c1 * scale)
+      t['y1'].fill_(float('nan'))
+      L1.forward()
+      if only:
+        assert L2._x_final and L2._x_gates, step                    # from the first step on
+        assert bool(torch.isnan(t['y1']).all()), step               # the fp32 tensor is NOT written
+      else:
+        assert not L2._x_gates and not bool(torch.isnan(t['y1']).any()), step
+      L2.forward()
+      t['dw'].zero_()
+      L2.backward_data(dy2, t['dx'], db=t['db'], db_accumulate=False)
+      L2.backward_weight(dy2, t['dw'], t['db'])
+    (_, L2a, ta), (_, L2r, tr) = A, R
+    assert rel(L2a.y, L2r.y) < 2e-6, (step, rel(L2a.y, L2r.y))
+    assert rel(ta['dx'], tr['dx']) < 2e-6, (step, rel(ta['dx'], tr['dx']))
+    assert rel(ta['dw'], tr['dw']) < 2e-6, (step, rel(ta['dw'], tr['dw']))
+    assert rel(ta['db'], tr['db'].double().cpu()) < 2e-6, (step, rel(ta['db'], tr['db'].double().cpu()))
+    # the image's header: word 0 = the largest magnitude of lrelu(y) written, word 1 = 2^-s with the bound at [2^14, 2^15)
+    ha = L2a.image_headers()[0].cpu().view(torch.float32)
+    amax = float(torch.nn.functional.leaky_relu(tr['y1'], 0.2).abs().max())
+    assert abs(float(ha[0]) - amax) <= 2e-6 * amax, (step, float(ha[0]), amax)
+    assert 2.0 <= amax / float(ha[1]) < 32768.0, (step, amax / float(ha[1]))
+  assert int(L2a.image_headers()[0].cpu()[5]) == 0      # nothing was ever refitted
+
+
+@gpu
 def test_output_gradient_roles_keep_separate_magnitude_histories(hip, hipenv):
   """Layer.set_dy_role: one layer object that sees gradients of two losses per step (the discriminator's fake pass with
   batch norm: D-loss gradients in the D step, ~1000 x larger G-loss gradients in the G step) keeps one header per role,
@@ -1330,6 +1409,25 @@ def test_weight_magnitude_from_the_arena_pass(hip, case, hipenv):
                                                    _lib.ptr(hdrs), _lib.stream()), 'advoc_weight_images_f32')
     for d in (0, 1):
       L.set_weight_image(d, pool.data_ptr() + offs[d], hdrs.data_ptr() + 16 * d)
+    # (r5) advoc_weight_images_l1_f32: the same images, and behind {max |w|, 2^-s} in 32-word headers the per-tap maxima over
+    # the image's rows n of sum_k |w[tap][n][k]| -- the factors of the a-priori bounds of the emitting launches; its scratch
+    # comes back zero
+    pool2 = torch.empty_like(pool)
+    hdrs2 = torch.zeros(64, dtype=torch.int32, device=dev)
+    l1 = torch.zeros(2 * 16 * 1024, dtype=torch.int64, device=dev)
+    _lib.check(_lib.load().advoc_weight_images_l1_f32(_lib.ptr(w), _lib.ptr(amax), _lib.ptr(table), 2, _lib.ptr(pool2),
+                                                      _lib.ptr(hdrs2), _lib.ptr(l1), _lib.stream()), 'advoc_weight_images_l1_f32')
+    assert torch.equal(pool, pool2) and int(l1.abs().sum()) == 0
+    h2 = hdrs2.cpu()
+    for i, d in enumerate(descs):
+      taps, n_total, ktot, b_kn = d[:4]
+      assert int(h2[32 * i + 2]) == taps and int(h2[32 * i + 3]) == ktot and int(h2[32 * i]) == int(amax) and \
+          int(h2[32 * i + 1]) == int(hdrs.cpu()[4 * i + 1])
+      wt = w.detach().double().cpu().reshape(taps, -1)
+      wt = wt.reshape(taps, ktot, n_total) if b_kn else wt.reshape(taps, n_total, ktot).transpose(1, 2)
+      want = wt.abs().sum(dim=1).max(dim=1).values                   # [tap]: max over n of the sum over k
+      got = h2[32 * i + 4:32 * i + 4 + taps].view(torch.float32).double()
+      assert bool(((got >= want) & (got <= want * (1 + 1e-5) + 1e-11)).all()), (got, want)    # an upper bound, and a tight one
     y.zero_()
     L.forward()
     dx0 = torch.zeros_like(x0)

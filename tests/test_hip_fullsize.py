@@ -219,6 +219,37 @@ PATCH_G = ('encoder_2', 'encoder_3', 'encoder_4', 'decoder_4', 'decoder_3', 'dec
 BIG_WGRAD_G = ('encoder_3', 'encoder_4', 'encoder_5', 'decoder_5', 'decoder_4', 'decoder_3', 'decoder_2')
 
 
+def read_gates(st, distinct, d_passes):
+  """The sign pattern of every (leaky) ReLU of the last forward passes, for the oracle's gate injection
+  (oracle/advoc_torch.py: build_generator / build_discriminator `gates`): {generator layer: gate} and
+  {'D/real/layer_k' | 'D/fake/layer_k': gate}, first `distinct` clips.  d_passes: [(tag, layers, {index: batch norm}, first
+  clip of the pass INSIDE the layers' tensors)].  A discriminator activation that exists as the next layer's operand image
+  only (conv.Layer.y_image_only: the fp32 tensor is never written) is read from that image's high plane."""
+  out = {}
+  names = ['encoder_%d' % (i + 1) for i in range(len(st['enc']))] + ['decoder_%d' % idx for idx in st['dec']]
+  for n in names:
+    k = int(n.split('_')[1])
+    z = (st['enc'][k - 1] if n.startswith('enc') else st['dec'][k])[:distinct]
+    b = st['g_bn'].get(n)
+    gate = (z * b['scale'] + b['shift'] if b is not None else z) > 0
+    if n.startswith('dec') and k in st['masks']:      # dropout behind the layer: a dropped value is 0
+      gate = gate & (st['masks'][k][0][:distinct] > 0)
+    out[n] = gate.cpu()
+  for tag, layers, bns, lo in d_passes:
+    for i in range(4):
+      nxt = layers[i + 1]
+      if getattr(nxt, '_x_gates', False):
+        N, H, W, C = nxt.x0.shape
+        h = nxt._img[0][:N * H * W * C * 2].view(torch.float16).reshape(N, H, W, C // 32, 2, 32)[:, :, :, :, 0, :]
+        gate = h.reshape(N, H, W, C)[lo:lo + distinct] > 0
+      else:
+        z = layers[i].y[lo:lo + distinct]
+        b = bns.get(i)
+        gate = (z * b['scale'] + b['shift'] if b is not None else z) > 0
+      out['D/%s/layer_%d' % (tag, i + 1)] = gate.cpu()
+  return out, names
+
+
 @gpu
 def test_full_model_train_loops_at_bench_size_match_the_float64_oracle(hip):
   """BASELINE configs[2] exactly as bench.py times it -- AdVoc-full, 64 clips x 256 frames, default dispatch, delayed
@@ -296,29 +327,56 @@ def test_full_model_train_loops_at_bench_size_match_the_float64_oracle(hip):
                                {k: v.double() for k, v in masks[bd].items()}, 'D', 8)
     P_at_d = collections.OrderedDict((k, v.clone()) for k, v in P64.items())
     d_opt.step(P64, gD)
+    # product: the train_loop in its two halves (advoc_model.py:285-289: D update on one batch, G update on the next).  The
+    # generator's gradients are differentiated at the discriminator parameters THIS run holds after its update (r5): an Adam
+    # step is ~lr whatever the size of a gradient, so a discriminator parameter whose gradient is round-off on both sides can
+    # move by +lr here and -lr in the oracle, and the image weight gradient sums with atomics -- compared across that
+    # difference the generator's most sensitive tensor (decoder_8's kernel, fed by the 1 x 3-point bottleneck) came out
+    # anywhere between 1.4e-4 and 6.6e-4 from run to run, on either side of this test's bar.  The parameters themselves are
+    # compared first, then adopted.
+    m.d_step(m._feed())
+    gates_d, _ = read_gates(st, DISTINCT, [('real', st['d_layers_2b'], {}, 0), ('fake', st['d_layers_2b'], {}, Bn)])
+    sd = m.state_dict()
+    for k in Dk:
+      assert rel(sd[k], P64[k]) < 1e-4, (step, k, rel(sd[k], P64[k]))
+      P64[k] = sd[k].double().cpu()
     gG, LG = A.grads_in_chunks(P64, batches[bg][0].double(), batches[bg][1].double(), cfg,
                                {k: v.double() for k, v in masks[bg].items()}, 'G', 8)
     P_at_g = collections.OrderedDict((k, v.clone()) for k, v in P64.items())
     g_opt.step(P64, gG)
-    # product
-    assert m.train_loop() == step + 1
+    m.g_step(m._feed())
+    gates_g, _ = read_gates(st, DISTINCT, [('fake', st['d_layers_fake'], {}, 0)])
+    assert m.step == step + 1
+    # GATE-FROZEN (r5): the same gradients against the float64 oracle evaluated with THIS run's sign patterns (every leaky /
+    # plain ReLU of the generator and of the discriminator's passes): a smooth function on both sides, every tensor held to
+    # 5e-4 with no recourse to what float32 achieves.  The free-running comparison below keeps its r3 form; its one sensitive
+    # tensor, decoder_8's kernel behind the 1 x 3-point bottleneck, lands between 6e-5 and 7e-4 from run to run depending on
+    # which side of zero a handful of bottleneck pre-activations fall.
+    fD, _ = A.grads_in_chunks(P_at_d, batches[bd][0].double(), batches[bd][1].double(), cfg,
+                              {k: v.double() for k, v in masks[bd].items()}, 'D', 8, gates=gates_d)
+    fG, _ = A.grads_in_chunks(P_at_g, batches[bg][0].double(), batches[bg][1].double(), cfg,
+                              {k: v.double() for k, v in masks[bg].items()}, 'G', 8, gates=gates_g)
+    frozen = {}
+    for net, want in (('d_G', fD), ('g_G', fG)):
+      for k, v in want.items():
+        frozen[k] = rel(st[net][k], v)
+    print('step %d: gate-frozen oracle: worst gradient rel-L2 vs float64 %.3g (%s)'
+          % (step + 1, max(frozen.values()), max(frozen, key=frozen.get)))
+    assert all(r <= 5e-4 for r in frozen.values()), sorted(frozen.items(), key=lambda kv: -kv[1])[:4]
     ls = m.losses()
     assert abs(ls['disc_loss'] - LD['d_loss']) < 1e-4 * max(1, abs(LD['d_loss'])), (step, ls, LD)
     assert abs(ls['gen_loss_GAN'] - LG['g_gan']) < 1e-4 * max(1, abs(LG['g_gan'])), (step, ls, LG)
     assert abs(ls['gen_loss_L1'] - LG['g_l1']) < 1e-4 * max(1, abs(LG['g_l1'])), (step, ls, LG)
+    # FREE-RUNNING: the oracle with its own gates.  A report with a FIXED bar since r5 (2e-3; r3 / r4: 5e-4 or three times what a
+    # float32 torch-CPU evaluation achieved on the tensor -- a bar that followed the observation, and flaky: the same build gave
+    # 6e-5 .. 7e-4 on decoder_8's kernel from run to run, each side of it).  What it can catch that the gate-frozen comparison
+    # cannot is a WRONG gate, and a wrong gate anywhere but at a pre-activation within round-off of zero is far beyond 2e-3.
     worst = {}
     for net, want in (('d_G', gD), ('g_G', gG)):
       for k, v in want.items():
-        r = rel(st[net][k], v)
-        worst[k] = r
-        if r > 5e-4:
-          # what plain float32 evaluation of the same graph achieves on this tensor (the 1 x 3 bottleneck of the
-          # full model is ill-conditioned in fp32: ReLU gates flip on round-off)
-          P32 = {kk: vv.float() for kk, vv in (P_at_d if net == 'd_G' else P_at_g).items()}
-          b = bd if net == 'd_G' else bg
-          g32, _ = A.grads_in_chunks(P32, batches[b][0], batches[b][1], cfg, masks[b], 'D' if net == 'd_G' else 'G', 8)
-          assert r <= 3 * rel(g32[k], v), (step, k, r, rel(g32[k], v))
+        worst[k] = rel(st[net][k], v)
     print('step %d: worst gradient rel-L2 vs float64 %.3g (%s)' % (step + 1, max(worst.values()), max(worst, key=worst.get)))
+    assert all(r <= 2e-3 for r in worst.values()), sorted(worst.items(), key=lambda kv: -kv[1])[:4]
     # delayed scaling is live from the second step on: every persistent image header holds a previous magnitude
     if step == 1:
       hdrs = [h for lay in list(GL.values()) + st['d_layers_2b'] + st['d_layers_fake'] for h in lay.image_headers()]

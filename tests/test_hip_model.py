@@ -475,7 +475,7 @@ def test_weight_magnitudes_follow_the_parameters(hip, monkeypatch):
     for lay, p in saved:
       lay.struct.w_amax = p
     for lay, d, off, idx in st['g_wimg']['uses']:
-      lay.set_weight_image(d, st['g_wimg']['pool'].data_ptr() + off, st['g_wimg']['hdrs'].data_ptr() + 16 * idx)
+      lay.set_weight_image(d, st['g_wimg']['pool'].data_ptr() + off, st['g_wimg']['hdrs'].data_ptr() + 128 * idx, l1=True)
     # same power of two, same weight images (bit-identical per layer: test_hip_conv.py); what is left is the order of the
     # split-K atomics of the small deep layers
     assert rel(out1, out0) < 2e-6, (rep, rel(out1, out0))
