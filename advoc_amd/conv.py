@@ -94,7 +94,7 @@ class Layer(object):
   # call's dx0 is -- writes THAT layer's output-gradient image (and its bias column sums) from its own epilogue
   # (advoc_conv_layer.dx_img): the image pass of the layer below disappears.  Off by default: measured on the one producer
   # that has it (discriminator layer_5 -> layer_4, the largest image pass of the step) the passes lose 0.31 ms per step and
-  # the producer, an issue-bound kernel, gains 0.18 ms; the step does not move (profiles/r04_i_*)
+  # the producer, an issue-bound kernel, gains 0.18 ms; the step does not move (NOTEBOOK.md section 7, profiles/r04_i_*)
   emit_dx = os.environ.get('ADVOC_EMIT_DX', '0') == '1'
   # (r5) ADVOC_DX_BOUNDED=0 turns it off: where the backward-data call of a layer runs on a patch kernel and the layer below
   # reads its output gradient only as an operand image, that image is written by this call's epilogue under a scale derived

@@ -8,7 +8,7 @@
 // a0 b1 + a1 b0 + a0 b0 with fp32 accumulation, unscaled exactly in the epilogue -- fp32-level error at 3 / 16
 // of the fp32 MFMA cost (roof in algorithmic fp32 flops: dense f16 MFMA / 3).
 //
-// Why it looks the way it does (measured on MI355X): the register-split kernel of igemm.hip and a
+// Why it looks the way it does (measured on MI355X, NOTEBOOK.md §4): the register-split kernel of igemm.hip and a
 // first image kernel (bf16 triples, six products) both stopped at ~170-190 algorithmic TFLOP/s with the matrix
 // pipe busy 45 % of the time; removing every MFMA from the loop bought 16 %, removing the loads 49 %.  The loaders
 // were bound by the L2's request rate: 32-96 useful bytes of every 128-byte line they asked for.  Here
@@ -378,7 +378,26 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
   const int trow = lane >> 3, tq = lane & 7;
   // consumers' operand images of the output (image_emit.h): one-pass scale from the consumer header's previous magnitude
   const bool emit0 = p.oimg[0].img != nullptr && !atomic_split, emit1 = p.oimg[1].img != nullptr && !atomic_split;
-  const float eup0 = emit0 ? emit_up_scale(p.oimg[0].hdr[2]) : 1.f, eup1 = emit1 ? emit_up_scale(p.oimg[1].hdr[2]) : 1.f;
+  // (r5) oimg_bounded: the a-priori scale of igemm_patch.hip (this kernel takes the remainder columns of a patch launch and
+  // the launches under 16 x 16 grid points: both write the same image under the same bound)
+  float eup0 = 1.f;
+  if (emit0) {
+    if (p.oimg_bounded) {
+      float bound = __uint_as_float(*p.a_amax) * emit_weight_bound(p, ktot);
+      if (p.obound_add) bound += __uint_as_float(*p.obound_add);
+      if (p.grad_act == ADVOC_ACT_NONE && p.bias) {      // a forward launch: + max |b|
+        float bm = 0.f;
+        for (int n = lane; n < p.n_total; n += 64) bm = fmaxf(bm, fabsf(p.bias[n]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bm = fmaxf(bm, __shfl_xor(bm, off, 64));
+        bound += bm;
+      }
+      eup0 = emit_up_scale_bounded(bound);
+    } else {
+      eup0 = emit_up_scale(p.oimg[0].hdr[2]);
+    }
+  }
+  const float eup1 = emit1 ? emit_up_scale(p.oimg[1].hdr[2]) : 1.f;
   float evmax0 = 0.f, evmax1 = 0.f;
   if (tid == 0) {      // (every workgroup that reaches an epilogue: the same value)
     if (emit0) p.oimg[0].hdr[1] = __float_as_uint(1.f / eup0);
@@ -394,6 +413,10 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
     const int ch = (di ? nt0 - p.n_split : nt0) + 4 * tq;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && (ks_idx == 0 || !atomic_split)) bias4 = *reinterpret_cast<const float4*>(p.bias + nt0 + 4 * tq);
+    // per-channel sums of destination 0 over the tile's rows (ocolsum_table: the bias gradient of the layer whose
+    // output-gradient image this launch writes)
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool no_store = p.d0_no_store && di == 0 && emit0;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       // ALL global loads of the block (pre-activation values, masks, the value to add to) are issued before anything is
@@ -453,13 +476,25 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
         if (d.accum) {
           v.x += old[ps].x; v.y += old[ps].y; v.z += old[ps].z; v.w += old[ps].w;
         }
-        *reinterpret_cast<float4*>(dst) = v;
+        if (!no_store) *reinterpret_cast<float4*>(dst) = v;
         if (di == 0) {
           if (emit0) emit4(p.oimg[0], eup0, v, (unsigned)off[ps], evmax0);
           if (emit1) emit4(p.oimg[1], eup1, v, (unsigned)off[ps], evmax1);
+          cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
         }
       }
       wave_lds_sync();
+    }
+    if (p.ocolsum_table && emit0 && di == 0) {
+#pragma unroll
+      for (int sh = 8; sh < 64; sh <<= 1) {
+        cs.x += __shfl_xor(cs.x, sh, 64); cs.y += __shfl_xor(cs.y, sh, 64);
+        cs.z += __shfl_xor(cs.z, sh, 64); cs.w += __shfl_xor(cs.w, sh, 64);
+      }
+      if (trow == 0) {
+        float* row = p.ocolsum_table + (size_t)((blockIdx.x + blockIdx.z * 7) & (kColsumReplicas - 1)) * d.c + ch;
+        unsafeAtomicAdd(row, cs.x); unsafeAtomicAdd(row + 1, cs.y); unsafeAtomicAdd(row + 2, cs.z); unsafeAtomicAdd(row + 3, cs.w);
+      }
     }
   }
   if (emit0) emit_finish(p.oimg[0], eup0, evmax0);
@@ -542,7 +577,7 @@ int launch_h21(const GatherGemmParams& p, hipStream_t stream, const char** name_
   return launch_h<2, 1, 2>(p, stream, name_only, tail, tail_ws, tail_cnt, ksplit);
 }
 
-// Tile choice (tools/micro/h3_sweep.py).  ADVOC_H3_TILE=1|2|3 forces 128x128 | 128x256 | 256x128,
+// Tile choice (tools/micro/h3_sweep.py, NOTEBOOK.md §4).  ADVOC_H3_TILE=1|2|3 forces 128x128 | 128x256 | 256x128,
 // ADVOC_H3_STAGES=2|3 the LDS stages.
 Pick pick_tile(const GatherGemmParams& p) {
   const Tuning& t = tuning();
@@ -551,7 +586,7 @@ Pick pick_tile(const GatherGemmParams& p) {
   if (N % 128 != 0 || t.h3_tile == 4) k = {2, 1, 2, 2};      // 64-column tiles (48 KiB: three workgroups per CU)
   else if (t.h3_tile == 5 && N % 256 == 0) k = {2, 4, 2, 4};  // 256 x 256, 8 waves
   // (r3: the 128 x 256 / 256 x 128 four-wave tiles, 256 x 128 on eight waves and the three-stage forms -- measured and
-  // rejected in r2, DESIGN.md section 7b -- are no longer compiled in: ADVOC_H3_TILE takes 1 | 4 | 5)
+  // rejected in r2, NOTEBOOK.md section 7b -- are no longer compiled in: ADVOC_H3_TILE takes 1 | 4 | 5)
   else if (t.h3_tile == 0 && N % 256 == 0) {
     // 256 x 256 on 8 waves (one workgroup per CU) streams half the bytes per flop of 128 x 128 and measured 1.2-1.35x
     // faster on every launch with >= 2 such tiles per CU (381 vs 284 TFLOP/s on D layer_4); below that the launch would
@@ -707,8 +742,11 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   if ((p.d[0].ximg || p.d[1].ximg) && (patch_nph == 0 || geom.rem != 0 || p.n_total == 32)) return ADVOC_ERR_UNSUPPORTED;
   const bool bounded_fwd = p.oimg_bounded && p.grad_act == ADVOC_ACT_NONE && !p.d[0].xpre && !p.d[1].p;
   if (p.oimg_bounded && !bounded_fwd) {
-    const bool ok = patch_nph != 0 && geom.rem == 0 && p.oimg[0].img && p.oimg[0].hdr && !p.oimg[1].img && !p.y_mask &&
-                    !p.d[0].gmask && !p.d[1].gmask && !p.d[0].accum && !p.d[1].accum && p.grad_act != ADVOC_ACT_NONE &&
+    // (the patch kernels' lean instances; remainder columns and launches without a patch plan on the per-tap kernel, whose
+    // generic epilogue takes masks too -- but an accumulating destination 0 needs a bound of what it holds: obound_add)
+    const bool ok = p.oimg[0].img && p.oimg[0].hdr && !p.oimg[1].img && !p.y_mask &&
+                    !p.d[0].gmask && !p.d[1].gmask && (!p.d[0].accum || (p.obound_add && patch_nph == 0)) && !p.d[1].accum &&
+                    (p.grad_act != ADVOC_ACT_NONE || p.d[0].xpre || p.d[1].p) &&
                     (!p.ocolsum_out || (p.ocolsum_table && p.d[0].c <= 1024));
     if (p.emit_report) *p.emit_report = ok ? 3 : 0;
     if (!ok) return ADVOC_ERR_UNSUPPORTED;
@@ -788,12 +826,34 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
     return launch_patch_gemm_h3(p, geom, patch_nph, stream, nullptr);
   }
-  if (patch_nph && p.oimg_bounded && !name_only) {
+  if (p.oimg_bounded && !name_only) {
+    // backward-data under the bound: the magnitude word and the replica table are cleared once, every launch of the call (the
+    // patches, their remainder columns -- or the per-tap launch alone) writes the image, the column sums are folded at the end
     hipError_t e = hipMemsetAsync(p.oimg[0].hdr, 0, 4, stream);
     if (e == hipSuccess && p.ocolsum_out)
       e = hipMemsetAsync(p.ocolsum_table, 0, sizeof(float) * kColsumReplicas * (size_t)p.d[0].c, stream);
     if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }
-    int rc = launch_patch_gemm_h3(p, geom, patch_nph, stream, nullptr);
+    int rc;
+    if (patch_nph && geom.rem == 0) {
+      rc = launch_patch_gemm_h3(p, geom, patch_nph, stream, nullptr);
+    } else if (patch_nph) {
+      GatherGemmParams pm = p;
+      pm.gw = geom.px * 16;
+      rc = launch_patch_gemm_h3(pm, geom, patch_nph, stream, nullptr);
+      if (rc == ADVOC_OK) {
+        GatherGemmParams pr = p;
+        pr.gw = geom.rem;
+        pr.gx_off = geom.px * 16;
+        rc = (tail.split > 1 && tail_ws && tail_cnt) ? launch_h21(pr, stream, nullptr, tail, tail_ws, tail_cnt, 1)
+                                                      : launch_h21(pr, stream, nullptr, TailPlan(), nullptr, nullptr, 1);
+      }
+    } else if (k.wgm == 4 && k.nt == 4) {
+      rc = launch_h<2, 4, 2, 4>(p, stream, nullptr, tail, tail_ws, tail_cnt, 1);
+    } else if (k.nt == 1) {
+      rc = launch_h21(p, stream, nullptr, tail, tail_ws, tail_cnt, 1);
+    } else {
+      rc = launch_h<2, 2, 2>(p, stream, nullptr, tail, tail_ws, tail_cnt, 1);
+    }
     if (rc == ADVOC_OK && p.ocolsum_out) rc = launch_colsum_reduce(p.ocolsum_table, p.ocolsum_out, p.d[0].c, stream);
     return rc;
   }

@@ -7,7 +7,7 @@
 // cuDNN / Eigen Conv2DBackpropInput / Conv2D kernels TF1 runs for models/advoc/advoc_model.py:25-69,185-199).  What
 // differs is the tile: igemm_h3.hip walks K = (tap, channel slice) and fetches a fresh [rows x 128 B] A tile for every
 // tap -- with stride-1 gathers the same input pixel is fetched 4 (2x2 phases, x4 phases) or 16 (4x4) times by one
-// workgroup and the launch is bound by the L2 -> LDS volume.  Here a workgroup owns a 16 x 16 PATCH
+// workgroup and the launch is bound by the L2 -> LDS volume (NOTEBOOK.md §4.2).  Here a workgroup owns a 16 x 16 PATCH
 // of grid points of one image:
 //   * per 32-channel K slice the patch's input HALO ((16 + e) x (16 + e) pixels, e = 2 or 3; one 128-byte line per
 //     pixel) goes global -> LDS once (LDS-DMA, zero padding from the descriptor's range check) and serves every tap
@@ -469,7 +469,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     // each.  Waves 4-7 run ONE BARRIER BEHIND waves 0-3 (an extra barrier in front of their loop, one behind the others'),
     // and wave w shares its SIMD with wave w + 4: whenever one wave of a SIMD multiplies the other one reads, so the matrix
     // pipe never waits for a fragment read and the LDS never serves all eight waves at once -- what r3 measured as the
-    // "rendezvous window" (-33 % with the barrier ablated) without giving up the rendezvous.
+    // "rendezvous window" (NOTEBOOK.md section 7a item 5: -33 % with the barrier ablated) without giving up the rendezvous.
     //   * early waves issue the DMAs of step n + 1 (B tile, halo piece) at the end of their R1(n), late waves theirs at the
     //     start of their M2(n - 1): the same barrier interval, right behind the barrier at which every wave has retired
     //     (lgkmcnt 0) its reads of the stage being refilled, and four intervals before anyone reads the new tile;

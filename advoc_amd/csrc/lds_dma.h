@@ -31,7 +31,7 @@ __device__ __forceinline__ u32x4s dma_rsrc(const void* base, unsigned bytes) {
 // intended block keeps stale bytes.  Whether they issue back to back depends on what else the SIMD has to issue: in r3
 // the kernels of this header (per-tap gather, image weight gradient) gave wrong elements in ~1 of 3 runs ONLY while
 // thin_wgrad_kernel's conflicted ds_add_f32 bursts ran beside them on the side stream, and never alone -- the "side-stream
-// race" of DESIGN.md section 5 (tools/micro/side_race_r4*.py: 8-10 of 12 runs wrong -> 0 of 60 with the s_nop).
+// race" of NOTEBOOK.md section 5 (tools/micro/side_race_r4*.py: 8-10 of 12 runs wrong -> 0 of 60 with the s_nop).
 // m0 is listed as clobbered so that the compiler never assumes a value of its own survives the statement.  (r5) clang
 // answers every such clobber with "-Winline-asm: clobber list contains reserved registers: m0" -- 186 copies per
 // translation unit, enough to hide a real warning; the clobber is what is wanted here (the compiler re-materialises M0
@@ -49,7 +49,7 @@ __device__ __forceinline__ void dma16(u32x4s rsrc, unsigned lds_base, int voffse
 // The rendezvous of an LDS-DMA ring: "my DMAs of the stage about to be read have landed (vmcnt <= VM), MY READS OF THE STAGE
 // ABOUT TO BE OVERWRITTEN HAVE RETURNED (lgkmcnt 0), everybody is here".
 //
-// The lgkmcnt(0) is what r3 did not have, and it is the cause of the "side-stream race" of DESIGN.md section 5 (found in r4,
+// The lgkmcnt(0) is what r3 did not have, and it is the cause of the "side-stream race" of NOTEBOOK.md section 5 (found in r4,
 // tools/micro/side_race_r4*.py).  s_barrier waits for no memory operation, and behind a raw __builtin_amdgcn_s_barrier() the
 // compiler owes the LDS reads nothing either: it puts their s_waitcnt lgkmcnt in front of the first MFMA that uses the
 // fragments, and it is free to sink that MFMA below the barrier -- in gather_gemm_h3_kernel<2,1,2,2> six ds_read_b128 of

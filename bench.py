@@ -693,7 +693,7 @@ def main():
   from advoc_amd.parallel import DataParallel
 
   # N > 1: the persistent launches leave 8 CUs (one per XCD) to RCCL's kernels unless the caller chose (r5; recorded in
-  # `dist.reserve_cus`).  An explicit ADVOC_RESERVE_CUS / ADVOC_DP_RESERVE_CUS is never overridden.
+  # `dist.reserve_cus`; NOTEBOOK.md section 5).  An explicit ADVOC_RESERVE_CUS / ADVOC_DP_RESERVE_CUS is never overridden.
   if int(os.environ.get('WORLD_SIZE', '1')) > 1 and 'ADVOC_DP_RESERVE_CUS' not in os.environ \
       and 'ADVOC_RESERVE_CUS' not in os.environ:
     os.environ['ADVOC_DP_RESERVE_CUS'] = '8'

@@ -1092,7 +1092,8 @@ def test_backward_data_writes_the_output_gradient_image_of_the_layer_below(hip, 
 
 
 @gpu
-@pytest.mark.parametrize('shape', ['d4_s1', 'd3_s2', 'dec_two_sources', 'thin_cout1', 'thin_two_sources'])
+@pytest.mark.parametrize('shape', ['d4_s1', 'd3_s2', 'dec_two_sources', 'thin_cout1', 'thin_two_sources', 'dec_rem_trim',
+                                   'deep_per_tap'])
 def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_priori_scale(hip, hipenv, shape):
   """r5: the backward-data call of a layer on a PATCH kernel writes the output-gradient image of the layer below from its
   epilogue under a scale derived from a bound of |dx| known before the launch (max|dy| max|w| taps K: nothing can leave the
@@ -1127,6 +1128,16 @@ def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_
     low = dict(kind=conv.DECONV, w=(4, 4, 64, 64), y=(2, 32, 36, 64), stride=(2, 2), pad=(1, 1))
     up = dict(kind=conv.DECONV, w=(4, 4, 1, 128), y=(2, 64, 72, 1), stride=(2, 2), pad=(1, 1), x1=(2, 32, 36, 64))
     want = 'thin_k_gemm_kernel<16, 4, true>'
+  elif shape == 'dec_rem_trim':   # the generator's decoders as they are: a 16 n + 1 wide grid (patches + a per-tap launch over
+    xin = torch.randn(2, 16, 17, 64, generator=g)     # the remainder column, both writing the image), a trimmed first source
+    low = dict(kind=conv.DECONV, w=(4, 4, 128, 64), y=(2, 32, 34, 128), stride=(2, 2), pad=(1, 1))
+    up = dict(kind=conv.DECONV, w=(4, 4, 64, 256), y=(2, 64, 66, 64), stride=(2, 2), pad=(1, 1), x1=(2, 32, 33, 128), in_w=33)
+    want = 'patch_gemm_h3_kernel<2, 1>'
+  elif shape == 'deep_per_tap':   # under 16 x 16 grid points: the per-tap kernel alone writes the image
+    xin = torch.randn(4, 4, 5, 64, generator=g)
+    low = dict(kind=conv.DECONV, w=(4, 4, 128, 64), y=(4, 8, 10, 128), stride=(2, 2), pad=(1, 1))
+    up = dict(kind=conv.DECONV, w=(4, 4, 64, 256), y=(4, 16, 18, 64), stride=(2, 2), pad=(1, 1), x1=(4, 8, 9, 128), in_w=9)
+    want = 'gather_gemm_h3_kernel'
   else:                           # upper: transposed conv over concat(lower output, skip): dx0 image only, dx1 fp32
     xin = torch.randn(2, 16, 16, 64, generator=g)
     low = dict(kind=conv.DECONV, w=(4, 4, 128, 64), y=(2, 32, 32, 128), stride=(2, 2), pad=(1, 1))
@@ -1145,10 +1156,11 @@ def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_
     # (max |w| on the device, as the train step keeps it: the thin kernel's bound reads it from there)
     w_amax = w_up.abs().max().reshape(1).view(torch.int32)
     Up = conv.Layer(up['kind'], y_lo, torch.empty(*up['y'], device=dev), w_up, None, x1=skip, stride=up['stride'],
-                    pad=up['pad'], in_act=conv.ACT_RELU if up['kind'] == conv.DECONV else conv.ACT_LRELU, w_amax=w_amax)
+                    pad=up['pad'], in_act=conv.ACT_RELU if up['kind'] == conv.DECONV else conv.ACT_LRELU, w_amax=w_amax,
+                    **({'in_w': up['in_w']} if 'in_w' in up else {}))
     for L in (Up, Lo):
       L.delayed_scale, L.reuse_images = True, True
-    assert Up.kernel_name(1) == want and 'h3' in Lo.kernel_name(1) and 'h3' in Lo.kernel_name(2), \
+    assert Up.kernel_name(1).startswith(want) and 'h3' in Lo.kernel_name(1) and 'h3' in Lo.kernel_name(2), \
         (Up.kernel_name(1), Lo.kernel_name(1), Lo.kernel_name(2))
     t = dict(g=torch.empty_like(y_lo), dskip=torch.empty_like(skip) if skip is not None else None,
              dx=torch.empty_like(xin), dw=torch.zeros_like(w_lo), db=torch.zeros_like(b_lo))
@@ -1159,7 +1171,8 @@ def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_
       Lo.forward()
       Up.forward()
       t['dw'].zero_()
-      t['g'].fill_(float('nan'))
+      # (a trimmed column of the tensor is never written by anybody: zero in the model, and zero here where it is read)
+      t['g'].fill_(float('nan') if emit else 0.0)
       Up.backward_data(dy_up * scale, t['g'], t['dskip'], grad_consumer=Lo if emit else None,
                        consumer_db=t['db'] if emit else None, consumer_db_accumulate=False)
       if emit:
@@ -1180,7 +1193,7 @@ def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_
     amax = float(tr['g'].abs().max())
     assert abs(float(ha[0]) - amax) <= 2e-6 * amax, (step, float(ha[0]), amax)
     top = amax / float(ha[1])
-    assert 2.0 <= top < 32768.0, (step, top)
+    assert 2.0 <= top < 65504.0, (step, top)
   assert int(La.image_headers()[-1].cpu()[5]) == 0      # nothing was ever refitted
 
 
@@ -1259,7 +1272,7 @@ def test_a_sole_reader_gets_the_output_as_its_operand_image_only(hip, hipenv, pr
     ha = L2a.image_headers()[0].cpu().view(torch.float32)
     amax = float(torch.nn.functional.leaky_relu(tr['y1'], 0.2).abs().max())
     assert abs(float(ha[0]) - amax) <= 2e-6 * amax, (step, float(ha[0]), amax)
-    assert 2.0 <= amax / float(ha[1]) < 32768.0, (step, amax / float(ha[1]))
+    assert 2.0 <= amax / float(ha[1]) < 65504.0, (step, amax / float(ha[1]))
   assert int(L2a.image_headers()[0].cpu()[5]) == 0      # nothing was ever refitted
 
 

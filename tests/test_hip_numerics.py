@@ -1,4 +1,4 @@
-"""The fp16-pair operand-image arithmetic (csrc/image.hip) on data that is NOT friendly: every contraction
+"""The fp16-pair operand-image arithmetic (csrc/image.hip, NOTEBOOK.md §4.1) on data that is NOT friendly: every contraction
 of the train step is fp32-exact-class only if one power-of-two scale per tensor is enough, so the image kernels are driven
 here with (a) log-normal activations (sigma = 3: magnitudes spread over > 2^17), (b) a real |STFT| of speech
 (tests/golden/mono.wav through the HIP extractor -- 6 decades between the loudest bin and the noise floor, the actual

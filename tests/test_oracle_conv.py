@@ -1,6 +1,6 @@
 """Closed-form checks of the conv-stack oracle itself (oracle/advoc_torch.py), on the CPU.
 
-The reference holds no test or golden tensor for the networks (PARITY UNPINNED), so
+The reference holds no test or golden tensor for the networks (PARITY UNPINNED, NOTEBOOK.md §2), so
 the oracle's transcription of the TF1 semantics is pinned here against hand-derivable cases: the
 asymmetric SAME padding, the transposed conv as the adjoint of the SAME conv, the tie gradient of
 tf.maximum, inference of the (1,2)-stride rule, the losses on a two-element example and TF's Adam

@@ -95,6 +95,6 @@ def test_lws_and_envelope_constants():
   """test_spectral.py:156-175 (envelope L1 after LWS / GL10: 0.01737 / 0.01686) and :178-208 (waveform L1 after LWS:
   0.0004236908353): need lws==1.2 (third-party C++, absent) and the resampled fixture.  The Griffin-Lim constants of the
   same test ARE reproduced to 0.1 % (tests/test_hip_inversion.py); the LWS restatement here reaches 5.7e-4 where lws 1.2
-  reaches 4.24e-4 on the complex-input call."""
+  reaches 4.24e-4 on the complex-input call (NOTEBOOK.md section 2)."""
   pytest.skip('lws 1.2 (the reference default phase estimator) is a third-party C++ package that is not installed: LWS parity is '
-              'unpinned; see DESIGN.md section 2')
+              'unpinned; see NOTEBOOK.md section 2')

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Round-4 hunt for the side-stream corruption: d_step / g_step with the weight gradients on the
+"""Round-4 hunt for the side-stream corruption (NOTEBOOK.md section 5): d_step / g_step with the weight gradients on the
 side stream against serial execution, EVERY gradient tensor and every backward-data output compared element by element,
 under a list of variants that each remove one suspect.  Prints, per variant, how many trials differed and where the
 wrong elements of the first differing tensors sit.

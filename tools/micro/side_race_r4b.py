@@ -2,7 +2,7 @@
 """Round-4 race hunt, part 2: AdVoc-small with batch norm, D step with the weight gradients on the side stream against the
 one-stream step; with captures of every tensor of the fake pass in program order (which is the first to differ).  (The r4
 session also split the culprit -- thin_wgrad_kernel's bias sums: memset / sums in the kernel / reduce, LDS atomics vs plain
-stores vs global atomics -- with temporary switches in thin.hip; results in DESIGN.md section 5.)"""
+stores vs global atomics -- with temporary switches in thin.hip; results in NOTEBOOK.md section 5.)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
