@@ -97,7 +97,7 @@ PROTOTYPES = {
     'advoc_segmented_amax_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p]),
     'advoc_conv_weight_image_desc': (ctypes.c_int, [_p, _i32, _p]),
     'advoc_weight_images_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p, _p]),
-    'advoc_weight_images_l1_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p]),
+    'advoc_weight_images_l1_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p, _p]),
     'advoc_conv_make_image': (ctypes.c_int, [_p, _i32, _p, _p]),
     'advoc_conv_forward': (ctypes.c_int, [_p, _p]),
     'advoc_conv_backward_data': (ctypes.c_int, [_p, _p, _p, _p, _i32, _i32, _p]),

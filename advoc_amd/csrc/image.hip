@@ -426,102 +426,92 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 // int64 in device memory {w offset from base (elements), taps, n_total, ktot, b_kn, index into the magnitude table, byte
 // offset of the image in the pool, index of its 4-word header}; same arithmetic and layout as split_weights_kernel's
 // fp16-pair form, the scale from the arena's magnitude table (advoc_segmented_amax_f32).
-// (r5) l1 != null (hdr_words >= 4 + kL1Taps): also sum_k |w[tap][n][k]| for every (tap, n) of the image, as 2^40 fixed point
-// (rounded up; integer atomics: the sums do not depend on the order) in l1[image][tap][n], n < kL1Cols -- what
-// weight_l1_finalize_kernel turns into the per-tap maxima the a-priori bounds of igemm_patch.hip read from the header
-constexpr int kL1Taps = 16, kL1Cols = 1024;
+// (r5) hdr_words >= 4 + kL1Taps: the kernel also leaves, in words 4 .. 4 + taps of the image's header, the per-tap maxima over
+// the image's rows n of sum_k |w[tap][n][k]| (float bits, rounded up) -- the factors of the a-priori bounds of igemm_patch.hip --
+// and taps / K in words 2 / 3.  A workgroup owns (tap, 32-row block) and walks its K tiles, so a row's sum is complete in
+// registers when the walk ends: one atomicMax per workgroup item into a word the launcher has zeroed, no scratch, no second
+// launch (a first version summed 2^40 fixed-point partials with 64-bit atomics per tile and folded them in a second kernel:
+// +0.18 ms per train step, profiles/r05_a_steady_census.md).
+constexpr int kL1Taps = 16;
 __global__ __launch_bounds__(256) void weight_images_kernel(const float* __restrict__ base,
                                                             const unsigned* __restrict__ amax,
                                                             const int64_t* __restrict__ table,
                                                             char* __restrict__ pool, unsigned* __restrict__ hdrs,
-                                                            int hdr_words, unsigned long long* __restrict__ l1) {
+                                                            int hdr_words) {
   __shared__ float tile[32][33];
+  __shared__ float s_rowmax[8];
   const int64_t* row = table + 8 * (int64_t)blockIdx.y;
   const float* w = base + row[0];
   const int taps = (int)row[1], n_total = (int)row[2], ktot = (int)row[3], b_kn = (int)row[4];
   uint16_t* wq = reinterpret_cast<uint16_t*>(pool + row[6]);
   unsigned* hdr = hdrs + (int64_t)hdr_words * row[7];
-  const bool want_l1 = l1 != nullptr && taps <= kL1Taps && n_total <= kL1Cols;
-  unsigned long long* l1_img = l1 + (int64_t)blockIdx.y * kL1Taps * kL1Cols;
+  const bool want_l1 = hdr_words >= 4 + kL1Taps && taps <= kL1Taps;
   const int tk = ktot / 32, tn = (n_total + 31) / 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const float up = up_scale(amax[row[5]]);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     hdr[1] = __float_as_uint(1.f / up);
     hdr[0] = amax[row[5]];                    // (r5) max |w|, see split_weights_kernel
+    if (hdr_words >= 4 + kL1Taps) { hdr[2] = want_l1 ? (unsigned)taps : 0u; hdr[3] = (unsigned)ktot; }
   }
-  for (int b = blockIdx.x; b < taps * tk * tn; b += gridDim.x) {
-    const int t = b / (tk * tn), r = b - t * (tk * tn);
-    const int k0 = (r / tn) * 32, n0 = (r % tn) * 32;
+  for (int item = blockIdx.x; item < taps * tn; item += gridDim.x) {
+    const int t = item / tn, n0 = (item - t * tn) * 32;
+    float sa[4] = {0.f, 0.f, 0.f, 0.f};       // this thread's share (k = k0 + tx) of sum_k |w| for rows n0 + ty + 8 i
+    for (int kt = 0; kt < tk; ++kt) {
+      const int k0 = kt * 32;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rr = ty + 8 * i;
-      float x = 0.f;
-      if (b_kn) {
-        const int k = k0 + rr, n = n0 + tx;
-        if (n < n_total) x = w[((int64_t)t * ktot + k) * n_total + n];
-        tile[rr][tx] = x;
-      } else {
-        const int n = n0 + rr, k = k0 + tx;
-        if (n < n_total) x = w[((int64_t)t * n_total + n) * ktot + k];
-        tile[tx][rr] = x;
+      for (int i = 0; i < 4; ++i) {
+        const int rr = ty + 8 * i;
+        float x = 0.f;
+        if (b_kn) {
+          const int k = k0 + rr, n = n0 + tx;
+          if (n < n_total) x = w[((int64_t)t * ktot + k) * n_total + n];
+          tile[rr][tx] = x;
+        } else {
+          const int n = n0 + rr, k = k0 + tx;
+          if (n < n_total) x = w[((int64_t)t * n_total + n) * ktot + k];
+          tile[tx][rr] = x;
+        }
       }
-    }
-    __syncthreads();
+      __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = n0 + ty + 8 * i, k = k0 + tx;
-      if (n < n_total) {
-        const float a = tile[tx][ty + 8 * i] * up;
-        const __half a0 = __float2half_rn(a);
-        const __half a1 = __float2half_rn(a - __half2float(a0));
-        const int64_t o = ((int64_t)t * n_total + n) * ktot + k;
-        uint16_t* q = wq + (o >> 5) * 64 + (o & 31);
-        q[0] = __half_as_ushort(a0);
-        q[32] = __half_as_ushort(a1);
+      for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, k = k0 + tx;
+        if (n < n_total) {
+          const float x = tile[tx][ty + 8 * i];
+          sa[i] += fabsf(x);
+          const float a = x * up;
+          const __half a0 = __float2half_rn(a);
+          const __half a1 = __float2half_rn(a - __half2float(a0));
+          const int64_t o = ((int64_t)t * n_total + n) * ktot + k;
+          uint16_t* q = wq + (o >> 5) * 64 + (o & 31);
+          q[0] = __half_as_ushort(a0);
+          q[32] = __half_as_ushort(a1);
+        }
       }
-      if (want_l1) {       // (uniform: the 32 lanes tx of a half wave hold the 32 k of one n)
-        float sa = n < n_total ? fabsf(tile[tx][ty + 8 * i]) : 0.f;
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) sa += __shfl_xor(sa, off, 64);
-        if (tx == 0 && n < n_total)
-          atomicAdd(l1_img + (int64_t)t * kL1Cols + n, __double2ull_ru((double)sa * 1.0000005 * 1099511627776.0));
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// hdr[4 + t] = float bits of max over n of l1[image][t][n] 2^-40 (rounded up), hdr[2] = the number of taps (the flag the
-// kernels test), hdr[3] = K; the sums are cleared on the way: the scratch is all zeros between launches
-__global__ __launch_bounds__(256) void weight_l1_finalize_kernel(const int64_t* __restrict__ table, unsigned* __restrict__ hdrs,
-                                                                 unsigned long long* __restrict__ l1) {
-  __shared__ unsigned long long red[256];
-  const int64_t* row = table + 8 * (int64_t)blockIdx.x;
-  const int taps = (int)row[1], n_total = (int)row[2], ktot = (int)row[3];
-  unsigned* hdr = hdrs + (int64_t)ADVOC_WEIGHT_HDR_L1_WORDS * row[7];
-  if (taps > kL1Taps || n_total > kL1Cols) {
-    if (threadIdx.x == 0) hdr[2] = 0u;
-    return;
-  }
-  unsigned long long* img = l1 + (int64_t)blockIdx.x * kL1Taps * kL1Cols;
-  for (int t = 0; t < taps; ++t) {
-    unsigned long long m = 0;
-    for (int n = threadIdx.x; n < n_total; n += 256) {
-      const unsigned long long v = img[(int64_t)t * kL1Cols + n];
-      img[(int64_t)t * kL1Cols + n] = 0;
-      m = v > m ? v : m;
-    }
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int s_ = 128; s_ > 0; s_ >>= 1) {
-      if ((int)threadIdx.x < s_) red[threadIdx.x] = red[threadIdx.x + s_] > red[threadIdx.x] ? red[threadIdx.x + s_] : red[threadIdx.x];
       __syncthreads();
     }
-    if (threadIdx.x == 0) hdr[4 + t] = __float_as_uint(__double2float_ru((double)red[0] * (1.0 / 1099511627776.0)));
-    __syncthreads();
+    if (want_l1) {
+      // rows: fold the 32 k-lanes of a half wave, then the largest of the block's 32 rows, rounded UP (an upper bound is
+      // what the consumers need: the additions above round to nearest, 1 + 2^-17 covers tk * 32 of them)
+      float m = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = sa[i];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        m = fmaxf(m, v);
+      }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      if ((threadIdx.x & 63) == 0) s_rowmax[threadIdx.x >> 6] = m;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s_rowmax[0], s_rowmax[1]), fmaxf(s_rowmax[2], s_rowmax[3])) * 1.00001f;
+        atomicMax(hdr + 4 + t, __float_as_uint(m));
+      }
+      __syncthreads();
+    }
   }
-  if (threadIdx.x == 0) { hdr[2] = (unsigned)taps; hdr[3] = (unsigned)ktot; }
 }
 
 int grid_for(int64_t items, int per_block) {
@@ -686,24 +676,23 @@ extern "C" int advoc_weight_images_f32(const float* base, const uint32_t* amax, 
   if (count > 65535) return ADVOC_ERR_UNSUPPORTED;
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(advoc::weight_images_kernel, dim3(256, (unsigned)count), dim3(256), 0, advoc::as_stream(stream), base,
-                     amax, table, reinterpret_cast<char*>(pool), hdrs, 4, (unsigned long long*)nullptr);
+                     amax, table, reinterpret_cast<char*>(pool), hdrs, 4);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }
 
 extern "C" int advoc_weight_images_l1_f32(const float* base, const uint32_t* amax, const int64_t* table, int32_t count,
-                                          void* pool, uint32_t* hdrs, uint64_t* l1_scratch, advoc_stream_t stream) {
+                                          void* pool, uint32_t* hdrs, advoc_stream_t stream) {
   if (count < 0) return ADVOC_ERR_BAD_SHAPE;
   if (count == 0) return ADVOC_OK;
-  if (!base || !amax || !table || !pool || !hdrs || !l1_scratch) return ADVOC_ERR_NULL;
+  if (!base || !amax || !table || !pool || !hdrs) return ADVOC_ERR_NULL;
   if (count > 65535) return ADVOC_ERR_UNSUPPORTED;
+  // (the per-tap maxima are raised with atomicMax: every header starts from zero)
+  hipError_t e = hipMemsetAsync(hdrs, 0, sizeof(uint32_t) * ADVOC_WEIGHT_HDR_L1_WORDS * (size_t)count, advoc::as_stream(stream));
+  if (e != hipSuccess) { advoc::note_hip_error(e); return ADVOC_ERR_HIP; }
   ADVOC_CLEAR_LAUNCH_ERROR();
   hipLaunchKernelGGL(advoc::weight_images_kernel, dim3(256, (unsigned)count), dim3(256), 0, advoc::as_stream(stream), base,
-                     amax, table, reinterpret_cast<char*>(pool), hdrs, ADVOC_WEIGHT_HDR_L1_WORDS,
-                     reinterpret_cast<unsigned long long*>(l1_scratch));
-  ADVOC_RETURN_IF_LAUNCH_FAILED();
-  hipLaunchKernelGGL(advoc::weight_l1_finalize_kernel, dim3((unsigned)count), dim3(256), 0, advoc::as_stream(stream), table,
-                     hdrs, reinterpret_cast<unsigned long long*>(l1_scratch));
+                     amax, table, reinterpret_cast<char*>(pool), hdrs, ADVOC_WEIGHT_HDR_L1_WORDS);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   return ADVOC_OK;
 }

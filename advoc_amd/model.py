@@ -518,13 +518,12 @@ class Advoc(Model):
       return
     pool = torch.empty(pool_bytes, dtype=torch.uint8, device=dev)
     # (r5) 32-word headers: {max |w|, 2^-s, taps, K, per-tap row-L1 maxima} (advoc_weight_images_l1_f32) -- the a-priori bounds of
-    # the launches that write operand images from their epilogues read them; its scratch (16 x 1024 sums per image) stays zero
+    # the launches that write operand images from their epilogues read them
     hdrs = torch.zeros(32 * len(rows), dtype=torch.int32, device=dev)
-    l1 = torch.zeros(len(rows) * 16 * 1024, dtype=torch.int64, device=dev)
     table = torch.tensor(rows, dtype=torch.int64, device=dev)
     for lay, direction, off, idx in uses:
       lay.set_weight_image(direction, pool.data_ptr() + off, hdrs.data_ptr() + 128 * idx, l1=True)
-    st[net + '_wimg'] = dict(pool=pool, hdrs=hdrs, table=table, count=len(rows), uses=uses, l1=l1)
+    st[net + '_wimg'] = dict(pool=pool, hdrs=hdrs, table=table, count=len(rows), uses=uses)
 
   # ------------------------------------------------------------------------------------------
   # batch-norm plumbing
@@ -679,7 +678,7 @@ class Advoc(Model):
     if wi:
       _lib.check(_lib.load().advoc_weight_images_l1_f32(
           _lib.ptr(st[net + '_param']), _lib.ptr(out), _lib.ptr(wi['table']), wi['count'], _lib.ptr(wi['pool']),
-          _lib.ptr(wi['hdrs']), _lib.ptr(wi['l1']), _lib.stream()), 'advoc_weight_images_l1_f32')
+          _lib.ptr(wi['hdrs']), _lib.stream()), 'advoc_weight_images_l1_f32')
 
   def _gen_forward(self, x):
     st = self._built

@@ -355,15 +355,15 @@ int advoc_conv_weight_image_desc(const advoc_conv_layer* layer, int32_t directio
  * aligned), index of its 4-word header in `hdrs`}.  Feeds advoc_conv_layer.w_img / w_img_hdr. */
 int advoc_weight_images_f32(const float* base, const uint32_t* amax, const int64_t* table, int32_t count, void* pool,
                             uint32_t* hdrs, advoc_stream_t stream);
-/* (r5) The same with ADVOC_WEIGHT_HDR_L1_WORDS-word headers (index of table column 7 in units of that many words): besides
- * {max |w|, 2^-s} in words 0, 1 a header receives word 2 = taps (0: none of the following), word 3 = K and words 4 .. 4 + taps
- * = float bits of max over the image's rows n of sum_k |w[tap][n][k]| -- the per-tap factors of the a-priori bounds the
- * backward-data / forward launches that write an operand image under ADVOC_DX_BOUNDED / ADVOC_Y_BOUNDED use instead of
- * max |w| * K (about 5 x tighter: two more bits for the small values of the image).  l1_scratch: count * 16 * 1024
- * uint64 of device memory, ZERO on entry and left zero. */
+/* (r5) The same with ADVOC_WEIGHT_HDR_L1_WORDS-word headers (index of table column 7 in units of that many words; the headers
+ * of ALL `count` images are zeroed first, so the table must use indices 0 .. count - 1): besides {max |w|, 2^-s} in words 0, 1 a
+ * header receives word 2 = taps (0: none of the following; images of more than 16 taps), word 3 = K and words 4 .. 4 + taps =
+ * float bits of max over the image's rows n of sum_k |w[tap][n][k]| (rounded up) -- the per-tap factors of the a-priori bounds
+ * the launches that write an operand image under ADVOC_DX_BOUNDED / ADVOC_Y_BOUNDED use instead of max |w| * K (about 5 x
+ * tighter: two more bits for the small values of the image); pass ADVOC_IMG_W_L1 with such headers. */
 #define ADVOC_WEIGHT_HDR_L1_WORDS 32
 int advoc_weight_images_l1_f32(const float* base, const uint32_t* amax, const int64_t* table, int32_t count, void* pool,
-                               uint32_t* hdrs, uint64_t* l1_scratch, advoc_stream_t stream);
+                               uint32_t* hdrs, advoc_stream_t stream);
 
 /* 1: the layer's output-gradient image pass can carry the bias gradient (db_fused above): dy_img present and cout such
  * that a thread of the image pass keeps one group of 8 channels (32 <= cout <= 1024, 256 % (cout / 8) == 0) */

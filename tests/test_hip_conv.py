@@ -1423,14 +1423,12 @@ def test_weight_magnitude_from_the_arena_pass(hip, case, hipenv):
     for d in (0, 1):
       L.set_weight_image(d, pool.data_ptr() + offs[d], hdrs.data_ptr() + 16 * d)
     # (r5) advoc_weight_images_l1_f32: the same images, and behind {max |w|, 2^-s} in 32-word headers the per-tap maxima over
-    # the image's rows n of sum_k |w[tap][n][k]| -- the factors of the a-priori bounds of the emitting launches; its scratch
-    # comes back zero
+    # the image's rows n of sum_k |w[tap][n][k]| -- the factors of the a-priori bounds of the emitting launches
     pool2 = torch.empty_like(pool)
     hdrs2 = torch.zeros(64, dtype=torch.int32, device=dev)
-    l1 = torch.zeros(2 * 16 * 1024, dtype=torch.int64, device=dev)
     _lib.check(_lib.load().advoc_weight_images_l1_f32(_lib.ptr(w), _lib.ptr(amax), _lib.ptr(table), 2, _lib.ptr(pool2),
-                                                      _lib.ptr(hdrs2), _lib.ptr(l1), _lib.stream()), 'advoc_weight_images_l1_f32')
-    assert torch.equal(pool, pool2) and int(l1.abs().sum()) == 0
+                                                      _lib.ptr(hdrs2), _lib.stream()), 'advoc_weight_images_l1_f32')
+    assert torch.equal(pool, pool2)
     h2 = hdrs2.cpu()
     for i, d in enumerate(descs):
       taps, n_total, ktot, b_kn = d[:4]
@@ -1440,7 +1438,7 @@ def test_weight_magnitude_from_the_arena_pass(hip, case, hipenv):
       wt = wt.reshape(taps, ktot, n_total) if b_kn else wt.reshape(taps, n_total, ktot).transpose(1, 2)
       want = wt.abs().sum(dim=1).max(dim=1).values                   # [tap]: max over n of the sum over k
       got = h2[32 * i + 4:32 * i + 4 + taps].view(torch.float32).double()
-      assert bool(((got >= want) & (got <= want * (1 + 1e-5) + 1e-11)).all()), (got, want)    # an upper bound, and a tight one
+      assert bool(((got >= want) & (got <= want * (1 + 3e-5) + 1e-11)).all()), (got, want)    # an upper bound, and a tight one
     y.zero_()
     L.forward()
     dx0 = torch.zeros_like(x0)
