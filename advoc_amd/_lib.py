@@ -57,6 +57,7 @@ class ConvLayer(ctypes.Structure):
       ('y_img', ImageOut * 2),
       ('wgrad_ws', _p), ('wgrad_ws_bytes', _i64),
       ('dx_img', DxImage),
+      ('dx1_amax', _p),
   ]
 
 WGRAD_TABLE_BYTES = 262144      # ADVOC_WGRAD_TABLE_BYTES

@@ -102,6 +102,11 @@ class Layer(object):
   # tensor to refit from) and the fp32 dx0 is NOT written: the image pass of the layer below (a read and a write of the
   # tensor) disappears at no extra store in the epilogue.  Needs reuse_images (the train step's guarantees).
   dx_bounded = os.environ.get('ADVOC_DX_BOUNDED', '1') == '1'
+  # ADVOC_DX_ACCUM=1: ... also from calls that ACCUMULATE into dx0 (the generator's encoder chain: a decoder's skip gradient
+  # arrives first, with its largest magnitude recorded -- dx1_amax / bound_add).  Built, value-checked
+  # (tests/test_hip_conv.py: enc_accum*) and OFF by default: same box, alternating, 38.56 / 38.50 / 38.66 ms without against
+  # 38.48 / 38.54 / 38.73 with it -- the accumulating epilogue pays in loads and image arithmetic what the seven passes cost.
+  dx_accum = os.environ.get('ADVOC_DX_ACCUM', '0') == '1'
   # (r5) ADVOC_Y_IMAGE_ONLY=0 turns it off: a layer whose output has ONE reader (add_image_consumer(..., exclusive=True)) that
   # reads it as an operand image and gates its backward-data pass on that image's signs (a patch kernel) writes the IMAGE
   # ONLY, under a scale from an a-priori bound of |y| (max|x| max|w| taps K + max|b|): the fp32 tensor -- half the bytes the
@@ -223,6 +228,7 @@ class Layer(object):
     self._x_emitted = set()        # sources of x_img written by their producers since the last forward
     self._db_done_for = None
     self._emits_dx = None          # advoc_conv_emits_dx_image(), asked once
+    self._emits_dx_acc = None      # ... as an accumulating call
     self._dx_table = None          # replica table of the column sums that ride in the dx image emission
     self._dy_emitted_for = None    # (dy pointer, db pointer or None): dy_img was written by the layer above's backward_data
     self._bias_fusable = bool(_lib.load().advoc_conv_bias_fusable(ctypes.byref(s)))
@@ -363,6 +369,10 @@ class Layer(object):
       out.append((k, c, src))
     return out
 
+  def tracks_dx1_amax(self):
+    """True when this layer's backward-data kernel raises dx1_amax (the image kernels: patch and per-tap)."""
+    return self.x1 is not None and '_h3_kernel' in self.kernel_name(1)
+
   def _image_only_consumer(self):
     """The one consumer this layer's output exists for as an image only (Layer.y_image_only), or None."""
     if not (Layer.y_image_only and self._exclusive and self._emits == 2 and self.reuse_images and len(self._consumers) == 1):
@@ -422,11 +432,11 @@ class Layer(object):
     self._x_current = bool(self.struct.x_img) and 'h3' in self.kernel_name(0)
     return self.y
 
-  def _dx_target(self, dx0, dx1, accum0, accum1, consumer, consumer_db):
+  def _dx_target(self, dx0, dx1, accum0, accum1, consumer, consumer_db, bound_add=None):
     """(the layer below (`consumer`) whose output-gradient image this backward_data call can write, kind) or (None, 0);
     kind 2: the thin matrix kernel under the one-pass scale (fp32 dx0 written too), 3: a patch kernel under the a-priori
     scale, image only."""
-    if consumer is None or dx0 is None or accum0 or accum1:
+    if consumer is None or dx0 is None or accum1 or (accum0 and (bound_add is None or not Layer.dx_accum)):
       return None, 0
     cs = consumer.struct
     if not (cs.dy_img and cs.dy_hdr):
@@ -435,9 +445,19 @@ class Layer(object):
       return None, 0
     if consumer_db is not None and not consumer._bias_fusable:
       return None, 0
-    if self._emits_dx is None:
-      self._emits_dx = int(_lib.load().advoc_conv_emits_dx_image(ctypes.byref(self.struct)))
-    kind = self._emits_dx
+    if accum0:
+      # an accumulating call (dx0 already holds a skip gradient whose largest magnitude is in bound_add): asked separately
+      if self._emits_dx_acc is None:
+        self.struct.dx_img.bound_add = bound_add.data_ptr()
+        try:
+          self._emits_dx_acc = int(_lib.load().advoc_conv_emits_dx_image(ctypes.byref(self.struct)))
+        finally:
+          self.struct.dx_img.bound_add = None
+      kind = self._emits_dx_acc if self._emits_dx_acc == 3 else 0
+    else:
+      if self._emits_dx is None:
+        self._emits_dx = int(_lib.load().advoc_conv_emits_dx_image(ctypes.byref(self.struct)))
+      kind = self._emits_dx
     # 3 / 4: a patch kernel / the thin matrix kernel under the a-priori scale (a launch that reports 2 runs as 4 when max |w|
     # is on the device); 2: the thin kernel under the one-pass scale (r4, off by default)
     if kind in (3, 4) or (kind == 2 and self.struct.w_amax):
@@ -456,14 +476,17 @@ class Layer(object):
     return consumer, kind
 
   def backward_data(self, dy, dx0=None, dx1=None, accum0=False, accum1=False, db=None, db_accumulate=True,
-                    grad_consumer=None, consumer_db=None, consumer_db_accumulate=True):
+                    grad_consumer=None, consumer_db=None, consumer_db_accumulate=True, dx1_amax=None, bound_add=None):
     """dx0 / dx1 <- gradient w.r.t. the inputs.  db (optional): the bias gradient buffer of this layer -- where the call
     builds the image of dy (image kernels, advoc_conv_bias_fusable) the per-channel sums are taken in the same pass and
     the backward_weight call that follows with the same dy skips its bias kernel.
     grad_consumer (optional): the Layer whose output y this layer reads as x0, i.e. whose output GRADIENT dx0 is; where the
     kernels allow (advoc_conv_emits_dx_image) this call writes that layer's output-gradient image itself, and with
     consumer_db its bias gradient (per-channel sums of dx0): its backward_data / backward_weight calls that follow with
-    dx0 (and consumer_db) then build neither."""
+    dx0 (and consumer_db) then build neither.
+    dx1_amax (optional, one int32 on the device, zeroed by the caller): receives the float bits of the largest |value| this
+    call writes to dx1 (image kernels only -- check tracks_dx1_amax()); bound_add: such a word for the tensor dx0 ACCUMULATES
+    into (accum0): with it an accumulating call can write the layer below's image too (r5: the encoder chain)."""
     _lib.require_device(dy)
     if tuple(dy.shape) != tuple(self.y.shape):
       raise _lib.AdvocHipError('dy shape {} != y shape {}'.format(tuple(dy.shape), tuple(self.y.shape)))
@@ -484,9 +507,11 @@ class Layer(object):
       if not db_accumulate:
         db.zero_()
       self.struct.db_fused = _lib.ptr(db)
-    target, dx_kind = self._dx_target(dx0, dx1, accum0, accum1, grad_consumer, consumer_db)
+    target, dx_kind = self._dx_target(dx0, dx1, accum0, accum1, grad_consumer, consumer_db, bound_add)
+    self.struct.dx1_amax = dx1_amax.data_ptr() if (dx1_amax is not None and dx1 is not None and self.tracks_dx1_amax()) else None
     if target is not None:
       self.struct.dx_img.mode = 3 if dx_kind == 3 else 0        # ADVOC_DX_BOUNDED | ADVOC_DX_IMAGE_ONLY
+      self.struct.dx_img.bound_add = bound_add.data_ptr() if (accum0 and bound_add is not None) else None
       if consumer_db is not None:
         _lib.require_device(consumer_db)
         if not consumer_db_accumulate:
@@ -517,6 +542,8 @@ class Layer(object):
       self.struct.dx_img.colsum = None
       self.struct.dx_img.table = None
       self.struct.dx_img.mode = 0
+      self.struct.dx_img.bound_add = None
+      self.struct.dx1_amax = None
     if target is not None:
       target._dy_emitted_for = (dx0.data_ptr(), consumer_db.data_ptr() if consumer_db is not None else None, dx_kind == 3)
     if fuse_db or db_by_producer:

@@ -474,11 +474,13 @@ namespace {
 // 0: no; 2: the thin matrix kernel's backward-data instance (one-pass scale, dx0 only); 3: a patch kernel under the a-priori
 // scale (ADVOC_DX_BOUNDED; dx1, when the layer has a second source, is an ordinary fp32 destination)
 int dx_image_launch(const advoc_conv_layer* L, const float* dy, float* dx0, float* dx1, int accum0, int accum1) {
-  if (!dx0 || accum0 || accum1 || !tuning().emit_dx) return 0;
+  if (!dx0 || accum1 || !tuning().emit_dx) return 0;
+  if (accum0 && !L->dx_img.bound_add) return 0;        // an accumulating destination needs a bound of what it holds
   GatherGemmParams p;
   bool b_kn;
-  if (build_backward_data(L, dy, dx0, dx1, 0, 0, p, b_kn) != ADVOC_OK) return 0;
-  if (p.y_mask || p.d[0].gmask || p.d[0].accum || p.d[0].c % 64 || p.d[0].c > 1024 || !image_colsum_ok(p.d[0].c)) return 0;
+  if (build_backward_data(L, dy, dx0, dx1, accum0, 0, p, b_kn) != ADVOC_OK) return 0;
+  p.obound_add = accum0 ? L->dx_img.bound_add : nullptr;
+  if (p.y_mask || p.d[0].gmask || p.d[0].c % 64 || p.d[0].c > 1024 || !image_colsum_ok(p.d[0].c)) return 0;
   p.a_img_out = L->dy_img; p.a_hdr_out = L->dy_img ? L->dy_hdr : nullptr;
   p.w_amax = L->w_amax;
   p.w_img = L->w_img[1]; p.w_img_hdr = L->w_img_hdr[1]; p.w_img_l1 = (L->img_flags & ADVOC_IMG_W_L1) != 0;
@@ -487,7 +489,7 @@ int dx_image_launch(const advoc_conv_layer* L, const float* dy, float* dx0, floa
   int emits = 0;
   const char* nm = nullptr;
   p.emit_report = &emits;
-  if (!dx1 && !L->x1.p && run_gather(p, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes) == ADVOC_OK && emits == 2)
+  if (!accum0 && !dx1 && !L->x1.p && run_gather(p, b_kn, nullptr, &nm, L->workspace, L->workspace_bytes) == ADVOC_OK && emits == 2)
     return 2;
   emits = 0;
   p.oimg_bounded = 1;
@@ -514,6 +516,7 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
   p.a_img_delayed = (L->img_flags & ADVOC_IMG_DY_DELAYED) != 0;
   p.a_img_emitted = (L->img_flags & ADVOC_IMG_DY_EMITTED) != 0;
   p.a_img_bounded = (L->img_flags & ADVOC_IMG_DY_BOUNDED) != 0;
+  p.d1_amax_out = (dx1 && L->x1.p) ? L->dx1_amax : nullptr;
   if (L->img_flags & ADVOC_IMG_X_GATES) {
     // the fp32 inputs were never written: gate on the sign of x_img (source 1 behind source 0 at its 256-byte-rounded size)
     if (!L->x_img || L->in_scale || L->in_mask) return ADVOC_ERR_UNSUPPORTED;
@@ -573,7 +576,8 @@ extern "C" int advoc_conv_backward_data(const advoc_conv_layer* L, const float* 
 extern "C" int advoc_conv_emits_dx_image(const advoc_conv_layer* L) {
   if (validate_layer(L) != ADVOC_OK) return 0;
   float dummy = 0.f;
-  return dx_image_launch(L, &dummy, &dummy, L->x1.p ? &dummy : nullptr, 0, 0);
+  // (with dx_img.bound_add set: as an ACCUMULATING call, accum0)
+  return dx_image_launch(L, &dummy, &dummy, L->x1.p ? &dummy : nullptr, L->dx_img.bound_add ? 1 : 0, 0);
 }
 
 extern "C" int advoc_conv_gates_on_image(const advoc_conv_layer* L) {

@@ -125,6 +125,10 @@ struct GatherGemmParams {
   const unsigned* a_amax;
   const unsigned* obound_add;
   int d0_no_store;         // != 0: destination 0 exists as the image only, its fp32 tensor is not written
+  unsigned* d1_amax_out;   // != null (backward-data): max |value written to destination 1| is raised here (float bits; zeroed by the
+                           // caller) -- the bound of "what the destination already holds" for the launch that ACCUMULATES into that
+                           // tensor later and writes its image (obound_add of that launch: a decoder's skip gradient, finished by
+                           // the encoder's backward-data pass)
   float* a_colsum;         // != null: the image pass of source 0 adds its per-channel sums over the logical pixels here (the
                            // bias gradient, when A is an output gradient); only honoured where image_colsum_ok(c0)
   // ---- tail split (filled in by the launcher, see launch_cfg) ----

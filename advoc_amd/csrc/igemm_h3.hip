@@ -398,7 +398,7 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
     }
   }
   const float eup1 = emit1 ? emit_up_scale(p.oimg[1].hdr[2]) : 1.f;
-  float evmax0 = 0.f, evmax1 = 0.f;
+  float evmax0 = 0.f, evmax1 = 0.f, dmax1 = 0.f;
   if (tid == 0) {      // (every workgroup that reaches an epilogue: the same value)
     if (emit0) p.oimg[0].hdr[1] = __float_as_uint(1.f / eup0);
     if (emit1) p.oimg[1].hdr[1] = __float_as_uint(1.f / eup1);
@@ -476,6 +476,7 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
         if (d.accum) {
           v.x += old[ps].x; v.y += old[ps].y; v.z += old[ps].z; v.w += old[ps].w;
         }
+        if (di == 1) dmax1 = fmaxf(fmaxf(dmax1, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         if (!no_store) *reinterpret_cast<float4*>(dst) = v;
         if (di == 0) {
           if (emit0) emit4(p.oimg[0], eup0, v, (unsigned)off[ps], evmax0);
@@ -499,6 +500,13 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
   }
   if (emit0) emit_finish(p.oimg[0], eup0, evmax0);
   if (emit1) emit_finish(p.oimg[1], eup1, evmax1);
+  if (p.d1_amax_out && !atomic_split) {      // max |value written to destination 1|: GatherGemmParams::d1_amax_out
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dmax1 = fmaxf(dmax1, __shfl_xor(dmax1, off, 64));
+    if (lane == 0 && dmax1 > 0.f &&
+        __float_as_uint(dmax1) > __hip_atomic_load(p.d1_amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(p.d1_amax_out, __float_as_uint(dmax1));
+  }
 }
 
 template <int MT, int NT, int NS, int WGM>
@@ -733,7 +741,7 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   // consumers' images from this launch's epilogue (image_emit.h): every epilogue must see the final value, so no K
   // split that meets in the destination with atomics (the workspace splits are fine: their last slice runs the epilogue)
   const bool want_emit = p.oimg[0].img != nullptr || p.oimg[1].img != nullptr;
-  if (want_emit) ksplit = 1;
+  if (want_emit || p.d1_amax_out) ksplit = 1;      // (every epilogue must see the final value)
   if (p.emit_report) *p.emit_report = 1;
   // (r5) the output-gradient image of the layer below under the a-priori scale (GatherGemmParams::oimg_bounded): the patch
   // kernels' lean backward-data instances, grids without remainder columns
@@ -745,7 +753,8 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     // (the patch kernels' lean instances; remainder columns and launches without a patch plan on the per-tap kernel, whose
     // generic epilogue takes masks too -- but an accumulating destination 0 needs a bound of what it holds: obound_add)
     const bool ok = p.oimg[0].img && p.oimg[0].hdr && !p.oimg[1].img && !p.y_mask &&
-                    !p.d[0].gmask && !p.d[1].gmask && (!p.d[0].accum || (p.obound_add && patch_nph == 0)) && !p.d[1].accum &&
+                    !p.d[0].gmask && !p.d[1].gmask && (!p.d[0].accum || (p.obound_add && (patch_nph == 0 || patch_nph == 4))) &&
+                    !p.d[1].accum &&
                     (p.grad_act != ADVOC_ACT_NONE || p.d[0].xpre || p.d[1].p) &&
                     (!p.ocolsum_out || (p.ocolsum_table && p.d[0].c <= 1024));
     if (p.emit_report) *p.emit_report = ok ? 3 : 0;
@@ -874,7 +883,7 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     const Tuning& tn = tuning();
     if (tail.split > 1 && tail_ws && tail_cnt)
       return launch_h21(pr, stream, nullptr, tail, tail_ws, tail_cnt, 1);
-    if (!want_emit && nkt >= 4 * tn.h3_rem_split_div && rtiles < (int64_t)tn.h3_rem_wgs_per_cu * device_cu_count() && tn.igemm_splitk) {
+    if (!want_emit && !p.d1_amax_out && nkt >= 4 * tn.h3_rem_split_div && rtiles < (int64_t)tn.h3_rem_wgs_per_cu * device_cu_count() && tn.igemm_splitk) {
       rsplit = (int)ceil_div((int64_t)tn.h3_rem_wgs_per_cu * device_cu_count(), rtiles);
       if (rsplit > nkt / tn.h3_rem_split_div) rsplit = nkt / tn.h3_rem_split_div;
       if (rsplit > 16) rsplit = 16;

@@ -200,6 +200,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // refitted, and the fp32 tensor need not exist (d0_no_store); the per-channel sums of the tensor -- the lower layer's
   // bias gradient, which used to ride in its image pass -- are taken here too (ocolsum_table).
   constexpr bool emit0 = NE >= 1, emit1 = !BWD && NE >= 2;
+  constexpr bool kNoMask = BWD && NE >= 1;       // the BWD-emitting instances take no dropout mask on their destinations
   float eup0_ = 1.f;
   if (emit0) {
     if (BWD) {
@@ -222,7 +223,10 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const float eup1 = emit1 ? sgpr_f(emit_up_scale(p.oimg[1].hdr[2])) : 1.f;
   // (the BWD-emitting instances are LEAN: no dropout mask on the destination, no accumulation -- the launcher checks -- so
   // that the epilogue's prefetched operands, the image arithmetic and the column sums fit the registers next to the tile)
-  constexpr bool kLean = BWD && NE >= 1;
+  // (NE = 2, backward-data: the same with an ACCUMULATING destination 0 -- the value already there is loaded and added before
+  // the image is written: the encoder chain, where a decoder's skip gradient arrived first)
+  constexpr bool kLean = BWD && NE == 1;
+  float dmax1 = 0.f;       // max |value| written to destination 1 (d1_amax_out)
   if (emit0 && threadIdx.x == 0) {
     if (emit0) p.oimg[0].hdr[1] = __float_as_uint(1.f / eup0);
     if (emit1) p.oimg[1].hdr[1] = __float_as_uint(1.f / eup1);
@@ -762,7 +766,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
         xp[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ob, 0, 0);                                   \
       }                                                                                                   \
       if (BWD && !kLean) old[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, ob, 0, 0);                 \
-      if (!kLean) mk[ps] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, off[ps], 0, 0);                     \
+      if (!kNoMask) mk[ps] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, off[ps], 0, 0);                   \
     }
     ADVOC_P3_PRELOAD(0);
 #pragma unroll
@@ -789,7 +793,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
           v[ps].x *= x.x > 0.f ? 1.f : gslope; v[ps].y *= x.y > 0.f ? 1.f : gslope;
           v[ps].z *= x.z > 0.f ? 1.f : gslope; v[ps].w *= x.w > 0.f ? 1.f : gslope;
         }
-        if (!kLean && has_mask) {
+        if (!kNoMask && has_mask) {
           const float ms = BWD ? d_gmask_scale : p.y_mask_scale;
           v[ps].x *= (float)(mk[ps] & 0xffu) * ms; v[ps].y *= (float)((mk[ps] >> 8) & 0xffu) * ms;
           v[ps].z *= (float)((mk[ps] >> 16) & 0xffu) * ms; v[ps].w *= (float)(mk[ps] >> 24) * ms;
@@ -798,6 +802,8 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
           v[ps].x += __uint_as_float(old[ps].x); v[ps].y += __uint_as_float(old[ps].y);
           v[ps].z += __uint_as_float(old[ps].z); v[ps].w += __uint_as_float(old[ps].w);
         }
+        if (BWD && di == 1 && p.d1_amax_out && off[ps] != kOob)
+          dmax1 = fmaxf(fmaxf(dmax1, fmaxf(fabsf(v[ps].x), fabsf(v[ps].y))), fmaxf(fabsf(v[ps].z), fabsf(v[ps].w)));
         so[ps] = (off[ps] == kOob || (abl & 128)) ? kOob : off[ps] * 4u;       // (128: timing only, every store dropped by the range check)
       }
       if (i + 1 < MT) { ADVOC_P3_PRELOAD(i + 1); }
@@ -836,6 +842,13 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   }
   __syncthreads();          // the next tile's DMAs overwrite the LDS this epilogue read
   }  // tiles
+  if (BWD && p.d1_amax_out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dmax1 = fmaxf(dmax1, __shfl_xor(dmax1, off, 64));
+    if (lane == 0 && dmax1 > 0.f &&
+        __float_as_uint(dmax1) > __hip_atomic_load(p.d1_amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(p.d1_amax_out, __float_as_uint(dmax1));
+  }
   if (emit0) emit_finish(p.oimg[0], eup0, evmax0);
   if (emit1) emit_finish(p.oimg[1], eup1, evmax1);
 }
@@ -848,7 +861,13 @@ __global__ __launch_bounds__(512, 1) void patch_gemm_h3_kernel(const GatherGemmP
 template <int NPH, int BWD, int NE = 0>
 int launch_patch(const GatherGemmParams& p_in, const PatchGeom& g, hipStream_t stream, const char** name_only) {
   using C = PCfg<NPH, 8>;
-  if (BWD && NE == 0 && !name_only && p_in.oimg[0].img) return launch_patch<NPH, BWD, BWD ? 1 : 0>(p_in, g, stream, name_only);
+  if (BWD && NE == 0 && !name_only && p_in.oimg[0].img) {
+    if (p_in.d[0].accum) {       // (the accumulating form exists for the four-phase instance: the encoders' backward-data)
+      if constexpr (NPH == 4) return launch_patch<NPH, BWD, BWD ? 2 : 0>(p_in, g, stream, name_only);
+      else return ADVOC_ERR_UNSUPPORTED;
+    }
+    return launch_patch<NPH, BWD, BWD ? 1 : 0>(p_in, g, stream, name_only);
+  }
   if (!BWD && NE == 0 && !name_only && (p_in.oimg[0].img || p_in.oimg[1].img)) {
     // forward launch with image consumers: the instance compiled for their number, consumers packed into oimg[0 .. n)
     GatherGemmParams q = p_in;

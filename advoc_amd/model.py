@@ -336,6 +336,7 @@ class Advoc(Model):
       if drop > 0:
         masks[idx] = (torch.zeros(B, hh, ww, c, dtype=torch.uint8, device=dev), 1.0 - drop)
     st['dec'], st['g_dec'], st['masks'] = d, gd, masks
+    st['g_skip_amax'] = torch.zeros(len(e), dtype=torch.int32, device=dev)      # conv.Layer.backward_data(dx1_amax=...)
 
     # ---- generator batch-norm state (use_batchnorm=True) ----
     # encoder k >= 2 feeds encoder k+1 (alone) and decoder k (second half of a concat);
@@ -967,6 +968,9 @@ class Advoc(Model):
       if name_ in gbn:
         return None, None
       return GL[name_], GG['generator/%s/conv2d_transpose/bias' % name_]
+    skip_amax = st['g_skip_amax']
+    skip_amax.zero_()
+    skip_tracked = set()
     lower, lower_db = below(last_idx) if dec else (None, None)
     GL['decoder_1'].backward_data(g_out, gd[last_idx] if dec else ge[-1], ge[0], grad_consumer=lower, consumer_db=lower_db)
     with self._wgrad_ctx():
@@ -982,8 +986,12 @@ class Advoc(Model):
         lay.backward_data(gd[idx], ge[-1], db=GG[s + '/bias'])
       else:
         lower, lower_db = below(dec[j - 1][0])
+        # (skip_amax[idx - 1]: the largest |skip gradient| written to ge[idx - 1] -- what the encoder's accumulating
+        # backward-data call below needs to bound the sum whose image it writes)
         lay.backward_data(gd[idx], gd[dec[j - 1][0]], ge[idx - 1], db=GG[s + '/bias'], grad_consumer=lower,
-                          consumer_db=lower_db)
+                          consumer_db=lower_db, dx1_amax=skip_amax[idx - 1:idx])
+        if lay.tracks_dx1_amax():
+          skip_tracked.add(idx - 1)
       with self._wgrad_ctx():
         lay.backward_weight(gd[idx], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
         self._g_grads_ready(self._last_param_of('generator/decoder_%d' % idx))
@@ -993,7 +1001,13 @@ class Advoc(Model):
       if 'encoder_%d' % (i + 1) in gbn:
         self._bn_backward(gbn['encoder_%d' % (i + 1)], ge[i], accumulate=True)
       if i > 0:
-        lay.backward_data(ge[i], ge[i - 1], accum0=True, db=GG[s + '/bias'])
+        # (r5) ge[i - 1] holds the decoder's skip gradient; this call adds the encoder path's and -- where the kernels can and the
+        # skip gradient's magnitude was recorded -- leaves the SUM as encoder_i's output-gradient image only
+        name_b = 'encoder_%d' % i
+        lower = GL[name_b] if (name_b not in gbn and (i - 1) in skip_tracked) else None
+        lay.backward_data(ge[i], ge[i - 1], accum0=True, db=GG[s + '/bias'], grad_consumer=lower,
+                          consumer_db=GG['generator/%s/conv2d/bias' % name_b] if lower is not None else None,
+                          bound_add=skip_amax[i - 1:i] if lower is not None else None)
       with self._wgrad_ctx():
         lay.backward_weight(ge[i], GG[s + '/kernel'], GG[s + '/bias'], accumulate=True)
         self._g_grads_ready(self._last_param_of('generator/encoder_%d' % (i + 1)))

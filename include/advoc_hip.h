@@ -329,10 +329,16 @@ typedef struct advoc_conv_layer {
    * the column sums and the magnitude are the only outputs -- the lower layer's image pass (a read and a write of the
    * whole tensor) disappears without the epilogue storing one byte more than it did.  Honoured by the patch kernels'
    * backward-data launches on grids without remainder columns (advoc_conv_emits_dx_image() == 3), without dropout
-   * mask / accumulation on either destination; `bound_add` (optional, device): float bits of a bound of what the
-   * destination already holds (reserved for accumulating calls). */
+   * mask on either destination and without accumulation -- except accum0 together with `bound_add` (device): float bits of a
+   * bound of |what dx0 already holds| (advoc_conv_layer.dx1_amax of the call that wrote it), four-phase and per-tap launches. */
   struct { uint16_t* img; uint32_t* hdr; float* colsum; float* table; int32_t mode; int32_t reserved;
            const uint32_t* bound_add; } dx_img;
+  /* optional (backward-data calls of the image kernels on a two-source layer, r5): the largest |value| the call writes to dx1 is
+   * raised here (float bits, device; the caller zeroes the word first).  It is the `bound_add` of the LATER call that
+   * accumulates into the same tensor and writes its image: a decoder's skip gradient arrives first, the encoder's
+   * backward-data pass adds its own and -- with dx_img under ADVOC_DX_BOUNDED | ADVOC_DX_IMAGE_ONLY and accum0 -- leaves the
+   * sum as the lower encoder's output-gradient image only. */
+  uint32_t* dx1_amax;
 } advoc_conv_layer;
 #define ADVOC_DX_BOUNDED 1
 #define ADVOC_DX_IMAGE_ONLY 2

@@ -1093,8 +1093,8 @@ def test_backward_data_writes_the_output_gradient_image_of_the_layer_below(hip, 
 
 @gpu
 @pytest.mark.parametrize('shape', ['d4_s1', 'd3_s2', 'dec_two_sources', 'thin_cout1', 'thin_two_sources', 'dec_rem_trim',
-                                   'deep_per_tap'])
-def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_priori_scale(hip, hipenv, shape):
+                                   'deep_per_tap', 'enc_accum', 'enc_accum_rem', 'enc_accum_deep'])
+def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_priori_scale(hip, hipenv, monkeypatch, shape):
   """r5: the backward-data call of a layer on a PATCH kernel writes the output-gradient image of the layer below from its
   epilogue under a scale derived from a bound of |dx| known before the launch (max|dy| max|w| taps K: nothing can leave the
   fp16 range -- no history, no refit check), with that layer's bias column sums, and does NOT write the fp32 tensor at
@@ -1106,6 +1106,7 @@ def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_
   destination stays an ordinary fp32 tensor (the generator's decoders)."""
   from advoc_amd import conv
   hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1, ADVOC_WGRAD_H3_MIN_M=1)
+  monkeypatch.setattr(conv.Layer, 'dx_accum', True)       # (the accumulating form is off by default: it does not pay, conv.py)
   dev = torch.device('cuda')
   g = torch.Generator().manual_seed(77)
   if shape == 'd4_s1':            # lower: 64 -> 128 stride 2; upper: 4x4 stride 1, 128 -> 256 on a 32 x 32 grid
@@ -1128,6 +1129,16 @@ def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_
     low = dict(kind=conv.DECONV, w=(4, 4, 64, 64), y=(2, 32, 36, 64), stride=(2, 2), pad=(1, 1))
     up = dict(kind=conv.DECONV, w=(4, 4, 1, 128), y=(2, 64, 72, 1), stride=(2, 2), pad=(1, 1), x1=(2, 32, 36, 64))
     want = 'thin_k_gemm_kernel<16, 4, true>'
+  elif shape in ('enc_accum', 'enc_accum_rem', 'enc_accum_deep'):
+    # the generator's encoder chain: dx0 ACCUMULATES into a tensor that already holds a skip gradient (a decoder wrote it, and
+    # recorded its largest magnitude: bound_add); the sum exists as the lower encoder's image only.  Four-phase patches, the
+    # same with a remainder column, and the per-tap kernel alone
+    hw = {'enc_accum': (64, 128), 'enc_accum_rem': (64, 130), 'enc_accum_deep': (16, 18)}[shape]
+    xin = torch.randn(2, hw[0], hw[1], 64, generator=g)
+    low = dict(kind=conv.CONV, w=(4, 4, 64, 128), y=(2, hw[0] // 2, hw[1] // 2, 128), stride=(2, 2), pad=(1, 1))
+    up = dict(kind=conv.CONV, w=(4, 4, 128, 256), y=(2, hw[0] // 4, (hw[1] // 2 + 1) // 2, 256), stride=(2, 2), pad=(1, 1),
+              x1=None, accum=True)
+    want = 'gather_gemm_h3_kernel' if shape == 'enc_accum_deep' else 'patch_gemm_h3_kernel<4, 1>'
   elif shape == 'dec_rem_trim':   # the generator's decoders as they are: a 16 n + 1 wide grid (patches + a per-tap launch over
     xin = torch.randn(2, 16, 17, 64, generator=g)     # the remainder column, both writing the image), a trimmed first source
     low = dict(kind=conv.DECONV, w=(4, 4, 128, 64), y=(2, 32, 34, 128), stride=(2, 2), pad=(1, 1))
@@ -1166,16 +1177,27 @@ def test_patch_backward_data_writes_the_lower_layers_gradient_image_under_the_a_
              dx=torch.empty_like(xin), dw=torch.zeros_like(w_lo), db=torch.zeros_like(b_lo))
     return Up, Lo, t
   A, R = make(), make()
+  accum = bool(up.get('accum'))
+  skip_grad = (torch.randn(*low['y'], generator=g) * 3.0).to(dev) if accum else None
   for step, scale in enumerate((1.0, 0.8, 1000.0, 1e-4, 1.0)):
     for (Up, Lo, t), emit in ((A, True), (R, False)):
       Lo.forward()
       Up.forward()
       t['dw'].zero_()
-      # (a trimmed column of the tensor is never written by anybody: zero in the model, and zero here where it is read)
-      t['g'].fill_(float('nan') if emit else 0.0)
-      Up.backward_data(dy_up * scale, t['g'], t['dskip'], grad_consumer=Lo if emit else None,
-                       consumer_db=t['db'] if emit else None, consumer_db_accumulate=False)
-      if emit:
+      if accum:
+        t['g'].copy_(skip_grad * scale)           # what the decoder left there, and its largest magnitude on the device
+        word = (skip_grad * scale).abs().max().reshape(1).view(torch.int32)
+        Up.backward_data(dy_up * scale, t['g'], accum0=True, grad_consumer=Lo if emit else None,
+                         consumer_db=t['db'] if emit else None, consumer_db_accumulate=False, bound_add=word if emit else None)
+        if emit:
+          assert Lo._dy_emitted_for is not None and Lo._dy_emitted_for[2], step
+          assert torch.equal(t['g'], skip_grad * scale), step                      # the fp32 tensor still holds the skip gradient only
+      else:
+        # (a trimmed column of the tensor is never written by anybody: zero in the model, and zero here where it is read)
+        t['g'].fill_(float('nan') if emit else 0.0)
+        Up.backward_data(dy_up * scale, t['g'], t['dskip'], grad_consumer=Lo if emit else None,
+                         consumer_db=t['db'] if emit else None, consumer_db_accumulate=False)
+      if emit and not accum:
         assert Lo._dy_emitted_for is not None and Lo._dy_emitted_for[2], step       # from the first step on: no history needed
         assert bool(torch.isnan(t['g']).all()), step                                 # the fp32 tensor is NOT written
       Lo.backward_data(t['g'], t['dx'], db=t['db'], db_accumulate=False)
