@@ -90,12 +90,13 @@ class Layer(object):
   # operand images from its own forward epilogue (advoc_conv_layer.y_img, csrc/image_emit.h) once the consumer's header
   # holds a previous magnitude -- the consumer's image pass (a read and a write of the whole tensor) disappears
   emit_images = os.environ.get('ADVOC_EMIT_IMAGES', '1') == '1'
-  # ADVOC_EMIT_DX=1 turns it on: a backward_data call given `grad_consumer` -- the layer below, whose output gradient this
+  # ADVOC_EMIT_DX_DELAYED=1 turns it on (the library's own ADVOC_EMIT_DX, default 1, is the kill switch of every dx_img and
+  # stays on): a backward_data call given `grad_consumer` -- the layer below, whose output gradient this
   # call's dx0 is -- writes THAT layer's output-gradient image (and its bias column sums) from its own epilogue
   # (advoc_conv_layer.dx_img): the image pass of the layer below disappears.  Off by default: measured on the one producer
   # that has it (discriminator layer_5 -> layer_4, the largest image pass of the step) the passes lose 0.31 ms per step and
   # the producer, an issue-bound kernel, gains 0.18 ms; the step does not move (NOTEBOOK.md section 7, profiles/r04_i_*)
-  emit_dx = os.environ.get('ADVOC_EMIT_DX', '0') == '1'
+  emit_dx = os.environ.get('ADVOC_EMIT_DX_DELAYED', '0') == '1'
   # (r5) ADVOC_DX_BOUNDED=0 turns it off: where the backward-data call of a layer runs on a patch kernel and the layer below
   # reads its output gradient only as an operand image, that image is written by this call's epilogue under a scale derived
   # from an a-priori bound of |dx| (max|dy| max|w| taps K: nothing can leave the fp16 range, so no history, no refit, no fp32

@@ -521,10 +521,16 @@ static bool fused_taps_plan(const GatherGemmParams& p, FusedGeom* out, int* cb_o
       g.ry = ry; g.rx = rx; g.ty = ty; g.tx = tx; g.tiles_y = tiles_y; g.tiles_x = tiles_x;
     }
   }
-  if (best < 0 || (int64_t)g.ry * g.rx > 8191) return false;       // (q * rx_magic) >> 20 is exact below 8192
+  if (best < 0) return false;
   g.dy_min = dy_min; g.dx_min = dx_min; g.ld = ld; g.w_floats = w_floats;
   g.n_eff = N; g.n0 = n0;
   g.rx_magic = ((1 << 20) + g.rx - 1) / g.rx;
+  // q / rx == (q * rx_magic) >> 20 for every q the kernel divides (q < R rounded up to its 16-row slab) iff
+  // q * (rx_magic * rx - 2^20) < 2^20; and the int product must not wrap.  Otherwise: the direct kernel.
+  {
+    const int64_t qmax = (int64_t)g.ry * g.rx + 15;
+    if (qmax * ((int64_t)g.rx_magic * g.rx - (1 << 20)) >= (1 << 20) || qmax * g.rx_magic >= ((int64_t)1 << 31)) return false;
+  }
   {
     bool pr = p.nphase == 4 && p.ntaps == 4 && p.osy == 2 && p.osx == 2 && p.grad_act == ADVOC_ACT_NONE;
     for (int ph = 0; pr && ph < 4; ++ph) pr = p.ooy[ph] == (ph >> 1) && p.oox[ph] == (ph & 1);

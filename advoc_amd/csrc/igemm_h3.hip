@@ -256,6 +256,9 @@ __device__ __forceinline__ void gather_gemm_h3_body(const GatherGemmParams& p) {
     for (int u = 0; u < NS; ++u) {
       // tile kt + u sits in stage u; the next tile to issue goes into stage (u + NS - 1) % NS, vacated by tile kt + u - 1
       // (lds_dma.h: the rendezvous also waits for this wave's own fragment reads of the stage the DMAs below overwrite)
+#ifdef ADVOC_H3_IGLP
+      __builtin_amdgcn_iglp_opt(ADVOC_H3_IGLP);
+#endif
       dma_ring_barrier<C::DMA_PER_TILE*(NS - 2)>();
       ADVOC_H3_ISSUE((u + NS - 1) % NS);
       if (ABL != 4 && kt + u < kt_end) ADVOC_H3_COMPUTE(u);
@@ -587,7 +590,9 @@ int launch_h21(const GatherGemmParams& p, hipStream_t stream, const char** name_
 
 // Tile choice (tools/micro/h3_sweep.py, NOTEBOOK.md §4).  ADVOC_H3_TILE=1|2|3 forces 128x128 | 128x256 | 256x128,
 // ADVOC_H3_STAGES=2|3 the LDS stages.
-Pick pick_tile(const GatherGemmParams& p) {
+// ws_split: the caller's workspace can hold the parked K slices (the 256 x 256 / kept 128 x 128 choices for under-filled
+// single-phase launches count on that split; without it they would run unsplit on a fraction of the chip).
+Pick pick_tile(const GatherGemmParams& p, bool ws_split = true) {
   const Tuning& t = tuning();
   const int N = p.n_total;
   Pick k = {2, 2, 2, 2};
@@ -613,7 +618,7 @@ Pick pick_tile(const GatherGemmParams& p) {
       // the workspace instead (launch_gather_gemm_h3): 224 us against 250 (128 x 128) and 291 (128 x 64)
       const int nkt = (p.c0 + p.c1) / 32 * p.ntaps;
       if (2 * t256 >= 3 * cus) k = {2, 4, 2, 4};
-      else if (p.nphase == 1 && 4 * t256 >= cus && 2 * t256 <= cus && nkt >= 128 && t.igemm_splitk) k = {2, 4, 2, 4};
+      else if (p.nphase == 1 && 4 * t256 >= cus && 2 * t256 <= cus && nkt >= 128 && t.igemm_splitk && ws_split) k = {2, 4, 2, 4};
     }
   }
   if (t.h3_tile == 0 && k.wgm == 2 && k.nt == 2) {
@@ -622,7 +627,7 @@ Pick pick_tile(const GatherGemmParams& p) {
     // (r4: not for single-phase launches from half a round on -- decoder_6 backward-data, 144 tiles x 256 K tiles: 190 us on
     // 128 x 64, 129 us on 128 x 128 tiles cut into three K slices each)
     const int64_t t128 = ceil_div((int64_t)p.batch * p.gh * p.gw, 128) * ceil_div(N, 128) * p.nphase;
-    const bool keep128 = t.h3_deep_plan && p.nphase == 1 && 2 * t128 >= device_cu_count() && t.igemm_splitk;
+    const bool keep128 = t.h3_deep_plan && p.nphase == 1 && 2 * t128 >= device_cu_count() && t.igemm_splitk && ws_split;
     if (t128 < 2 * device_cu_count() && !keep128) k = {2, 1, 2, 2};
   }
   return k;
@@ -678,20 +683,28 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
   const int64_t hdr_bytes = 256 + kColsumBytes;       // operand headers + the bias-gradient replica table (image.hip)
   const int64_t wq_bytes = round256((int64_t)4 * taps * N * ktot);
   const int64_t i0_bytes = round256(4 * e0), i1_bytes = round256(4 * e1);
-  const Pick k = pick_tile(p);
   PatchGeom geom;
   const int patch_nph = patch_plan(p, &geom);       // stride-1 gathers: igemm_patch.hip
-  const int BM = 32 * k.mt * k.wgm, BN = 64 * k.nt;
-  const int64_t tiles = ceil_div((int64_t)p.batch * p.gh * p.gw, BM) * ceil_div(N, BN) * p.nphase;
+  const int64_t need = hdr_bytes + wq_bytes + i0_bytes + i1_bytes;
   const int nkt = ktot / 32 * p.ntaps;
+  Pick k;
+  int BM, BN, ksplit;
+  int64_t tiles, rtiles, tail_bytes;
+  TailPlan tail;
+  // planned twice at most: a workspace too small for the parked K slices (tail_bytes) re-plans without them -- tile choice
+  // included -- instead of running the slices' tiles unsplit
+  for (int ws_split = 1; ws_split >= 0; --ws_split) {
+  k = pick_tile(p, ws_split != 0);
+  BM = 32 * k.mt * k.wgm; BN = 64 * k.nt;
+  tiles = ceil_div((int64_t)p.batch * p.gh * p.gw, BM) * ceil_div(N, BN) * p.nphase;
   // Small pixel grids with deep contractions (encoder_5.., decoder_5.. and their gradients) would leave CUs idle:
   // split K until the launch holds ~4 workgroups per CU, keeping >= 8 K tiles per slice (igemm.hip does the same)
   // (measured, tools/micro/deep_sweep.py / profiles/r02_deep_sweep.txt: with these kernels the atomic epilogue + the
   // zero-fill cost more than idle CUs down to a quarter of the chip -- encoder_6 backward-data 278 -> 116 us, decoder_6
   // forward 365 -> 213 us, encoder_5 forward 487 -> 393 us without the split; and never on 64 Ki-output tiles)
-  int ksplit = 1;
-  TailPlan tail;
-  if (!patch_nph && tiles < device_cu_count() && tiles <= 256 && (k.wgm == 2 || tuning().h3_deep_split > 0 || tuning().h3_deep_plan) &&
+  ksplit = 1;
+  tail = TailPlan();
+  if (ws_split && !patch_nph && tiles < device_cu_count() && tiles <= 256 && (k.wgm == 2 || tuning().h3_deep_split > 0 || tuning().h3_deep_plan) &&
       tuning().igemm_splitk) {
     // Few tiles, deep contraction (the 8 x 17-point layers and below): every tile is cut into K slices that meet in the
     // WORKSPACE -- the tail-split mechanism with no whole tiles: the last slice to arrive sums the parked partial tiles
@@ -720,22 +733,23 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     if (ksplit > 16) ksplit = 16;
     if (ksplit < 1) ksplit = 1;
   }
-  if (tail.split < 2 && ksplit == 1 && !patch_nph) tail = plan_tail(tiles, nkt);
+  if (ws_split && tail.split < 2 && ksplit == 1 && !patch_nph) tail = plan_tail(tiles, nkt);
   // the per-tap launch that takes the 1..4 remainder columns of a patch launch (below): one 128 x 64 tile per workgroup
   // and under one workgroup per CU it runs at the latency of a single K pipeline (~1 us per K tile, 60-90 us for 1-3 % of
   // the layer's work): its tiles are cut into K slices that meet in the workspace, like the deep layers' above
-  int64_t rtiles = 0;
+  rtiles = 0;
   if (patch_nph && geom.rem) {
     rtiles = ceil_div((int64_t)p.batch * p.gh * geom.rem, 128) * ceil_div(N, 64) * p.nphase;
-    if (tuning().h3_rem_ws && rtiles <= 256 && tuning().igemm_splitk) {
+    if (ws_split && tuning().h3_rem_ws && rtiles <= 256 && tuning().igemm_splitk) {
       int split = (int)ceil_div((int64_t)tuning().h3_rem_wgs_per_cu * device_cu_count(), rtiles);
       if (split > nkt / tuning().h3_rem_split_div) split = nkt / tuning().h3_rem_split_div;
       if (split > 16) split = 16;
       if (split >= 2) { tail.main = 0; tail.rem = (int)rtiles; tail.split = split; }
     }
   }
-  const int64_t tail_bytes = (int64_t)sizeof(float) * tail.rem * tail.split * (patch_nph ? 128 * 64 : BM * BN);
-  const int64_t need = hdr_bytes + wq_bytes + i0_bytes + i1_bytes;
+  tail_bytes = (int64_t)sizeof(float) * tail.rem * tail.split * (patch_nph ? 128 * 64 : BM * BN);
+  if (scratch_query || !scratch || scratch_bytes >= need + tail_bytes || tail_bytes == 0) break;
+  }
   if (scratch_query) { *scratch_query = need + tail_bytes; return ADVOC_OK; }
   if (!scratch || scratch_bytes < need) return ADVOC_ERR_UNSUPPORTED;
   // consumers' images from this launch's epilogue (image_emit.h): every epilogue must see the final value, so no K

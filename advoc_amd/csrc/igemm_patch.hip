@@ -855,7 +855,19 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 
 template <int NPH, int BWD, int NE, int HALF = 0, int GI = 0>
 __global__ __launch_bounds__(512, 1) void patch_gemm_h3_kernel(const GatherGemmParams p, const PatchGeom g) {
+#ifdef ADVOC_CLOCK_PROBE
+  // Diagnostic build only (tools/micro/build_variant.sh clk "-DADVOC_CLOCK_PROBE"): the shader clock this launch ran at =
+  // s_memtime ticks (shader cycles) per s_memrealtime tick (100 MHz), first wave of a few workgroups.
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   patch_gemm_h3_body<NPH, 8, BWD, NE, HALF, GI>(p, g);
+#ifdef ADVOC_CLOCK_PROBE
+  if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    printf("clk <%d,%d,%d,%d,%d> wg %3d: %llu cycles in %llu ticks of 10 ns = %.3f GHz\n", NPH, BWD, NE, HALF, GI, (int)blockIdx.x,
+           c1 - c0, r1 - r0, 0.1 * (double)(c1 - c0) / (double)(r1 - r0));
+  }
+#endif
 }
 
 template <int NPH, int BWD, int NE = 0>

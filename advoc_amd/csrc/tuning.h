@@ -42,7 +42,7 @@ struct Tuning {
   int h3_rem_wgs_per_cu;   // ADVOC_H3_REM_WGS_PER_CU  workgroups per CU the K split of that launch aims at
   int h3_deep_split;    // ADVOC_H3_DEEP_SPLIT    > 0: that many K slices for every deep-layer launch (experiments)
   int h3_patch_s1n128;  // ADVOC_H3_PATCH_S1N128  1: the 128-column instance of the 4x4 stride-1 patch kernel (<5,.>)
-  int emit_dx;          // ADVOC_EMIT_DX          1: backward-data calls honour advoc_conv_layer.dx_img (the lower layer's dy image from the epilogue)
+  int emit_dx;          // ADVOC_EMIT_DX          1: backward-data calls honour advoc_conv_layer.dx_img (0: kill switch); (the lower layer's dy image from the epilogue)
   int h3_deep_plan;     // ADVOC_H3_DEEP_PLAN     1: r4's tile / K-slice choice for the launches under one round of tiles, 0: r3's
   int h3_deep_stages;   // ADVOC_H3_DEEP_STAGES   LDS stages of the 128 x 64 per-tap tile (2 | 3 | 4)
   int h3_rem_split_div; // ADVOC_H3_REM_SPLIT_DIV  K tiles per slice, at least

@@ -322,7 +322,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, c
 }
 __global__ __launch_bounds__(512, 2) void wgrad_h3_256_kernel(const WgradParams p, const WgradImages im, int tiles_n,
                                                               int tiles, int chunk) {
+#ifdef ADVOC_CLOCK_PROBE
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();   // see igemm_patch.hip
+#endif
   wgrad_h3_body<4, 4>(p, im, tiles_n, tiles, chunk);
+#ifdef ADVOC_CLOCK_PROBE
+  if (threadIdx.x == 0 && (blockIdx.x & 127) == 0) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    printf("clk wgrad_h3_256 wg %3d of %d: %llu cycles in %llu ticks of 10 ns = %.3f GHz\n", (int)blockIdx.x, (int)gridDim.x, c1 - c0,
+           r1 - r0, 0.1 * (double)(c1 - c0) / (double)(r1 - r0));
+  }
+#endif
 }
 
 // 256 x 256 tiles when both matrix dimensions divide and the pixel grid is long enough to give every workgroup (one per

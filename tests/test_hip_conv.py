@@ -438,6 +438,36 @@ def test_deep_launches_cut_into_k_slices_on_every_tile(hip, case, tile, split, h
 
 
 @gpu
+def test_tile_choice_follows_the_workspace_the_caller_really_gave(hip, hipenv):
+  """ The 256 x 256 tile of an under-filled single-phase launch (encoder_5 forward: 68 tiles on 256 CUs) counts on
+  its K slices meeting in the workspace.  A caller whose workspace holds the operand images but not the parked slices gets
+  the launch re-planned -- tile choice included -- rather than 68 unsplit workgroups: another kernel instance, the same
+  result up to the order of one sum."""
+  from advoc_amd import conv
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(11)
+  x0 = torch.randn(64, 16, 34, 256, generator=g).to(dev)
+  w = (torch.randn(4, 4, 256, 512, generator=g) * 0.02).to(dev)
+
+  def run(shrink):
+    y = torch.full((64, 8, 17, 512), float('nan'), device=dev)
+    L = conv.Layer(0, x0, y, w, None, stride=(2, 2), in_act=1)
+    if shrink:
+      L.struct.workspace_bytes -= shrink
+    L.forward()
+    torch.cuda.synchronize()
+    return L.kernel_name(0), y
+
+  n_full, y_full = run(0)
+  if n_full != 'gather_gemm_h3_kernel<2, 4, 2, 4>':
+    pytest.skip('the plan of this device does not take the 256 x 256 tile here: ' + n_full)
+  n_small, y_small = run(1 << 20)
+  assert 'gather_gemm_h3_kernel' in n_small and n_small != n_full, (n_full, n_small)
+  assert torch.isfinite(y_small).all()
+  assert rel(y_small, y_full.double()) < 1e-6, rel(y_small, y_full.double())
+
+
+@gpu
 @pytest.mark.parametrize('mode', ['default', 'k_split_workspace'])
 @pytest.mark.parametrize('case,want', H3_N32, ids=[c[0][0] for c in H3_N32])
 def test_layer_32_column_launches_on_the_image_kernel(hip, case, want, mode, hipenv):
@@ -540,6 +570,52 @@ def test_weight_gradient_k_slices_summed_in_order(hip, hipenv, tile):
   d1, d2 = run(1), run(1)
   if tile == 2:
     assert torch.equal(d1, d2) and torch.equal(d1, a)
+
+
+@gpu
+def test_two_streams_share_the_k_slice_scratch_in_order(hip, hipenv):
+  """ Layers that sum their K slices in order share ONE scratch buffer per device.  Two layers called from two
+  streams with nothing else ordering them (conv.Layer.backward_weight makes the second stream wait for the first launch's
+  event) give, bit for bit, what the same calls give one after the other on one stream -- on every one of many rounds, with
+  the streams swapping who goes first and a long kernel in front of the first caller so that the second would overtake it."""
+  from advoc_amd import conv
+  dev = torch.device('cuda')
+  g = torch.Generator().manual_seed(47)
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_WGRAD_H3_MIN_M=1, ADVOC_WGRAD_H3_ORDERED=2)
+  layers = []
+  for cin, cout, tile in ((128, 256, 2), (256, 128, 1)):
+    x = torch.randn(4, 32, 66, cin, generator=g).to(dev)
+    w = (torch.randn(4, 4, cin, cout, generator=g) * 0.05).to(dev)
+    dy = torch.randn(4, 16, 33, cout, generator=g).to(dev)
+    y = torch.empty(4, 16, 33, cout, device=dev)
+    hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_WGRAD_H3_MIN_M=1, ADVOC_WGRAD_H3_ORDERED=2, ADVOC_WGRAD_H3_TILE=tile)
+    L = conv.Layer(conv.CONV, x, y, w, None, stride=(2, 2), pad=(1, 1), in_act=conv.ACT_LRELU)
+    assert 'wgrad_h3' in L.kernel_name(2) and L.struct.wgrad_ws
+    layers.append((L, dy, w))
+  assert layers[0][0].struct.wgrad_ws == layers[1][0].struct.wgrad_ws          # one scratch, two users
+  serial = []
+  for L, dy, w in layers:
+    dw = torch.full_like(w, float('nan'))
+    L.backward_weight(dy, dw)
+    torch.cuda.synchronize()
+    serial.append(dw)
+  streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+  junk = torch.randn(32 * 1024 * 1024, device=dev)
+  for rnd in range(12):
+    order = (0, 1) if rnd % 2 == 0 else (1, 0)
+    outs = [None, None]
+    torch.cuda.synchronize()
+    for k, i in enumerate(order):
+      L, dy, w = layers[i]
+      with torch.cuda.stream(streams[k]):
+        if k == 0:
+          for _ in range(3):
+            junk.mul_(1.0000001)                    # the first caller's launch starts late ...
+        outs[i] = torch.full_like(w, float('nan'))
+        L.backward_weight(dy, outs[i])              # ... and the second caller's must still wait for it
+    torch.cuda.synchronize()
+    for i in (0, 1):
+      assert torch.equal(outs[i], serial[i]), (rnd, i, rel(outs[i], serial[i]))
 
 
 @gpu
