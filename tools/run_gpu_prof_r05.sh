@@ -14,10 +14,15 @@ timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLE
 T=$(ls $OUT/trace/*/*kernel_trace.csv | head -1); F=$(ls $OUT/fetch/*/*counter_collection.csv | head -1); W=$(ls $OUT/write/*/*counter_collection.csv | head -1); S=$(ls $OUT/sq/*/*counter_collection.csv | head -1)
 python tools/trace_summary.py $T --skip-first 0 > $OUT/r05_${TAG}_kernel_trace.md
 python tools/trace_gaps.py $T > $OUT/r05_${TAG}_launch_gaps.txt
-python tools/trace_steady.py $T 2 > $OUT/r05_${TAG}_steady_census.md
+python tools/trace_steady.py $T 2 $OUT/r05_${TAG}_step_sequence.txt > $OUT/r05_${TAG}_steady_census.md
 python tools/pmc_summary.py $F $W --json $OUT/r05_traffic.json > $OUT/r05_${TAG}_pmc_hbm.md
 python tools/sq_summary.py $S > $OUT/r05_${TAG}_pmc_mfma.md
 rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/sq
+# shader clock inside the real step (probe build: tools/micro/build_variant.sh clk "-DADVOC_CLOCK_PROBE")
+if [ -f advoc_amd/csrc/libadvoc_hip_clk.so ]; then
+  ADVOC_HIP_LIB=$PWD/advoc_amd/csrc/libadvoc_hip_clk.so timeout 600 python bench.py --train-only --no-cpu-baseline --steps 4 --warmup 3 --prof-steps 0 > $OUT/clk.log 2>&1
+  python tools/clock_summary.py $OUT/clk.log > $OUT/r05_${TAG}_shader_clock.md; rm -f $OUT/clk.log
+fi
 python tools/micro/lws_time.py > $OUT/r05_${TAG}_lws_time.txt 2>&1
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/ltrace -- python tools/micro/lws_time.py > $OUT/ltrace.log 2>&1; echo lws trace rc=$?
 T=$(ls $OUT/ltrace/*/*kernel_trace.csv | head -1)
