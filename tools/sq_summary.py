@@ -5,9 +5,8 @@ SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, --
 mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs): fraction of the matrix pipes' cycles that
 carried an MFMA at the clock the kernel actually ran at (GRBM_GUI_ACTIVE is summed over the 8 XCDs; the SQ_WAIT_* /
 SQ_ACTIVE_* / SQ_WAVE_CYCLES counters are in quad-cycles, MI355X_MICROARCH.md).
-(r5) Against the instruction count of patch_gemm_h3_kernel<1,0> and the shader clock probed inside the step
-(profiles/r05_shader_clock.md, r05_winograd_and_layer4_account.md) SQ_VALU_MFMA_BUSY_CYCLES reads 24 cycles per
-v_mfma_f32_32x32x16_f16, not the 32 the pipe is occupied: the column is a RELATIVE measure, x 4/3 for the fp16 x 3 kernels."""
+(r5) Checked against the instruction count of patch_gemm_h3_kernel<1,0> and the shader clock probed inside the step
+(profiles/r05_winograd_and_layer4_account.md): 0.729 by this column, 0.75 by instruction count x 32 cycles / probed cycles."""
 import collections
 import csv
 import os
