@@ -553,21 +553,24 @@ class Layer(object):
       self._dy_built = True
     self._dy_current_ptr = dy.data_ptr() if (self.struct.dy_img and 'h3' in self.kernel_name(1)) else None
 
-  _wgrad_scratch_use = {}        # device -> (stream id, event behind the last launch that used the shared K-slice scratch)
+  _wgrad_scratch_use = {}        # device -> stream of the last launch that used the shared K-slice scratch
 
   def backward_weight(self, dy, dw, db=None, accumulate=False):
     """dw (+ db) <- gradients of the kernel (and bias).  Layers that sum their K slices in order share ONE scratch buffer
     per device (advoc_conv_layer.wgrad_ws).  Calls on one stream are ordered by the stream (the model runs every weight
     gradient on its side stream, or everything on one); a call that arrives on ANOTHER stream first makes that stream wait
-    for the last launch that used the scratch (an event), so two models, or a profiled and an unprofiled step, never have
-    two launches writing the same partial tiles."""
+    for everything queued on the last user's stream (which includes the last launch that used the scratch), so two models,
+    or a profiled and an unprofiled step, never have two launches writing the same partial tiles.  (r5: nothing is recorded
+    per call any more -- the per-call event record put a marker packet, ~6 us of idle queue, behind every weight-gradient
+    launch of the step: profiles/r05_b_step_sequence.txt.)"""
     _lib.require_device(dy)
     scratch_user = bool(self.struct.wgrad_ws)
     if scratch_user:
       cur = torch.cuda.current_stream(dy.device)
       last = Layer._wgrad_scratch_use.get(dy.device)
-      if last is not None and last[0] != cur.cuda_stream:
-        cur.wait_event(last[1])
+      if last is not None and last.cuda_stream != cur.cuda_stream:
+        cur.wait_stream(last)
+      Layer._wgrad_scratch_use[dy.device] = cur
     _lib.require_device(dw)
     if tuple(dw.shape) != tuple(self.weight.shape):
       raise _lib.AdvocHipError('dw shape mismatch')
@@ -588,10 +591,6 @@ class Layer(object):
           _lib.stream()), 'advoc_conv_backward_weight'))
     finally:
       self.struct.img_flags = 0
-    if scratch_user:
-      ev = last[1] if last is not None else torch.cuda.Event()     # (one event per device, re-recorded)
-      ev.record(cur)
-      Layer._wgrad_scratch_use[dy.device] = (cur.cuda_stream, ev)
     self._x_current = False                # one use per forward: the caller may rewrite the inputs before the next call
     if 'h3' in self.kernel_name(2):        # the image-based weight gradient has (re)built whatever was not current
       self._x_built = self._x_built or bool(self.struct.x_img)

@@ -237,8 +237,10 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 
   const float gslope = act_slope_p(p.grad_act);
   const int src_c0 = p.c0, src_c1 = p.c1, src_p0 = p.a0_pitch, src_p1 = p.a1_pitch;
-#ifdef ADVOC_DIAG
-  const int abl = g.ablate;       // timing experiments only (ADVOC_H3_PATCH_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier, 8 no halo DMA, 16 no B DMA, 64 no epilogue, 128 epilogue stores dropped
+#ifdef ADVOC_P3_ABL        // (timing experiments, tools/micro/build_ablations.sh: the switches below as a COMPILE-TIME constant --
+  constexpr int abl = ADVOC_P3_ABL;     // no branch in the K loop, the product's schedule minus what is left out)
+#elif defined(ADVOC_DIAG)
+  const int abl = g.ablate;       // timing experiments only (ADVOC_H3_PATCH_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier, 8 no halo DMA, 16 no B DMA, 64 no epilogue, 256 / 512 no A / B fragment reads, 1024 every B tile from one L2-resident slab, 2048 halo address arithmetic without its DMA, 4096 no halo pieces in the K loop, 128 epilogue stores dropped
 #else
   // (r5) a compile-time zero in the product library: as a run-time value every `if (abl & ...)` was a branch in the K loop --
   // one in front of each rendezvous, MFMA group and DMA slot -- i.e. a basic-block boundary the scheduler does not move
@@ -330,6 +332,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
                             : (int)0x80000000;                                                            \
       unsigned char* d_ = smem_b + (HB) * C::HALO_BYTES + blk_ * 1024;                                    \
       if (blk_ >= C::HALO_BLOCKS || (abl & 9)) continue;                                                  \
+      if (abl & 2048) { asm volatile("" ::"v"(voff_), "s"(lds_address(d_))); continue; }                  \
       if (kAsmDma) dma16(second_ ? ra_a1 : ra_a0, lds_address(d_), voff_, 0);                             \
       else if (second_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_void_p)(d_), 16, voff_, 0, 0, 0); \
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (lds_void_p)(d_), 16, voff_, 0, 0, 0);         \
@@ -342,7 +345,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   {                                                                                                       \
     if (C::PIN) __builtin_amdgcn_sched_barrier(0);                                                        \
     const int wtap_ = __builtin_amdgcn_readlane(tapv_b, S2 ? ((SL) & 3) * 4 + (T) : (T)) >> 16;           \
-    const int wslab_ = (wtap_ * p.n_total * ktot + (S2 ? (SL) >> 2 : (SL)) * 32) * 4;                     \
+    const int wslab_ = (abl & 1024) ? 0 : (wtap_ * p.n_total * ktot + (S2 ? (SL) >> 2 : (SL)) * 32) * 4;  \
     _Pragma("unroll") for (int k = 0; k < C::BPW; ++k) {                                                  \
       unsigned char* d_ = smem_b + C::OFF_B + (ST) * C::B_STAGE + (wave * C::BPW + k) * 1024;             \
       if (!(abl & 17) && (!HALF || b_cols)) {                                                             \
@@ -364,15 +367,19 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     const int sl_ = ((half ^ ((((l32 & 15) + dxo_) >> 1) & 7)) ^ (2 * (KS))) * 16;                        \
     const int ad_ = (h_base + toff_) * 128 + sl_;                                                         \
     _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                        \
-      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                    \
-        REG[i][pl] = *reinterpret_cast<const f16x8*>(Hx + (ad_ ^ (4 * pl * 16)) + i * (2 * hw * 128));    \
+      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                  \
+        if (abl & 256) asm volatile("" : "=v"(REG[i][pl]));        /* (timing only: no A fragment reads) */ \
+        else REG[i][pl] = *reinterpret_cast<const f16x8*>(Hx + (ad_ ^ (4 * pl * 16)) + i * (2 * hw * 128)); \
+      }                                                                                                   \
   }
 #define ADVOC_P3_LOAD_B(REG, ST, KS)                                                                      \
   {                                                                                                       \
     const unsigned char* Bx = smem_b + C::OFF_B + (ST) * C::B_STAGE;                                      \
     _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                        \
-      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                    \
-        REG[j][pl] = *reinterpret_cast<const f16x8*>(Bx + (bfrag ^ ((4 * pl + 2 * (KS)) * 16)) + j * 32 * 128); \
+      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                  \
+        if (abl & 512) asm volatile("" : "=v"(REG[j][pl]));        /* (timing only: no B fragment reads) */ \
+        else REG[j][pl] = *reinterpret_cast<const f16x8*>(Bx + (bfrag ^ ((4 * pl + 2 * (KS)) * 16)) + j * 32 * 128); \
+      }                                                                                                   \
   }
   // three fp16 products per 32x32x16 block, small terms first (a0 b1, a1 b0, a0 b0); product-major so that consecutive
   // MFMAs write different accumulators
@@ -491,7 +498,8 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
 #define ADVOC_P3_BAR(WAITS)                                                                               \
     {                                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                  \
-      asm volatile(WAITS "s_barrier" ::: "memory");                                                       \
+      if (abl & 4) asm volatile(WAITS "s_nop 0" ::: "memory");     /* (timing only: the waits without the barrier) */ \
+      else asm volatile(WAITS "s_barrier" ::: "memory");                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                  \
     }
     // the DMAs that feed step N: its B tile into stage N & 1, and piece (N - 1) % NST of the halo of the slice behind
@@ -503,7 +511,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
         const int sl_ = n_ / NST, tt_ = n_ - sl_ * NST;                                                   \
         if (n_ & 1) { ADVOC_P3_B(sl_, tt_, 1); } else { ADVOC_P3_B(sl_, tt_, 0); }                        \
       }                                                                                                   \
-      if (n_ >= 1) {                                                                                      \
+      if (n_ >= 1 && !(abl & 4096)) {                                                                     \
         const int ps_ = (n_ - 1) / NST, pt_ = (n_ - 1) - ps_ * NST;                                       \
         if (ps_ + 1 < nslices) {                                                                          \
           if (ps_ & 1) { ADVOC_P3_HALO(ps_ + 1, pt_, 0); } else { ADVOC_P3_HALO(ps_ + 1, pt_, 1); }       \
