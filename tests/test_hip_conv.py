@@ -453,7 +453,10 @@ def test_tile_choice_follows_the_workspace_the_caller_really_gave(hip, hipenv):
     y = torch.full((64, 8, 17, 512), float('nan'), device=dev)
     L = conv.Layer(0, x0, y, w, None, stride=(2, 2), in_act=1)
     if shrink:
-      L.struct.workspace_bytes -= shrink
+      # (the workspace is one buffer per device, grown by whatever ran before: count from what THIS layer asks for)
+      need = hip.advoc_conv_workspace_bytes(ctypes.byref(L.struct), 0)
+      assert 0 < need <= L.struct.workspace_bytes
+      L.struct.workspace_bytes = need - shrink
     L.forward()
     torch.cuda.synchronize()
     return L.kernel_name(0), y
