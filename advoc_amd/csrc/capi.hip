@@ -56,6 +56,7 @@ Tuning read_env() {
   t.wgrad_h3_min_m = env_int("ADVOC_WGRAD_H3_MIN_M", 128);
   t.wgrad_h3_tile = env_int("ADVOC_WGRAD_H3_TILE", 0);
   t.wgrad_h3_rounds = env_int("ADVOC_WGRAD_H3_ROUNDS", 0);
+  t.wgrad_h3_rows = env_int("ADVOC_WGRAD_H3_ROWS", 1);
   t.wgrad_h3_ordered = env_int("ADVOC_WGRAD_H3_ORDERED", 1);
   t.h3 = env_int("ADVOC_H3", 1);
   t.h3_tile = env_int("ADVOC_H3_TILE", 0);

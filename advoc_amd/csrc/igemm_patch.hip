@@ -870,6 +870,7 @@ __global__ __launch_bounds__(512, 1) void patch_gemm_h3_kernel(const GatherGemmP
 #endif
   patch_gemm_h3_body<NPH, 8, BWD, NE, HALF, GI>(p, g);
 #ifdef ADVOC_CLOCK_PROBE
+  __syncthreads();         // (the workgroup's life, not its first wave's: without the K loop's barriers they differ)
   if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) {
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     printf("clk <%d,%d,%d,%d,%d> wg %3d: %llu cycles in %llu ticks of 10 ns = %.3f GHz\n", NPH, BWD, NE, HALF, GI, (int)blockIdx.x,

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include <string>
+#include <utility>
 
 #include "conv_internal.h"
 #include "lds_dma.h"
@@ -35,6 +36,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_void_p;
+
+#ifdef ADVOC_WH3_ABL       // (timing experiments, tools/micro/build_ablations.sh: parts of the K loop compiled out -- 1 no DMA, 2 no MFMA,
+constexpr int wabl = ADVOC_WH3_ABL;   // 4 waits without the barrier, 8 no fragment reads, 32 DMA instructions dropped but their addresses computed)
+#else
+constexpr int wabl = 0;
+#endif
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression in the body
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 constexpr int WK = 32;              // grid points per K tile
 constexpr int BLK = WK * 128;       // bytes of one 32-channel block of a K tile
@@ -60,9 +74,9 @@ struct WgradImages {
   const unsigned* p_hdr; const unsigned* q_hdr;   // {amax bits, 2^-s}
 };
 
-template <int WGM, int NT>
+template <int WGM, int NT, bool ROW>
 __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradImages& im, int tiles_n, int tiles,
-                                              int chunk) {
+                                              int chunk, int gwp) {
   using C = WCfg<WGM, NT>;
   constexpr int STAGE = C::STAGE, MT = C::MT;
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
@@ -81,7 +95,10 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   const int b0 = (tile_id % tiles_n) * C::COLS;
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   const int rows_total = p.ntaps * ca;
-  const int M = p.batch * p.gh * p.gw;                 // < 2^31 (launcher)
+  // (r5) gwp != 0: ROW MODE -- the reduction axis is (image, grid row, column padded to gwp = a multiple of WK), so that a
+  // K tile never leaves its grid row (see the address arithmetic below); 0: the flat axis of grid points
+  constexpr bool rowm = ROW;           // (gwp != 0: the launcher picks the instance)
+  const int M = p.batch * p.gh * (rowm ? gwp : p.gw);  // < 2^31 (launcher)
   const int g_begin = zchunk * chunk;
   const int g_end = g_begin + chunk < M ? g_begin + chunk : M;
   const int nkt = (g_end - g_begin + WK - 1) / WK;
@@ -117,7 +134,7 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   const int pc4 = p_c * 4, qc4 = q_c * 4;
 #pragma unroll
   for (int s = 0; s < SL; ++s) {
-    const unsigned g = (unsigned)(g_begin + lpix + 8 * s);
+    const unsigned g = (unsigned)((rowm ? 0 : g_begin) + lpix + 8 * s);
     const unsigned t = g / (unsigned)p.gw;
     gx[s] = (int)(g - t * (unsigned)p.gw);
     const int gi = (int)(t / (unsigned)p.gh);
@@ -134,15 +151,69 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   const int p_wrapx = p_row - p.gw * p.sx * pc4, q_wrapx = q_row - p.gw * qc4;                  // column wrap: next row
   const int p_wrapy = p.P.h * p_pitch * pc4 - p.gh * p_row, q_wrapy = p.Q.h * q_pitch * qc4 - p.gh * q_row;   // next image
   int g_left = g_end - (g_begin + lpix);                             // slot s is inside the chunk while 8 s < g_left
+  // (r5) ROW MODE.  Measured in shader cycles with parts of the loop compiled out (profiles/r05_wgrad_k_loop_cycles.md): the
+  // DMA instructions of a K tile cost nothing, their ADDRESS ARITHMETIC 20 % of the launch -- ~110 vector / scalar
+  // instructions per wave and tile for the eight offsets (column and row wraps, tap bounds, chunk end, per slot).  With the
+  // grid rows padded to a multiple of WK a tile lies in ONE grid row: image, row, the tap's row bound and both row offsets
+  // are wave-uniform scalars advanced once per tile; a slot is its lane's column constant plus a scalar, one column bound
+  // and one select: 7 vector instructions.  Columns beyond gw are out-of-range offsets: zeros, like a tile's tail was.
+  const int lpsx = lpix * p.sx;                                       // lane constants of ROW MODE
+  const unsigned pk = (unsigned)(lpsx * pc4 + dx * pc4 + p_choff + lchunk16), qk = (unsigned)(lpix * qc4 + q_choff + lchunk16);
+  const unsigned c_p8 = (unsigned)(8 * p.sx * pc4), c_q8 = (unsigned)(8 * qc4);
+  const int c_s8 = 8 * p.sx;
+  // the tile's scalars: points left in the chunk, first column, grid row, image -- and what the slots need of them: the P / Q
+  // byte offset of (row, first column) or 0x80000000 when the whole tile reads zeros (behind the chunk's end, the tap's
+  // row outside the image, a row / column block that does not exist), the tap's first input column, the columns left
+  int rw_left = g_end - g_begin, rw_x0 = 0, rw_gy = 0, rw_gi = 0, rw_xs = 0, rw_gwl = 0;
+  unsigned rw_pe = 0x80000000u, rw_qe = 0x80000000u;
+  int n_left = 0, n_x0 = 0, n_gy = 0, n_gi = 0, n_xs = 0, n_gwl = 0, rtt = 0;     // (the K loop's pieces)
+  unsigned n_pe = 0, n_qe = 0;
+  bool rc1[SL] = {};
+#define ADVOC_WH3_DERIVE_P(LEFT, X0, GY, GI, PE)                                                         \
+  {                                                                                                      \
+    const int py_ = (GY) * p.sy + dy;                                                                    \
+    const bool ok_ = ((LEFT) > 0) & ((unsigned)py_ < (unsigned)p.P.h) & p_live;                          \
+    PE = ok_ ? (unsigned)(((GI) * p.P.h + py_) * p_pitch * pc4 + (X0) * p.sx * pc4) : 0x80000000u;       \
+  }
+#define ADVOC_WH3_DERIVE_Q(LEFT, X0, GY, GI, QE, XS, GWL)                                                \
+  {                                                                                                      \
+    const bool ok_ = ((LEFT) > 0) & q_live;                                                              \
+    QE = ok_ ? (unsigned)(((GI) * p.Q.h + (GY)) * q_pitch * qc4 + (X0) * qc4) : 0x80000000u;             \
+    XS = (X0) * p.sx + dx;                                                                               \
+    GWL = p.gw - (X0);                                                                                   \
+  }
+#define ADVOC_WH3_ADVANCE(LEFT, X0, GY, GI)       /* n_* <- the tile behind (LEFT, X0, GY, GI) */          \
+  {                                                                                                      \
+    n_left = (LEFT) - WK;                                                                                \
+    const int x_ = (X0) + WK;                                                                            \
+    const int wx_ = x_ >= gwp ? 1 : 0;                                                                   \
+    n_x0 = wx_ ? 0 : x_;                                                                                 \
+    const int y_ = (GY) + wx_;                                                                           \
+    const int wy_ = y_ == p.gh ? 1 : 0;                                                                  \
+    n_gy = wy_ ? 0 : y_;                                                                                 \
+    n_gi = (GI) + wy_;                                                                                   \
+  }
+  if (rowm) {
+    const int row_ = g_begin / gwp;
+    rw_x0 = g_begin - row_ * gwp;
+    rw_gi = row_ / p.gh;
+    rw_gy = row_ - rw_gi * p.gh;
+    ADVOC_WH3_DERIVE_P(rw_left, rw_x0, rw_gy, rw_gi, rw_pe);
+    ADVOC_WH3_DERIVE_Q(rw_left, rw_x0, rw_gy, rw_gi, rw_qe, rw_xs, rw_gwl);
+  }
 
   // The DMA of a K tile is split in two: its 2 SL buffer offsets (ADDR: plain VALU work without a branch, computed one
   // tile ahead so that it sits in the same basic block as the previous tile's MFMAs and issues in their shadow) and the
   // loads themselves (FIRE, right behind the barrier).
   int pvn[SL], qvn[SL];
-#define ADVOC_WH3_ADDR()                                                                                 \
-  {                                                                                                      \
-    _Pragma("unroll") for (int s = 0; s < SL; ++s) {                                                     \
-      const bool in_ = 8 * s < g_left;                                                                   \
+#define ADVOC_WH3_ADDR_S(s)                                                                              \
+    if (rowm) {                                                                                          \
+      const bool rc_ = lpix < rw_gwl - 8 * (s);                                                          \
+      const bool rp_ = rc_ & ((unsigned)(lpsx + rw_xs + (s) * c_s8) < (unsigned)p.P.w);                  \
+      pvn[s] = rp_ ? (int)(pk + rw_pe + (s) * c_p8) : (int)0x80000000;                                   \
+      qvn[s] = rc_ ? (int)(qk + rw_qe + (s) * c_q8) : (int)0x80000000;                                   \
+    } else {                                                                                             \
+      const bool in_ = 8 * (s) < g_left;                                                                 \
       const int py_ = __mul24(gy[s], p.sy) + dy, px_ = __mul24(gx[s], p.sx) + dx;                        \
       const bool pok_ = in_ && p_live && (unsigned)py_ < (unsigned)p.P.h && (unsigned)px_ < (unsigned)p.P.w; \
       pvn[s] = pok_ ? po[s] : (int)0x80000000;                                                           \
@@ -156,13 +227,28 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
       gy[s] -= cy_ ? p.gh : 0;                                                                           \
       po[s] += p_step + (cx_ ? p_wrapx : 0) + (cy_ ? p_wrapy : 0);                                       \
       qo[s] += q_step + (cx_ ? q_wrapx : 0) + (cy_ ? q_wrapy : 0);                                       \
+    }
+#define ADVOC_WH3_ADDR_TILE()                                                                            \
+  {                                                                                                      \
+    if (rowm) {                                                                                          \
+      ADVOC_WH3_ADVANCE(rw_left, rw_x0, rw_gy, rw_gi);                                                   \
+      rw_left = n_left; rw_x0 = n_x0; rw_gy = n_gy; rw_gi = n_gi;                                        \
+      ADVOC_WH3_DERIVE_P(rw_left, rw_x0, rw_gy, rw_gi, rw_pe);                                           \
+      ADVOC_WH3_DERIVE_Q(rw_left, rw_x0, rw_gy, rw_gi, rw_qe, rw_xs, rw_gwl);                            \
+    } else {                                                                                             \
+      g_left -= WK;                                                                                      \
     }                                                                                                    \
-    g_left -= WK;                                                                                       \
+  }
+#define ADVOC_WH3_ADDR()                                                                                 \
+  {                                                                                                      \
+    _Pragma("unroll") for (int s = 0; s < SL; ++s) ADVOC_WH3_ADDR_S(s);                                  \
+    ADVOC_WH3_ADDR_TILE();                                                                               \
   }
 #define ADVOC_WH3_FIRE(ST)                                                                               \
   {                                                                                                      \
     const unsigned st_ = lds0 + (ST) * STAGE;                                                            \
     _Pragma("unroll") for (int s = 0; s < SL; ++s) {                                                     \
+      if (wabl & 33) { asm volatile("" ::"v"(pvn[s]), "v"(qvn[s])); continue; }                           \
       dma16(rs_p, st_ + wave * BLK + s * 1024, pvn[s]);                                                  \
       dma16(rs_q, st_ + (C::PB + wave) * BLK + s * 1024, qvn[s]);                                        \
     }                                                                                                    \
@@ -204,7 +290,8 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bq[j][0], acc[i][j], 0, 0, 0);    \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bq[j][0], acc[i][j], 0, 0, 0);    \
           const int d_ = (ks * MT + i) * NT + j;                                                         \
-          if (d_ < 2 * SL) {                                                                             \
+          if (d_ < 2 * SL && (wabl & 32)) asm volatile("" ::"v"(pvn[d_ >> 1]), "v"(qvn[d_ >> 1]));      \
+          if (d_ < 2 * SL && !(wabl & 33)) {                                                             \
             if (d_ & 1) dma16(rs_q, nst_ + (C::PB + wave) * BLK + (d_ >> 1) * 1024, qvn[d_ >> 1]);       \
             else dma16(rs_p, nst_ + wave * BLK + (d_ >> 1) * 1024, pvn[d_ >> 1]);                        \
             WH3_DMA_FENCE;                                                                               \
@@ -241,6 +328,7 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   ADVOC_WH3_ADDR();
   ADVOC_WH3_FIRE(0);
   ADVOC_WH3_ADDR();
+#ifdef ADVOC_WH3_R4_LOOP       // (A/B builds only: the loop as the compiler scheduled it up to r5's first half)
   for (int kt = 0; kt < nkt; kt += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -252,7 +340,133 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
       ADVOC_WH3_ADDR();
     }
   }
+#else
+  // (r5) THE K TILE WITH EVERY INSTRUCTION PLACED.  The ISA of the loop above (llvm's own interleaving, strategy 0) had, per K
+  // tile: the second k step's fragment reads BETWEEN the three MFMAs of one accumulator (each such pair of extra issue slots
+  // is a ~40-cycle stall of a dependent MFMA chain: MI355X_MICROARCH.md, "one EXTRA issue slot between two MFMAs on the SAME
+  // accumulator"), the tile's eight DMAs in one burst, and the ~45 vector / scalar instructions of the next tile's addresses
+  // BEHIND the last MFMA, in front of the barrier -- exposed, with the first k step's 24 reads and their latency behind it.
+  // Here: MFMAs product-major (consecutive MFMAs write different accumulators); one filler per MFMA gap, fenced -- under the
+  // first k step's MFMAs the second k step's fragments, then the DMAs one at a time; under the second k step's MFMAs the next
+  // tile's addresses, one pixel slot at a time.  Only the first k step's reads stay exposed behind the barrier.
+#define ADVOC_WH3_FENCE __builtin_amdgcn_sched_barrier(0)
+#define ADVOC_WH3_LOADF(AF, BQ, F, KS)                                                                   \
+  {                                                                                                      \
+    if ((F) < 2 * MT) {                                                                                  \
+      const unsigned char* b_ = Pb + (wm * MT + ((F) >> 1)) * BLK;                                       \
+      const int pl_ = ((F) & 1) ? tr_pl1 : tr_pl0;                                                       \
+      const short4v x0_ = ADVOC_WH3_FRAG(b_, pl_, KS, 0), x1_ = ADVOC_WH3_FRAG(b_, pl_, KS, 1);          \
+      if (wabl & 8) asm volatile("" : "=v"(AF[(F) >> 1][(F) & 1]));                                      \
+      else AF[(F) >> 1][(F) & 1] = __builtin_bit_cast(f16x8, __builtin_shufflevector(x0_, x1_, 0, 1, 2, 3, 4, 5, 6, 7)); \
+    } else {                                                                                             \
+      const int f_ = (F) - 2 * MT;                                                                       \
+      const unsigned char* b_ = Qb + (wn * NT + (f_ >> 1)) * BLK;                                        \
+      const int pl_ = (f_ & 1) ? tr_pl1 : tr_pl0;                                                        \
+      const short4v x0_ = ADVOC_WH3_FRAG(b_, pl_, KS, 0), x1_ = ADVOC_WH3_FRAG(b_, pl_, KS, 1);          \
+      if (wabl & 8) asm volatile("" : "=v"(BQ[f_ >> 1][f_ & 1]));                                        \
+      else BQ[f_ >> 1][f_ & 1] = __builtin_bit_cast(f16x8, __builtin_shufflevector(x0_, x1_, 0, 1, 2, 3, 4, 5, 6, 7)); \
+    }                                                                                                    \
+  }
+  // MFMA m of a k step: product m / NG (a0 b1, a1 b0, a0 b0), block (i, j) = m % NG
+#define ADVOC_WH3_MFMA1(AF, BQ, M)                                                                       \
+  {                                                                                                      \
+    constexpr int pr_ = (M) / NG, ij_ = (M) % NG, i_ = ij_ / NT, j_ = ij_ % NT;                          \
+    if (!(wabl & 2))                                                                                     \
+      acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i_][pr_ == 1 ? 1 : 0], BQ[j_][pr_ == 0 ? 1 : 0], acc[i_][j_], 0, 0, 0); \
+  }
+  constexpr int NG = MT * NT, M0 = 3 * NG, NF = 2 * (MT + NT), NFILL = NF + 2 * SL;
+  for (int kt = 0; kt < nkt; kt += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (wabl & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else dma_ring_barrier<0>();    // (lds_dma.h: own DMAs landed AND own reads of the stage about to be refilled returned)
+      const unsigned nst_ = lds0 + (u ^ 1) * STAGE;                  // the stage filled under this tile's MFMAs
+      const unsigned char* Pb = wsm + u * STAGE;
+      const unsigned char* Qb = Pb + C::PB * BLK;
+      f16x8 af0[MT][2], bq0[NT][2], af1[MT][2], bq1[NT][2];
+      ADVOC_WH3_FENCE;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) ADVOC_WH3_LOADF(af0, bq0, f, 0);
+      ADVOC_WH3_FENCE;
+      // first k step: filler f sits behind MFMA f * M0 / NFILL
+      static_for<M0>([&](auto mc_) {
+           constexpr int M = decltype(mc_)::value;
+           ADVOC_WH3_MFMA1(af0, bq0, M);
+#pragma unroll
+           for (int f = 0; f < NFILL; ++f) {
+             if (f * M0 / NFILL != M) continue;
+             if (f < NF) {
+               ADVOC_WH3_LOADF(af1, bq1, f, 1);
+             } else if (!(wabl & 33)) {
+               const int d_ = f - NF;
+               if (d_ & 1) dma16(rs_q, nst_ + (C::PB + wave) * BLK + (d_ >> 1) * 1024, qvn[d_ >> 1]);
+               else dma16(rs_p, nst_ + wave * BLK + (d_ >> 1) * 1024, pvn[d_ >> 1]);
+             } else if (wabl & 32) {
+               asm volatile("" ::"v"(pvn[(f - NF) >> 1]), "v"(qvn[(f - NF) >> 1]));
+             }
+           }
+           ADVOC_WH3_FENCE;
+      });
+      // second k step: the next tile's addresses, slot s behind MFMA (2 s + 1) M0 / (2 SL)
+      static_for<M0>([&](auto mc_) {
+           constexpr int M = decltype(mc_)::value;
+           ADVOC_WH3_MFMA1(af1, bq1, M);
+           if constexpr (ROW) {
+             // ROW MODE: the next tile's eight offsets in 3 SL pieces of 2-3 vector instructions, piece q behind MFMA
+             // q M0 / (3 SL); the tile's scalar advance computed on the side (n_*) in three more gaps, committed behind the last
+             constexpr int NP = 3 * SL;
+#pragma unroll
+             for (int q = 0; q < NP; ++q) {
+               if (q * M0 / NP != M) continue;
+               const int sl = q / 3, part = q % 3;
+               if (part == 0) {
+                 rc1[sl] = lpix < rw_gwl - 8 * sl;
+                 rtt = lpsx + (rw_xs + sl * c_s8);
+                 asm volatile("" : "+v"(rtt));          // (pins: the piece is computed HERE, not sunk to where it is used)
+               } else if (part == 1) {
+                 pvn[sl] = (rc1[sl] & ((unsigned)rtt < (unsigned)p.P.w)) ? (int)(pk + (rw_pe + sl * c_p8)) : (int)0x80000000;
+                 asm volatile("" : "+v"(pvn[sl]));
+               } else {
+                 qvn[sl] = rc1[sl] ? (int)(qk + (rw_qe + sl * c_q8)) : (int)0x80000000;
+                 asm volatile("" : "+v"(qvn[sl]));
+               }
+             }
+             if (M == 1) {
+               ADVOC_WH3_ADVANCE(rw_left, rw_x0, rw_gy, rw_gi);
+               asm volatile("" : "+s"(n_left), "+s"(n_x0), "+s"(n_gy), "+s"(n_gi));
+             }
+             if (M == 5) {
+               ADVOC_WH3_DERIVE_P(n_left, n_x0, n_gy, n_gi, n_pe);
+               asm volatile("" : "+s"(n_pe));
+             }
+             if (M == 9) {
+               ADVOC_WH3_DERIVE_Q(n_left, n_x0, n_gy, n_gi, n_qe, n_xs, n_gwl);
+               asm volatile("" : "+s"(n_qe), "+s"(n_xs), "+s"(n_gwl));
+             }
+             if (M == M0 - 1) {
+               rw_left = n_left; rw_x0 = n_x0; rw_gy = n_gy; rw_gi = n_gi;
+               rw_pe = n_pe; rw_qe = n_qe; rw_xs = n_xs; rw_gwl = n_gwl;
+             }
+           } else {
+#pragma unroll
+             for (int sl = 0; sl < SL; ++sl)
+               if ((2 * sl + 1) * M0 / (2 * SL) == M) { ADVOC_WH3_ADDR_S(sl); }
+           }
+           ADVOC_WH3_FENCE;
+      });
+      if constexpr (!ROW) ADVOC_WH3_ADDR_TILE();
+    }
+  }
+#undef ADVOC_WH3_FENCE
+#undef ADVOC_WH3_LOADF
+#undef ADVOC_WH3_MFMA1
+#endif
 #undef ADVOC_WH3_ADDR
+#undef ADVOC_WH3_ADDR_S
+#undef ADVOC_WH3_ADDR_TILE
+#undef ADVOC_WH3_DERIVE_P
+#undef ADVOC_WH3_DERIVE_Q
+#undef ADVOC_WH3_ADVANCE
 #undef ADVOC_WH3_FIRE
 #undef ADVOC_WH3_COMPUTE
 #undef ADVOC_WH3_FRAG
@@ -316,23 +530,40 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p, 
   *out = p.accumulate ? *out + sum : sum;
 }
 
+// Four instances: tile edge 128 | 256, reduction axis in ROW MODE (grid rows padded to a multiple of WK: the launcher's
+// choice, wgrad_h3_plan) or flat (`_flat`: the deep layers' short rows).
+#ifdef ADVOC_CLOCK_PROBE
+#define ADVOC_WH3_PROBE_BEGIN const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#define ADVOC_WH3_PROBE_END(NAME)                                                                        \
+  __syncthreads();         /* (the workgroup's life, not its first wave's) */                            \
+  if (threadIdx.x == 0 && (blockIdx.x & 127) == 0) {                                                     \
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();   \
+    printf("clk " NAME " wg %3d of %d: %llu cycles in %llu ticks of 10 ns = %.3f GHz\n", (int)blockIdx.x, (int)gridDim.x,  \
+           c1 - c0, r1 - r0, 0.1 * (double)(c1 - c0) / (double)(r1 - r0));                                \
+  }
+#else
+#define ADVOC_WH3_PROBE_BEGIN
+#define ADVOC_WH3_PROBE_END(NAME)
+#endif
 __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, const WgradImages im, int tiles_n,
-                                                          int tiles, int chunk) {
-  wgrad_h3_body<2, 2>(p, im, tiles_n, tiles, chunk);
+                                                          int tiles, int chunk, int gwp) {
+  wgrad_h3_body<2, 2, true>(p, im, tiles_n, tiles, chunk, gwp);
+}
+__global__ __launch_bounds__(256, 2) void wgrad_h3_flat_kernel(const WgradParams p, const WgradImages im, int tiles_n,
+                                                               int tiles, int chunk, int gwp) {
+  wgrad_h3_body<2, 2, false>(p, im, tiles_n, tiles, chunk, gwp);
 }
 __global__ __launch_bounds__(512, 2) void wgrad_h3_256_kernel(const WgradParams p, const WgradImages im, int tiles_n,
-                                                              int tiles, int chunk) {
-#ifdef ADVOC_CLOCK_PROBE
-  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();   // see igemm_patch.hip
-#endif
-  wgrad_h3_body<4, 4>(p, im, tiles_n, tiles, chunk);
-#ifdef ADVOC_CLOCK_PROBE
-  if (threadIdx.x == 0 && (blockIdx.x & 127) == 0) {
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    printf("clk wgrad_h3_256 wg %3d of %d: %llu cycles in %llu ticks of 10 ns = %.3f GHz\n", (int)blockIdx.x, (int)gridDim.x, c1 - c0,
-           r1 - r0, 0.1 * (double)(c1 - c0) / (double)(r1 - r0));
-  }
-#endif
+                                                              int tiles, int chunk, int gwp) {
+  ADVOC_WH3_PROBE_BEGIN
+  wgrad_h3_body<4, 4, true>(p, im, tiles_n, tiles, chunk, gwp);
+  ADVOC_WH3_PROBE_END("wgrad_h3_256")
+}
+__global__ __launch_bounds__(512, 2) void wgrad_h3_256_flat_kernel(const WgradParams p, const WgradImages im, int tiles_n,
+                                                                   int tiles, int chunk, int gwp) {
+  ADVOC_WH3_PROBE_BEGIN
+  wgrad_h3_body<4, 4, false>(p, im, tiles_n, tiles, chunk, gwp);
+  ADVOC_WH3_PROBE_END("wgrad_h3_256_flat")
 }
 
 // 256 x 256 tiles when both matrix dimensions divide and the pixel grid is long enough to give every workgroup (one per
@@ -385,13 +616,18 @@ int wgrad_h3_make_image(const Operand& o, int batch, uint16_t* img, unsigned* hd
 // {amax, 2^-s} words; the caller has filled them (wgrad_h3_make_image or an earlier forward / backward-data launch).
 namespace {
 // tile edge, tiles, K slices and grid points per slice of a launch
-struct WgradPlan { int edge, tiles_n; int64_t tiles, ksplit, chunk; };
+struct WgradPlan { int edge, tiles_n; int64_t tiles, ksplit, chunk; int gwp; };
 bool wgrad_h3_plan(const WgradParams& p, WgradPlan& pl) {
   const bool big = wgrad_big_tile(p);
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   const int edge = big ? 256 : 128;
   const int tiles_m = (p.ntaps * ca + edge - 1) / edge, tiles_n = (cb + edge - 1) / edge;
-  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
+  // row mode (kernel): grid rows padded to a multiple of WK when that wastes <= 4 % of the reduction axis
+  // (ADVOC_WGRAD_H3_ROWS=0: never)
+  const bool rows_on = tuning().wgrad_h3_rows != 0;
+  const int gwp_ = (p.gw + WK - 1) / WK * WK;
+  const int gwp = (rows_on && (gwp_ - p.gw) * 25 <= gwp_) ? gwp_ : 0;
+  const int64_t M = (int64_t)p.batch * p.gh * (gwp ? gwp : p.gw);
   // 64 KiB of LDS: two workgroups per CU; 128 KiB: one
   const int64_t resident = (big ? 1 : 2) * (int64_t)(tuning().reserve_cus ? persistent_cu_count() : device_cu_count());
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
@@ -406,7 +642,7 @@ bool wgrad_h3_plan(const WgradParams& p, WgradPlan& pl) {
   int64_t chunk = ceil_div(ceil_div(M, ksplit), WK) * WK;
   ksplit = ceil_div(M, chunk);
   if (chunk > 0x3fffffffLL || tiles * ksplit > 0x7fffffffLL) return false;
-  pl = {edge, tiles_n, tiles, ksplit, chunk};
+  pl = {edge, tiles_n, tiles, ksplit, chunk, gwp};
   return true;
 }
 }  // namespace
@@ -440,12 +676,14 @@ int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned*
   const int edge = pl.edge, tiles_n = pl.tiles_n;
   const int64_t tiles = pl.tiles, ksplit = pl.ksplit, chunk = pl.chunk;
   constexpr int lds128 = 2 * WCfg<2, 2>::STAGE, lds256 = 2 * WCfg<4, 4>::STAGE;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
-  static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_256_kernel),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
-  if (attr != hipSuccess) { note_hip_error(attr); return ADVOC_ERR_HIP; }
-  if (attr2 != hipSuccess) { note_hip_error(attr2); return ADVOC_ERR_HIP; }
+  static const hipError_t attrs[4] = {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds128),
+      hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_flat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds128),
+      hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds256),
+      hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_256_flat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          lds256)};
+  for (hipError_t a : attrs)
+    if (a != hipSuccess) { note_hip_error(a); return ADVOC_ERR_HIP; }
   // K slices through scratch and an ordered sum when the caller's scratch holds them; fp32 atomics into the zeroed dw else
   WgradParams pp = p;
   const int64_t part_bytes = tiles * ksplit * (int64_t)edge * edge * 4;
@@ -461,12 +699,15 @@ int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned*
     }
   }
   ADVOC_CLEAR_LAUNCH_ERROR();
-  if (big)
-    hipLaunchKernelGGL(wgrad_h3_256_kernel, dim3((unsigned)(tiles * ksplit)), dim3(512), lds256, stream, pp,
-                       im, tiles_n, (int)tiles, (int)chunk);
+  const dim3 grid((unsigned)(tiles * ksplit));
+  if (big && pl.gwp)
+    hipLaunchKernelGGL(wgrad_h3_256_kernel, grid, dim3(512), lds256, stream, pp, im, tiles_n, (int)tiles, (int)chunk, pl.gwp);
+  else if (big)
+    hipLaunchKernelGGL(wgrad_h3_256_flat_kernel, grid, dim3(512), lds256, stream, pp, im, tiles_n, (int)tiles, (int)chunk, 0);
+  else if (pl.gwp)
+    hipLaunchKernelGGL(wgrad_h3_kernel, grid, dim3(256), lds128, stream, pp, im, tiles_n, (int)tiles, (int)chunk, pl.gwp);
   else
-    hipLaunchKernelGGL(wgrad_h3_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), lds128, stream, pp, im,
-                       tiles_n, (int)tiles, (int)chunk);
+    hipLaunchKernelGGL(wgrad_h3_flat_kernel, grid, dim3(256), lds128, stream, pp, im, tiles_n, (int)tiles, (int)chunk, 0);
   ADVOC_RETURN_IF_LAUNCH_FAILED();
   if (ordered) {
     const unsigned nb = (unsigned)(tiles * edge * edge / 256);

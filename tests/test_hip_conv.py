@@ -517,6 +517,48 @@ def test_layer_operand_image_weight_gradient(hip, case, hipenv):
   assert 'h3' not in L2.kernel_name(2)
 
 
+# (r5) ROW MODE of the image weight gradient (wgrad_h3.hip): grid rows of 64 and 32 points (exact), 63 and 31 (one padded
+# column: zeros), a transposed conv with a skip source and a trimmed column, a stride-1 4 x 4 gather whose taps leave the image
+WROWS = [
+    ('wrow_enc',    0, (2, 16, 128), 128, 0, 256, 0, (2, 2), None, 1, False, 0),
+    ('wrow_d4',     0, (2, 9, 64), 128, 0, 256, 0, (1, 1), (1, 1), 1, False, 0),
+    ('wrow_d4_31',  0, (3, 5, 32), 128, 0, 256, 0, (1, 1), (1, 1), 1, False, 0),
+    ('wrow_dec',    1, (2, 8, 32), 128, 128, 256, 1, (2, 2), (1, 1), 2, True, 0),
+]
+
+
+@gpu
+@pytest.mark.parametrize('tile', [1, 2], ids=['128', '256'])
+@pytest.mark.parametrize('case', WROWS, ids=[c[0] for c in WROWS])
+def test_weight_gradient_row_mode_equals_the_flat_axis(hip, case, tile, hipenv):
+  """wgrad_h3.hip row mode (K tiles that never leave a grid row: scalar row arithmetic, 7 vector instructions per slot) and
+  the flat reduction axis are the same sum in another order: both against the float64 oracle in all directions, and against
+  each other to the order of one fp32 sum."""
+  from advoc_amd import conv
+  c = build_case(case)
+  dev = torch.device('cuda')
+  x0 = c['x0'].to(dev)
+  x1 = c['x1'].to(dev) if c['x1'] is not None else None
+  w = c['w'].to(dev)
+  cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+  y = torch.empty(x0.shape[0], c['oh'], c['out_w'], cout, device=dev)
+  dy = c['dy'].to(dev)
+  out = {}
+  for rows in (1, 0):
+    hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_WGRAD_H3_MIN_M=1, ADVOC_WGRAD_H3_TILE=tile, ADVOC_WGRAD_H3_ROWS=rows)
+    L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
+    assert L.kernel_name(2) == ('wgrad_h3_256_kernel' if tile == 2 else 'wgrad_h3_kernel'), L.kernel_name(2)
+    dw = torch.full_like(w, float('nan'))
+    L.backward_weight(dy, dw)
+    torch.cuda.synchronize()
+    out[rows] = dw
+    test_layer_all_directions(hip, case)
+  assert torch.isfinite(out[1]).all()
+  assert rel(out[1], out[0]) < 1e-6, rel(out[1], out[0])
+  if case[0] in ('wrow_d4', 'wrow_d4_31'):          # (padded rows cut the sum into other K tiles: the mode was really taken)
+    assert not torch.equal(out[1], out[0])
+
+
 WG256 = [c for c in H3 if c[0] in ('h3_enc', 'h3_dec_skip', 'h3_dec_first')]      # (the others: 128 / 384 columns)
 
 

@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+mkdir -p gpurun_out
+V=${1:-clkw2}
+ADVOC_HIP_LIB=$PWD/advoc_amd/csrc/libadvoc_hip_$V.so timeout 900 python -m pytest tests/test_hip_conv.py -m gpu -x -q -k "weight_gradient or k_slices or two_streams" 2>&1 | tail -2
+for v in clk $V clk $V; do
+  ADVOC_HIP_LIB=$PWD/advoc_amd/csrc/libadvoc_hip_$v.so timeout 600 python bench.py --train-only --no-cpu-baseline --steps 4 --warmup 3 --prof-steps 0 > /tmp/clk_$v.txt 2>&1
+  echo "== $v"
+  python tools/clock_summary.py /tmp/clk_$v.txt | grep "wgrad" | awk -F'|' '{printf "%s %s cyc n %s  %s GHz %s us\n",$2,$3,$4,$5,$8}'
+  grep -o '"ms_per_step": [0-9.]*' /tmp/clk_$v.txt | head -1
+done

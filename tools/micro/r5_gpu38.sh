@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+for v in $1; do
+  ADVOC_HIP_LIB=$PWD/advoc_amd/csrc/libadvoc_hip_$v.so timeout 600 python bench.py --train-only --no-cpu-baseline --steps 4 --warmup 3 --prof-steps 0 > /tmp/clk_$v.txt 2>&1
+  echo "== $v"
+  python tools/clock_summary.py /tmp/clk_$v.txt | grep "wgrad" | awk -F'|' '{printf "%s %s cyc n %s  %s GHz %s us\n",$2,$3,$4,$5,$8}' | awk '$5>=5' | head -4
+done
