@@ -27,6 +27,7 @@
 // each of them whatever the tap offset and the halo width (a swizzle by the linear pixel index is 2-way conflicted
 // whenever the halo pitch is odd: 25 % of the LDS cycles of the 4x4 kernel were replays, 450 -> 510 TFLOP/s with the
 // DMAs ablated once fixed).
+#include <utility>
 #include <string>
 
 #include "common.h"
@@ -58,6 +59,14 @@ __device__ __forceinline__ float act_slope_p(int act) {
 //   5  as 1 with 128 columns (r4: AdVoc-small's layer_4 backward-data, 256 -> 128 channels), waves as in 3
 // (W = 4 wavefronts, one per SIMD with 512 registers and register-carried fragments, was built and measured 0.85-1.0 x
 // the 8-wave form: the code paths are kept behind CARRY / DOUBLE_B, only W = 8 is instantiated.)
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 template <int NPH, int W>
 struct PCfg {
   static constexpr bool S2 = NPH == 2 || NPH == 3;
@@ -521,6 +530,48 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     if (late) ADVOC_P3_FEED(1);              // (their "M2(-1)")
     ADVOC_P3_BAR("s_waitcnt vmcnt(0)\n\t");  // slice 0's halo and B(0) have landed, from everybody
     if (late) ADVOC_P3_BAR("");
+#ifndef ADVOC_P3_STEP_LOOP
+    // (r5) THE SAME SCHEDULE WITH A K SLICE AS THE LOOP BODY.  Measured in shader cycles with parts of the loop compiled out
+    // (profiles/r05_layer4_k_loop_cycles.md): fragment reads 0, barriers -2 %, but the halo pieces -9 % although they are a
+    // tenth of the DMA bytes, and only -3 % when the piece's DMA instruction goes and its address arithmetic stays: what cost
+    // was the CONTROL FLOW of the feeds -- in the step loop below (r4; ADVOC_P3_STEP_LOOP builds) slice and tap come from a
+    // division of the step index and every feed asks at run time which stage, which halo buffer, which piece, is there a
+    // next slice, is there a next step: basic-block boundaries around every MFMA group, the same thing the ablation switches
+    // had been.  With the 16 tap steps of a slice unrolled the tap is a compile-time constant: stage, halo piece (and whether
+    // the step carries one at all: 6 of 16) and whether a B feed stays inside the slice are decided by the compiler; what is
+    // left at run time is "is there a next slice" in 9 of a slice's 32 feeds.  layer_4 forward, 128 images: 4.18 M -> 3.82 M
+    // cycles (-8.6 %), 2.30 -> 2.20 ms (the clock gives 4 % back: 1.82 -> 1.74 GHz).  (Two loops -- halo steps / plain steps --
+    // or one per wave group spill 900-2 400 registers; a single loop over the unrolled slice does not.)
+    for (int s = 0; s < nslices; ++s) {
+      const int hb = s & 1;
+      const bool more = s + 1 < nslices;
+      static_for<NST>([&](auto tc_) {
+        constexpr int t = decltype(tc_)::value, u = t & 1;
+        ADVOC_P3_LOAD_A(a0, hb, t, 0);
+        ADVOC_P3_LOAD_B(b0, u, 0);
+        ADVOC_P3_LOAD_A(a1, hb, t, 1);
+        if (!late) {
+          if constexpr (t + 1 < NST) { ADVOC_P3_B(s, t + 1, u ^ 1); } else { if (more) ADVOC_P3_B(s + 1, 0, u ^ 1); }
+          if constexpr (t * W * HPS < C::HALO_BLOCKS) { if (more) ADVOC_P3_HALO(s + 1, t, hb ^ 1); }
+        }
+        ADVOC_P3_BAR("s_waitcnt lgkmcnt(0)\n\t");
+        ADVOC_P3_MFMA(a0, b0);
+        ADVOC_P3_BAR("");
+        ADVOC_P3_LOAD_B(b0, u, 1);
+        if (late) ADVOC_P3_BAR("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t") else ADVOC_P3_BAR("s_waitcnt lgkmcnt(0)\n\t");
+        if (late) {
+          if constexpr (t + 2 < NST) { ADVOC_P3_B(s, t + 2, u); } else { if (more) ADVOC_P3_B(s + 1, t + 2 - NST, u); }
+          if constexpr (t + 1 < NST) {
+            if constexpr ((t + 1) * W * HPS < C::HALO_BLOCKS) { if (more) ADVOC_P3_HALO(s + 1, t + 1, hb ^ 1); }
+          } else {
+            if (s + 2 < nslices) ADVOC_P3_HALO(s + 2, 0, hb);
+          }
+        }
+        ADVOC_P3_MFMA(a1, b0);
+        if (late) ADVOC_P3_BAR("") else ADVOC_P3_BAR("s_waitcnt vmcnt(0)\n\t");
+      });
+    }
+#else
     for (int n = 0; n < nsteps; n += 2) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -548,6 +599,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
         if (late) ADVOC_P3_BAR("") else ADVOC_P3_BAR("s_waitcnt vmcnt(0)\n\t");
       }
     }
+#endif
     if (!late) ADVOC_P3_BAR("");
 #undef ADVOC_P3_FEED
 #undef ADVOC_P3_BAR
@@ -556,6 +608,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   for (int s = 0; s < nslices; ++s) {
     const int hb = s & 1;
     const bool more = s + 1 < nslices;
+    // (unrolling this loop -- the tap step a compile-time constant here too -- changes nothing: 1.00 on every instance, r5)
     for (int t = 0; t < NST; t += 2) {
 #ifdef ADVOC_P3_IGLP
       __builtin_amdgcn_iglp_opt(ADVOC_P3_IGLP);
