@@ -19,7 +19,7 @@ struct Tuning {
   int wgrad_h3_min_m;   // ADVOC_WGRAD_H3_MIN_M smallest pixel grid (batch x gh x gw) that takes the image-based weight gradient
   int wgrad_h3_tile;    // ADVOC_WGRAD_H3_TILE  1: 128 x 128, 2: 256 x 256 forced (where the shape allows)
   int wgrad_h3_ordered; // ADVOC_WGRAD_H3_ORDERED 0: K slices of the image weight gradient always meet in fp32 atomics; 1: the 256 x 256 tile's through wgrad_ws when the layer has it; 2: the 128 x 128 tile's too
-  int wgrad_h3_rows;    // ADVOC_WGRAD_H3_ROWS    1: the image weight gradient's reduction axis in row mode (grid rows padded to 32) where that wastes <= 4 %; 0: always flat
+  int wgrad_h3_rows;    // ADVOC_WGRAD_H3_ROWS    1: the image weight gradient's address arithmetic per grid ROW (scalar) where rows have >= 32 points; 0: always per slot (flat); 2: row mode or unsupported (tests)
   int wgrad_h3_rounds;  // ADVOC_WGRAD_H3_ROUNDS  > 0: K chunks per tile = this many rounds of the chip (default: 1)
   int h3;               // ADVOC_H3             0: no operand-image kernels (register-split path instead)
   int h3_tile;          // ADVOC_H3_TILE        1: 128x128, 4: 128x64, 5: 256x256 (8 waves) forced

@@ -95,10 +95,10 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   const int b0 = (tile_id % tiles_n) * C::COLS;
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   const int rows_total = p.ntaps * ca;
-  // (r5) gwp != 0: ROW MODE -- the reduction axis is (image, grid row, column padded to gwp = a multiple of WK), so that a
-  // K tile never leaves its grid row (see the address arithmetic below); 0: the flat axis of grid points
+  // (r5) gwp != 0 (instances with ROW): grid rows of >= WK points -- a K tile touches at most TWO grid rows, and its address
+  // arithmetic is scalar per row (below); 0: the per-slot wrap arithmetic of r2 (the deep layers' short rows)
   constexpr bool rowm = ROW;           // (gwp != 0: the launcher picks the instance)
-  const int M = p.batch * p.gh * (rowm ? gwp : p.gw);  // < 2^31 (launcher)
+  const int M = p.batch * p.gh * p.gw;                 // < 2^31 (launcher)
   const int g_begin = zchunk * chunk;
   const int g_end = g_begin + chunk < M ? g_begin + chunk : M;
   const int nkt = (g_end - g_begin + WK - 1) / WK;
@@ -153,53 +153,68 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   int g_left = g_end - (g_begin + lpix);                             // slot s is inside the chunk while 8 s < g_left
   // (r5) ROW MODE.  Measured in shader cycles with parts of the loop compiled out (profiles/r05_wgrad_k_loop_cycles.md): the
   // DMA instructions of a K tile cost nothing, their ADDRESS ARITHMETIC 20 % of the launch -- ~110 vector / scalar
-  // instructions per wave and tile for the eight offsets (column and row wraps, tap bounds, chunk end, per slot).  With the
-  // grid rows padded to a multiple of WK a tile lies in ONE grid row: image, row, the tap's row bound and both row offsets
-  // are wave-uniform scalars advanced once per tile; a slot is its lane's column constant plus a scalar, one column bound
-  // and one select: 7 vector instructions.  Columns beyond gw are out-of-range offsets: zeros, like a tile's tail was.
+  // instructions per wave and tile for the eight offsets (column and row wraps, tap bounds, chunk end, per slot).  With grid
+  // rows of at least WK points the WK consecutive points of a tile lie in at most TWO grid rows, A (from column x0) and B
+  // (the next row, from column 0; possibly the next image's first): image, row, the tap's row bound and the byte offsets of
+  // both rows are wave-uniform scalars advanced once per tile; a slot is a lane constant plus row A's or row B's scalar
+  // (one compare against the row break, selects), one column bound, one chunk-end compare: 11 vector instructions, no
+  // multiply.  A row whose tap row lies outside the image, a block that does not exist or a tile behind the chunk's end
+  // is the scalar 0x80000000: the sum is out of the buffer's range and the DMA writes zeros.
   const int lpsx = lpix * p.sx;                                       // lane constants of ROW MODE
   const unsigned pk = (unsigned)(lpsx * pc4 + dx * pc4 + p_choff + lchunk16), qk = (unsigned)(lpix * qc4 + q_choff + lchunk16);
   const unsigned c_p8 = (unsigned)(8 * p.sx * pc4), c_q8 = (unsigned)(8 * qc4);
   const int c_s8 = 8 * p.sx;
-  // the tile's scalars: points left in the chunk, first column, grid row, image -- and what the slots need of them: the P / Q
-  // byte offset of (row, first column) or 0x80000000 when the whole tile reads zeros (behind the chunk's end, the tap's
-  // row outside the image, a row / column block that does not exist), the tap's first input column, the columns left
-  int rw_left = g_end - g_begin, rw_x0 = 0, rw_gy = 0, rw_gi = 0, rw_xs = 0, rw_gwl = 0;
-  unsigned rw_pe = 0x80000000u, rw_qe = 0x80000000u;
-  int n_left = 0, n_x0 = 0, n_gy = 0, n_gi = 0, n_xs = 0, n_gwl = 0, rtt = 0;     // (the K loop's pieces)
-  unsigned n_pe = 0, n_qe = 0;
-  bool rc1[SL] = {};
-#define ADVOC_WH3_DERIVE_P(LEFT, X0, GY, GI, PE)                                                         \
+  // the tile: points left in the chunk, first column, grid row, image; derived: row break rb (points of the tile in row
+  // A), P / Q byte offsets of (row A, column x0) and (row B, column -rb), the tap's input column of those two
+  int rw_left = g_end - g_begin, rw_x0 = 0, rw_gy = 0, rw_gi = 0, rw_rb = 0, rw_xa = 0, rw_xb = 0;
+  unsigned rw_pa = 0x80000000u, rw_pb = 0x80000000u, rw_qa = 0x80000000u, rw_qb = 0x80000000u;
+  int n_left = 0, n_x0 = 0, n_gy = 0, n_gi = 0, n_rb = 0, n_xa = 0, n_xb = 0, rtt = 0;     // (the K loop's pieces)
+  unsigned n_pa = 0, n_pb = 0, n_qa = 0, n_qb = 0;
+  bool rcw[SL] = {}, rci[SL] = {};
+#define ADVOC_WH3_DERIVE_P(LEFT, X0, GY, GI, PA, PB)                                                     \
   {                                                                                                      \
-    const int py_ = (GY) * p.sy + dy;                                                                    \
-    const bool ok_ = ((LEFT) > 0) & ((unsigned)py_ < (unsigned)p.P.h) & p_live;                          \
-    PE = ok_ ? (unsigned)(((GI) * p.P.h + py_) * p_pitch * pc4 + (X0) * p.sx * pc4) : 0x80000000u;       \
+    const int rb_ = p.gw - (X0);                                                                         \
+    const int wy_ = (GY) + 1 == p.gh ? 1 : 0;                                                            \
+    const int gyb_ = wy_ ? 0 : (GY) + 1, gib_ = (GI) + wy_;                                              \
+    const int pya_ = (GY) * p.sy + dy, pyb_ = gyb_ * p.sy + dy;                                          \
+    const bool oka_ = ((LEFT) > 0) & ((unsigned)pya_ < (unsigned)p.P.h) & p_live;                        \
+    const bool okb_ = ((LEFT) > rb_) & ((unsigned)pyb_ < (unsigned)p.P.h) & p_live;                      \
+    const unsigned va_ = (unsigned)((((GI) * p.P.h + pya_) * p_pitch + (X0) * p.sx) * pc4);              \
+    const unsigned vb_ = (unsigned)(((gib_ * p.P.h + pyb_) * p_pitch - rb_ * p.sx) * pc4);               \
+    PA = oka_ ? va_ : 0x80000000u;                                                                       \
+    PB = okb_ ? vb_ : 0x80000000u;                                                                       \
   }
-#define ADVOC_WH3_DERIVE_Q(LEFT, X0, GY, GI, QE, XS, GWL)                                                \
+#define ADVOC_WH3_DERIVE_Q(LEFT, X0, GY, GI, QA, QB, XA, XB, RB)                                         \
   {                                                                                                      \
-    const bool ok_ = ((LEFT) > 0) & q_live;                                                              \
-    QE = ok_ ? (unsigned)(((GI) * p.Q.h + (GY)) * q_pitch * qc4 + (X0) * qc4) : 0x80000000u;             \
-    XS = (X0) * p.sx + dx;                                                                               \
-    GWL = p.gw - (X0);                                                                                   \
+    const int rb_ = p.gw - (X0);                                                                         \
+    const int wy_ = (GY) + 1 == p.gh ? 1 : 0;                                                            \
+    const int gyb_ = wy_ ? 0 : (GY) + 1, gib_ = (GI) + wy_;                                              \
+    const unsigned va_ = (unsigned)((((GI) * p.Q.h + (GY)) * q_pitch + (X0)) * qc4);                     \
+    const unsigned vb_ = (unsigned)(((gib_ * p.Q.h + gyb_) * q_pitch - rb_) * qc4);                      \
+    QA = (((LEFT) > 0) & q_live) ? va_ : 0x80000000u;                                                    \
+    QB = (((LEFT) > rb_) & q_live) ? vb_ : 0x80000000u;                                                  \
+    XA = (X0) * p.sx + dx;                                                                               \
+    XB = dx - rb_ * p.sx;                                                                                \
+    RB = rb_;                                                                                            \
   }
-#define ADVOC_WH3_ADVANCE(LEFT, X0, GY, GI)       /* n_* <- the tile behind (LEFT, X0, GY, GI) */          \
+#define ADVOC_WH3_ADVANCE(LEFT, X0, GY, GI)       /* n_* <- the tile behind (LEFT, X0, GY, GI): at most one row on */ \
   {                                                                                                      \
     n_left = (LEFT) - WK;                                                                                \
     const int x_ = (X0) + WK;                                                                            \
-    const int wx_ = x_ >= gwp ? 1 : 0;                                                                   \
-    n_x0 = wx_ ? 0 : x_;                                                                                 \
+    const int wx_ = x_ >= p.gw ? 1 : 0;                                                                  \
+    n_x0 = wx_ ? x_ - p.gw : x_;                                                                         \
     const int y_ = (GY) + wx_;                                                                           \
     const int wy_ = y_ == p.gh ? 1 : 0;                                                                  \
     n_gy = wy_ ? 0 : y_;                                                                                 \
     n_gi = (GI) + wy_;                                                                                   \
   }
   if (rowm) {
-    const int row_ = g_begin / gwp;
-    rw_x0 = g_begin - row_ * gwp;
+    const int row_ = g_begin / p.gw;
+    rw_x0 = g_begin - row_ * p.gw;
     rw_gi = row_ / p.gh;
     rw_gy = row_ - rw_gi * p.gh;
-    ADVOC_WH3_DERIVE_P(rw_left, rw_x0, rw_gy, rw_gi, rw_pe);
-    ADVOC_WH3_DERIVE_Q(rw_left, rw_x0, rw_gy, rw_gi, rw_qe, rw_xs, rw_gwl);
+    ADVOC_WH3_DERIVE_P(rw_left, rw_x0, rw_gy, rw_gi, rw_pa, rw_pb);
+    ADVOC_WH3_DERIVE_Q(rw_left, rw_x0, rw_gy, rw_gi, rw_qa, rw_qb, rw_xa, rw_xb, rw_rb);
   }
 
   // The DMA of a K tile is split in two: its 2 SL buffer offsets (ADDR: plain VALU work without a branch, computed one
@@ -208,10 +223,11 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   int pvn[SL], qvn[SL];
 #define ADVOC_WH3_ADDR_S(s)                                                                              \
     if (rowm) {                                                                                          \
-      const bool rc_ = lpix < rw_gwl - 8 * (s);                                                          \
-      const bool rp_ = rc_ & ((unsigned)(lpsx + rw_xs + (s) * c_s8) < (unsigned)p.P.w);                  \
-      pvn[s] = rp_ ? (int)(pk + rw_pe + (s) * c_p8) : (int)0x80000000;                                   \
-      qvn[s] = rc_ ? (int)(qk + rw_qe + (s) * c_q8) : (int)0x80000000;                                   \
+      const bool w_ = lpix >= rw_rb - 8 * (s);                      /* the slot's point lies in row B */    \
+      const bool in_ = lpix < rw_left - 8 * (s);                                                         \
+      const bool rp_ = in_ & ((unsigned)(lpsx + (s) * c_s8 + (w_ ? rw_xb : rw_xa)) < (unsigned)p.P.w);   \
+      pvn[s] = rp_ ? (int)(pk + (s) * c_p8 + (w_ ? rw_pb : rw_pa)) : (int)0x80000000;                    \
+      qvn[s] = in_ ? (int)(qk + (s) * c_q8 + (w_ ? rw_qb : rw_qa)) : (int)0x80000000;                    \
     } else {                                                                                             \
       const bool in_ = 8 * (s) < g_left;                                                                 \
       const int py_ = __mul24(gy[s], p.sy) + dy, px_ = __mul24(gx[s], p.sx) + dx;                        \
@@ -233,8 +249,8 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
     if (rowm) {                                                                                          \
       ADVOC_WH3_ADVANCE(rw_left, rw_x0, rw_gy, rw_gi);                                                   \
       rw_left = n_left; rw_x0 = n_x0; rw_gy = n_gy; rw_gi = n_gi;                                        \
-      ADVOC_WH3_DERIVE_P(rw_left, rw_x0, rw_gy, rw_gi, rw_pe);                                           \
-      ADVOC_WH3_DERIVE_Q(rw_left, rw_x0, rw_gy, rw_gi, rw_qe, rw_xs, rw_gwl);                            \
+      ADVOC_WH3_DERIVE_P(rw_left, rw_x0, rw_gy, rw_gi, rw_pa, rw_pb);                                    \
+      ADVOC_WH3_DERIVE_Q(rw_left, rw_x0, rw_gy, rw_gi, rw_qa, rw_qb, rw_xa, rw_xb, rw_rb);               \
     } else {                                                                                             \
       g_left -= WK;                                                                                      \
     }                                                                                                    \
@@ -350,6 +366,8 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
   // first k step's MFMAs the second k step's fragments, then the DMAs one at a time; under the second k step's MFMAs the next
   // tile's addresses, one pixel slot at a time.  Only the first k step's reads stay exposed behind the barrier.
 #define ADVOC_WH3_FENCE __builtin_amdgcn_sched_barrier(0)
+// a wave-uniform value computed HERE and kept in a scalar register (the compiler may have had it in a vector register)
+#define ADVOC_WH3_SPIN(X) { X = (decltype(X))__builtin_amdgcn_readfirstlane((int)(X)); asm volatile("" : "+s"(X)); }
 #define ADVOC_WH3_LOADF(AF, BQ, F, KS)                                                                   \
   {                                                                                                      \
     if ((F) < 2 * MT) {                                                                                  \
@@ -420,32 +438,34 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
                if (q * M0 / NP != M) continue;
                const int sl = q / 3, part = q % 3;
                if (part == 0) {
-                 rc1[sl] = lpix < rw_gwl - 8 * sl;
-                 rtt = lpsx + (rw_xs + sl * c_s8);
+                 rcw[sl] = lpix >= rw_rb - 8 * sl;
+                 rci[sl] = lpix < rw_left - 8 * sl;
+                 rtt = lpsx + sl * c_s8 + (rcw[sl] ? rw_xb : rw_xa);
                  asm volatile("" : "+v"(rtt));          // (pins: the piece is computed HERE, not sunk to where it is used)
                } else if (part == 1) {
-                 pvn[sl] = (rc1[sl] & ((unsigned)rtt < (unsigned)p.P.w)) ? (int)(pk + (rw_pe + sl * c_p8)) : (int)0x80000000;
+                 pvn[sl] = (rci[sl] & ((unsigned)rtt < (unsigned)p.P.w)) ? (int)(pk + sl * c_p8 + (rcw[sl] ? rw_pb : rw_pa))
+                                                                         : (int)0x80000000;
                  asm volatile("" : "+v"(pvn[sl]));
                } else {
-                 qvn[sl] = rc1[sl] ? (int)(qk + (rw_qe + sl * c_q8)) : (int)0x80000000;
+                 qvn[sl] = rci[sl] ? (int)(qk + sl * c_q8 + (rcw[sl] ? rw_qb : rw_qa)) : (int)0x80000000;
                  asm volatile("" : "+v"(qvn[sl]));
                }
              }
              if (M == 1) {
                ADVOC_WH3_ADVANCE(rw_left, rw_x0, rw_gy, rw_gi);
-               asm volatile("" : "+s"(n_left), "+s"(n_x0), "+s"(n_gy), "+s"(n_gi));
+               ADVOC_WH3_SPIN(n_left); ADVOC_WH3_SPIN(n_x0); ADVOC_WH3_SPIN(n_gy); ADVOC_WH3_SPIN(n_gi);
              }
              if (M == 5) {
-               ADVOC_WH3_DERIVE_P(n_left, n_x0, n_gy, n_gi, n_pe);
-               asm volatile("" : "+s"(n_pe));
+               ADVOC_WH3_DERIVE_P(n_left, n_x0, n_gy, n_gi, n_pa, n_pb);
+               ADVOC_WH3_SPIN(n_pa); ADVOC_WH3_SPIN(n_pb);
              }
              if (M == 9) {
-               ADVOC_WH3_DERIVE_Q(n_left, n_x0, n_gy, n_gi, n_qe, n_xs, n_gwl);
-               asm volatile("" : "+s"(n_qe), "+s"(n_xs), "+s"(n_gwl));
+               ADVOC_WH3_DERIVE_Q(n_left, n_x0, n_gy, n_gi, n_qa, n_qb, n_xa, n_xb, n_rb);
+               ADVOC_WH3_SPIN(n_qa); ADVOC_WH3_SPIN(n_qb); ADVOC_WH3_SPIN(n_xa); ADVOC_WH3_SPIN(n_xb); ADVOC_WH3_SPIN(n_rb);
              }
              if (M == M0 - 1) {
                rw_left = n_left; rw_x0 = n_x0; rw_gy = n_gy; rw_gi = n_gi;
-               rw_pe = n_pe; rw_qe = n_qe; rw_xs = n_xs; rw_gwl = n_gwl;
+               rw_pa = n_pa; rw_pb = n_pb; rw_qa = n_qa; rw_qb = n_qb; rw_xa = n_xa; rw_xb = n_xb; rw_rb = n_rb;
              }
            } else {
 #pragma unroll
@@ -458,6 +478,7 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
     }
   }
 #undef ADVOC_WH3_FENCE
+#undef ADVOC_WH3_SPIN
 #undef ADVOC_WH3_LOADF
 #undef ADVOC_WH3_MFMA1
 #endif
@@ -622,12 +643,10 @@ bool wgrad_h3_plan(const WgradParams& p, WgradPlan& pl) {
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   const int edge = big ? 256 : 128;
   const int tiles_m = (p.ntaps * ca + edge - 1) / edge, tiles_n = (cb + edge - 1) / edge;
-  // row mode (kernel): grid rows padded to a multiple of WK when that wastes <= 4 % of the reduction axis
-  // (ADVOC_WGRAD_H3_ROWS=0: never)
-  const bool rows_on = tuning().wgrad_h3_rows != 0;
-  const int gwp_ = (p.gw + WK - 1) / WK * WK;
-  const int gwp = (rows_on && (gwp_ - p.gw) * 25 <= gwp_) ? gwp_ : 0;
-  const int64_t M = (int64_t)p.batch * p.gh * (gwp ? gwp : p.gw);
+  // row mode (kernel): grid rows of at least WK points (ADVOC_WGRAD_H3_ROWS=0: never)
+  const int gwp = (tuning().wgrad_h3_rows != 0 && p.gw >= WK) ? p.gw : 0;
+  if (tuning().wgrad_h3_rows == 2 && !gwp) return false;       // (tests: row mode or nothing)
+  const int64_t M = (int64_t)p.batch * p.gh * p.gw;
   // 64 KiB of LDS: two workgroups per CU; 128 KiB: one
   const int64_t resident = (big ? 1 : 2) * (int64_t)(tuning().reserve_cus ? persistent_cu_count() : device_cu_count());
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
@@ -657,6 +676,9 @@ int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned*
                     const unsigned* q_hdr, hipStream_t stream, const char** name_only) {
   if (!wgrad_h3_eligible(p)) return ADVOC_ERR_UNSUPPORTED;
   const bool big = wgrad_big_tile(p);
+  WgradPlan pl;
+  if (!wgrad_h3_plan(p, pl)) return ADVOC_ERR_UNSUPPORTED;
+  // (one name per tile size: the `_flat` instances -- grid rows under WK points -- are the same kernel to every caller)
   if (name_only) { *name_only = big ? "wgrad_h3_256_kernel" : "wgrad_h3_kernel"; return ADVOC_OK; }
   if (!p_img || !q_img || !p_hdr || !q_hdr) return ADVOC_ERR_NULL;
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
@@ -671,8 +693,6 @@ int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned*
   im.q0_bytes = (int)((int64_t)4 * p.batch * p.Q.h * p.Q.pitch0 * p.Q.c0);
   im.q1_bytes = (int)((int64_t)4 * p.batch * p.Q.h * p.Q.pitch1 * p.Q.c1);
   im.p_hdr = p_hdr; im.q_hdr = q_hdr;
-  WgradPlan pl;
-  if (!wgrad_h3_plan(p, pl)) return ADVOC_ERR_UNSUPPORTED;
   const int edge = pl.edge, tiles_n = pl.tiles_n;
   const int64_t tiles = pl.tiles, ksplit = pl.ksplit, chunk = pl.chunk;
   constexpr int lds128 = 2 * WCfg<2, 2>::STAGE, lds256 = 2 * WCfg<4, 4>::STAGE;
