@@ -1,3 +1,4 @@
+# The round-end call: whole GPU suite, bitwise repeatability of the patch kernels, then the evidence set (run_gpu_prof_r05.sh final)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 2700 python -m pytest tests -m gpu -x -q > gpurun_out/r5_tests_final.txt 2>&1
