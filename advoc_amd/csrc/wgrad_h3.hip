@@ -368,7 +368,8 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
 #define ADVOC_WH3_FENCE __builtin_amdgcn_sched_barrier(0)
 // a wave-uniform value computed HERE and kept in a scalar register (the compiler may have had it in a vector register)
 #define ADVOC_WH3_SPIN(X) { X = (decltype(X))__builtin_amdgcn_readfirstlane((int)(X)); asm volatile("" : "+s"(X)); }
-#define ADVOC_WH3_LOADF(AF, BQ, F, KS)                                                                   \
+#define ADVOC_WH3_LOADF(AF, BQ, F, KS) ADVOC_WH3_LOADF2(AF, BQ, F, KS, Pb, Qb)
+#define ADVOC_WH3_LOADF2(AF, BQ, F, KS, Pb, Qb)                                                                   \
   {                                                                                                      \
     if ((F) < 2 * MT) {                                                                                  \
       const unsigned char* b_ = Pb + (wm * MT + ((F) >> 1)) * BLK;                                       \
@@ -393,6 +394,113 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
       acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i_][pr_ == 1 ? 1 : 0], BQ[j_][pr_ == 0 ? 1 : 0], acc[i_][j_], 0, 0, 0); \
   }
   constexpr int NG = MT * NT, M0 = 3 * NG, NF = 2 * (MT + NT), NFILL = NF + 2 * SL;
+#ifndef ADVOC_WH3_TOPBAR
+  // THE RENDEZVOUS INSIDE THE SECOND K STEP.  With the barrier at the top of a tile (ADVOC_WH3_TOPBAR builds) both waves of a
+  // SIMD stand behind it together and then read the first k step's fragments with nothing in the matrix pipe: 9 % of the
+  // launch (profiles/r05_wgrad_k_loop_cycles.md).  All reads of the running stage are over once the second k step's
+  // fragments are in registers, i.e. when the first k step's MFMAs are through; so the tile's one rendezvous (own DMAs of
+  // the next tile landed, own reads of this stage returned, everybody here) sits HALF WAY THROUGH THE SECOND K STEP, and
+  // behind it the NEXT tile's first-k-step fragments are read under the rest of this tile's MFMAs, into the registers the
+  // first k step has left.  DMAs go out in the first gaps of a tile (the stage they fill was released by the rendezvous
+  // before), the next-but-one tile's addresses are computed in the first half of the second k step.
+  constexpr int HALF = M0 / 2;
+  f16x8 af0[MT][2], bq0[NT][2], af1[MT][2], bq1[NT][2];
+  dma_ring_barrier<0>();
+  {
+    const unsigned char* Pb = wsm;
+    const unsigned char* Qb = Pb + C::PB * BLK;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) ADVOC_WH3_LOADF(af0, bq0, f, 0);
+  }
+  for (int kt = 0; kt < nkt; kt += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const unsigned nst_ = lds0 + (u ^ 1) * STAGE;                  // the stage filled under this tile's MFMAs
+      const unsigned char* Pb = wsm + u * STAGE;
+      const unsigned char* Qb = Pb + C::PB * BLK;
+      const unsigned char* Pn = wsm + (u ^ 1) * STAGE;
+      const unsigned char* Qn = Pn + C::PB * BLK;
+      ADVOC_WH3_FENCE;
+      // first k step: the next tile's DMAs, then this tile's second-k-step fragments; filler f behind MFMA f * M0 / NFILL
+      static_for<M0>([&](auto mc_) {
+           constexpr int M = decltype(mc_)::value;
+           ADVOC_WH3_MFMA1(af0, bq0, M);
+#pragma unroll
+           for (int f = 0; f < NFILL; ++f) {
+             if (f * M0 / NFILL != M) continue;
+             if (f >= 2 * SL) {
+               ADVOC_WH3_LOADF(af1, bq1, f - 2 * SL, 1);
+             } else if (!(wabl & 33)) {
+               if (f & 1) dma16(rs_q, nst_ + (C::PB + wave) * BLK + (f >> 1) * 1024, qvn[f >> 1]);
+               else dma16(rs_p, nst_ + wave * BLK + (f >> 1) * 1024, pvn[f >> 1]);
+             } else if (wabl & 32) {
+               asm volatile("" ::"v"(pvn[f >> 1]), "v"(qvn[f >> 1]));
+             }
+           }
+           ADVOC_WH3_FENCE;
+      });
+      // second k step, first half: the addresses of the tile after next; then the rendezvous; second half: the next tile's
+      // first-k-step fragments
+      static_for<M0>([&](auto mc_) {
+           constexpr int M = decltype(mc_)::value;
+           ADVOC_WH3_MFMA1(af1, bq1, M);
+           if constexpr (ROW) {
+             constexpr int NP = 3 * SL;
+#pragma unroll
+             for (int q = 0; q < NP; ++q) {
+               if (q * HALF / NP != M) continue;
+               const int sl = q / 3, part = q % 3;
+               if (part == 0) {
+                 rcw[sl] = lpix >= rw_rb - 8 * sl;
+                 rci[sl] = lpix < rw_left - 8 * sl;
+                 rtt = lpsx + sl * c_s8 + (rcw[sl] ? rw_xb : rw_xa);
+                 asm volatile("" : "+v"(rtt));          // (pins: the piece is computed HERE, not sunk to where it is used)
+               } else if (part == 1) {
+                 pvn[sl] = (rci[sl] & ((unsigned)rtt < (unsigned)p.P.w)) ? (int)(pk + sl * c_p8 + (rcw[sl] ? rw_pb : rw_pa))
+                                                                         : (int)0x80000000;
+                 asm volatile("" : "+v"(pvn[sl]));
+               } else {
+                 qvn[sl] = rci[sl] ? (int)(qk + sl * c_q8 + (rcw[sl] ? rw_qb : rw_qa)) : (int)0x80000000;
+                 asm volatile("" : "+v"(qvn[sl]));
+               }
+             }
+             if (M == HALF / 6) {
+               ADVOC_WH3_ADVANCE(rw_left, rw_x0, rw_gy, rw_gi);
+               ADVOC_WH3_SPIN(n_left); ADVOC_WH3_SPIN(n_x0); ADVOC_WH3_SPIN(n_gy); ADVOC_WH3_SPIN(n_gi);
+             }
+             if (M == HALF / 2) {
+               ADVOC_WH3_DERIVE_P(n_left, n_x0, n_gy, n_gi, n_pa, n_pb);
+               ADVOC_WH3_SPIN(n_pa); ADVOC_WH3_SPIN(n_pb);
+             }
+             if (M == 5 * HALF / 6) {
+               ADVOC_WH3_DERIVE_Q(n_left, n_x0, n_gy, n_gi, n_qa, n_qb, n_xa, n_xb, n_rb);
+               ADVOC_WH3_SPIN(n_qa); ADVOC_WH3_SPIN(n_qb); ADVOC_WH3_SPIN(n_xa); ADVOC_WH3_SPIN(n_xb); ADVOC_WH3_SPIN(n_rb);
+             }
+             if (M == M0 - 1) {
+               rw_left = n_left; rw_x0 = n_x0; rw_gy = n_gy; rw_gi = n_gi;
+               rw_pa = n_pa; rw_pb = n_pb; rw_qa = n_qa; rw_qb = n_qb; rw_xa = n_xa; rw_xb = n_xb; rw_rb = n_rb;
+             }
+           } else {
+#pragma unroll
+             for (int sl = 0; sl < SL; ++sl)
+               if ((2 * sl + 1) * HALF / (2 * SL) == M) { ADVOC_WH3_ADDR_S(sl); }
+           }
+           if (M == HALF - 1) {
+             ADVOC_WH3_FENCE;
+             if (wabl & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+             else dma_ring_barrier<0>();    // (own DMAs of the next tile landed, own reads of this stage returned, everybody here)
+           }
+           if (M >= HALF) {
+#pragma unroll
+             for (int f = 0; f < NF; ++f)
+               if (HALF + f * HALF / NF == M) ADVOC_WH3_LOADF2(af0, bq0, f, 0, Pn, Qn);
+           }
+           ADVOC_WH3_FENCE;
+      });
+      if constexpr (!ROW) ADVOC_WH3_ADDR_TILE();
+    }
+  }
+#else
   for (int kt = 0; kt < nkt; kt += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -477,9 +585,11 @@ __device__ __forceinline__ void wgrad_h3_body(const WgradParams& p, const WgradI
       if constexpr (!ROW) ADVOC_WH3_ADDR_TILE();
     }
   }
+#endif
 #undef ADVOC_WH3_FENCE
 #undef ADVOC_WH3_SPIN
 #undef ADVOC_WH3_LOADF
+#undef ADVOC_WH3_LOADF2
 #undef ADVOC_WH3_MFMA1
 #endif
 #undef ADVOC_WH3_ADDR
