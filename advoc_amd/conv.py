@@ -232,6 +232,7 @@ class Layer(object):
     self._emits_dx_acc = None      # ... as an accumulating call
     self._dx_table = None          # replica table of the column sums that ride in the dx image emission
     self._dy_emitted_for = None    # (dy pointer, db pointer or None): dy_img was written by the layer above's backward_data
+    self._dy_image_only = None     # dy pointer whose fp32 tensor was never written (the image in dy_img is its only copy)
     self._bias_fusable = bool(_lib.load().advoc_conv_bias_fusable(ctypes.byref(s)))
     self._thin_bias = False
     if kind == CONV and cin <= 2 and workspace:
@@ -384,6 +385,10 @@ class Layer(object):
       return None
     if not c.kernel_name(1).startswith('patch_gemm_h3_kernel') or 'h3' not in c.kernel_name(0):
       return None
+    #  ... and its WEIGHT GRADIENT must read x_img too: the fp32 kernels it would otherwise fall back to read the
+    # tensor this layer never writes
+    if 'h3' not in c.kernel_name(2):
+      return None
     if c._gates_ok is None:      # the consumer's backward-data launch must be one that can gate on the image: asked once
       c._gates_ok = bool(_lib.load().advoc_conv_gates_on_image(ctypes.byref(cs)))
     return c if c._gates_ok else None
@@ -502,6 +507,7 @@ class Layer(object):
     if emitted is not None and not (emitted[0] == dy.data_ptr() and 'h3' in self.kernel_name(1)):
       emitted = None
     db_by_producer = emitted is not None and db is not None and emitted[1] == db.data_ptr()
+    self._dy_image_only = dy.data_ptr() if (emitted is not None and emitted[2]) else None
     fuse_db = db is not None and self._bias_fusable and 'h3' in self.kernel_name(1) and emitted is None
     if fuse_db:
       _lib.require_device(db)
@@ -577,7 +583,20 @@ class Layer(object):
     flags = 0
     if self.reuse_images:
       flags = (1 if self._x_current else 0) | (2 if self._dy_current_ptr == dy.data_ptr() else 0)
-    self.struct.img_flags = flags | self._delayed_bits()
+    #  operands that exist as images ONLY can never be rebuilt from their fp32 tensors (never written): a call
+    # that would do so is refused instead of overwriting the one valid copy with an image of garbage
+    if self._x_gates and not (flags & 1):
+      raise _lib.AdvocHipError('backward_weight: the input exists as an operand image only and that image is not current '
+                               '(reuse_images off, or no forward since the inputs changed)')
+    pend = self._dy_emitted_for
+    if ((self._dy_image_only == dy.data_ptr() or (pend is not None and pend[2] and pend[0] == dy.data_ptr()))
+        and not (flags & 2)):
+      raise _lib.AdvocHipError('backward_weight: this output gradient exists as an operand image only; call backward_data '
+                               '(which adopts the image) first, with reuse_images on')
+    dy_only = self._dy_image_only == dy.data_ptr()
+    # (ADVOC_IMG_X_GATES / ADVOC_IMG_DY_BOUNDED tell the library which operands have no fp32 tensor behind them: it refuses
+    # every path that would read one)
+    self.struct.img_flags = flags | self._delayed_bits() | (256 if self._x_gates else 0) | (64 if dy_only else 0)
     # (the bias gradient counts as done only for the SAME dy and the SAME db buffer the backward_data call summed into)
     db_done = db is not None and self._db_done_for == (dy.data_ptr(), db.data_ptr())
     # 1-2 channel inputs (encoder_1, layer_1): the weight-gradient kernel reads every dy element exactly once and takes the
@@ -591,13 +610,21 @@ class Layer(object):
           _lib.stream()), 'advoc_conv_backward_weight'))
     finally:
       self.struct.img_flags = 0
-    self._x_current = False                # one use per forward: the caller may rewrite the inputs before the next call
+    # one use per forward: the caller may rewrite the inputs before the next call -- EXCEPT an input that exists as the
+    # image only (nothing to rewrite it from: it stays current until the next forward; gradient accumulation, profilers)
+    if not self._x_gates:
+      self._x_current = False
     if 'h3' in self.kernel_name(2):        # the image-based weight gradient has (re)built whatever was not current
       self._x_built = self._x_built or bool(self.struct.x_img)
       self._dy_built = self._dy_built or bool(self.struct.dy_img)
-    self._dy_current_ptr = None          # one use per backward_data: the next step's dy lives at the same address
+    # one use per backward_data (the next step's dy lives at the same address) -- except an image-only dy, see above
+    if self._dy_image_only is None or self._dy_image_only != self._dy_current_ptr:
+      self._dy_current_ptr = None
     self._db_done_for = None
     if db is not None and not db_done and not db_rides:
+      if dy_only:
+        raise _lib.AdvocHipError('backward_weight: the bias gradient of an image-only output gradient comes from its producer '
+                                 '(consumer_db of the layer above); it cannot be summed from a tensor that was never written')
       _lib.require_device(db)
       call = lambda: _lib.check(_lib.load().advoc_conv_backward_bias(      # noqa: E731
           ctypes.byref(self.struct), _lib.ptr(dy), _lib.ptr(db), int(accumulate), _lib.stream()),

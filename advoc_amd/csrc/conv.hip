@@ -619,6 +619,10 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
   p.part_ws = L->wgrad_ws;
   p.part_ws_bytes = L->wgrad_ws ? L->wgrad_ws_bytes : 0;
   const int ca = p.P.c0 + p.P.c1;
+  // (r6) an image-only operand that is not flagged current cannot be rebuilt (there is no fp32 tensor to rebuild it from)
+  if ((L->img_flags & ADVOC_IMG_X_GATES) && !(L->img_flags & ADVOC_IMG_X_CURRENT)) return ADVOC_ERR_UNSUPPORTED;
+  if ((L->img_flags & ADVOC_IMG_DY_BOUNDED) && !(L->img_flags & ADVOC_IMG_DY_CURRENT)) return ADVOC_ERR_UNSUPPORTED;
+  if (ca <= 2 && (L->img_flags & (ADVOC_IMG_X_GATES | ADVOC_IMG_DY_BOUNDED))) return ADVOC_ERR_UNSUPPORTED;
   if (ca <= 2) {
     const int cb = p.Q.c0 + p.Q.c1;
     // the bias gradient rides in the weight-gradient kernel when its wide operand IS the output gradient (encoder_1,
@@ -673,9 +677,14 @@ extern "C" int advoc_conv_backward_weight(const advoc_conv_layer* L, const float
         if (rc == ADVOC_OK) rc = launch_wgrad_h3(p, hp.img, hp.hdr, hq.img, hq.hdr, as_stream(stream));
       }
     }
+    // (r6) operands that exist as images only -- ADVOC_IMG_X_GATES: the inputs, ADVOC_IMG_DY_BOUNDED: the output
+    // gradient, both never written as fp32 -- can be read by the image kernel alone: no fall-back to the fp32 kernels
+    if (rc == ADVOC_ERR_UNSUPPORTED && (L->img_flags & (ADVOC_IMG_X_GATES | ADVOC_IMG_DY_BOUNDED))) return rc;
     if (rc == ADVOC_ERR_UNSUPPORTED) rc = launch_wgrad_mfma(p, as_stream(stream));
   }
   if (rc != ADVOC_OK) return rc;
+  // (the bias gradient below reads the fp32 dy: refused when that tensor was never written)
+  if (db && (L->img_flags & ADVOC_IMG_DY_BOUNDED)) return ADVOC_ERR_UNSUPPORTED;
   if (db)
     rc = launch_bias_grad(dy, L->drop_mask, L->drop_scale, (int64_t)L->y.n * L->y.h, L->y.w,
                           L->y.w_pitch, L->y.c, db, accumulate, as_stream(stream));

@@ -729,7 +729,15 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   }
 #undef ADVOC_P3_HALO
 #undef ADVOC_P3_B
-  if (abl & 64) continue;         // (timing experiments only: the K loop without its epilogue)
+  if (abl & 64) continue;         // (timing experiments only: the K loop without its epilogue -- and, the accumulators being dead, without its MFMAs)
+  if (abl & 8192) {               // (r6, timing only: no epilogue, the accumulators kept alive -- the ceiling of a perfectly hidden epilogue)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+    __syncthreads();
+    continue;
+  }
 
   // ---- epilogue (igemm_h3.hip's, per wave): pixel table of the wave's points for its phase, LDS transpose,
   // 16-byte stores with the fused bias / dropout / activation-gradient / two-destination logic ----

@@ -335,7 +335,7 @@ def test_full_model_train_loops_at_bench_size_match_the_float64_oracle(hip):
     # anywhere between 1.4e-4 and 6.6e-4 from run to run, on either side of this test's bar.  The parameters themselves are
     # compared first, then adopted.
     m.d_step(m._feed())
-    gates_d, _ = read_gates(st, DISTINCT, [('real', st['d_layers_2b'], {}, 0), ('fake', st['d_layers_2b'], {}, Bn)])
+    gates_d, names_g = read_gates(st, DISTINCT, [('real', st['d_layers_2b'], {}, 0), ('fake', st['d_layers_2b'], {}, Bn)])
     sd = m.state_dict()
     for k in Dk:
       assert rel(sd[k], P64[k]) < 1e-4, (step, k, rel(sd[k], P64[k]))
@@ -347,6 +347,33 @@ def test_full_model_train_loops_at_bench_size_match_the_float64_oracle(hip):
     m.g_step(m._feed())
     gates_g, _ = read_gates(st, DISTINCT, [('fake', st['d_layers_fake'], {}, 0)])
     assert m.step == step + 1
+    # (r6, VERDICT r5 item 5a / ADVICE r5) the read-back sign patterns -- the generator's from its fp32 pre-activations, the
+    # discriminator's partly from the fp16 high plane of an operand IMAGE (y_image_only) -- against the float64 oracle's OWN
+    # forward passes at the same parameters: a kernel (or an image-sign path) that computes a wrong gate cannot hide behind the
+    # gate-frozen comparison below, whose gates are this run's.  Up to 1e-4 of the gates may differ (pre-activations within
+    # round-off of zero).  And the north-star's literal bar at the BENCHED dispatch: generator output within 1e-4 rel-L2.
+    for tagp, P_at, bi, gts, passes in (('D', P_at_d, bd, gates_d, ('real', 'fake')), ('G', P_at_g, bg, gates_g, ('fake',))):
+      xb, tb = batches[bi][0].double(), batches[bi][1].double()
+      col = []
+      with torch.no_grad():
+        gen64 = A.build_generator(P_at, xb, cfg, {k: v.double() for k, v in masks[bi].items()}, collect=col)
+        flips = tot = 0
+        for n, c in zip(names_g, col):
+          flips += int((gts[n] != (c > 0)).sum())
+          tot += c.numel()
+        for tag in passes:
+          acts = []
+          A.build_discriminator(P_at, xb, tb if tag == 'real' else gen64, cfg, collect=acts)
+          for i in range(4):
+            flips += int((gts['D/%s/layer_%d' % (tag, i + 1)] != (acts[i] > 0)).sum())
+            tot += acts[i].numel()
+      print('step %d %s pass: gates that differ from the float64 forward passes: %d of %d' % (step + 1, tagp, flips, tot))
+      assert flips <= 1e-4 * tot, (tagp, flips, tot)
+      if tagp == 'G':
+        r_gen = rel(st['gen_out'][:DISTINCT], gen64)
+        print('step %d: generator output at the 64-clip dispatch vs float64: rel-L2 %.3g' % (step + 1, r_gen))
+        assert r_gen < 1e-4, r_gen
+        assert torch.equal(st['gen_out'][:DISTINCT], st['gen_out'][Bn - DISTINCT:])      # the tiled clips: identical rows
     # GATE-FROZEN (r5): the same gradients against the float64 oracle evaluated with THIS run's sign patterns (every leaky /
     # plain ReLU of the generator and of the discriminator's passes): a smooth function on both sides, every tensor held to
     # 5e-4 with no recourse to what float32 achieves.  The free-running comparison below keeps its r3 form; its one sensitive
@@ -545,7 +572,8 @@ def test_full_model_with_batch_norm_train_loop_at_bench_size_matches_the_float64
   frozen = compare(fD, fG)
   top = sorted(frozen.items(), key=lambda kv: -kv[1])[:6]
   print('gate-frozen oracle: worst gradients rel-L2 vs float64: %s' % ', '.join('%s %.3g' % kv for kv in top))
-  # (bar: 1e-3, a fixed number -- measured 4.0e-4 .. 6.2e-4 from run to run, uniformly over the generator's tensors: what is
+  # (bar: 7e-4, a fixed number -- measured 4.0e-4 .. 6.2e-4 from run to run, uniformly over the generator's tensors: what is
   # left with every gate frozen is fp32 round-off through batch statistics over 24 samples; float32 torch-CPU's own distance on
   # this graph is 3.5e-3, r4 accepted 2.7e-2 here)
-  assert all(r <= 1e-3 for r in frozen.values()), top
+  # (r6: 7e-4 -- VERDICT r5 item 5b)
+  assert all(r <= 7e-4 for r in frozen.values()), top
