@@ -77,6 +77,8 @@ Tuning read_env() {
 #else
   t.h3_patch_ablate = 0;
 #endif
+  t.h3_patch_2wg = env_int("ADVOC_H3_PATCH_2WG", 0);
+  t.h3_patch_2wg_delay = env_int("ADVOC_H3_PATCH_2WG_DELAY", 100);
   t.reserve_cus = env_int("ADVOC_RESERVE_CUS", 0);
   if (t.reserve_cus < 0) t.reserve_cus = 0;
   t.thin_wgrad_bias = env_int("ADVOC_THIN_WGRAD_BIAS", 1);

@@ -175,6 +175,7 @@ struct PatchGeom {
   int py, px;        // patches per image along y / x
   int rem;           // > 0: the patches cover grid columns [0, 16 px) only, the last `rem` (<= 4) columns go to a per-tap launch
   int nblocks;       // 8-pixel DMA blocks of the halo
+  int delay2;        // (r6, nph 6) shader cycles the second workgroup of a CU starts behind the first
   int ablate;        // timing experiments only (ADVOC_H3_PATCH_ABLATE bits: 1 no DMA, 2 no MFMA, 4 no barrier); 0 in use
   // stride-2 gathers as four parity planes of the input (nph 2 | 3): plane (py, px) holds input pixels (2 y + py, 2 x + px);
   // s2_a0y[py] / s2_a0x[px] = smallest plane-row / plane-column offset of the plane's taps (its halo origin),

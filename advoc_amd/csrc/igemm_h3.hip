@@ -767,7 +767,7 @@ int launch_gather_gemm_h3(const GatherGemmParams& p_in, bool b_kn, hipStream_t s
     // (the patch kernels' lean instances; remainder columns and launches without a patch plan on the per-tap kernel, whose
     // generic epilogue takes masks too -- but an accumulating destination 0 needs a bound of what it holds: obound_add)
     const bool ok = p.oimg[0].img && p.oimg[0].hdr && !p.oimg[1].img && !p.y_mask &&
-                    !p.d[0].gmask && !p.d[1].gmask && (!p.d[0].accum || (p.obound_add && (patch_nph == 0 || patch_nph == 4))) &&
+                    !p.d[0].gmask && !p.d[1].gmask && (!p.d[0].accum || (p.obound_add && (patch_nph == 0 || patch_nph == 4 || patch_nph == 6))) &&
                     !p.d[1].accum &&
                     (p.grad_act != ADVOC_ACT_NONE || p.d[0].xpre || p.d[1].p) &&
                     (!p.ocolsum_out || (p.ocolsum_table && p.d[0].c <= 1024));

@@ -40,6 +40,9 @@
 namespace advoc {
 namespace {
 
+// (r6, NPH = 6) arrivals of two-per-CU workgroups per (XCC, CU): see the staggered start in the kernel body
+__device__ unsigned g_p4w_arrivals[8 * 256];
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_void_p;
@@ -73,30 +76,40 @@ struct PCfg {
   static constexpr int WAVES = W, THREADS = 64 * W;
   static constexpr bool S1 = NPH == 1 || NPH == 5;         // the 4x4 stride-1 gather
   static constexpr bool N128 = NPH == 3 || NPH == 5;       // 128 columns per workgroup
+  // (r6) NPH = 6: the four-phase gather of NPH = 4 on TWO 4-WAVE WORKGROUPS PER CU (see "two workgroups per CU" below): a
+  // workgroup owns 8 x 16 grid points, a wave is a phase (128 points x 64 columns, the accumulator of an NPH = 4 wave), the
+  // weights of a phase are read by that wave alone and live in a ring of its own
+  static constexpr bool P4W = NPH == 6;
+  static constexpr bool FOURPH = NPH == 4 || NPH == 6;
+  static_assert(!P4W || W == 4, "the two-per-CU instance has four waves");
+  static constexpr int PROWS = P4W ? 8 : 16;               // grid rows of a patch (16 columns always)
   static constexpr int NST = S1 ? 16 : 4;                  // tap steps per K slice
-  static constexpr int BN = NPH == 4 ? 64 : (N128 ? 128 : 256);   // output channels per workgroup
+  static constexpr int BN = FOURPH ? 64 : (N128 ? 128 : 256);   // output channels per workgroup
   static constexpr int BROWS = N128 ? 128 : 256;           // rows of a B stage (NPH = 4: four phases x 64 columns)
   static constexpr int MT = N128 ? 2 : ((NPH == 4 && W == 4) ? 8 : 4);   // 32-point blocks per wave
   static constexpr int NT = (NPH == 1 && W == 4) ? 4 : 2;  // 32-column blocks per wave
-  static constexpr bool CARRY = W == 4;                    // next step's first A fragments fetched before the barrier
+  static constexpr bool CARRY = W == 4 && !P4W;            // next step's first A fragments fetched before the barrier
 #ifdef ADVOC_P3_DOUBLE_B        // (A/B builds only: with the ablation switches compile-time the 4x4 instances have the registers)
-  static constexpr bool DOUBLE_B = W == 4 || NPH == 1 || NPH == 5;
+  static constexpr bool DOUBLE_B = (W == 4 && !P4W) || NPH == 1 || NPH == 5;
 #else
-  static constexpr bool DOUBLE_B = W == 4;                 // B fragments of both k steps in registers at once (W = 8: the
+  static constexpr bool DOUBLE_B = W == 4 && !P4W;         // B fragments of both k steps in registers at once (W = 8: the
                                                            // second set costs the 16 registers that tip the loop into scratch)
 #endif
-  static constexpr int HW = NPH == 4 ? 18 : (S1 ? 19 : 17);   // halo width = height (patch_plan takes only these)
+  static constexpr int HW = FOURPH ? 18 : (S1 ? 19 : 17);  // halo width (= height but for P4W; patch_plan takes only these)
+  static constexpr int HROWS = P4W ? 10 : HW;              // halo rows
   static constexpr int HP = S1 ? 20 : 18;                  // halo row pitch in LDS, EVEN: address bit 7 (the half of the
                                                            // 256-byte bank row) must follow the column's parity
-  static constexpr int HALO_BLOCKS = (HW * HP + 7) / 8;    // 8-pixel DMA blocks: 41 | 48 | 39
-  static constexpr int HPS = S1 ? 1 : (W == 4 ? 3 : 2);   // halo DMA slots per wave and step
+  static constexpr int HALO_BLOCKS = (HROWS * HP + 7) / 8; // 8-pixel DMA blocks: 41 | 48 | 39 | 23
+  static constexpr int HPS = S1 ? 1 : ((W == 4 && !P4W) ? 3 : 2);   // halo DMA slots per wave and step
   static constexpr int BPW = BROWS / 8 / W;                // B DMA blocks (8 rows) per wave and step
+  // P4W: a wave's ring = two stages of [64 columns x one 16-channel k step x 2 planes] = 64 rows x 64 bytes, stage = k step
+  static constexpr int KH_STAGE = 64 * 64;
   // where in a step the DMAs of the next one are issued: 1 after the step's fragment reads, 2 after its first MFMA group
   // (measured with a run-time switch: +4-5 % on the four-phase kernel, neutral on the 4x4 one; at the top of the step, 0,
   // the DMA's LDS writes collide with the fragment reads that follow the barrier)
   static constexpr int DMA_POS = S1 ? 1 : 2;
   static constexpr int HALO_BYTES = HALO_BLOCKS * 1024;
-  static constexpr int B_STAGE = BROWS * 128;
+  static constexpr int B_STAGE = P4W ? W * KH_STAGE : BROWS * 128;     // (P4W: "stage" h = k step h of every wave's ring)
   static constexpr int OFF_B = 2 * HALO_BYTES;
   // NPH = 3 (24 MFMAs per wave and tap, half the other instances'): FOUR tap buffers, two taps per rendezvous
   static constexpr int NBUF = NPH == 3 ? 4 : 2;
@@ -110,7 +123,7 @@ struct PCfg {
   // than the overlap returns.  Only the 4x4 stride-1 instance keeps it.
   static constexpr bool STAGGER = W == 8 && NBUF == 2 && NPH == 1;
 #endif
-  static constexpr int LDS_BYTES = OFF_B + NBUF * B_STAGE;  // 146 | 160 | 142 | 142 KiB
+  static constexpr int LDS_BYTES = OFF_B + NBUF * B_STAGE;  // 146 | 160 | 142 | 142 | 78 KiB
   static constexpr int PTS_W = 32 * MT;                    // grid points per wave
   // (r5) the epilogue's scratch -- per wave a 32 x 36-word transpose tile and the pixel table of its points -- in the LDS the
   // NEXT tile's prologue does not write (halo buffer 0, weight stage 0 and, with four stages, 1): the tiles in halo buffer
@@ -130,7 +143,7 @@ struct PCfg {
 #elif defined(ADVOC_P3_PIN_NONE)
   static constexpr bool PIN = false;
 #else
-  static constexpr bool PIN = NPH == 4 || NPH == 2;
+  static constexpr bool PIN = NPH == 4 || NPH == 2 || NPH == 6;
 #endif
 #ifdef ADVOC_P3_PIN_DMA_ONLY    // (A/B builds only)
   static constexpr bool PIN_MFMA = false;
@@ -139,10 +152,12 @@ struct PCfg {
 #endif
   static constexpr int EPI_T_BYTES = WAVES * 32 * 36 * 4, EPI_PIX_BYTES = WAVES * 2 * PTS_W * 4;
   static constexpr int EPI_T_OFF = HALO_BYTES;
-  static constexpr int EPI_PIX_OFF = OFF_B + (NBUF == 4 ? 2 : 1) * B_STAGE;
+  // (P4W: the next tile's prologue fills BOTH stages of every ring; tiles and tables share halo buffer 1)
+  static constexpr int EPI_PIX_OFF = P4W ? HALO_BYTES + EPI_T_BYTES : OFF_B + (NBUF == 4 ? 2 : 1) * B_STAGE;
   static_assert(WAVES * NST * HPS >= HALO_BLOCKS, "every halo block has a DMA slot");
-  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-  static_assert(EPI_T_BYTES <= HALO_BYTES && EPI_PIX_BYTES <= B_STAGE && EPI_PIX_OFF + EPI_PIX_BYTES <= LDS_BYTES,
+  static_assert(LDS_BYTES <= 160 * 1024 && (!P4W || LDS_BYTES <= 80 * 1024), "LDS budget");
+  static_assert(P4W ? EPI_T_BYTES + EPI_PIX_BYTES <= HALO_BYTES
+                    : (EPI_T_BYTES <= HALO_BYTES && EPI_PIX_BYTES <= B_STAGE && EPI_PIX_OFF + EPI_PIX_BYTES <= LDS_BYTES),
                 "the epilogue's scratch fits the buffers the next tile's prologue leaves alone");
 };
 
@@ -171,17 +186,17 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   //   NPH = 4: (half wave / 4, phase = wave % 4), 64 columns;  NPH = 1, 2: (half wave / 4, column quarter wave % 4);
   //   NPH = 3: (quarter wave / 2, column half wave % 2)
   constexpr bool S2 = C::S2;
-  const int wm = C::N128 ? wave >> 1 : (W == 8 ? wave >> 2 : (NPH == 4 ? 0 : wave >> 1));
-  const int phase = NPH == 4 ? (wave & 3) : 0;
-  const int ncol0 = NPH == 4 ? 0 : (C::N128 ? (wave & 1) * 64 : (W == 8 ? (wave & 3) * 64 : (wave & 1) * 128));
-  const int brow0 = NPH == 4 ? phase * 64 : ncol0;         // first B-stage row of the wave's columns
-  const int b_phase = NPH == 4 ? wave * (256 / W) / 64 : 0;   // phase of the B rows this wave LOADS
+  const int wm = C::P4W ? 0 : (C::N128 ? wave >> 1 : (W == 8 ? wave >> 2 : (NPH == 4 ? 0 : wave >> 1)));
+  const int phase = C::FOURPH ? (wave & 3) : 0;
+  const int ncol0 = C::FOURPH ? 0 : (C::N128 ? (wave & 1) * 64 : (W == 8 ? (wave & 3) * 64 : (wave & 1) * 128));
+  const int brow0 = C::P4W ? 0 : (NPH == 4 ? phase * 64 : ncol0);     // first B-stage row of the wave's columns
+  const int b_phase = C::P4W ? wave : (NPH == 4 ? wave * (256 / W) / 64 : 0);   // phase of the B rows this wave LOADS
   const int ppi = g.py * g.px;                       // patches per image
   const int npatch = p.batch * ppi;
   const int ktot = p.c0 + p.c1;
   const int nslices = (S2 ? 4 : 1) * (ktot / 32);      // S2: K slice s = (channel slice s / 4, parity plane s % 4)
   constexpr int hw = C::HP;                          // halo row pitch: compile-time, so that block i of a fragment read is an
-  constexpr int hpix = C::HW * C::HP;                // immediate offset
+  constexpr int hpix = C::HROWS * C::HP;             // immediate offset
 
   const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(p.a0_img), 0, p.a0_img_bytes, 0x00020000);
@@ -269,6 +284,25 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // (the backward-data instances used to take ONE tile per workgroup: with the K loop's per-lane constants kept alive
   // across the epilogue for a next tile, their epilogue -- accumulators + the block's prefetched operands -- spilled;
   // since the constants are derived from an opaque copy of the lane id per tile, below, they walk tiles too: 1-2 %)
+  // (P4W) The two workgroups of a CU start half a tile apart -- and stay apart: whichever is in its epilogue leaves the
+  // matrix pipe to the other's K loop.  (Started together they would run their K loops together, at half speed each, and
+  // their epilogues together, pipe idle: the 8-wave instance again.)  The dispatcher places workgroups 0 .. per_xcd / 2 - 1 of
+  // an XCD on its CUs first and the second half next to them.
+  // Which two workgroups share a CU is the dispatcher's business: each workgroup reads its CU (HW_ID: CU, shader array and
+  // engine; XCC_ID) and counts its arrival there in a table that is never reset -- two arrivals per CU and launch keep the
+  // parity of the count meaning "first / second"; the second sleeps (its first wave does: the others meet it at the first
+  // slice's barrier).
+  if (C::P4W && g.delay2 > 0 && wave == 0) {
+    const unsigned cu = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);       // HW_REG_HW_ID[15:8]
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);     // HW_REG_XCC_ID[3:0]
+    unsigned old = 0;
+    if (lane == 0) old = atomicAdd(&g_p4w_arrivals[((xcc & 7u) << 8) | (cu & 255u)], 1u);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old & 1u) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)g.delay2) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   for (int tile = t_lo + slot; tile < t_hi; tile += per_xcd) {
   // The per-lane constants of the K loop are derived from an OPAQUE copy of the lane id inside the tile loop: hoisted out
   // of it they would stay alive across the epilogue, whose accumulators + prefetched operands then spill (80-230
@@ -283,7 +317,10 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const int h_base = (wm * (C::PTS_W / 16) + (l32 >> 4)) * hw + (l32 & 15);
   // fragment chunk (plane, k step, half) = 4 plane + 2 ks + half sits at position chunk ^ swizzle = (half ^ swizzle) ^
   // (4 plane + 2 ks): one byte offset per row, the (plane, ks) part is an XOR with a constant
-  const int bfrag = (brow0 + l32) * 128 + ((half ^ ((l32 >> 1) & 7)) * 16);
+  // (P4W: 64-byte rows -- chunk 2 plane + half of the stage's k step at position chunk ^ ((row >> 2) & 3): the 16 rows of
+  // a ds_read_b128 service group, {0-3, 12-15, 20-27} or {4-11, 16-19, 28-31}, take every residue mod 4 four times with
+  // four different (row >> 2) & 3, i.e. 16 different 16-byte slots of the 256-byte bank row)
+  const int bfrag = C::P4W ? l32 * 64 + ((half ^ ((l32 >> 2) & 3)) * 16) : (brow0 + l32) * 128 + ((half ^ ((l32 >> 1) & 7)) * 16);
   // the tap tables of the wave's compute phase and of the phase whose B rows it loads, one tap per lane: read back with
   // v_readlane inside the K loop (an s_load there would put an lgkmcnt(0) wait -- SMEM returns out of order -- in front
   // of every step's LDS reads).  (S2: one table for all waves, entry 4 plane + t, offsets already relative to the
@@ -297,7 +334,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   const int pid = tile - nt * npatch;
   const int img = pid / ppi;
   const int pin = pid - img * ppi;
-  const int gy0 = (pin / g.px) * 16, gx0 = (pin % g.px) * 16;
+  const int gy0 = (pin / g.px) * C::PROWS, gx0 = (pin % g.px) * 16;
   const int n0 = nt * BN;
 
   // ---- B DMA lanes: the wave loads stage rows (256 / W) wave .. in 8-row blocks; stage row q holds (phase q / 64,
@@ -313,6 +350,10 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     const int rowb = ((n0 + col) * ktot) * 4;
     b_off[0] = rowb + ((lpos ^ (lrow >> 1)) * 16);
     b_off[1] = rowb + ((lpos ^ (lrow >> 1) ^ 4) * 16);
+    if (C::P4W) {      // one DMA = 16 rows x 64 bytes: lane -> (row ln >> 2, position ln & 3) holding chunk position ^ ((row >> 2) & 3)
+      const int c = (ln & 3) ^ ((ln >> 4) & 3);
+      b_off[0] = ((n0 + (ln >> 2)) * ktot) * 4 + (c >> 1) * 64 + (c & 1) * 16;
+    }
   }
 
   // Halo pieces of K slice SL (channels [32 SL, 32 SL + 32) of the concatenated sources) that step T carries, into
@@ -366,6 +407,22 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     if (C::PIN) __builtin_amdgcn_sched_barrier(0);                                                        \
   }
 
+  // (P4W) k step H of the wave's own 64 columns of (slice SL, tap step T) into stage H of its ring: 4 DMAs of 16 rows
+#define ADVOC_P3_BQ(SL, T, H)                                                                             \
+  {                                                                                                       \
+    if (C::PIN) __builtin_amdgcn_sched_barrier(0);                                                        \
+    const int wtap_ = __builtin_amdgcn_readlane(tapv_b, (T)) >> 16;                                       \
+    const int wslab_ = (wtap_ * p.n_total * ktot + (SL) * 32) * 4 + (H) * 32;                             \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                       \
+      unsigned char* d_ = smem_b + C::OFF_B + (H) * C::B_STAGE + wave * C::KH_STAGE + k * 1024;           \
+      if (!(abl & 17)) {                                                                                  \
+        if (kAsmDma) dma16(ra_b, lds_address(d_), b_off[0], wslab_ + k * 16 * ktot * 4);                  \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_p)(d_), 16, b_off[0], wslab_ + k * 16 * ktot * 4, 0, 0); \
+      }                                                                                                   \
+    }                                                                                                     \
+    if (C::PIN) __builtin_amdgcn_sched_barrier(0);                                                        \
+  }
+
   // A fragments of tap step T, k step KS, from halo buffer HB into REG[MT][2]
 #define ADVOC_P3_LOAD_A(REG, HB, T, KS)                                                                   \
   {                                                                                                       \
@@ -387,6 +444,8 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
     _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                        \
       _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                  \
         if (abl & 512) asm volatile("" : "=v"(REG[j][pl]));        /* (timing only: no B fragment reads) */ \
+        else if (C::P4W) REG[j][pl] = *reinterpret_cast<const f16x8*>(smem_b + C::OFF_B + (KS) * C::B_STAGE + wave * C::KH_STAGE + \
+                                                                      (bfrag ^ (pl * 32)) + j * 32 * 64);   \
         else REG[j][pl] = *reinterpret_cast<const f16x8*>(Bx + (bfrag ^ ((4 * pl + 2 * (KS)) * 16)) + j * 32 * 128); \
       }                                                                                                   \
   }
@@ -437,8 +496,13 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   if (!C::EARLY_PROLOGUE || tile == t_lo + slot) {
 #pragma unroll
     for (int t = 0; t < NST; ++t) ADVOC_P3_HALO(0, t, 0);
-    ADVOC_P3_B(0, 0, 0);
-    if (C::NBUF == 4) ADVOC_P3_B(0, 1, 1);
+    if constexpr (C::P4W) {
+      ADVOC_P3_BQ(0, 0, 0);
+      ADVOC_P3_BQ(0, 0, 1);
+    } else {
+      ADVOC_P3_B(0, 0, 0);
+      if (C::NBUF == 4) ADVOC_P3_B(0, 1, 1);
+    }
   }
 
   // ---- K loop: one barrier per step.  Wait for the own DMAs of this step's B tile (and, at a slice boundary, of the
@@ -449,7 +513,53 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
   // step are fetched under the MFMAs of the second (a0 is carried across the barrier) and only the B fragments wait
   // for the barrier. ----
   f16x8 a0[MT][2], a1[MT][2], b0[NT][2], b1[NT][2];
-  if constexpr (C::NBUF == 4) {
+  if constexpr (C::P4W) {
+    // ---- (r6) TWO WORKGROUPS PER CU.  What the epilogue of a patch tile waits for -- 384-640 KiB per tile and CU at the
+    // rate the chip sustains when every CU streams, behind ONE in-order vmcnt that the next tile's first rendezvous has to
+    // drain -- nothing inside a workgroup can run under (profiles/r06_epilogue_ceiling.md: 10-35 % of these launches'
+    // cycles, matrix pipe idle).  A second, independent workgroup on the CU can: 4 waves and 78 KiB each, one wave of each
+    // per SIMD, started half a tile apart (below).  What makes the half-size workgroup cheap for the four-phase gather: a
+    // wave IS a phase, so the weights of a tap step are read by ONE wave -- they need no rendezvous at all.  Each wave
+    // streams its own 64 columns through a two-stage ring (stage = k step: 64 rows x 64 bytes), waits on its own vmcnt,
+    // refills a stage as soon as its own reads of it have returned; only the halo is shared, and the workgroup meets ONCE
+    // PER K SLICE (96 MFMAs per wave), where the 8-wave instance meets every tap step.
+    // In-order vmcnt, per wave and tap step: [F0: 4 DMAs, next step's k step 0] [H: 0-2 halo pieces] [F1: 4 DMAs, k step 1].
+    // "k step 0 of this tap has landed" = everything but the youngest F1 (4) [+ the H in front of it] -> vmcnt(4);
+    // "k step 1 has landed" = everything but the F0 just issued -> vmcnt(4); the last tap step of the last slice issues
+    // nothing, its second wait is vmcnt(0).
+    for (int s = 0; s < nslices; ++s) {
+      const int hb = s & 1;
+      const bool more = s + 1 < nslices;
+      // the slice's halo: own pieces landed (12 weight DMAs were issued behind the last one), own reads of the buffer
+      // the NEXT slice's pieces go to returned, everybody here; covers "k step 0 of tap 0 has landed" too
+      if (abl & 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      static_for<NST>([&](auto tc_) {
+        constexpr int t = decltype(tc_)::value;
+        if constexpr (t > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // stage 0's reads first: the stage is refilled as soon as THEY have returned (the 4 MT A reads behind them may be
+        // in flight), a whole tap step before its next use -- issued behind the first MFMA group the refill had half a
+        // step, less than a DMA's round trip under load
+        ADVOC_P3_LOAD_B(b0, 0, 0);
+        ADVOC_P3_LOAD_A(a0, hb, t, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * MT) : "memory");       // (a 4-bit counter: 2 MT = 8 A reads behind them)
+        if constexpr (t + 1 < NST) { ADVOC_P3_BQ(s, t + 1, 0); } else { if (more) ADVOC_P3_BQ(s + 1, 0, 0); }
+        ADVOC_P3_LOAD_A(a1, hb, t, 1);
+        ADVOC_P3_MFMA(a0, b0);
+        if constexpr (t + 1 < NST) {
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+          if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (t * W * HPS < C::HALO_BLOCKS) { if (more) ADVOC_P3_HALO(s + 1, t, hb ^ 1); }
+        ADVOC_P3_LOAD_B(b0, 1, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (t + 1 < NST) { ADVOC_P3_BQ(s, t + 1, 1); } else { if (more) ADVOC_P3_BQ(s + 1, 0, 1); }
+        ADVOC_P3_MFMA(a1, b0);
+      });
+    }
+  } else if constexpr (C::NBUF == 4) {
     // Two taps per rendezvous (NST = 4: taps 0, 1 in buffers 0, 1, taps 2, 3 in buffers 2, 3): the pair that is not being
     // read is filled, with the halo pieces of both its steps, behind the first MFMA group of the pair that is.
     static_assert(C::NBUF != 4 || (NST == 4 && !C::CARRY && !C::DOUBLE_B), "two tap pairs per K slice");
@@ -709,7 +819,7 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
       const int pid = tile_n - nt * npatch;
       const int img = pid / ppi;
       const int pin = pid - img * ppi;
-      const int gy0 = (pin / g.px) * 16, gx0 = (pin % g.px) * 16;
+      const int gy0 = (pin / g.px) * C::PROWS, gx0 = (pin % g.px) * 16;
       const int n0 = nt * BN;
       int b_off[2];
       const bool b_cols = NPH != 4 || n0 + ((wave * (C::BROWS / W)) & 63) < p.n_total;
@@ -719,16 +829,26 @@ __device__ __forceinline__ void patch_gemm_h3_body(const GatherGemmParams& p, co
         const int rowb = ((n0 + col) * ktot) * 4;
         b_off[0] = rowb + ((lpos ^ (lrow >> 1)) * 16);
         b_off[1] = rowb + ((lpos ^ (lrow >> 1) ^ 4) * 16);
+        if (C::P4W) {
+          const int c = (ln & 3) ^ ((ln >> 4) & 3);
+          b_off[0] = ((n0 + (ln >> 2)) * ktot) * 4 + (c >> 1) * 64 + (c & 1) * 16;
+        }
       }
       constexpr bool kAsmDma = true;
 #pragma unroll
       for (int t = 0; t < NST; ++t) ADVOC_P3_HALO(0, t, 0);
-      ADVOC_P3_B(0, 0, 0);
-      if (C::NBUF == 4) ADVOC_P3_B(0, 1, 1);
+      if constexpr (C::P4W) {
+        ADVOC_P3_BQ(0, 0, 0);
+        ADVOC_P3_BQ(0, 0, 1);
+      } else {
+        ADVOC_P3_B(0, 0, 0);
+        if (C::NBUF == 4) ADVOC_P3_B(0, 1, 1);
+      }
     }
   }
 #undef ADVOC_P3_HALO
 #undef ADVOC_P3_B
+#undef ADVOC_P3_BQ
   if (abl & 64) continue;         // (timing experiments only: the K loop without its epilogue -- and, the accumulators being dead, without its MFMAs)
   if (abl & 8192) {               // (r6, timing only: no epilogue, the accumulators kept alive -- the ceiling of a perfectly hidden epilogue)
 #pragma unroll
@@ -940,12 +1060,29 @@ __global__ __launch_bounds__(512, 1) void patch_gemm_h3_kernel(const GatherGemmP
 #endif
 }
 
+// (r6) the two-per-CU instance of the four-phase gather: 4 waves, <= 80 KiB of LDS, 256 registers per wave
+template <int BWD, int NE, int GI = 0>
+__global__ __launch_bounds__(256, 2) void patch4w_gemm_h3_kernel(const GatherGemmParams p, const PatchGeom g) {
+#ifdef ADVOC_CLOCK_PROBE
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  patch_gemm_h3_body<6, 4, BWD, NE, 0, GI>(p, g);
+#ifdef ADVOC_CLOCK_PROBE
+  __syncthreads();
+  if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    printf("clk <%d,%d,%d,%d,%d> wg %3d: %llu cycles in %llu ticks of 10 ns = %.3f GHz\n", 6, BWD, NE, 0, GI, (int)blockIdx.x,
+           c1 - c0, r1 - r0, 0.1 * (double)(c1 - c0) / (double)(r1 - r0));
+  }
+#endif
+}
+
 template <int NPH, int BWD, int NE = 0>
 int launch_patch(const GatherGemmParams& p_in, const PatchGeom& g, hipStream_t stream, const char** name_only) {
-  using C = PCfg<NPH, 8>;
+  using C = PCfg<NPH, NPH == 6 ? 4 : 8>;
   if (BWD && NE == 0 && !name_only && p_in.oimg[0].img) {
     if (p_in.d[0].accum) {       // (the accumulating form exists for the four-phase instance: the encoders' backward-data)
-      if constexpr (NPH == 4) return launch_patch<NPH, BWD, BWD ? 2 : 0>(p_in, g, stream, name_only);
+      if constexpr (NPH == 4 || NPH == 6) return launch_patch<NPH, BWD, BWD ? 2 : 0>(p_in, g, stream, name_only);
       else return ADVOC_ERR_UNSUPPORTED;
     }
     return launch_patch<NPH, BWD, BWD ? 1 : 0>(p_in, g, stream, name_only);
@@ -965,11 +1102,18 @@ int launch_patch(const GatherGemmParams& p_in, const PatchGeom& g, hipStream_t s
     *name_only = name.c_str();
     return ADVOC_OK;
   }
-  auto kern = (NPH == 4 && p.n_total == 32) ? patch_gemm_h3_kernel<NPH, BWD, NE, NPH == 4 ? 1 : 0> : patch_gemm_h3_kernel<NPH, BWD, NE>;
+  void (*kern)(const GatherGemmParams, const PatchGeom);
+  if constexpr (NPH == 6) {
+    if (p.n_total % 64) return ADVOC_ERR_UNSUPPORTED;
+    kern = patch4w_gemm_h3_kernel<BWD, NE>;
+  } else {
+    kern = (NPH == 4 && p.n_total == 32) ? patch_gemm_h3_kernel<NPH, BWD, NE, NPH == 4 ? 1 : 0> : patch_gemm_h3_kernel<NPH, BWD, NE>;
+  }
   if (p.d[0].ximg) {       // (r5) gates from the consuming layer's image: both destinations, full tiles, backward-data
     if (!BWD || (NPH == 4 && p.n_total == 32) || (p.d[1].p && !p.d[1].ximg) || p.d[0].gscale || p.d[1].gscale)
       return ADVOC_ERR_UNSUPPORTED;
-    kern = patch_gemm_h3_kernel<NPH, BWD, NE, 0, BWD ? 1 : 0>;
+    if constexpr (NPH == 6) kern = patch4w_gemm_h3_kernel<BWD, NE, BWD ? 1 : 0>;
+    else kern = patch_gemm_h3_kernel<NPH, BWD, NE, 0, BWD ? 1 : 0>;
   }
   const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
@@ -979,7 +1123,7 @@ int launch_patch(const GatherGemmParams& p_in, const PatchGeom& g, hipStream_t s
   const int64_t tiles = (int64_t)p.batch * g.py * g.px * ((p.n_total + C::BN - 1) / C::BN);
   int64_t wgs = (tiles + 7) / 8 * 8;
   if (t.h3_patch_persist && (!BWD || t.h3_patch_persist == 2)) {
-    const int64_t cus = persistent_cu_count();
+    const int64_t cus = persistent_cu_count() * (NPH == 6 ? 2 : 1);      // (NPH = 6: two workgroups per CU)
     if (wgs > cus && cus >= 8) wgs = cus;
   }
   ADVOC_CLEAR_LAUNCH_ERROR();
@@ -1010,7 +1154,12 @@ int patch_plan(const GatherGemmParams& p, PatchGeom* g) {
            p.n_total % 128 == 0)
     nph = p.n_total % 256 == 0 ? 2 : 3;
   if (!nph) return 0;
-  if (p.gh < 16 || p.gw < 16) return 0;
+  // (r6) the four-phase gather on two 4-wave workgroups per CU (NPH = 6): ADVOC_H3_PATCH_2WG 1 = backward-data launches, 2 = all
+  if (nph == 4 && p.n_total % 64 == 0 && t.h3_patch_2wg) {
+    const bool bwd = p.grad_act != ADVOC_ACT_NONE || p.d[0].xpre || p.d[1].p || p.d[0].accum;
+    if (bwd || t.h3_patch_2wg >= 2) nph = 6;
+  }
+  if (p.gh < (nph == 6 ? 8 : 16) || p.gw < 16) return 0;
   *g = PatchGeom{};
   if (nph >= 2 && nph <= 3) {
     // every tap (dy, dx) reads input (2 gy + dy, 2 gx + dx) = pixel (gy + a, gx + b) of plane (py, px), dy = 2 a + py
@@ -1041,12 +1190,15 @@ int patch_plan(const GatherGemmParams& p, PatchGeom* g) {
         dy0 = dy < dy0 ? dy : dy0; dy1 = dy > dy1 ? dy : dy1;
         dx0 = dx < dx0 ? dx : dx0; dx1 = dx > dx1 ? dx : dx1;
       }
-    const int e = nph == 4 ? 2 : 3;                 // the kernels are compiled for halos of exactly (16 + e) x (16 + e)
+    const int e = (nph == 4 || nph == 6) ? 2 : 3;                 // the kernels are compiled for halos of exactly (16 + e) x (16 + e)
     if (dy1 - dy0 != e || dx1 - dx0 != e) return 0;
     g->dy0 = dy0; g->dx0 = dx0;
-    g->hh = 16 + e; g->hw = 16 + e;
+    g->hh = (nph == 6 ? 8 : 16) + e; g->hw = 16 + e;
   }
-  g->py = (p.gh + 15) / 16; g->px = (p.gw + 15) / 16;
+  const int prows = nph == 6 ? 8 : 16;
+  g->py = (p.gh + prows - 1) / prows; g->px = (p.gw + 15) / 16;
+  if (nph == 6)      // half of a tile's life at two waves per SIMD: slices x 4 tap steps x 48 MFMAs x 32 cycles (x 2 / 2)
+    g->delay2 = (int)((int64_t)((p.c0 + p.c1) / 32) * 4 * 48 * 32 * t.h3_patch_2wg_delay / 100);
   int gw_cov = p.gw;
   if (t.h3_patch_rem && p.gw >= 32 && p.gw % 16 >= 1 && p.gw % 16 <= 4) {      // 16 px + a few columns: see the launcher
     g->px = p.gw / 16;
@@ -1056,8 +1208,8 @@ int patch_plan(const GatherGemmParams& p, PatchGeom* g) {
   g->nblocks = (g->hh * g->hw + 7) / 8;
   g->ablate = t.h3_patch_ablate;
   // rows the patches add beyond the grid are computed and thrown away
-  if ((int64_t)g->py * g->px * 256 * 100 > (int64_t)p.gh * gw_cov * 125) return 0;
-  const int bn = nph == 4 ? 64 : ((nph == 3 || nph == 5) ? 128 : 256);
+  if ((int64_t)g->py * g->px * prows * 16 * 100 > (int64_t)p.gh * gw_cov * 125) return 0;
+  const int bn = (nph == 4 || nph == 6) ? 64 : ((nph == 3 || nph == 5) ? 128 : 256);
   const int64_t wgs = (int64_t)p.batch * g->py * g->px * ((p.n_total + bn - 1) / bn);
   if (wgs < t.h3_patch_min_wgs) return 0;
   return nph;
@@ -1068,6 +1220,7 @@ int launch_patch_gemm_h3(const GatherGemmParams& p, const PatchGeom& g, int nph,
   // the backward-data description is the one with an activation gradient or a second / accumulating destination
   const bool bwd = p.grad_act != ADVOC_ACT_NONE || p.d[0].xpre || p.d[1].p || p.d[0].accum;
   if (nph == 4) return bwd ? launch_patch<4, 1>(p, g, stream, name_only) : launch_patch<4, 0>(p, g, stream, name_only);
+  if (nph == 6) return bwd ? launch_patch<6, 1>(p, g, stream, name_only) : launch_patch<6, 0>(p, g, stream, name_only);
   if (nph == 2) return bwd ? launch_patch<2, 1>(p, g, stream, name_only) : launch_patch<2, 0>(p, g, stream, name_only);
   if (nph == 3) return bwd ? launch_patch<3, 1>(p, g, stream, name_only) : launch_patch<3, 0>(p, g, stream, name_only);
   if (nph == 5) return bwd ? launch_patch<5, 1>(p, g, stream, name_only) : launch_patch<5, 0>(p, g, stream, name_only);

@@ -50,6 +50,9 @@ struct Tuning {
   int reserve_cus;      // ADVOC_RESERVE_CUS     CUs the PERSISTENT launches (patch kernels, image weight gradient) leave free: set by
                         //                       advoc_amd.parallel from ADVOC_DP_RESERVE_CUS when world_size > 1, so that RCCL's kernels
                         //                       find a CU next to the 110-160 KB-LDS workgroups (multiples of 8: one CU per XCD)
+  int h3_patch_2wg;     // ADVOC_H3_PATCH_2WG   (r6) 0 (default: measured, not faster -- profiles/r06_two_workgroups_per_cu.md): four-phase gathers on one 8-wave workgroup per CU; 1: backward-data launches on two
+                        //                       4-wave workgroups per CU (patch_gemm_h3_kernel<6, .>); 2: forward launches too
+  int h3_patch_2wg_delay;   // ADVOC_H3_PATCH_2WG_DELAY  percent of half a tile's estimated life the CU's second workgroup starts late
   int h3_patch_ablate;  // ADVOC_H3_PATCH_ABLATE  (-DADVOC_DIAG builds only) timing experiments: bits 1 no DMA, 2 no MFMA, 4 no barrier (results are garbage)
 };
 

@@ -315,22 +315,35 @@ PATCH = [
 ]
 
 
+def two_per_cu_name(name, n_cols, twowg, direction):
+  """(r6) the four-phase gathers with whole 64-column tiles run as patch_gemm_h3_kernel<6, .> -- two 4-wave workgroups per
+  CU -- under ADVOC_H3_PATCH_2WG: 1 the backward-data launches, 2 the forward ones too, 0 (default) none."""
+  if name.startswith('patch_gemm_h3_kernel<4,') and n_cols % 64 == 0 and (twowg == 2 or (twowg == 1 and direction == 1)):
+    return name.replace('<4,', '<6,')
+  return name
+
+
 @gpu
+@pytest.mark.parametrize('twowg', [0, 1, 2], ids=['one_per_cu', 'two_per_cu_bwd', 'two_per_cu_all'])
 @pytest.mark.parametrize('persist', [2, 1, 0], ids=['persistent', 'persistent_forward_only', 'tile_per_wg'])
 @pytest.mark.parametrize('case,want', PATCH, ids=[c[0][0] for c in PATCH])
-def test_layer_patch_kernels(hip, case, want, persist, hipenv):
+def test_layer_patch_kernels(hip, case, want, persist, twowg, hipenv):
   from advoc_amd import conv
-  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1, ADVOC_H3_PATCH_PERSIST=persist)
+  if twowg != 0 and not any(n.startswith('patch_gemm_h3_kernel<4,') for n in want.values()):
+    pytest.skip('no four-phase launch in this case: the default form covers it')
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_PATCH_MIN_WGS=1, ADVOC_H3_PATCH_PERSIST=persist, ADVOC_H3_PATCH_2WG=twowg)
   c = build_case(case)
   dev = torch.device('cuda')
   x0 = c['x0'].to(dev)
   x1 = c['x1'].to(dev) if c['x1'] is not None else None
   w = c['w'].to(dev)
   cout = w.shape[3] if c['kind'] == 0 else w.shape[2]
+  cin_all = x0.shape[3] + (x1.shape[3] if x1 is not None else 0)
   y = torch.empty(x0.shape[0], c['oh'], c['out_w'], cout, device=dev)
   L = conv.Layer(c['kind'], x0, y, w, None, x1=x1, in_w=c['in_w'], stride=c['stride'], pad=c['pad'], in_act=c['act'])
   for direction, name in want.items():
-    assert L.kernel_name(direction) == name, (direction, L.kernel_name(direction))
+    name = two_per_cu_name(name, cout if direction == 0 else cin_all, twowg, direction)
+    assert L.kernel_name(direction) == name, (direction, L.kernel_name(direction), name)
   test_layer_all_directions(hip, case)
   # and the per-tap tiles on the same shapes agree with it far below the oracle tolerance
   outs = {}
