@@ -71,6 +71,7 @@ PROTOTYPES = {
     'advoc_target_arch': (ctypes.c_char_p, []),
     'advoc_last_hip_error': (ctypes.c_char_p, []),
     'advoc_tuning_reload': (None, []),
+    'advoc_clock_probe_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int32]),
     'advoc_stft_mag_f32': (ctypes.c_int, [_p, _i64, _i64, _p, _p, _i32, _i32, _i64, _p, _p]),
     'advoc_stft_c64': (ctypes.c_int, [_p, _i64, _i64, _p, _p, _i32, _i32, _i64, _p, _p]),
     'advoc_stft_twiddle_host': (ctypes.c_int, [_p, _i32]),

@@ -673,9 +673,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p, 
            c1 - c0, r1 - r0, 0.1 * (double)(c1 - c0) / (double)(r1 - r0));                                \
   }
 #else
-#define ADVOC_WH3_PROBE_BEGIN
-#define ADVOC_WH3_PROBE_END(NAME)
+// (r6) product build: the shader clock of the roofline kernel, always on -- workgroup 0's first thread leaves its start
+// stamps in memory (no register lives across the body) and adds (shader cycles, 10 ns ticks, 1) of its life to three
+// counters advoc_clock_probe_read() returns: clock = 0.1 cycles / ticks.  bench.py prints it beside the roofline fraction
+// (`roofline.clock_ghz`): the dense peak assumes 2.4 GHz, this kernel sustains ~1.6 on real operands.
+#define ADVOC_WH3_PROBE_BEGIN                                                                            \
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                                                             \
+    g_wgrad_clk_start[0] = __builtin_amdgcn_s_memtime();                                                  \
+    g_wgrad_clk_start[1] = __builtin_amdgcn_s_memrealtime();                                              \
+  }
+#define ADVOC_WH3_PROBE_END(NAME)                                                                        \
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                                                             \
+    atomicAdd(&g_wgrad_clk[0], __builtin_amdgcn_s_memtime() - g_wgrad_clk_start[0]);                      \
+    atomicAdd(&g_wgrad_clk[1], __builtin_amdgcn_s_memrealtime() - g_wgrad_clk_start[1]);                  \
+    atomicAdd(&g_wgrad_clk[2], 1ull);                                                                     \
+  }
 #endif
+__device__ unsigned long long g_wgrad_clk_start[2];
+__device__ unsigned long long g_wgrad_clk[3];
 __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradParams p, const WgradImages im, int tiles_n,
                                                           int tiles, int chunk, int gwp) {
   wgrad_h3_body<2, 2, true>(p, im, tiles_n, tiles, chunk, gwp);
@@ -692,9 +707,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_h3_256_kernel(const WgradParams 
 }
 __global__ __launch_bounds__(512, 2) void wgrad_h3_256_flat_kernel(const WgradParams p, const WgradImages im, int tiles_n,
                                                                    int tiles, int chunk, int gwp) {
+#ifdef ADVOC_CLOCK_PROBE
   ADVOC_WH3_PROBE_BEGIN
+#endif
   wgrad_h3_body<4, 4, false>(p, im, tiles_n, tiles, chunk, gwp);
+#ifdef ADVOC_CLOCK_PROBE
   ADVOC_WH3_PROBE_END("wgrad_h3_256_flat")
+#endif
 }
 
 // 256 x 256 tiles when both matrix dimensions divide and the pixel grid is long enough to give every workgroup (one per
@@ -788,8 +807,12 @@ int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned*
   const bool big = wgrad_big_tile(p);
   WgradPlan pl;
   if (!wgrad_h3_plan(p, pl)) return ADVOC_ERR_UNSUPPORTED;
-  // (one name per tile size: the `_flat` instances -- grid rows under WK points -- are the same kernel to every caller)
-  if (name_only) { *name_only = big ? "wgrad_h3_256_kernel" : "wgrad_h3_kernel"; return ADVOC_OK; }
+  // (r6: the `_flat` instances -- grid rows under WK points -- under their own names, as rocprofv3 lists them: bench.py's
+  // per-kernel rows and the committed counter passes then average the SAME launches)
+  if (name_only) {
+    *name_only = big ? (pl.gwp ? "wgrad_h3_256_kernel" : "wgrad_h3_256_flat_kernel") : (pl.gwp ? "wgrad_h3_kernel" : "wgrad_h3_flat_kernel");
+    return ADVOC_OK;
+  }
   if (!p_img || !q_img || !p_hdr || !q_hdr) return ADVOC_ERR_NULL;
   const int ca = p.P.c0 + p.P.c1, cb = p.Q.c0 + p.Q.c1;
   int64_t pb0, pb1, qb0, qb1;
@@ -851,3 +874,18 @@ int launch_wgrad_h3(const WgradParams& p, const uint16_t* p_img, const unsigned*
 }
 
 }  // namespace advoc
+
+// {shader cycles, 10 ns ticks, launches} of wgrad_h3_256_kernel's first workgroup since the last reset (synchronous copies)
+extern "C" int advoc_clock_probe_read(uint64_t* out3_host, int32_t reset) {
+  if (!out3_host) return ADVOC_ERR_NULL;
+  unsigned long long v[3] = {0, 0, 0};
+  hipError_t e = hipMemcpyFromSymbol(v, HIP_SYMBOL(advoc::g_wgrad_clk), sizeof(v));
+  if (e != hipSuccess) { advoc::note_hip_error(e); return ADVOC_ERR_HIP; }
+  for (int i = 0; i < 3; ++i) out3_host[i] = v[i];
+  if (reset) {
+    const unsigned long long z[3] = {0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(advoc::g_wgrad_clk), z, sizeof(z));
+    if (e != hipSuccess) { advoc::note_hip_error(e); return ADVOC_ERR_HIP; }
+  }
+  return ADVOC_OK;
+}

@@ -46,6 +46,7 @@ Extra objects on the JSON line:
                 one all-reduce of the generator's gradient arena -- evidence that RCCL saw N ranks.
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -93,7 +94,7 @@ def synth_waveforms(batch, seed, device):
 
 def mfma_pipe(name):
   """(peak TFLOP/s in algorithmic fp32 flops, description) of the matrix pipe a kernel instance runs on."""
-  if '_h3_kernel' in name or '_h3_256_kernel' in name:
+  if '_h3_kernel' in name or '_h3_256_kernel' in name or '_h3_flat_kernel' in name or '_h3_256_flat_kernel' in name:
     return H3_PEAK_TFLOPS, 'f16 MFMA, 3 partial products per fp32 product (2500 / 3 TFLOP/s algorithmic)'
   if name.endswith(', true>') and (name.startswith('gather_gemm_kernel<') or name.startswith('wgrad_mfma_kernel<')):
     return X6_PEAK_TFLOPS, 'bf16 MFMA, 6 partial products per fp32 product (2500 / 6 TFLOP/s algorithmic)'
@@ -160,9 +161,10 @@ def cpu_baseline_legs(model_small, threads):
   from oracle import advoc_torch as A
   from oracle import spectral_np as S
   legs = {}
-  r = cpu_baseline(model_small, threads, 8, iters=2)
-  legs['train_batch8'] = dict(value=r['value'], unit=r['unit'], seconds=r['seconds'], iterations=r['iterations'], cores=threads,
-                              sample=r['sample'] + ' (the reference\'s default train_batch_size, advoc_model.py:18)')
+  if not model_small:      # (the headline is batch 8 since r6; the r1-r5 headline setting kept as a leg)
+    r = cpu_baseline(model_small, threads, 4, iters=2)
+    legs['train_batch4'] = dict(value=r['value'], unit=r['unit'], seconds=r['seconds'], iterations=r['iterations'], cores=threads,
+                                sample=r['sample'] + ' (rounds 1-5 quoted this setting as the headline)')
   r = cpu_baseline(not model_small, threads, 8, iters=2 if not model_small else 1)
   legs['other_model_batch8'] = dict(value=r['value'], unit=r['unit'], seconds=r['seconds'], iterations=r['iterations'],
                                     cores=threads, sample=r['sample'])
@@ -209,7 +211,7 @@ def cpu_baseline_sweep(model_small):
   iteration is already 3 x slower than the best setting's iterations is reported from that one iteration."""
   ncores = os.cpu_count() or 8
   settings = sorted(set(t for t in (8, 16, 32, 64, ncores) if 0 < t <= ncores))
-  batch = 8 if model_small else 4
+  batch = 8          # (r6: the reference's default train_batch_size, advoc_model.py:18, as BASELINE.md section 3 names it; r1-r5: 4 for the full model)
   sweep, best_iter, skipped = [], None, []
   for t in settings:
     if sweep and sweep[-1]['value'] < 0.6 * max(r['value'] for r in sweep):
@@ -273,57 +275,80 @@ def extractor_leg(torch, spectral, su, wav, launches=30):
   def clips_of(n):
     return wav[:, :, 0, 0].repeat((n + wav.shape[0] - 1) // wav.shape[0], 1)[:n].contiguous()
 
+  # (r6) Every timed region ROTATES over enough (input, output) buffer sets that their sum is beyond three Infinity Caches
+  # (256 MiB): a hot loop over ONE set of the train feed's size -- 34 MB in, 145 MB out -- is served by that cache and read
+  # 64 us where the same launch takes 82 us inside the train step.  `sets` is reported per leg.
+  def n_sets(set_bytes):
+    return max(1, -(-3 * 256 * 1024 * 1024 // int(set_bytes)))
+
+  def rotating(calls):
+    state = {'i': 0}
+
+    def call():
+      calls[state['i']]()
+      state['i'] = (state['i'] + 1) % len(calls)
+    return call
+
   def run_stft(clips):
-    x = clips_of(clips)
-    out = torch.empty(clips, CLIP_FRAMES, 513, dtype=torch.float32, device=x.device)
-    call = lambda: _lib.check(lib.advoc_stft_mag_f32(_lib.ptr(x), clips, x.shape[1], _lib.ptr(win), _lib.ptr(tw),   # noqa: E731
-                                                     1024, 256, CLIP_FRAMES, _lib.ptr(out), _lib.stream()), 'stft')
-    return event_timed(torch, call, launches), clips * (CLIP_SAMPLES * 4 + CLIP_FRAMES * 513 * 4)
+    nbytes = clips * (CLIP_SAMPLES * 4 + CLIP_FRAMES * 513 * 4)
+    sets = n_sets(nbytes)
+    calls = []
+    for _ in range(sets):
+      x = clips_of(clips).clone()
+      out = torch.empty(clips, CLIP_FRAMES, 513, dtype=torch.float32, device=x.device)
+      calls.append(lambda x=x, out=out: _lib.check(lib.advoc_stft_mag_f32(
+          _lib.ptr(x), clips, x.shape[1], _lib.ptr(win), _lib.ptr(tw), 1024, 256, CLIP_FRAMES, _lib.ptr(out), _lib.stream()), 'stft'))
+    return event_timed(torch, rotating(calls), launches), nbytes, sets
 
   def run_triple(clips, fused):
     # waveform -> (|X|, mel, pinv(mel)) through the C ABI with preallocated outputs, like run_stft (the Python wrapper's
     # per-call allocations are part of the train step's time, not of the kernels'): the ONE launch of
     # SpectralUtil.extract_training_triple (csrc/extract.hip), or the two launches it replaced (stft + mel_pinv)
-    x = clips_of(clips)
-    mag = torch.empty(clips, CLIP_FRAMES, 513, dtype=torch.float32, device=x.device)
-    mel = torch.empty(clips, CLIP_FRAMES, 80, dtype=torch.float32, device=x.device)
-    inv = torch.empty(clips, CLIP_FRAMES, 513, dtype=torch.float32, device=x.device)
+    nbytes = clips * (CLIP_SAMPLES * 4 + CLIP_FRAMES * (80 + 2 * 513) * 4)
+    sets = n_sets(nbytes)
     runs, wp, inv_t = su._const('packed')
     tab, unscale = su._const('pairs')
+    calls = []
+    for _ in range(sets):
+      x = clips_of(clips).clone()
+      mag = torch.empty(clips, CLIP_FRAMES, 513, dtype=torch.float32, device=x.device)
+      mel = torch.empty(clips, CLIP_FRAMES, 80, dtype=torch.float32, device=x.device)
+      inv = torch.empty(clips, CLIP_FRAMES, 513, dtype=torch.float32, device=x.device)
 
-    def call_fused():
-      _lib.check(lib.advoc_stft_mel_pinv_f32(_lib.ptr(x), clips, x.shape[1], _lib.ptr(win), _lib.ptr(tw), 1024, 256,
-                                             CLIP_FRAMES, _lib.ptr(wp), _lib.ptr(runs), int(wp.numel()), 513, 80,
-                                             _lib.ptr(tab), _lib.ptr(unscale), _lib.ptr(mag), _lib.ptr(mel), _lib.ptr(inv),
-                                             _lib.stream()), 'stft_mel_pinv')
+      def call_fused(x=x, mag=mag, mel=mel, inv=inv):
+        _lib.check(lib.advoc_stft_mel_pinv_f32(_lib.ptr(x), clips, x.shape[1], _lib.ptr(win), _lib.ptr(tw), 1024, 256,
+                                               CLIP_FRAMES, _lib.ptr(wp), _lib.ptr(runs), int(wp.numel()), 513, 80,
+                                               _lib.ptr(tab), _lib.ptr(unscale), _lib.ptr(mag), _lib.ptr(mel), _lib.ptr(inv),
+                                               _lib.stream()), 'stft_mel_pinv')
 
-    def call_two():
-      _lib.check(lib.advoc_stft_mag_f32(_lib.ptr(x), clips, x.shape[1], _lib.ptr(win), _lib.ptr(tw), 1024, 256,
-                                        CLIP_FRAMES, _lib.ptr(mag), _lib.stream()), 'stft')
-      _lib.check(lib.advoc_mel_pinv_f32(_lib.ptr(mag), _lib.ptr(wp), _lib.ptr(runs), _lib.ptr(inv_t), _lib.ptr(mel),
-                                        _lib.ptr(inv), clips * CLIP_FRAMES, 513, 80, int(wp.numel()), _lib.stream()),
-                 'mel_pinv')
-    return (event_timed(torch, call_fused if fused else call_two, launches),
-            clips * (CLIP_SAMPLES * 4 + CLIP_FRAMES * (80 + 2 * 513) * 4))
+      def call_two(x=x, mag=mag, mel=mel, inv=inv):
+        _lib.check(lib.advoc_stft_mag_f32(_lib.ptr(x), clips, x.shape[1], _lib.ptr(win), _lib.ptr(tw), 1024, 256,
+                                          CLIP_FRAMES, _lib.ptr(mag), _lib.stream()), 'stft')
+        _lib.check(lib.advoc_mel_pinv_f32(_lib.ptr(mag), _lib.ptr(wp), _lib.ptr(runs), _lib.ptr(inv_t), _lib.ptr(mel),
+                                          _lib.ptr(inv), clips * CLIP_FRAMES, 513, 80, int(wp.numel()), _lib.stream()),
+                   'mel_pinv')
+      calls.append(call_fused if fused else call_two)
+    return event_timed(torch, rotating(calls), launches), nbytes, sets
 
   nb = 2 * wav.shape[0]
-  ms_l, bytes_l = run_stft(512)
-  ms_b, bytes_b = run_stft(nb)
+  ms_l, bytes_l, sets_l = run_stft(512)
+  ms_b, bytes_b, sets_b = run_stft(nb)
   gbs = bytes_l / (ms_l * 1e-3) / 1e9
   out = dict(kernel='stft1024_hop256_kernel', bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
-             frac=gbs / HBM_PEAK_GBS, clips_per_launch=512, bytes_per_launch=bytes_l, avg_launch_ms=ms_l,
+             frac=gbs / HBM_PEAK_GBS, clips_per_launch=512, bytes_per_launch=bytes_l, avg_launch_ms=ms_l, buffer_sets_rotated=sets_l,
              frames_per_s=512 * CLIP_FRAMES / (ms_l * 1e-3),
-             at_train_feed=dict(clips_per_launch=nb, avg_launch_ms=ms_b, achieved=bytes_b / (ms_b * 1e-3) / 1e9,
+             at_train_feed=dict(clips_per_launch=nb, avg_launch_ms=ms_b, achieved=bytes_b / (ms_b * 1e-3) / 1e9, buffer_sets_rotated=sets_b,
                                 frac=bytes_b / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 frames_per_s=nb * CLIP_FRAMES / (ms_b * 1e-3)))
   fused_max = getattr(su, 'FUSED_MAX_FRAMES', 0)
   res = {}
   for tag, clips in (('bulk', 512), ('feed', nb)):
-    ms_f, by = run_triple(clips, True)
-    ms_2, _ = run_triple(clips, False)
+    ms_f, by, sets = run_triple(clips, True)
+    ms_2, _, _ = run_triple(clips, False)
     uses_fused = clips * CLIP_FRAMES <= fused_max            # what SpectralUtil.extract_training_triple launches at this size
     ms = ms_f if uses_fused else ms_2
     res[tag] = dict(clips_per_launch=clips, avg_ms=ms, achieved=by / (ms * 1e-3) / 1e9, frac=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    buffer_sets_rotated=sets,
                     path='one launch (stft_mel_pinv_kernel)' if uses_fused else 'two launches (stft1024_hop256_kernel + mel_pinv_kernel)',
                     one_launch_ms=ms_f, two_launches_ms=ms_2)
   out['triple'] = dict(what='waveform -> |X|, mel, pinv(mel) (1 397 760 B per clip) as SpectralUtil.extract_training_triple '
@@ -543,12 +568,24 @@ def roofline_from(prof, model, batch, ms_per_step, prof_steps, verbose):
   roofline = dict(bound=top['bound'], kernel=name, achieved=top['achieved'], peak=top['peak'], unit=top['unit'],
                   frac=top['frac'], traffic=traffic, traffic_source=traffic_source,
                   algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
+                  traffic_population='(r6) `traffic` and `algorithmic_bytes_per_launch` average the SAME launches: the C calls '
+                                     'that run `%s` (the `_flat` instances of the short-row layers are rows of their own in `kernels`)' % name,
                   launches=r['launches'], avg_launch_ms=r['ms'] / r['launches'],
                   share_of_step=r['ms'] / prof_steps / ms_per_step, instrumented_steps=prof_steps,
                   measured='HIP events per launch on %d serial steps right after the timed region' % prof_steps,
                   launch_covers=('wgrad_h3_256_kernel + the wgrad_reduce_kernel that sums its K slices in order (one C call; '
                                  'rocprofv3 lists the two separately)') if name == 'wgrad_h3_256_kernel' else name,
                   kernels=kernels[:24])
+  cp = getattr(prof, 'clock_probe', None)
+  if cp and cp[1] > 0:
+    # (r6) the shader clock wgrad_h3_256_kernel ran at in these steps (its first workgroup's s_memtime / s_memrealtime,
+    # advoc_clock_probe_read): the dense peak the fraction is priced against assumes 2.4 GHz
+    ghz = 0.1 * cp[0] / cp[1]
+    roofline.update(clock_ghz=ghz, clock_launches_probed=cp[2], peak_clock_ghz=2.4,
+                    frac_of_peak_at_this_clock=(top['frac'] * 2.4 / ghz) if (name == 'wgrad_h3_256_kernel' and ghz > 0) else None,
+                    clock_note='clock_ghz: wgrad_h3_256_kernel, workgroup 0, every launch of the instrumented steps; '
+                               'frac_of_peak_at_this_clock = frac x 2.4 / clock_ghz = the schedule\'s share of the matrix '
+                               'pipe, the rest of the gap to 1.0 is the sustained clock under this kernel\'s power draw')
   if top['bound'] == 'mfma':
     roofline.update(pipe=mfma_pipe(name)[1],
                     vs_fp32_mfma_peak=top['achieved'] / FP32_MFMA_PEAK_TFLOPS,
@@ -586,7 +623,14 @@ def train_leg(torch, model_name, B, steps, warmup, dp, dev, prof_steps):
       return out
     wav = pool[state['i'] % len(pool)]
     state['i'] += 1
-    mag, mel, inv = su.extract_training_triple(wav)
+    if state.get('timed') is not None:       # (instrumented steps: the extractor's launch(es) between two HIP events)
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      mag, mel, inv = su.extract_training_triple(wav)
+      e1.record()
+      state['timed'].append((e0, e1))
+    else:
+      mag, mel, inv = su.extract_training_triple(wav)
     state['pending'] = (inv[B:], mag[B:], wav[B:], mel[B:])
     return inv[:B], mag[:B], wav[:B], mel[:B]
   model(feed)
@@ -608,10 +652,19 @@ def train_leg(torch, model_name, B, steps, warmup, dp, dev, prof_steps):
   if prof_steps > 0:
     prof = conv.LaunchProfiler()
     conv.Layer.profiler = prof
+    state['timed'] = []
+    from advoc_amd import _lib as _l
+    clk = (ctypes.c_uint64 * 3)()
+    _l.check(_l.load().advoc_clock_probe_read(clk, 1), 'advoc_clock_probe_read')       # reset: count the instrumented steps only
     for _ in range(prof_steps):
       model.train_loop()
     torch.cuda.synchronize()
     conv.Layer.profiler = None
+    _l.check(_l.load().advoc_clock_probe_read(clk, 0), 'advoc_clock_probe_read')
+    prof.clock_probe = [int(v) for v in clk]
+    prof.extract_ms = [e0.elapsed_time(e1) for e0, e1 in state['timed']]
+    prof.extract_clips = 2 * B
+    state['timed'] = None
   return elapsed, model, su, pool, prof
 
 
@@ -653,6 +706,59 @@ def dist_report(torch, dp, model):
               g_arena_bytes=nbytes, g_arena_allreduce_ms=ms,
               g_arena_allreduce_busbw_gbs=nbytes * 2 * (dp.world_size - 1) / dp.world_size / (ms * 1e-3) / 1e9,
               rccl='torch.distributed backend "nccl" = RCCL on ROCm' if dp.backend == 'nccl' else 'host-staged (wiring check)')
+
+
+def dist_step_check(torch, dp, dev):
+  """(r6) Correctness evidence beside the throughput of an N-GPU run: ONE AdVoc-small train_loop (32 frames, 2 clips per rank)
+  on a global batch sharded over the ranks -- real RCCL, the asynchronous bucketed all-reduce, the deferred discriminator
+  update -- against the same loop on the whole global batch in ONE process on rank 0 (tests/test_hip_parallel.py's contract:
+  the arena of a rank holds the SUM over ranks, Adam applies 1/N).  Called by every rank; rank 0 gets the dict."""
+  from advoc_amd.model import AdvocSmall, Modes
+  T, per = 32, 2
+  GB = per * dp.world_size
+
+  def make(batch):
+    m = AdvocSmall(Modes.TRAIN)
+    m.subseq_len, m.train_batch_size = T, batch
+    m.build(batch_size=batch, seed=13)
+    return m
+  g = torch.Generator().manual_seed(21)
+  batches = []
+  for _ in range(2):
+    target = torch.rand(GB, T, 513, 1, generator=g) * 2
+    batches.append((target * (0.5 + torch.rand(GB, T, 513, 1, generator=g)) - 0.1, target))
+
+  def run(model, lo, hi):
+    it = iter(batches)
+
+    def feed():
+      x, t = next(it)
+      return x[lo:hi].to(dev), t[lo:hi].to(dev)
+    model(feed)
+    model.train_loop()
+    torch.cuda.synchronize()
+    st = model._built
+    return {k: v.detach().double().cpu() for name in ('d_G', 'g_G') for k, v in st[name].items()}
+  m = make(per)
+  dp.attach(m)
+  dp.broadcast_parameters(m)
+  mine = run(m, dp.rank * per, (dp.rank + 1) * per)
+  out = None
+  if dp.rank == 0:
+    from advoc_amd.parallel import DataParallel as _DP
+    ref_model = _DP().attach(make(GB))           # (a DataParallel that is not enabled: the plain single-process step)
+    ref = run(ref_model, 0, GB)
+    worst = {'discriminator': 0.0, 'generator': 0.0}
+    for k, v in ref.items():
+      e = float((mine[k] / dp.world_size - v).norm() / v.norm().clamp_min(1e-30))
+      net = 'discriminator' if k.startswith('discriminator') else 'generator'
+      worst[net] = max(worst[net], e)
+    # bars of tests/test_hip_parallel.py: D gradients at the initial weights 2e-5; G gradients behind D's first Adam step 5e-3
+    ok = worst['discriminator'] < 2e-5 and worst['generator'] < 5e-3
+    out = dict(step_equals_single_gpu=bool(ok), worst_rel_l2_first_step_gradients=worst,
+               what='AdVoc-small, 32 frames, %d clips sharded over %d ranks vs one process on rank 0' % (GB, dp.world_size))
+  dp.barrier()
+  return out
 
 
 def free_port():
@@ -717,10 +823,27 @@ def main():
   delayed = ({'exact_refits': int(model.image_refits()), 'values_out_of_window': int(model.image_saturations())}
              if dp.rank == 0 else None)
   dist_info = dist_report(torch, dp, model)
+  if dp.enabled:
+    try:
+      chk = dist_step_check(torch, dp, dev)
+    except Exception as e:     # never take the headline line down; the failure is in the line
+      chk = dict(step_equals_single_gpu=False, error=repr(e))
+    if dist_info is not None and chk is not None:
+      dist_info.update(chk)
 
   extractor = inference = small = loader_res = None
   if dp.rank == 0 and not args.train_only:
     extractor = extractor_leg(torch, spectral, su, pool[0][:B])
+    if prof is not None and getattr(prof, 'extract_ms', None):
+      # (r6) the same launch INSIDE the train step (instrumented steps: one HIP-event pair around the extractor call of every
+      # train_loop): operands cold, the previous step's Adam pass just behind it -- the figure the roofline claim is about
+      ms_in = sum(prof.extract_ms) / len(prof.extract_ms)
+      by = prof.extract_clips * (CLIP_SAMPLES * 4 + CLIP_FRAMES * (80 + 2 * 513) * 4)
+      extractor['triple']['in_step'] = dict(us=ms_in * 1e3, clips_per_launch=prof.extract_clips, calls=len(prof.extract_ms),
+                                            achieved=by / (ms_in * 1e-3) / 1e9, frac=by / (ms_in * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            what='SpectralUtil.extract_training_triple as the train step calls it (its launch and '
+                                                 'its output allocation), HIP events on the launch stream')
+      extractor['triple']['in_step_us'] = ms_in * 1e3
     mel0 = su.mag_to_mel_linear_spec(spectral.stft_magnitude(pool[0][:B], 1024, 256, pad_end=False))
     inference = inference_leg(torch, AdvocSmall if args.model == 'small' else Advoc, Modes, su, mel0)
     inference['joint_sc09'] = joint_leg(torch)

@@ -50,6 +50,12 @@ const char* advoc_target_arch(void);
  * selection overrides for A/B measurements and tests) once, on first use; this re-reads them. */
 void advoc_tuning_reload(void);
 
+/* (r6) Diagnostic: the shader clock the dominant kernel of the train step (wgrad_h3_256_kernel) actually ran at.  Its first
+ * workgroup adds {shader cycles, ticks of 10 ns, 1} of its life to three device counters on every launch; this call copies
+ * them to out3_host (synchronously -- a measurement call, not part of the data path) and, with reset != 0, zeroes them.
+ * clock [GHz] = 0.1 * out3[0] / out3[1].  (No counterpart in the reference: bench.py's `roofline.clock_ghz`.) */
+int advoc_clock_probe_read(uint64_t* out3_host, int32_t reset);
+
 /* ------------------------------------------------------------------------------------------
  * Feature extractor
  * ---------------------------------------------------------------------------------------- */

@@ -47,6 +47,8 @@ P1F, P1B = 'patch_gemm_h3_kernel<1, 0>', 'patch_gemm_h3_kernel<1, 1>'
 P2F, P2B = 'patch_gemm_h3_kernel<2, 0>', 'patch_gemm_h3_kernel<2, 1>'
 P3F = 'patch_gemm_h3_kernel<3, 0>'
 W256, W128 = 'wgrad_h3_256_kernel', 'wgrad_h3_kernel'
+# (r6) grid rows under 32 points: the `_flat` instances under their own names (as rocprofv3 lists them)
+W256F, W128F = 'wgrad_h3_256_flat_kernel', 'wgrad_h3_flat_kernel'
 
 # (name, layer, forward, backward-data, backward-weight); None = not asserted (edge / tiny layers on the r1 kernels)
 FULL = [
@@ -57,13 +59,13 @@ FULL = [
     # 256 x 256 tiles, on that tile cut into three K slices; its four-phase backward-data and decoder_5 forward, 272 such
     # tiles on 256 CUs, on 128 x 128 tiles; decoder_6 backward-data, 144 128 x 128 tiles, on those cut into three K slices)
     ('encoder_5', layer(0, BF, 16, 33, 512, 0, 512, (2, 2)), 'gather_gemm_h3_kernel<2, 4, 2, 4>',
-     'gather_gemm_h3_kernel<2, 2, 2, 2>', W256),
+     'gather_gemm_h3_kernel<2, 2, 2, 2>', W256F),
     ('decoder_6', layer(1, BF, 4, 9, 512, 512, 512, (2, 2), trim=1), 'gather_gemm_h3_kernel<2, 1, 2, 2>',
      'gather_gemm_h3_kernel<2, 2, 2, 2>', None),
     ('encoder_7', layer(0, BF, 4, 9, 512, 0, 512, (2, 2)), 'gather_gemm_h3_kernel<2, 1, 2, 2>',
      'gather_gemm_h3_kernel<2, 1, 2, 2>', None),
     ('decoder_5', layer(1, BF, 8, 17, 512, 512, 512, (2, 2), trim=1), 'gather_gemm_h3_kernel<2, 2, 2, 2>',
-     'gather_gemm_h3_kernel<2, 2, 2, 2>', W256),
+     'gather_gemm_h3_kernel<2, 2, 2, 2>', W256F),
     ('decoder_4', layer(1, BF, 16, 33, 512, 512, 256, (2, 2), trim=1), P4F, P2B, W256),
     ('decoder_3', layer(1, BF, 32, 65, 256, 256, 128, (2, 2), trim=1), P4F, P2B, W256),
     ('decoder_2', layer(1, BF, 64, 129, 128, 128, 64, (2, 2), trim=1), P4F, P2B, W256),

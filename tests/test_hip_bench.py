@@ -73,6 +73,8 @@ def test_bench_gpus_8_first_run_wiring_on_one_device(hip):
   assert len(set(x['pid'] for x in d['ranks'])) == 8
   assert d['reserve_cus'] == 8 and 'bench.py default' in d['reserve_cus_source']
   assert d['params_equal_across_ranks'] is True and len(set(x['param_sha1_16'] for x in d['ranks'])) == 1
+  # (r6) correctness beside the throughput: one global-batch step over the 8 ranks equals the single-process step on rank 0
+  assert d['step_equals_single_gpu'] is True, d
 
 
 @gpu

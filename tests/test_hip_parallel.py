@@ -5,8 +5,10 @@ normalisation, the asynchronous bucketed all-reduce of the generator arena and A
 have to line up for that.
 
 The GPU box has ONE device and RCCL refuses two ranks on one device, so the ranks share cuda:0 and
-the collectives go through gloo (ADVOC_DP_BACKEND=gloo: host-staged, same call sites).  The RCCL
-transport itself is exercised by bench.py --gpus N on the multi-GPU node."""
+the collectives go through gloo (ADVOC_DP_BACKEND=gloo: host-staged, same call sites).  With two or more
+devices visible the same comparison also runs over real RCCL, one device per rank
+(test_two_ranks_over_rccl_on_two_devices_equal_one_process: skips with the reason on one device); bench.py
+--gpus N carries the same check in its line (dist.step_equals_single_gpu)."""
 import os
 import socket
 import sys
@@ -37,9 +39,9 @@ def _global_batches():
   return out
 
 
-def _train(model, batches, lo, hi):
+def _train(model, batches, lo, hi, device_index=0):
   """STEPS train_loops; returns the final state and the (rank-summed) gradients of the FIRST loop."""
-  dev = torch.device('cuda', 0)
+  dev = torch.device('cuda', device_index)
   it = iter(batches)
 
   def feed():
@@ -67,18 +69,24 @@ def _make(batch, bn=False):
   return m
 
 
-def _worker(rank, world, port, out_dir, bn):
+def _worker(rank, world, port, out_dir, bn, rccl=False):
   sys.path.insert(0, ROOT)
   os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
-                    MASTER_PORT=str(port), ADVOC_DP_BACKEND='gloo', ADVOC_DP_DEVICE='0')
+                    MASTER_PORT=str(port))
+  if rccl:       # one device per rank, collectives over RCCL (xGMI where the devices are linked)
+    os.environ.update(ADVOC_DP_BACKEND='nccl', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    os.environ.pop('ADVOC_DP_DEVICE', None)
+    torch.cuda.set_device(rank)
+  else:
+    os.environ.update(ADVOC_DP_BACKEND='gloo', ADVOC_DP_DEVICE='0')
   from advoc_amd.parallel import DataParallel
   dp = DataParallel(bucket_bytes=1 << 20).init_from_env()       # 1 MiB buckets: several async pieces
-  assert dp.enabled and dp.world_size == world
+  assert dp.enabled and dp.world_size == world and dp.backend == ('nccl' if rccl else 'gloo')
   local = GLOBAL_B // world
   m = _make(local, bn)
   dp.attach(m)
   dp.broadcast_parameters(m)
-  state, first = _train(m, _global_batches(), rank * local, (rank + 1) * local)
+  state, first = _train(m, _global_batches(), rank * local, (rank + 1) * local, device_index=rank if rccl else 0)
   torch.save(state, os.path.join(out_dir, 'rank%d.pt' % rank))
   torch.save(first, os.path.join(out_dir, 'grads%d.pt' % rank))
   dp.barrier()
@@ -86,9 +94,22 @@ def _worker(rank, world, port, out_dir, bn):
 
 @gpu
 @pytest.mark.parametrize('bn', [False, True])
-def test_two_ranks_equal_one_process_on_the_global_batch(hip, tmp_path, bn):
+def test_two_ranks_over_rccl_on_two_devices_equal_one_process(hip, tmp_path, bn):
+  """(r6) PARITY ON FIRST CONTACT: the same contract with one DEVICE per rank and the collectives on real
+  RCCL -- the asynchronous bucketed all-reduce on RCCL's stream next to the backward kernels, the deferred discriminator
+  update, synchronised batch norm.  Needs two visible devices; on the 1-GPU boxes this suite has run on so far it skips
+  (the reason says so), and runs by itself the first time `pytest -m gpu` sees a multi-GPU node."""
+  if torch.cuda.device_count() < 2:
+    pytest.skip('needs >= 2 devices for RCCL between two ranks (this box has %d): the gloo test above covers the call sites'
+                % torch.cuda.device_count())
+  test_two_ranks_equal_one_process_on_the_global_batch(hip, tmp_path, bn, rccl=True)
+
+
+@gpu
+@pytest.mark.parametrize('bn', [False, True])
+def test_two_ranks_equal_one_process_on_the_global_batch(hip, tmp_path, bn, rccl=False):
   """bn=True additionally needs the batch statistics summed over the ranks (synchronised batch norm)."""
-  mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), bn), nprocs=2, join=True)
+  mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), bn, rccl), nprocs=2, join=True)
   r0 = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
   r1 = torch.load(os.path.join(str(tmp_path), 'rank1.pt'))
   single, g_single = _train(_make(GLOBAL_B, bn), _global_batches(), 0, GLOBAL_B)
