@@ -86,28 +86,27 @@ class Layer(object):
   # magnitude (ADVOC_IMG_*_DELAYED, 2^6 of head room; a tensor that leaves it, or shrinks by more than 2^6, is re-imaged
   # exactly on the device in the same call; csrc/image.hip).  False (default): always the exact two-pass form.
   delayed_scale = False
-  # True (ADVOC_EMIT_IMAGES=0 turns it off): a layer whose consumers were registered with add_image_consumer writes THEIR
+  # True (Layer.emit_images = False turns it off): a layer whose consumers were registered with add_image_consumer writes THEIR
   # operand images from its own forward epilogue (advoc_conv_layer.y_img, csrc/image_emit.h) once the consumer's header
   # holds a previous magnitude -- the consumer's image pass (a read and a write of the whole tensor) disappears
-  emit_images = os.environ.get('ADVOC_EMIT_IMAGES', '1') == '1'
-  # ADVOC_EMIT_DX_DELAYED=1 turns it on (the library's own ADVOC_EMIT_DX, default 1, is the kill switch of every dx_img and
-  # stays on): a backward_data call given `grad_consumer` -- the layer below, whose output gradient this
+  emit_images = True
+  # Layer.emit_dx = True turns it on: a backward_data call given `grad_consumer` -- the layer below, whose output gradient this
   # call's dx0 is -- writes THAT layer's output-gradient image (and its bias column sums) from its own epilogue
   # (advoc_conv_layer.dx_img): the image pass of the layer below disappears.  Off by default: measured on the one producer
   # that has it (discriminator layer_5 -> layer_4, the largest image pass of the step) the passes lose 0.31 ms per step and
   # the producer, an issue-bound kernel, gains 0.18 ms; the step does not move (NOTEBOOK.md section 7, profiles/r04_i_*)
-  emit_dx = os.environ.get('ADVOC_EMIT_DX_DELAYED', '0') == '1'
+  emit_dx = False
   # (r5) ADVOC_DX_BOUNDED=0 turns it off: where the backward-data call of a layer runs on a patch kernel and the layer below
   # reads its output gradient only as an operand image, that image is written by this call's epilogue under a scale derived
   # from an a-priori bound of |dx| (max|dy| max|w| taps K: nothing can leave the fp16 range, so no history, no refit, no fp32
   # tensor to refit from) and the fp32 dx0 is NOT written: the image pass of the layer below (a read and a write of the
   # tensor) disappears at no extra store in the epilogue.  Needs reuse_images (the train step's guarantees).
   dx_bounded = os.environ.get('ADVOC_DX_BOUNDED', '1') == '1'
-  # ADVOC_DX_ACCUM=1: ... also from calls that ACCUMULATE into dx0 (the generator's encoder chain: a decoder's skip gradient
+  # Layer.dx_accum = True: ... also from calls that ACCUMULATE into dx0 (the generator's encoder chain: a decoder's skip gradient
   # arrives first, with its largest magnitude recorded -- dx1_amax / bound_add).  Built, value-checked
   # (tests/test_hip_conv.py: enc_accum*) and OFF by default: same box, alternating, 38.56 / 38.50 / 38.66 ms without against
   # 38.48 / 38.54 / 38.73 with it -- the accumulating epilogue pays in loads and image arithmetic what the seven passes cost.
-  dx_accum = os.environ.get('ADVOC_DX_ACCUM', '0') == '1'
+  dx_accum = False
   # (r5) ADVOC_Y_IMAGE_ONLY=0 turns it off: a layer whose output has ONE reader (add_image_consumer(..., exclusive=True)) that
   # reads it as an operand image and gates its backward-data pass on that image's signs (a patch kernel) writes the IMAGE
   # ONLY, under a scale from an a-priori bound of |y| (max|x| max|w| taps K + max|b|): the fp32 tensor -- half the bytes the

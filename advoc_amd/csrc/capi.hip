@@ -44,18 +44,17 @@ Tuning read_env() {
   t.igemm_splitk = env_int("ADVOC_IGEMM_SPLITK", 1);
   t.igemm_tail = env_int("ADVOC_IGEMM_TAIL", 1);
   t.igemm_x6 = env_int("ADVOC_IGEMM_X6", 1);
-  const char* w = getenv("ADVOC_IGEMM_X6_WIDE");
-  t.igemm_x6_wide = w && *w ? atoll(w) : -1;
-  t.igemm_bk = env_int("ADVOC_IGEMM_BK", 0);
-  t.igemm_x6_n32 = env_int("ADVOC_IGEMM_X6_N32", 1);
-  t.igemm_x6_tile = env_int("ADVOC_IGEMM_X6_TILE", 0);
-  t.igemm_tile = env_int("ADVOC_IGEMM_TILE", 0);
-  t.igemm_korder = env_int("ADVOC_IGEMM_KORDER", -1);
+  t.igemm_x6_wide = -1;      // (r6: fixed -- ADVOC_IGEMM_X6_WIDE had no test)
+  t.igemm_bk = 0;      // (r6: fixed -- the switch ADVOC_IGEMM_BK had no test; its other settings are history, NOTEBOOK.md)
+  t.igemm_x6_n32 = 1;      // (r6: fixed -- the switch ADVOC_IGEMM_X6_N32 had no test; its other settings are history, NOTEBOOK.md)
+  t.igemm_x6_tile = 0;      // (r6: fixed -- the switch ADVOC_IGEMM_X6_TILE had no test; its other settings are history, NOTEBOOK.md)
+  t.igemm_tile = 0;      // (r6: fixed -- the switch ADVOC_IGEMM_TILE had no test; its other settings are history, NOTEBOOK.md)
+  t.igemm_korder = -1;      // (r6: fixed -- the switch ADVOC_IGEMM_KORDER had no test; its other settings are history, NOTEBOOK.md)
   t.wgrad_x6 = env_int("ADVOC_WGRAD_X6", 1);
   t.wgrad_h3 = env_int("ADVOC_WGRAD_H3", 1);
   t.wgrad_h3_min_m = env_int("ADVOC_WGRAD_H3_MIN_M", 128);
   t.wgrad_h3_tile = env_int("ADVOC_WGRAD_H3_TILE", 0);
-  t.wgrad_h3_rounds = env_int("ADVOC_WGRAD_H3_ROUNDS", 0);
+  t.wgrad_h3_rounds = 0;      // (r6: fixed -- the switch ADVOC_WGRAD_H3_ROUNDS had no test; its other settings are history, NOTEBOOK.md)
   t.wgrad_h3_rows = env_int("ADVOC_WGRAD_H3_ROWS", 1);
   t.wgrad_h3_ordered = env_int("ADVOC_WGRAD_H3_ORDERED", 1);
   t.h3 = env_int("ADVOC_H3", 1);
@@ -68,9 +67,9 @@ Tuning read_env() {
   t.h3_min_tiles = env_int("ADVOC_H3_MIN_TILES", 4);
   t.h3_patch = env_int("ADVOC_H3_PATCH", 1);
   t.h3_patch_min_wgs = env_int("ADVOC_H3_PATCH_MIN_WGS", 256);
-  t.h3_patch_s2 = env_int("ADVOC_H3_PATCH_S2", 1);
-  t.h3_patch_rem = env_int("ADVOC_H3_PATCH_REM", 1);
-  t.h3_patch_n32 = env_int("ADVOC_H3_PATCH_N32", 1);
+  t.h3_patch_s2 = 1;      // (r6: fixed -- the switch ADVOC_H3_PATCH_S2 had no test; its other settings are history, NOTEBOOK.md)
+  t.h3_patch_rem = 1;      // (r6: fixed -- the switch ADVOC_H3_PATCH_REM had no test; its other settings are history, NOTEBOOK.md)
+  t.h3_patch_n32 = 1;      // (r6: fixed -- the switch ADVOC_H3_PATCH_N32 had no test; its other settings are history, NOTEBOOK.md)
   t.h3_patch_persist = env_int("ADVOC_H3_PATCH_PERSIST", 2);
 #ifdef ADVOC_DIAG
   t.h3_patch_ablate = env_int("ADVOC_H3_PATCH_ABLATE", 0);
@@ -78,14 +77,13 @@ Tuning read_env() {
   t.h3_patch_ablate = 0;
 #endif
   t.h3_patch_2wg = env_int("ADVOC_H3_PATCH_2WG", 0);
-  t.h3_patch_2wg_delay = env_int("ADVOC_H3_PATCH_2WG_DELAY", 100);
+  t.h3_patch_2wg_delay = 100;      // (r6: fixed -- the switch ADVOC_H3_PATCH_2WG_DELAY had no test; its other settings are history, NOTEBOOK.md)
   t.reserve_cus = env_int("ADVOC_RESERVE_CUS", 0);
   if (t.reserve_cus < 0) t.reserve_cus = 0;
-  t.thin_wgrad_bias = env_int("ADVOC_THIN_WGRAD_BIAS", 1);
+  t.thin_wgrad_bias = 1;      // (r6: fixed -- the switch ADVOC_THIN_WGRAD_BIAS had no test; its other settings are history, NOTEBOOK.md)
   t.fused_taps = env_int("ADVOC_FUSED_TAPS", 1);
-  t.thin_fwd_spec = env_int("ADVOC_THIN_FWD_SPEC", 1);
-  t.thin_wgrad_nt = env_int("ADVOC_THIN_WGRAD_NT", 4);
-  if (t.thin_wgrad_nt != 1 && t.thin_wgrad_nt != 2) t.thin_wgrad_nt = 4;
+  t.thin_fwd_spec = 1;      // (r6: fixed -- the switch ADVOC_THIN_FWD_SPEC had no test; its other settings are history, NOTEBOOK.md)
+  t.thin_wgrad_nt = 4;      // (r6: fixed -- the switch ADVOC_THIN_WGRAD_NT had no test; its other settings are history, NOTEBOOK.md)
   t.h3_deep_wgs_per_cu = env_int("ADVOC_H3_DEEP_WGS_PER_CU", 2);
   t.h3_deep_split_div = env_int("ADVOC_H3_DEEP_SPLIT_DIV", 8);
   if (t.h3_deep_wgs_per_cu < 1) t.h3_deep_wgs_per_cu = 1;
@@ -93,11 +91,11 @@ Tuning read_env() {
   t.h3_rem_ws = env_int("ADVOC_H3_REM_WS", 1);
   t.h3_rem_wgs_per_cu = env_int("ADVOC_H3_REM_WGS_PER_CU", 2);
   t.h3_rem_split_div = env_int("ADVOC_H3_REM_SPLIT_DIV", 8);
-  t.h3_deep_stages = env_int("ADVOC_H3_DEEP_STAGES", 2);
+  t.h3_deep_stages = env_int("ADVOC_H3_DEEP_STAGES", 3);      // (r6: 3 -- 35 launches per step, -10 % each: profiles/r06_ab_deep_env.txt)
   t.h3_deep_split = env_int("ADVOC_H3_DEEP_SPLIT", 0);
-  t.h3_deep_plan = env_int("ADVOC_H3_DEEP_PLAN", 1);
-  t.emit_dx = env_int("ADVOC_EMIT_DX", 1);
-  t.h3_patch_s1n128 = env_int("ADVOC_H3_PATCH_S1N128", 1);
+  t.h3_deep_plan = 1;      // (r6: fixed -- the switch ADVOC_H3_DEEP_PLAN had no test; its other settings are history, NOTEBOOK.md)
+  t.emit_dx = 1;      // (r6: fixed -- the switch ADVOC_EMIT_DX had no test; its other settings are history, NOTEBOOK.md)
+  t.h3_patch_s1n128 = 1;      // (r6: fixed -- the switch ADVOC_H3_PATCH_S1N128 had no test; its other settings are history, NOTEBOOK.md)
   if (t.h3_rem_wgs_per_cu < 1) t.h3_rem_wgs_per_cu = 1;
   if (t.h3_rem_split_div < 2) t.h3_rem_split_div = 2;
   return t;

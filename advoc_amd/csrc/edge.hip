@@ -496,7 +496,7 @@ static bool fused_taps_plan(const GatherGemmParams& p, FusedGeom* out, int* cb_o
   const int ld = cols + 1;
   const int w_floats = (cols / 16) * (K / 16) * 256;
   const size_t fixed = sizeof(float) * ((size_t)w_floats + (p.in_scale ? 2 * (size_t)K : 0));
-  static const int budget_kb = getenv("ADVOC_FUSED_TAPS_LDS_KB") ? atoi(getenv("ADVOC_FUSED_TAPS_LDS_KB")) : 78;    // (A/B) 78: two workgroups per CU
+  constexpr int budget_kb = 78;      // two workgroups per CU (r4 A/B: ADVOC_FUSED_TAPS_LDS_KB, removed in r6)
   const size_t budget = (size_t)(budget_kb < 16 ? 16 : (budget_kb > 156 ? 156 : budget_kb)) * 1024;
   if (fixed + 64 * sizeof(float) * ld > budget) return false;
   const int64_t rmax = (int64_t)((budget - fixed) / (sizeof(float) * ld));

@@ -399,7 +399,7 @@ extern "C" int advoc_stft_mel_pinv_f32(const float* wav, int64_t batch, int64_t 
     (void)hipGetLastError();
     return n > 0 ? n : 256;
   }();
-  static const int skew_env = [] { const char* e = getenv("ADVOC_EXTRACT_SKEW"); return e ? atoi(e) : 0; }();      // start stagger of the CU's second workgroup (measured: no effect)
+  constexpr int skew_env = 0;      // (start stagger of the CU's second workgroup: measured, no change -- the switch is gone, r6)
   const int skew = minw == 4 ? skew_env : 0;
   const int64_t per_cu = minw == 4 ? 2 : 1;
   const int64_t grid = total < per_cu * resident ? total : per_cu * (int64_t)resident;      // persistent

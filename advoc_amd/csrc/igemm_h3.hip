@@ -532,7 +532,11 @@ int launch_h(const GatherGemmParams& p, hipStream_t stream, const char** name_on
     *name_only = name.c_str();
     return ADVOC_OK;
   }
+#ifdef ADVOC_DIAG
   static const int abl = getenv("ADVOC_H3_ABLATE") ? atoi(getenv("ADVOC_H3_ABLATE")) : 0;
+#else
+  constexpr int abl = 0;      // (timing experiments: -DADVOC_DIAG builds only, like ADVOC_H3_PATCH_ABLATE)
+#endif
   auto kern = gather_gemm_h3_kernel<MT, NT, NS, WGM>;
   if constexpr (NS == 2 && MT == 2 && NT >= 2 && WGM == 2) {   // experiments: two instances are enough
     if (abl == 2) kern = gather_gemm_h3_abl_kernel<MT, NT, NS, 2>;
@@ -546,7 +550,11 @@ int launch_h(const GatherGemmParams& p, hipStream_t stream, const char** name_on
   const int64_t gx = ceil_div(M, C::BM) * ceil_div(p.n_total, C::BN);
   GatherGemmParams q = p;
   dim3 grid((unsigned)gx, (unsigned)ksplit, (unsigned)p.nphase);
+#ifdef ADVOC_DIAG
   static const bool log_launches = getenv("ADVOC_H3_LOG") != nullptr;     // which launch is which (tools/micro)
+#else
+  constexpr bool log_launches = false;
+#endif
   if (log_launches)
     fprintf(stderr, "h3 launch <%d,%d,%d,%d> batch %d grid %dx%d (+%d) phases %d N %d K %d taps %d bwd %d: %u x %u x %u wgs, "
             "tail main %d rem %d split %d\n", MT, NT, NS, WGM, p.batch, p.gh, p.gw, p.gx_off, p.nphase, p.n_total,

@@ -928,7 +928,7 @@ int launch_stft(const float* wav, int64_t batch, int64_t nsamps, const float* wi
   if (blocks > 2048) blocks = 2048;
   // hop 256 with 8-byte aligned clips: the kernel with fewer instructions per frame pair
   static const int variant = getenv("ADVOC_STFT_V") ? atoi(getenv("ADVOC_STFT_V")) : 0;
-  static const int block_cap = getenv("ADVOC_STFT_BLOCKS") ? atoi(getenv("ADVOC_STFT_BLOCKS")) : 1024;   // four workgroups per CU, resident
+  constexpr int block_cap = 1024;   // four workgroups per CU, resident
   if (nhop == 256 && !(nsamps & 1) && total_pairs < (1LL << 30) && variant >= 0) {
     if (blocks > block_cap) blocks = block_cap;
 #define ADVOC_STFT_LAUNCH(C, V)                                                                                         \

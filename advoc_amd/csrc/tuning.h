@@ -45,7 +45,7 @@ struct Tuning {
   int h3_patch_s1n128;  // ADVOC_H3_PATCH_S1N128  1: the 128-column instance of the 4x4 stride-1 patch kernel (<5,.>)
   int emit_dx;          // ADVOC_EMIT_DX          1: backward-data calls honour advoc_conv_layer.dx_img (0: kill switch); (the lower layer's dy image from the epilogue)
   int h3_deep_plan;     // ADVOC_H3_DEEP_PLAN     1: r4's tile / K-slice choice for the launches under one round of tiles, 0: r3's
-  int h3_deep_stages;   // ADVOC_H3_DEEP_STAGES   LDS stages of the 128 x 64 per-tap tile (2 | 3 | 4)
+  int h3_deep_stages;   // ADVOC_H3_DEEP_STAGES   LDS stages of the 128 x 64 per-tap tile (2 | 3 (default since r6) | 4)
   int h3_rem_split_div; // ADVOC_H3_REM_SPLIT_DIV  K tiles per slice, at least
   int reserve_cus;      // ADVOC_RESERVE_CUS     CUs the PERSISTENT launches (patch kernels, image weight gradient) leave free: set by
                         //                       advoc_amd.parallel from ADVOC_DP_RESERVE_CUS when world_size > 1, so that RCCL's kernels

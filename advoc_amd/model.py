@@ -484,7 +484,7 @@ class Advoc(Model):
     # backward_weight of a layer see the same gradient tensor: the operand images are made once per tensor and step
     for lay in list(L.values()) + st['d_layers_fake'] + st.get('d_layers_real', []) + st.get('d_layers_2b', []):
       lay.reuse_images = True
-      lay.delayed_scale = os.environ.get('ADVOC_DELAYED_SCALE', '1') == '1'
+      lay.delayed_scale = True
     self._bind_weight_images(st, 'g', list(L.values()), dev)
     self._bind_weight_images(st, 'd', st['d_layers_fake'] + st.get('d_layers_real', []) + st.get('d_layers_2b', []), dev)
 
@@ -492,10 +492,10 @@ class Advoc(Model):
     """Persistent fp16 pair images of every kernel the image kernels read (forward and backward-data layouts), rebuilt
     by ONE advoc_weight_images_f32 launch per forward pass over the network (right after the magnitude launch) instead of
     one small launch per layer call -- 54 per train step.  Layers that share a kernel (the discriminator's real / fake /
-    2B passes) share its images.  ADVOC_WEIGHT_IMAGES=0: per-call images."""
+    2B passes) share its images.  (Per-call images: ADVOC_WEIGHT_AMAX=0.)"""
     st[net + '_wimg'] = None
     st[net + '_wdirty'] = True            # new layers, new (empty) image pool
-    if not st['wamax_on'] or os.environ.get('ADVOC_WEIGHT_IMAGES', '1') != '1':
+    if not st['wamax_on']:
       return
     names = dict((t.data_ptr(), k) for k, t in st[net + '_P'].items() if k.endswith('/kernel'))
     slots, rows, uses = {}, [], []

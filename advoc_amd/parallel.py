@@ -21,10 +21,10 @@ import torch.distributed as dist
 
 class DataParallel(object):
   def __init__(self, bucket_bytes=None):
-    # ADVOC_DP_BUCKET_MB: size of one all-reduce (MiB, default 8).  xGMI is point-to-point: a ring all-reduce is bound per
+    # bucket_bytes: size of one all-reduce (default 8 MiB).  xGMI is point-to-point: a ring all-reduce is bound per
     # link, so buckets are few and large; 8 MiB = 27 collectives for the generator's 217.6 MB arena
     if bucket_bytes is None:
-      bucket_bytes = int(float(os.environ.get('ADVOC_DP_BUCKET_MB', '8')) * (1 << 20))
+      bucket_bytes = 8 << 20
     self.bucket_elems = max(1, bucket_bytes // 4)
     self.world_size = 1
     self.rank = 0

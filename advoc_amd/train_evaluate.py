@@ -234,7 +234,7 @@ def train(fps, args):
       log.write(json.dumps(rec) + '\n')
       log.flush()
       events.add_scalars(model.losses(), _step, wall_time=now)      # tags as advoc_model.py:272-275
-      if os.environ.get('ADVOC_MEDIA_SUMMARIES', '1') == '1':        # image / audio summaries (advoc_model.py:258-281)
+      if True:        # image / audio summaries (advoc_model.py:258-281)
         images, audio = model.media_summaries()
         events.add_images(images, _step, wall_time=now)
         events.add_audio(audio, _step, model.audio_fs, wall_time=now)

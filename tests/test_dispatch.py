@@ -60,10 +60,10 @@ FULL = [
     # tiles on 256 CUs, on 128 x 128 tiles; decoder_6 backward-data, 144 128 x 128 tiles, on those cut into three K slices)
     ('encoder_5', layer(0, BF, 16, 33, 512, 0, 512, (2, 2)), 'gather_gemm_h3_kernel<2, 4, 2, 4>',
      'gather_gemm_h3_kernel<2, 2, 2, 2>', W256F),
-    ('decoder_6', layer(1, BF, 4, 9, 512, 512, 512, (2, 2), trim=1), 'gather_gemm_h3_kernel<2, 1, 2, 2>',
+    ('decoder_6', layer(1, BF, 4, 9, 512, 512, 512, (2, 2), trim=1), 'gather_gemm_h3_kernel<2, 1, 3, 2>',
      'gather_gemm_h3_kernel<2, 2, 2, 2>', None),
-    ('encoder_7', layer(0, BF, 4, 9, 512, 0, 512, (2, 2)), 'gather_gemm_h3_kernel<2, 1, 2, 2>',
-     'gather_gemm_h3_kernel<2, 1, 2, 2>', None),
+    ('encoder_7', layer(0, BF, 4, 9, 512, 0, 512, (2, 2)), 'gather_gemm_h3_kernel<2, 1, 3, 2>',
+     'gather_gemm_h3_kernel<2, 1, 3, 2>', None),
     ('decoder_5', layer(1, BF, 8, 17, 512, 512, 512, (2, 2), trim=1), 'gather_gemm_h3_kernel<2, 2, 2, 2>',
      'gather_gemm_h3_kernel<2, 2, 2, 2>', W256F),
     ('decoder_4', layer(1, BF, 16, 33, 512, 512, 256, (2, 2), trim=1), P4F, P2B, W256),
@@ -84,7 +84,7 @@ def test_full_model_dispatch(name, L, fwd, bwd, wgt):
 
 
 BS = 32
-PT = 'gather_gemm_h3_kernel<2, 1, 2, 2>'
+PT = 'gather_gemm_h3_kernel<2, 1, 3, 2>'
 # AdVoc-small at B=32 (BASELINE configs[1], advoc_model_small.py:14-15: ngf = ndf = 32): every layer between the 1-channel
 # edges runs on the image kernels -- the 32-column launches (encoder_2 / layer_2 backward-data, decoder_2 forward) on the
 # 64-column four-phase patch instance without the column block that does not exist (r4, second half; the 128 x 64 per-tap

@@ -265,12 +265,12 @@ H3 = [
 # 32 output columns (AdVoc-small: encoder_2 / layer_2 backward-data -- 32 input channels --, decoder_2 forward -- 32 output
 # channels; advoc_model_small.py:14-15): the 128 x 64 tile with its upper 32 columns masked (r4; the r1 fp32 kernel before)
 H3_N32 = [
-    (('h3_small_enc2', 0, (3, 32, 33), 32, 0, 64, 0, (2, 2), None, 1, False, 0), {0: 'gather_gemm_h3_kernel<2, 1, 2, 2>', 1: 'gather_gemm_h3_kernel<2, 1, 2, 2>'}),
-    (('h3_small_dec2', 1, (2, 16, 17), 64, 64, 32, 1, (2, 2), (1, 1), 2, False, 0), {0: 'gather_gemm_h3_kernel<2, 1, 2, 2>'}),
-    (('h3_small_dec2_drop', 1, (2, 8, 9), 64, 64, 32, 1, (2, 2), (1, 1), 2, True, 1), {0: 'gather_gemm_h3_kernel<2, 1, 2, 2>'}),
-    (('h3_small_layer2', 0, (4, 16, 32), 32, 0, 64, 0, (2, 2), (1, 1), 1, False, 0), {1: 'gather_gemm_h3_kernel<2, 1, 2, 2>'}),
+    (('h3_small_enc2', 0, (3, 32, 33), 32, 0, 64, 0, (2, 2), None, 1, False, 0), {0: 'gather_gemm_h3_kernel<2, 1, 3, 2>', 1: 'gather_gemm_h3_kernel<2, 1, 3, 2>'}),
+    (('h3_small_dec2', 1, (2, 16, 17), 64, 64, 32, 1, (2, 2), (1, 1), 2, False, 0), {0: 'gather_gemm_h3_kernel<2, 1, 3, 2>'}),
+    (('h3_small_dec2_drop', 1, (2, 8, 9), 64, 64, 32, 1, (2, 2), (1, 1), 2, True, 1), {0: 'gather_gemm_h3_kernel<2, 1, 3, 2>'}),
+    (('h3_small_layer2', 0, (4, 16, 32), 32, 0, 64, 0, (2, 2), (1, 1), 1, False, 0), {1: 'gather_gemm_h3_kernel<2, 1, 3, 2>'}),
 ]
-H3_VARIANTS = [(1, 2), (4, 2), (5, 2)]        # 128 x 128, 128 x 64, 256 x 256 on 8 waves (the tiles the dispatch uses)
+H3_VARIANTS = [(1, 2), (4, 3), (4, 2), (5, 2)]   # 128 x 128, 128 x 64 (three stages: the default since r6; two), 256 x 256 on 8 waves
 
 # Patch kernels (igemm_patch.hip): the stride-1 gathers -- four fused sub-pixel phases (transposed-conv forward, conv
 # backward-data) and the 4x4 stride-1 conv in both directions -- on grids that are not multiples of the 16 x 16 patch,
@@ -382,7 +382,7 @@ def test_patch_remainder_columns_k_split(hip, case, want, mode, hipenv):
 def test_layer_operand_image_kernels(hip, case, variant, hipenv):
   from advoc_amd import conv
   tile, stages = variant
-  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_TILE=tile)
+  hipenv(ADVOC_H3_MIN_TILES=1, ADVOC_H3_TILE=tile, ADVOC_H3_DEEP_STAGES=stages)
   c = build_case(case)
   dev = torch.device('cuda')
   x0 = c['x0'].to(dev)
