@@ -374,7 +374,8 @@ def test_full_model_train_loops_at_bench_size_match_the_float64_oracle(hip):
         r_gen = rel(st['gen_out'][:DISTINCT], gen64)
         print('step %d: generator output at the 64-clip dispatch vs float64: rel-L2 %.3g' % (step + 1, r_gen))
         assert r_gen < 1e-4, r_gen
-        assert torch.equal(st['gen_out'][:DISTINCT], st['gen_out'][Bn - DISTINCT:])      # the tiled clips: identical rows
+        # (the last of the 8 tilings against the first: the same clips through other tiles / K-slice orders of the same launches)
+        assert rel(st['gen_out'][Bn - DISTINCT:], gen64) < 1e-4 and rel(st['gen_out'][Bn - DISTINCT:], st['gen_out'][:DISTINCT]) < 1e-5
     # GATE-FROZEN (r5): the same gradients against the float64 oracle evaluated with THIS run's sign patterns (every leaky /
     # plain ReLU of the generator and of the discriminator's passes): a smooth function on both sides, every tensor held to
     # 5e-4 with no recourse to what float32 achieves.  The free-running comparison below keeps its r3 form; its one sensitive
