@@ -372,6 +372,9 @@ extern "C" int advoc_conv_forward(const advoc_conv_layer* L, advoc_stream_t stre
     // magnitude pass over each source, into the reserved word 7 of the header the launch writes (the image kernels read the
     // magnitude of their input image from its header)
     if (L->x0.w_pitch != L->x0.w || (L->x1.p && L->x1.w_pitch != L->x1.w)) return ADVOC_ERR_UNSUPPORTED;
+    // (r6) the bound is taken from the RAW inputs: an input affine (batch norm) or an input dropout mask (scale
+    // > 1) the kernel applies on load would make it too small, and an image-only output has no fp32 tensor to fall back on
+    if (L->in_scale || L->in_shift || L->in_mask) return ADVOC_ERR_UNSUPPORTED;
     unsigned* word = L->y_img[0].hdr + 7;
     hipError_t e = hipMemsetAsync(word, 0, 4, as_stream(stream));
     if (e != hipSuccess) { note_hip_error(e); return ADVOC_ERR_HIP; }

@@ -1432,6 +1432,26 @@ def test_a_sole_reader_gets_the_output_as_its_operand_image_only(hip, hipenv, pr
     assert abs(float(ha[0]) - amax) <= 2e-6 * amax, (step, float(ha[0]), amax)
     assert 2.0 <= amax / float(ha[1]) < 65504.0, (step, amax / float(ha[1]))
   assert int(L2a.image_headers()[0].cpu()[5]) == 0      # nothing was ever refitted
+  # (r6) an input that exists as its image only stays CURRENT until the next forward: a second backward_weight after
+  # the same forward (gradient accumulation, a profiler's re-run) reads the image again and reproduces the gradient -- it
+  # used to rebuild the image from the never-written fp32 tensor (NaN poison here) and overwrite the one valid copy ...
+  _, L2a, ta = A
+  again = torch.zeros_like(ta['dw'])
+  L2a.backward_data(dy2, ta['dx'])
+  L2a.backward_weight(dy2, again)
+  assert torch.isfinite(again).all() and rel(again, ta['dw']) < 1e-6, rel(again, ta['dw'])
+  L2a.backward_weight(dy2, again)
+  assert torch.isfinite(again).all() and rel(again, ta['dw']) < 1e-6
+  # ... and a call that could only rebuild it is refused, in Python and by the library itself
+  from advoc_amd import _lib
+  L2a._x_current = False
+  with pytest.raises(_lib.AdvocHipError, match='image only'):
+    L2a.backward_weight(dy2, again)
+  import ctypes
+  L2a.struct.img_flags = 256            # ADVOC_IMG_X_GATES without ADVOC_IMG_X_CURRENT
+  rc = _lib.load().advoc_conv_backward_weight(ctypes.byref(L2a.struct), _lib.ptr(dy2), _lib.ptr(again), None, 0, _lib.stream())
+  L2a.struct.img_flags = 0
+  assert rc != 0
 
 
 @gpu
