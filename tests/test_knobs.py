@@ -45,6 +45,15 @@ def test_library_path_override(tmp_path):
   assert bad.returncode != 0
 
 
+def _free_port():
+  import socket
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
 def test_dp_reserve_becomes_the_library_switch():
   """ADVOC_DP_RESERVE_CUS=k is honoured by DataParallel only when there is more than one rank (or ADVOC_DP_FORCE): it becomes
   ADVOC_RESERVE_CUS for the persistent launches; an explicit ADVOC_RESERVE_CUS wins."""
@@ -52,10 +61,10 @@ def test_dp_reserve_becomes_the_library_switch():
           'dp = DataParallel().init_from_env(backend="gloo")\n'
           'print(dp.reserve_source, os.environ.get("ADVOC_RESERVE_CUS"))\n')
   base = dict(os.environ, PYTHONPATH=ROOT, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
-              MASTER_PORT='29431', ADVOC_DP_FORCE='1', ADVOC_DP_RESERVE_CUS='16')
+              MASTER_PORT=str(_free_port()), ADVOC_DP_FORCE='1', ADVOC_DP_RESERVE_CUS='16')
   base.pop('ADVOC_RESERVE_CUS', None)
   out = subprocess.run([sys.executable, '-c', code], env=base, capture_output=True, text=True, cwd=ROOT)
   assert out.returncode == 0 and out.stdout.split()[-2:] == ['dp', '16'], (out.stdout, out.stderr[-400:])
-  out = subprocess.run([sys.executable, '-c', code], env=dict(base, ADVOC_RESERVE_CUS='24', MASTER_PORT='29432'),
+  out = subprocess.run([sys.executable, '-c', code], env=dict(base, ADVOC_RESERVE_CUS='24', MASTER_PORT=str(_free_port())),
                        capture_output=True, text=True, cwd=ROOT)
   assert out.returncode == 0 and out.stdout.split()[-2:] == ['user', '24'], (out.stdout, out.stderr[-400:])
